@@ -1,0 +1,159 @@
+/* pfst_hip.h -- C ABI of libpfst_hip.so: the MI355X (gfx950) kernels of the PFST train step.
+ *
+ * The reference (zhu-xlab/PFST, `rsiseg`) has no native layer: every op below is, in the
+ * reference, a PyTorch/mmcv call inside PFGST.train_step (rsiseg/models/uda/pfgst.py:129-356).
+ * Each entry point names the reference call it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates); no hidden state,
+ *     no allocation, no synchronisation inside; work is enqueued on `stream` (a hipStream_t);
+ *   - tensors are fp32 NCHW; `*_bs` arguments are batch strides in elements so a channel slice of
+ *     a bigger tensor can be passed (concatenations are never materialised);
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 unsupported);
+ *     pfst_last_error() returns a static description of the last failure of the calling process;
+ *   - re-entrant per stream.
+ * The parser in pfst_amd/_lib.py reads this file to build the ctypes signatures, so keep one
+ * declaration per statement and only the scalar types used below.
+ */
+#ifndef PFST_HIP_H
+#define PFST_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pfst_stream_t; /* hipStream_t */
+
+int pfst_abi_version(void);
+const char* pfst_last_error(void);
+
+/* ---- elementwise utilities -------------------------------------------------------------- */
+int pfst_fill_f32(float* p, long long n, float value, pfst_stream_t stream);
+/* y[i] += alpha * x[i]   (autograd's gradient accumulation) */
+int pfst_axpy_f32(float* y, const float* x, float alpha, long long n, pfst_stream_t stream);
+/* int64 / uint8 label conversions (decode_head.py:209 `.type(torch.LongTensor)`) */
+int pfst_i64_to_u8(const long long* src, unsigned char* dst, long long n, pfst_stream_t stream);
+int pfst_u8_to_i64(const unsigned char* src, long long* dst, long long n, pfst_stream_t stream);
+
+/* ---- dense convolution as implicit GEMM on fp32 MFMA (F.conv2d, groups=1) ---------------
+ * resnet.py:169-209 (Bottleneck 1x1/3x3), resnet.py:593-624 (stem), aspp_head.py:32-42,85-92,
+ * fcn_head.py:40-49, decode_head.py:242-247 (conv_seg), mmcv pointwise convs. */
+/* w[Cout][Cin][T] -> wk_fprop[(t*Cin+ci)][Cout] and wk_dgrad[(t*Cout+co)][Cin] (either may be NULL) */
+int pfst_conv_pack_weight(const float* w, float* wk_fprop, float* wk_dgrad, int Cout, int Cin, int T, pfst_stream_t stream);
+/* out[n][m][oy][ox] (+)= bias[m] + sum_{t,c} wk[(t*C+c)][m] * in[n][c][sy][sx]
+ *   mode 0 (fprop): sy = oy*stride + ty*dil - pad          in = x,  C = Cin,  M = Cout
+ *   mode 1 (dgrad): sy = (oy + pad - ty*dil) / stride      in = dy, C = Cout, M = Cin  (exact division only)
+ * ksize in {1,3}; accumulate != 0 adds into `out`. */
+int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
+                    int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
+                    int mode, int accumulate, pfst_stream_t stream);
+/* dw[co][ci][t] += sum_{n,oy,ox} dy[n][co][oy][ox] * x[n][ci][oy*stride+ty*dil-pad][...]   (atomic fp32 adds) */
+int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
+                    int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
+                    pfst_stream_t stream);
+/* db[c] += sum_{n,hw} dy[n][c][hw] */
+int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream);
+
+/* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
+ * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
+int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
+                   int N, int C, int H, int W, int dil, int flip, int accumulate, pfst_stream_t stream);
+int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
+                         int N, int C, int H, int W, int dil, pfst_stream_t stream);
+
+/* ---- BatchNorm2d, training mode (nn.BatchNorm2d inside mmcv ConvModule; eps 1e-5, momentum .1) */
+/* batch mean / 1/sqrt(biased var + eps) per channel; updates running stats (unbiased var) when
+ * running_mean != NULL.  ws: >= 2*C doubles of scratch. */
+int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
+                  float* running_mean, float* running_var, float momentum, float eps, double* ws, pfst_stream_t stream);
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
+                  const float* mean, const float* invstd, const float* gamma, const float* beta,
+                  int N, int C, int HW, int relu, pfst_stream_t stream);
+/* backward of the above: dz = dy * (y > 0 if relu); dres (+)= dz; dgamma += sum dz*xhat; dbeta += sum dz;
+ * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles. */
+int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
+                     const float* mean, const float* invstd, const float* gamma,
+                     float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
+                     float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream);
+
+/* ---- pooling / resize ---------------------------------------------------------------------- */
+/* nn.MaxPool2d(3, 2, 1) (resnet.py:638); idx holds the winning tap 0..8 */
+int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream);
+int pfst_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=False) (ops/wrappers.py:27) and its adjoint */
+int pfst_resize_bilinear(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, pfst_stream_t stream);
+int pfst_resize_bilinear_bwd(const float* dy, long long dy_bs, float* dx, long long dx_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, int accumulate, pfst_stream_t stream);
+/* nn.AdaptiveAvgPool2d(1) (aspp_head.py:69-77): y[n][c] = mean_hw x */
+int pfst_global_avgpool(const float* x, long long x_bs, float* y, int N, int C, int HW, pfst_stream_t stream);
+/* dx[n][c][hw] (+)= dy[n][c] * scale */
+int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, pfst_stream_t stream);
+/* v[n][c] = sum_hw dy[n][c][hw]  (adjoint of the 1x1 -> HxW bilinear broadcast) */
+int pfst_reduce_hw(const float* dy, long long dy_bs, float* v, int N, int C, int HW, pfst_stream_t stream);
+/* nn.Dropout2d (decode_head.py:103-107): y = x * mask[n][c] */
+int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream);
+
+/* ---- fused bilinear-upsample + softmax cross-entropy + accuracy (decode_head.py:249-283,
+ * cross_entropy_loss.py:45-65, accuracy.py:6-61).  logits are [N][C][h][w]; labels/weights [N][H][W].
+ * acc[0] += sum_i w_i*cw[y_i]*nll_i (0 at ignore), acc[1] += #correct, acc[2] += #non-ignored.
+ * lse[N][H][W] (log-sum-exp of the upsampled logits) is saved for the backward. */
+int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
+                         const float* class_weight, int H, int W, int ignore_index, float* lse, double* acc, pfst_stream_t stream);
+/* dlogits[n][c][ly][lx] (+)= scale * sum_p bilin(p->l) * w_p*cw[y_p] * (softmax_c(p) - [c==y_p]) */
+int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
+                         const float* class_weight, int H, int W, int ignore_index, const float* lse, float scale,
+                         float* dlogits, int accumulate, pfst_stream_t stream);
+
+/* ---- pseudo labels (pfgst.py:259-268 + encoder_decoder.py:77-81): bilinear upsample of the teacher
+ * logits, softmax, (max prob, first arg-max), prob >= threshold counted into count[0] */
+int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
+                      long long* label_i64, unsigned char* label_u8, unsigned long long* count, pfst_stream_t stream);
+
+/* ---- class mix (dacs_transforms.py:110-144, pfgst.py:281-300) ------------------------------- */
+/* presence[v] = 1 if label value v occurs (torch.unique over the batch) */
+int pfst_label_presence(const unsigned char* label, long long n, int* presence256, pfst_stream_t stream);
+/* mask[n][p] = 1 if gt[n][p] is one of classes[n][0..K) (entries < 0 are padding) */
+int pfst_class_mask(const unsigned char* gt, const int* classes, int K, unsigned char* mask, int N, long long HW, pfst_stream_t stream);
+/* mixed = M*src + (1-M)*trg for image, label and pixel weight; the target weight is
+ * q = conf_count[0] / (N*HW) (thre_type 'all').  mixed_lbl_i64 may be NULL. */
+int pfst_class_mix(const float* img, const float* trg_img, const unsigned char* gt, const unsigned char* pseudo,
+                   const unsigned char* mask, const unsigned long long* conf_count, float* mixed_img,
+                   unsigned char* mixed_lbl, long long* mixed_lbl_i64, float* mixed_w, int N, int Cimg, long long HW, pfst_stream_t stream);
+
+/* ---- PFGSTLoss (pfgst_loss.py:44-234), kernel 3x3, cosine similarity, top-k ------------------ */
+/* sim[n][k][y][x] = cos(f[n][:,y,x], f[n][:,y+dy_k,x+dx_k]) (0 outside); norm[n][y][x] = |f| */
+int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, float* sim, float* norm, pfst_stream_t stream);
+/* d feat (+)= adjoint of pfst_sim_map for upstream gradient gsim[n][9][H][W] */
+int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
+                     float* dfeat, int accumulate, pfst_stream_t stream);
+/* source statistics: sets (neighbour label == / != centre label, centre != 255) of src sims.
+ * gt is full resolution [N][Hg][Wg] uint8, nearest-sampled to HxW.  stats[0..5] = n_pos, sum_pos, sumsq_pos, n_neg, sum_neg, sumsq_neg */
+int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double* stats, pfst_stream_t stream);
+/* losses[0..3] = -w*mean_pos, w*mean_neg, w*std_pos, w*std_neg and gsim = d(sum of the four)/d sim */
+int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, const double* stats,
+                      float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream);
+/* prob[n][c][y][x] = softmax_c(logits[n][c][y*ds][x*ds]) (nearest down-scaling by ds) */
+int pfst_softmax_down(const float* logits, int N, int C, int h, int w, int ds, float* prob, int H, int W, pfst_stream_t stream);
+/* valid[n][y][x] = (gt != 255) && all 9 dilated neighbours un-mixed; count[0] = #valid */
+int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char* mix_mask, int N, int H, int W, int Hg, int Wg, int dil,
+                        unsigned char* valid, unsigned char* all9, unsigned long long* count, pfst_stream_t stream);
+/* top-k target losses; acc[0] += sum loc_pos, acc[1] += sum loc_neg over valid pixels;
+ * gP[n][9][y][x] = d(w_pos*mean loc_pos + w_neg*mean loc_neg)/d cross_prob (0 when count <= 1) */
+int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
+                       int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream);
+/* d logits[n][c][y*ds][x*ds] += softmax-backward( sum_k gP[k] * prob_c(neighbour k) ) */
+int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds,
+                        float* dlogits, int h, int w, pfst_stream_t stream);
+/* out[0] = w_pos*acc[0]/(4*count), out[1] = w_neg*acc[1]/(3*count)  (zeros when count <= 1) */
+int pfst_sim_loss_finalize(const double* acc, const unsigned long long* count, int top_k, float w_pos, float w_neg, float* out, pfst_stream_t stream);
+
+/* ---- EMA teacher + AdamW on flat parameter arenas (pfgst.py:105-127, torch.optim.AdamW) ------ */
+int pfst_ema_update(float* teacher, const float* student, long long n, float alpha, pfst_stream_t stream);
+int pfst_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, pfst_stream_t stream);
+
+/* ---- loss bookkeeping (base.py:177-222) ------------------------------------------------------- */
+/* out[0] = loss_weight*acc[0]/numel ; out[1] = 100*(acc[1]+eps)/(acc[2]+eps) */
+int pfst_ce_finalize(const double* acc, double numel, float loss_weight, float* out, pfst_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+// Shared device helpers for the pfst_hip kernels (gfx950 / CDNA4 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PFST_OK 0
+#define PFST_ERR_ARG (-1)
+#define PFST_ERR_LAUNCH (-2)
+#define PFST_ERR_UNSUPPORTED (-3)
+
+#define PFST_CHECK_ARG(cond)                                   \
+  do {                                                         \
+    if (!(cond)) {                                             \
+      pfst_set_error(__FILE__, __LINE__, #cond);               \
+      return PFST_ERR_ARG;                                     \
+    }                                                          \
+  } while (0)
+
+#define PFST_CHECK_LAUNCH()                                    \
+  do {                                                         \
+    hipError_t e_ = hipGetLastError();                         \
+    if (e_ != hipSuccess) {                                    \
+      pfst_set_error(__FILE__, __LINE__, hipGetErrorString(e_)); \
+      return PFST_ERR_LAUNCH;                                  \
+    }                                                          \
+  } while (0)
+
+void pfst_set_error(const char* file, int line, const char* msg);
+
+typedef long long i64;
+
+static inline int cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
+
+// grid size for a grid-stride elementwise kernel: cap at 256 CUs x 8 blocks
+static inline int ew_grid(i64 n, int block = 256) {
+  i64 g = (n + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of a double; result valid in thread 0.  blockDim.x must be a multiple of 64, <= 1024.
+__device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 doubles */) {
+  v = wave_sum_d(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  return r;
+}
+
+// torch's area_pixel_compute_source_index for bilinear, align_corners=False
+// (ATen/native/UpSample.h): src = max(0, scale*(dst+0.5)-0.5)
+__device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+  l0 = 1.f - l1;
+}

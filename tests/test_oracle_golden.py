@@ -1,0 +1,172 @@
+"""Pin the CPU oracle: (1) known-answer values held by the reference's own tests for this path,
+(2) golden vectors produced by executing the reference's files (tests/golden/make_golden.py)."""
+import os
+import random
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pfst_oracle as O
+from pfst_amd.synthetic import fill_state_dict, synth_batch
+
+G = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert np.allclose(a, b, rtol=rtol, atol=atol), f'max abs err {err}'
+
+
+# ---- known answers from the reference's tests (values, not code) --------------------------------
+def test_ce_known_answers():
+    # tests/test_models/test_losses/test_ce_loss.py:25-39 : CE([[100,-100]], label 1) = 200
+    s = torch.tensor([[100., -100.]])
+    assert float(O.ce_loss(s, torch.tensor([1]), ignore_index=-100)) == pytest.approx(200.0)
+    # :118-153 class_weight [0.8, 0.2] -> 40
+    assert float(O.ce_loss(s, torch.tensor([1]), class_weight=[0.8, 0.2], ignore_index=-100)) == pytest.approx(40.0)
+    # :43-86 with ignore 255 and avg_non_ignore=False: sum over kept / numel
+    g = torch.Generator().manual_seed(0)
+    logits, lab = torch.rand(5, 10, generator=g), torch.randint(0, 10, (5,), generator=g)
+    lab[0], lab[3] = 255, 255
+    exp = torch.nn.functional.cross_entropy(logits, lab, reduction='sum', ignore_index=255) / lab.numel()
+    assert float(O.ce_loss(logits, lab)) == pytest.approx(float(exp), rel=1e-6)
+
+
+def test_accuracy_known_answers():
+    # tests/test_models/test_losses/test_utils.py:44-129
+    pred = torch.tensor([[0.2, 0.3, 0.6, 0.5], [0.1, 0.1, 0.2, 0.6], [0.9, 0.0, 0.0, 0.1],
+                         [0.4, 0.7, 0.1, 0.1], [0.0, 0.0, 0.99, 0.0]])
+    t1 = torch.LongTensor([2, 3, 0, 1, 2])
+    t2 = torch.LongTensor([2, 3, 1, 1, 2])
+    assert float(O.accuracy(pred, t1, ignore_index=None)) == pytest.approx(100.0)
+    assert float(O.accuracy(pred, t2, ignore_index=None)) == pytest.approx(80.0)
+    t3 = torch.LongTensor([2, 3, 0, 255, 2])
+    assert float(O.accuracy(pred, t3, ignore_index=255)) == pytest.approx(100.0)
+    t4 = torch.LongTensor([2, 255, 1, 1, 2])   # ignore one, one wrong of four -> 75
+    assert float(O.accuracy(pred, t4, ignore_index=255)) == pytest.approx(75.0)
+
+
+# ---- golden vectors from the executed reference ---------------------------------------------------
+@pytest.fixture(scope='module')
+def small():
+    return np.load(os.path.join(G, 'small_ops.npz'))
+
+
+def test_ce_and_accuracy_golden(small):
+    lg, lb, w = (torch.from_numpy(small[k]) for k in ('ce_logits', 'ce_label', 'ce_weight'))
+    _close(O.ce_loss(lg, lb, w, loss_weight=0.4), small['ce_loss_w'], 1e-5)
+    _close(O.ce_loss(lg, lb, None, loss_weight=0.4), small['ce_loss_now'], 1e-5)
+    _close(O.ce_loss(lg, lb, w, class_weight=[0.5, 1, 1.5, 2, 0.7, 1.2]), small['ce_loss_cw'], 1e-5)
+    _close(O.accuracy(lg, lb), small['acc'], 1e-6)
+
+
+def test_class_mix_golden(small):
+    gt = torch.from_numpy(small['mix_gt'])
+    np.random.seed(11)
+    masks = O.class_masks(gt)
+    assert np.array_equal(masks.numpy(), small['mix_masks'])
+    mi, ml, mw = O.class_mix(masks, torch.from_numpy(small['mix_img']), torch.from_numpy(small['mix_trg']),
+                             gt, torch.from_numpy(small['mix_pl']), torch.from_numpy(small['mix_pw']))
+    assert np.array_equal(mi.numpy(), small['mixed_img'])
+    assert np.array_equal(ml.numpy(), small['mixed_lbl'])
+    assert np.array_equal(mw.numpy(), small['mixed_w'])
+
+
+def test_pfgst_loss_golden(small):
+    lt = torch.from_numpy(small['pl_logits_trg']).requires_grad_()
+    xs = torch.from_numpy(small['pl_x_src']).requires_grad_()
+    losses, ex = O.pfgst_loss(lt, torch.from_numpy(small['pl_x_ema']), xs, torch.from_numpy(small['pl_gt_src']),
+                              torch.from_numpy(small['pl_mix_masks']), O.DEFAULT_LOSS_W)
+    vals = np.array([float(v.sum()) for v in losses.values()])
+    _close(vals, small['pl_losses'], 1e-5, 1e-7)
+    sum(v.sum() for v in losses.values()).backward()
+    _close(lt.grad, small['pl_grad_logits'], 1e-4, 1e-9)
+    _close(xs.grad, small['pl_grad_xsrc'], 1e-4, 1e-9)
+    _close(ex['density'], small['pl_vis_density'], 1e-5)
+    assert np.array_equal(ex['trg_mask'].numpy(), small['pl_vis_mask'])
+
+
+@pytest.fixture(scope='module')
+def seg():
+    return np.load(os.path.join(G, 'segmentor.npz'))
+
+
+def test_state_dict_layout_matches_reference(seg):
+    sd = O.init_state_dict(6, 3)
+    assert list(sd.keys()) == [str(k) for k in seg['keys']]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in seg['shapes']]
+    assert sum(sd[k].numel() for k in O.param_keys(sd)) == 43579868
+
+
+def test_segmentor_forward_backward_golden(seg):
+    torch.set_num_threads(8)
+    sd = fill_state_dict(O.init_state_dict(6, 3), 5)
+    pk = O.param_keys(sd)
+    for k in pk:
+        sd[k].requires_grad_(True)
+    batch = synth_batch(2, 64, 6, seed=1234)
+    w = torch.from_numpy(seg['pix_weight'])
+    losses, feats, logits, dec, _ = O.segmentor_forward_train(sd, batch['img'], batch['gt_semantic_seg'], w)
+    loss, log = O.parse_losses(losses)
+    _close(logits.detach(), seg['logits'], 1e-4, 1e-5)
+    _close(dec.detach(), seg['decoded'], 1e-4, 1e-5)
+    _close(feats[0].detach()[:, :8], seg['c1'], 1e-4, 1e-5)
+    _close(feats[3].detach()[:, :8], seg['c4'], 1e-4, 1e-5)
+    assert list(log.keys()) == [str(k) for k in seg['log_keys']]
+    _close(np.array(list(log.values())), seg['log_vals'], 1e-5)
+    loss.backward()
+    names = [str(n) for n in seg['grad_names']]
+    assert names == pk
+    gn = np.array([float(sd[k].grad.norm()) for k in pk])
+    _close(gn, seg['grad_norms'], 2e-3, 1e-7)
+    for key in seg.files:
+        if key.startswith('grad|'):
+            g = sd[key[5:]].grad
+            _close(g.numpy().reshape(g.shape[0], -1)[:16, :32], seg[key], 2e-3, 1e-7)
+    with torch.no_grad():
+        _close(sd['backbone.layer2.1.bn2.running_mean'], seg['rm|backbone.layer2.1.bn2'], 1e-4, 1e-6)
+        _close(sd['backbone.layer2.1.bn2.running_var'], seg['rv|backbone.layer2.1.bn2'], 1e-4, 1e-6)
+        ema_logits, _ = O.encode_decode(sd, batch['target_img'])
+    _close(ema_logits, seg['ema_logits'], 1e-4, 1e-5)
+
+
+def test_full_train_step_golden():
+    """Two PFGST.train_step iterations incl. EMA, pseudo-labels, class-mix RNG stream, PFGSTLoss, AdamW."""
+    torch.set_num_threads(8)
+    gold = np.load(os.path.join(G, 'train_step.npz'))
+    student = fill_state_dict(O.init_state_dict(6, 3), 9)
+    keys = [str(k) for k in gold['keys']]
+    assert keys == ['model.' + k for k in student] + ['ema_model.' + k for k in student]
+    # the reference fills model.* and ema_model.* at consecutive positions: rebuild the teacher likewise
+    both = OrderedDict(('model.' + k, v.clone()) for k, v in student.items())
+    both.update(('ema_model.' + k, v.clone()) for k, v in student.items())
+    fill_state_dict(both, 9)
+    student = OrderedDict((k[6:], v) for k, v in both.items() if k.startswith('model.'))
+    teacher = OrderedDict((k[10:], v) for k, v in both.items() if k.startswith('ema_model.'))
+    m = O.OraclePFGST(student, pseudo_threshold=0.30, teacher_sd=teacher)
+    assert int(gold['n_student_params']) == sum(student[k].numel() for k in m.pkeys)
+    random.seed(0)
+    np.random.seed(0)
+    for it in range(2):
+        batch = synth_batch(2, 128, 6, seed=1234 + it)
+        log, ex = m.train_step(batch, return_extras=True)
+        assert list(log.keys()) == [str(k) for k in gold[f'it{it}_log_keys']]
+        _close(np.array(list(log.values())), gold[f'it{it}_log_vals'], 2e-4, 2e-6)
+        assert np.array_equal(ex['trg_mask'].numpy(), gold[f'it{it}_ignore_mask_trg'])
+        # mixed label map (vis|seg_mask_mix[1]): where weight>0 label else 255 -- weights are >0 here
+        ml = torch.where(ex['mixed_w'].unsqueeze(1) > 0, ex['mixed_lbl'], torch.full_like(ex['mixed_lbl'], 255))
+        assert np.array_equal(ml.numpy(), gold[f'it{it}_mixed_lbl'])
+        if it == 0:
+            gn = np.array([float(g.norm()) for g in ex['grads'].values()])
+            _close(gn, gold['it0_grad_norms'], 3e-3, 1e-7)
+            _close(ex['grads']['decode_head.conv_seg.weight'], gold['it0_grad|decode_head.conv_seg.weight'], 2e-3, 1e-8)
+            _close(ex['grads']['backbone.stem.0.weight'], gold['it0_grad|backbone.stem.0.weight'], 3e-3, 1e-7)
+    for k in gold.files:
+        if k.startswith('final|'):
+            name = k[6:]
+            t = m.student[name[6:]] if name.startswith('model.') else m.teacher[name[10:]]
+            _close(t.detach().reshape(-1)[:4096], gold[k], 1e-4, 1e-6)
