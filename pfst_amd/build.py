@@ -1,0 +1,57 @@
+"""Build libpfst_hip.so (hand-written HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+`python -m pfst_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libpfst_hip.so')
+SOURCES = ['conv_mfma.hip', 'dwconv.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'pfgst_loss.hip', 'optim.hip', 'api.cpp']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+
+
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src, os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'pfst_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, src):
+            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f'--- {s} failed\n{out.decode()}\n')
+        elif verbose and out.strip():
+            print(out.decode())
+    if failed:
+        raise RuntimeError('hipcc failed')
+    if force or procs or not os.path.exists(LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,217 @@
+// BatchNorm2d in TRAINING mode (+ ReLU, + residual add) and its backward: HBM-bound passes.
+// Reference: nn.BatchNorm2d(eps=1e-5, momentum=0.1) inside mmcv ConvModule and
+// rsiseg/models/backbones/resnet.py:273-305 (Bottleneck: bn -> relu, bn3 + identity -> relu).
+// The teacher also runs BN in train mode (pfgst.py:247-251 only switches dropout off).
+//
+// Statistics are accumulated in fp64 (per-thread fp32 loads, fp64 sums), one atomic pair per block.
+#include "common.h"
+#include "../../include/pfst_hip.h"
+
+namespace {
+
+constexpr int BN_SPLIT_TARGET = 2048;  // aim for this many blocks in the reduction passes
+
+// grid: (splits, C, N); each block reduces a contiguous chunk of one (image, channel) plane
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, i64 x_bs, int HW, int chunk,
+                                                       double* __restrict__ ws) {
+  __shared__ double sm[16];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* xp = x + (i64)n * x_bs + (i64)c * HW;
+  const int beg = blockIdx.x * chunk;
+  const int end = min(beg + chunk, HW);
+  double s = 0.0, ss = 0.0;
+  if ((chunk & 3) == 0 && (HW & 3) == 0 && ((uintptr_t)xp & 15) == 0) {
+    for (int i = (beg >> 2) + threadIdx.x; i < (end >> 2); i += blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(xp)[i];
+      s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
+      const float v = xp[i];
+      s += (double)v;
+      ss += (double)v * (double)v;
+    }
+  }
+  s = block_sum_d(s, sm);
+  ss = block_sum_d(ss, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s);
+    atomicAdd(&ws[2 * c + 1], ss);
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double count, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = ws[2 * c] / count;
+  double var = ws[2 * c + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+// grid: (blocks over HW, C, N)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ res,
+                                                       i64 res_bs, float* __restrict__ y, i64 y_bs,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int C, int HW, int relu) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float sc = invstd[c] * gamma[c];
+  const float sh = beta[c] - mean[c] * sc;
+  const float* xp = x + (i64)n * x_bs + (i64)c * HW;
+  const float* rp = res ? res + (i64)n * res_bs + (i64)c * HW : nullptr;
+  float* yp = y + (i64)n * y_bs + (i64)c * HW;
+  const int stride = gridDim.x * blockDim.x;
+  if ((HW & 3) == 0 && (((uintptr_t)xp | (uintptr_t)yp | (uintptr_t)rp) & 15) == 0) {
+    const int n4 = HW >> 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(xp)[i];
+      v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+      if (rp) {
+        const float4 r = reinterpret_cast<const float4*>(rp)[i];
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      reinterpret_cast<float4*>(yp)[i] = v;
+    }
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
+      float v = fmaf(xp[i], sc, sh);
+      if (rp) v += rp[i];
+      if (relu) v = fmaxf(v, 0.f);
+      yp[i] = v;
+    }
+  }
+}
+
+// backward pass 1: ws[2c] += sum dz, ws[2c+1] += sum dz*xhat     grid: (splits, C, N)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
+                                                            i64 y_bs, const float* __restrict__ x, i64 x_bs,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int HW, int chunk, int relu, double* __restrict__ ws) {
+  __shared__ double sm[16];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mu = mean[c], is = invstd[c];
+  const i64 base = (i64)c * HW;
+  const float* gp = dy + (i64)n * dy_bs + base;
+  const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
+  const float* xp = x + (i64)n * x_bs + base;
+  const int beg = blockIdx.x * chunk;
+  const int end = min(beg + chunk, HW);
+  double s = 0.0, sx = 0.0;
+  for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    float dz = gp[i];
+    if (relu && !(yp[i] > 0.f)) dz = 0.f;
+    const float xh = (xp[i] - mu) * is;
+    s += (double)dz;
+    sx += (double)dz * (double)xh;
+  }
+  s = block_sum_d(s, sm);
+  sx = block_sum_d(sx, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&ws[2 * c], s);
+    atomicAdd(&ws[2 * c + 1], sx);
+  }
+}
+
+// backward pass 2     grid: (blocks over HW, C, N)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
+                                                           i64 y_bs, const float* __restrict__ x, i64 x_bs,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, float* __restrict__ dx, i64 dx_bs,
+                                                           float* __restrict__ dres, i64 dres_bs, int dres_acc,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int C, int HW, double inv_count, int relu, const double* __restrict__ ws) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float mu = mean[c], is = invstd[c];
+  const float m1 = (float)(ws[2 * c] * inv_count), m2 = (float)(ws[2 * c + 1] * inv_count);
+  const float gs = gamma[c] * is;
+  if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+    if (dgamma) dgamma[c] += (float)ws[2 * c + 1];
+    if (dbeta) dbeta[c] += (float)ws[2 * c];
+  }
+  const i64 base = (i64)c * HW;
+  const float* gp = dy + (i64)n * dy_bs + base;
+  const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
+  const float* xp = x + (i64)n * x_bs + base;
+  float* dxp = dx + (i64)n * dx_bs + base;
+  float* drp = dres ? dres + (i64)n * dres_bs + base : nullptr;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
+    float dz = gp[i];
+    if (relu && !(yp[i] > 0.f)) dz = 0.f;
+    const float xh = (xp[i] - mu) * is;
+    dxp[i] = gs * (dz - m1 - xh * m2);
+    if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
+  }
+}
+
+// split one HW plane into `splits` chunks (multiples of 4) so the reduction launches ~BN_SPLIT_TARGET blocks
+inline void split_for(int HW, int C, int N, int& splits, int& chunk) {
+  i64 planes = (i64)C * N;
+  splits = (int)(BN_SPLIT_TARGET / (planes > 0 ? planes : 1));
+  const int max_splits = (HW + 1023) / 1024;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  chunk = (HW + splits - 1) / splits;
+  chunk = (chunk + 3) & ~3;
+  splits = (HW + chunk - 1) / chunk;
+}
+
+}  // namespace
+
+extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
+                             float* running_mean, float* running_var, float momentum, float eps, double* ws, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && mean && invstd && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+  int splits, chunk;
+  split_for(HW, C, N, splits, chunk);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C, N), dim3(256), 0, s, x, x_bs, HW, chunk, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, C, (double)N * HW, mean, invstd, running_mean,
+                     running_var, momentum, eps);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                             int N, int C, int HW, int relu, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && mean && invstd && gamma && beta && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  int gx = cdiv(HW, 256 * 4 * 4);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, residual, res_bs, y, y_bs, mean,
+                     invstd, gamma, beta, C, HW, relu);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
+                                const float* mean, const float* invstd, const float* gamma,
+                                float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
+                                float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!relu || y);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+  int splits, chunk;
+  split_for(HW, C, N, splits, chunk);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, HW,
+                     chunk, relu, ws);
+  int gx = cdiv(HW, 256 * 4);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, dx,
+                     dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, 1.0 / ((double)N * HW), relu, ws);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

@@ -1,0 +1,399 @@
+// Dense convolution (groups = 1) as implicit GEMM on the CDNA4 fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate -- keeps the reference's
+// fp32 numerics; gfx950 has no xf32/TF32 path).
+//
+// Reference ops replaced: every F.conv2d with groups=1 on the PFST hot path
+// (rsiseg/models/backbones/resnet.py:169-209,593-624, decode_heads/aspp_head.py:32-42,85-92,
+// fcn_head.py:40-49, decode_head.py:242-247) and their autograd data / weight gradients.
+//
+// Layout (NCHW fp32, per image):   OUT[m][p] = sum_k WK[k][m] * IN[c(k)][src(p, tap(k))]
+//   GEMM M = output channels, N = output pixels (contiguous in memory -> coalesced), K = (tap, c).
+//   WK is the weight re-packed K-major ([tap*C + c][M]) so both LDS tiles are filled by
+//   row-contiguous, coalesced global reads and read back conflict-free (lane = column).
+//   One 256-thread block (4 waves) computes a BM x 128 tile; each wave owns a 64x64 (or 32x32)
+//   sub-tile as 32x32 MFMA accumulators; K advances 16 per step through a double-buffered LDS
+//   tile with register-staged prefetch (one barrier per step).
+#include "common.h"
+#include "../../include/pfst_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BN = 128;  // pixels per block tile
+constexpr int BK = 16;   // K per step
+
+__device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, int div, int lim, int& s) {
+  int v = o * a + t * b + c0;
+  if (div == 2) {
+    if (v & 1) return false;
+    v >>= 1;
+  }
+  s = v;
+  return v >= 0 && v < lim;
+}
+
+template <int BM, bool GENERIC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(
+    const float* __restrict__ in, i64 in_bs, const float* __restrict__ wk, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate) {
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_RPP = 256 / BM;   // A rows loaded per pass
+  constexpr int A_N = BK / A_RPP;   // A loads per thread per step
+  constexpr int B_N = BK / 2;       // B loads per thread per step
+
+  __shared__ float As[2][BK][BM];
+  __shared__ float Bs[2][BK][BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi;
+  const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM, n = blockIdx.z;
+  const int K = C * ks * ks;
+  const int KT = (K + BK - 1) / BK;
+  in += (i64)n * in_bs;
+  out += (i64)n * out_bs;
+
+  const int bj = tid & (BN - 1), br0 = tid >> 7;
+  const int p = p0 + bj;
+  const bool pvalid = p < P;
+  const int oy = pvalid ? p / Wo : 0;
+  const int ox = pvalid ? p - oy * Wo : 0;
+  const int am = tid % BM, ar0 = tid / BM;
+  const bool amvalid = (m0 + am) < M;
+
+  float areg[A_N], breg[B_N];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int k = k0 + ar0 + i * A_RPP;
+      areg[i] = (amvalid && k < K) ? wk[(i64)k * M + m0 + am] : 0.f;
+    }
+    if (!GENERIC) {
+      // C % 16 == 0: the whole K-slice shares one tap (wave-uniform address arithmetic)
+      const int tap = k0 / C, ci0 = k0 - tap * C;
+      const int ty = tap / ks, tx = tap - ty * ks;
+      int sy, sx;
+      const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+      const float* src = in + (i64)(ci0 + br0) * HiWi + (ok ? sy * Wi + sx : 0);
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) breg[i] = ok ? src[(i64)(2 * i) * HiWi] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) {
+        const int k = k0 + br0 + 2 * i;
+        float v = 0.f;
+        if (pvalid && k < K) {
+          const int tap = k / C, ci = k - tap * C;
+          const int ty = tap / ks, tx = tap - ty * ks;
+          int sy, sx;
+          if (src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) && src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx))
+            v = in[(i64)ci * HiWi + sy * Wi + sx];
+        }
+        breg[i] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + 2 * i][bj] = breg[i];
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tile(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = kk * 2 + lh;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[cur][krow][wm0 + i * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][krow][wn0 + j * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int pp = p0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && pp < P) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[m];
+          const i64 idx = (i64)m * P + pp;
+          if (accumulate) v += out[idx];
+          out[idx] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dW[m][j] += sum_{n,p} dY[n][m][p] * X[n][ci(j)][src(p, tap(j))],  j = ci*T + tap
+// GEMM M = Cout, N = Cin*T, K = pixels (split over images and pixel chunks; fp32 atomics combine).
+// Both operands are K(pixel)-contiguous in memory: LDS tiles are [row][k] with a +1 pad.
+// ---------------------------------------------------------------------------------------------
+constexpr int WBJ = 128, WBK = 32, WLD = WBK + 1;
+
+template <int BM, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len) {
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = WBJ / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_N = BM / 8, B_N = WBJ / 8;
+  constexpr int KS = T == 9 ? 3 : 1;
+
+  extern __shared__ float smem[];
+  float(*As)[BM][WLD] = reinterpret_cast<float(*)[BM][WLD]>(smem);
+  float(*Bs)[WBJ][WLD] = reinterpret_cast<float(*)[WBJ][WLD]>(smem + 2 * BM * WLD);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
+  const int j0 = blockIdx.x * WBJ, m0 = blockIdx.y * BM;
+  const int n = blockIdx.z / chunks, chunk = blockIdx.z - n * chunks;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)n * x_bs;
+  dy += (i64)n * dy_bs;
+
+  const int kcol = tid & 31, r0 = tid >> 5;
+  float areg[A_N], breg[B_N];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tile = [&](int pk) {
+    const int p = pk + kcol;
+    const bool pv = p < pend;
+    const int oy = pv ? p / Wo : 0, ox = pv ? p - oy * Wo : 0;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int m = m0 + r0 + 8 * i;
+      areg[i] = (pv && m < M) ? dy[(i64)m * P + p] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+      const int j = j0 + r0 + 8 * i;
+      float v = 0.f;
+      if (pv && j < J) {
+        const int ci = j / T, tap = j - ci * T;
+        const int ty = tap / KS, tx = tap - ty * KS;
+        const int sy = oy * stride + ty * dil - pad, sx = ox * stride + tx * dil - pad;
+        if (sy >= 0 && sy < Hi && sx >= 0 && sx < Wi) v = x[(i64)ci * HiWi + sy * Wi + sx];
+      }
+      breg[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = breg[i];
+  };
+
+  const int KT = (pend - pbeg + WBK - 1) / WBK;
+  load_tile(pbeg);
+  store_tile(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tile(pbeg + (kt + 1) * WBK);
+#pragma unroll
+    for (int kk = 0; kk < WBK / 2; ++kk) {
+      const int kc = kk * 2 + lh;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[cur][wm0 + i * 32 + l31][kc];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][wn0 + j * 32 + l31][kc];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
+                                   int Cout, int Cin, int T) {
+  const i64 total = (i64)Cout * Cin * T;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    if (wf) {  // i = (t*Cin + ci)*Cout + co
+      const int co = (int)(i % Cout);
+      const i64 r = i / Cout;
+      const int ci = (int)(r % Cin), t = (int)(r / Cin);
+      wf[i] = w[((i64)co * Cin + ci) * T + t];
+    }
+    if (wd) {  // i = (t*Cout + co)*Cin + ci
+      const int ci = (int)(i % Cin);
+      const i64 r = i / Cin;
+      const int co = (int)(r % Cout), t = (int)(r / Cout);
+      wd[i] = w[((i64)co * Cin + ci) * T + t];
+    }
+  }
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ db, int N, int C, int HW) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = dy + (i64)n * dy_bs + (i64)c * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += (double)p[i];
+  }
+  s = block_sum_d(s, sm);
+  if (threadIdx.x == 0) db[c] += (float)s;
+}
+
+template <int BM, bool G>
+int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
+                 int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
+  dim3 grid(cdiv((i64)Ho * Wo, BN), cdiv(M, BM), N);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, G>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                     Ho, Wo, ks, a, b, c, d, acc);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+template <int BM, int T>
+int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+                 int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+  const int P = Ho * Wo, J = Cin * T;
+  const int tiles = cdiv(J, WBJ) * cdiv(M, BM);
+  // split the pixel (K) range so that the launch has >= ~1024 blocks, chunks of >= 512 pixels
+  int chunks = 1;
+  while ((i64)tiles * N * chunks < 1024 && P / (chunks * 2) >= 512) chunks *= 2;
+  int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
+  chunks = cdiv(P, chunk_len);
+  dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
+  const size_t lds = (size_t)2 * (BM + WBJ) * WLD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BM, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, T>), grid, dim3(256), lds, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
+                     stride, dil, pad, chunks, chunk_len);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+}  // namespace
+
+extern "C" int pfst_conv_pack_weight(const float* w, float* wk_fprop, float* wk_dgrad, int Cout, int Cin, int T, pfst_stream_t stream) {
+  PFST_CHECK_ARG(w && (wk_fprop || wk_dgrad) && Cout > 0 && Cin > 0 && (T == 1 || T == 9));
+  const i64 n = (i64)Cout * Cin * T;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, w, wk_fprop, wk_dgrad, Cout, Cin, T);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
+                               int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
+                               int mode, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(in && wk && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
+  PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
+  const int span = (ksize - 1) * dil;
+  if (mode == 0) {
+    PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
+  } else {  // dgrad: `in` is dy (Hi x Wi = forward output), `out` is dx (Ho x Wo = forward input)
+    PFST_CHECK_ARG(Hi == (Ho + 2 * pad - span - 1) / stride + 1 && Wi == (Wo + 2 * pad - span - 1) / stride + 1);
+  }
+  int a, b, c, d;
+  if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
+  hipStream_t s = (hipStream_t)stream;
+  const bool generic = (C % BK) != 0;
+#define PFST_IGEMM(BM_)                                                                                             \
+  return generic ? launch_igemm<BM_, true>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s) \
+                 : launch_igemm<BM_, false>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s)
+  if (M > 64) { PFST_IGEMM(128); }
+  if (M > 32) { PFST_IGEMM(64); }
+  PFST_IGEMM(32);
+#undef PFST_IGEMM
+}
+
+extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
+                               int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
+                               pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && dy && dw && N > 0 && Cin > 0 && Cout > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0);
+  const int span = (ksize - 1) * dil;
+  PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
+  PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo);
+  hipStream_t s = (hipStream_t)stream;
+#define PFST_WGRAD(BM_)                                                                                          \
+  return ksize == 3 ? launch_wgrad<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s) \
+                    : launch_wgrad<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s)
+  if (Cout > 64) { PFST_WGRAD(128); }
+  if (Cout > 32) { PFST_WGRAD(64); }
+  PFST_WGRAD(32);
+#undef PFST_WGRAD
+}
+
+extern "C" int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && db && N > 0 && C > 0 && HW > 0);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, db, N, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

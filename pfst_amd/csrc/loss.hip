@@ -1,0 +1,270 @@
+// Fused bilinear-upsample + softmax cross-entropy + accuracy, pseudo-labelling and class-mix.
+// The full-resolution logits (b x C x S x S; 201 MB per head per pass at b=8, S=1024, C=6) are never
+// materialised: every full-resolution pixel interpolates its C logits from the low-resolution map
+// (which stays L2 resident) in registers.
+// Reference: rsiseg/models/decode_heads/decode_head.py:249-283 (resize + CE + accuracy),
+// losses/cross_entropy_loss.py:45-65, losses/utils.py:60-69, losses/accuracy.py:6-61,
+// uda/pfgst.py:259-300 (pseudo labels, class mix), utils/dacs_transforms.py:110-144.
+#include "common.h"
+#include "../../include/pfst_hip.h"
+
+namespace {
+
+struct Bilin {
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+};
+__device__ __forceinline__ Bilin make_bilin(int oy, int ox, float sh, float sw, int h, int w) {
+  Bilin b;
+  bilin_src(oy, sh, h, b.y0, b.y1, b.ly0, b.ly1);
+  bilin_src(ox, sw, w, b.x0, b.x1, b.lx0, b.lx1);
+  return b;
+}
+__device__ __forceinline__ float interp(const float* __restrict__ p, int w, const Bilin& b) {
+  return b.ly0 * (b.lx0 * p[b.y0 * w + b.x0] + b.lx1 * p[b.y0 * w + b.x1]) +
+         b.ly1 * (b.lx0 * p[b.y1 * w + b.x0] + b.lx1 * p[b.y1 * w + b.x1]);
+}
+
+// grid: (blocks over H*W, N).  One thread per full-resolution pixel.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int C, int h, int w,
+                                                     const unsigned char* __restrict__ label, const float* __restrict__ pw,
+                                                     const float* __restrict__ cw, int H, int W, int ignore, float sh, float sw,
+                                                     float* __restrict__ lse, double* __restrict__ acc) {
+  __shared__ double sm[16];
+  const int n = blockIdx.y;
+  const float* lp = logits + (i64)n * C * h * w;
+  const int hw = h * w;
+  double loss = 0.0, correct = 0.0, valid = 0.0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < H * W; p += gridDim.x * blockDim.x) {
+    const int oy = p / W, ox = p - oy * W;
+    const Bilin b = make_bilin(oy, ox, sh, sw, h, w);
+    const int lab = label[(i64)n * H * W + p];
+    float mx = -INFINITY, zl = 0.f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float z = interp(lp + (i64)c * hw, w, b);
+      if (z > mx) { mx = z; arg = c; }
+      if (c == lab) zl = z;
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __expf(interp(lp + (i64)c * hw, w, b) - mx);
+    const float l = mx + __logf(se);
+    lse[(i64)n * H * W + p] = l;
+    if (lab != ignore && lab < C) {
+      float wgt = pw ? pw[(i64)n * H * W + p] : 1.f;
+      if (cw) wgt *= cw[lab];
+      loss += (double)(wgt * (l - zl));
+      valid += 1.0;
+      if (arg == lab) correct += 1.0;
+    }
+  }
+  loss = block_sum_d(loss, sm);
+  correct = block_sum_d(correct, sm);
+  valid = block_sum_d(valid, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], loss);
+    atomicAdd(&acc[1], correct);
+    atomicAdd(&acc[2], valid);
+  }
+}
+
+// grid: (blocks over h*w, C, N).  One thread per low-resolution logit; gathers its full-res footprint.
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int C, int h, int w,
+                                                     const unsigned char* __restrict__ label, const float* __restrict__ pw,
+                                                     const float* __restrict__ cw, int H, int W, int ignore, float sh, float sw,
+                                                     const float* __restrict__ lse, float scale, float* __restrict__ dlogits,
+                                                     int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* lp = logits + ((i64)n * C + c) * h * w;
+  const unsigned char* lab = label + (i64)n * H * W;
+  const float* ls = lse + (i64)n * H * W;
+  const float* pwp = pw ? pw + (i64)n * H * W : nullptr;
+  float* dp = dlogits + ((i64)n * C + c) * h * w;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < h * w; i += gridDim.x * blockDim.x) {
+    const int iy = i / w, ix = i - iy * w;
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, H - 1);
+    ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, W - 1);
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly0, ly1;
+      bilin_src(oy, sh, h, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        Bilin b;
+        b.y0 = y0; b.y1 = y1; b.ly0 = ly0; b.ly1 = ly1;
+        bilin_src(ox, sw, w, b.x0, b.x1, b.lx0, b.lx1);
+        const float wx = (b.x0 == ix ? b.lx0 : 0.f) + (b.x1 == ix ? b.lx1 : 0.f);
+        if (wx == 0.f) continue;
+        const int p = oy * W + ox;
+        const int l = lab[p];
+        if (l == ignore || l >= C) continue;
+        float g = pwp ? pwp[p] : 1.f;
+        if (cw) g *= cw[l];
+        const float prob = __expf(interp(lp, w, b) - ls[p]);
+        acc = fmaf(wy * wx * g, prob - (l == c ? 1.f : 0.f), acc);
+      }
+    }
+    acc *= scale;
+    dp[i] = accumulate ? dp[i] + acc : acc;
+  }
+}
+
+// grid: (blocks over H*W, N)
+__global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, int C, int h, int w, int H, int W,
+                                                           float sh, float sw, float thr, long long* __restrict__ l64,
+                                                           unsigned char* __restrict__ l8, unsigned long long* __restrict__ count) {
+  __shared__ double sm[16];
+  const int n = blockIdx.y;
+  const float* lp = logits + (i64)n * C * h * w;
+  const int hw = h * w;
+  double cnt = 0.0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < H * W; p += gridDim.x * blockDim.x) {
+    const int oy = p / W, ox = p - oy * W;
+    const Bilin b = make_bilin(oy, ox, sh, sw, h, w);
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float z = interp(lp + (i64)c * hw, w, b);
+      if (z > mx) { mx = z; arg = c; }   // strict '>' keeps the FIRST maximum like torch.max
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
+    const float pmax = 1.f / se;         // softmax value of the arg-max class
+    if (pmax >= thr) cnt += 1.0;
+    if (l64) l64[(i64)n * H * W + p] = arg;
+    if (l8) l8[(i64)n * H * W + p] = (unsigned char)arg;
+  }
+  cnt = block_sum_d(cnt, sm);
+  if (threadIdx.x == 0 && cnt > 0.0) atomicAdd(count, (unsigned long long)cnt);
+}
+
+__global__ void label_presence_kernel(const unsigned char* __restrict__ label, i64 n, int* __restrict__ presence) {
+  __shared__ int flags[256];
+  flags[threadIdx.x] = 0;
+  __syncthreads();
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) flags[label[i]] = 1;
+  __syncthreads();
+  if (flags[threadIdx.x]) presence[threadIdx.x] = 1;
+}
+
+// grid: (blocks over HW, N)
+__global__ void class_mask_kernel(const unsigned char* __restrict__ gt, const int* __restrict__ classes, int K,
+                                  unsigned char* __restrict__ mask, i64 HW) {
+  __shared__ unsigned char lut[256];
+  const int n = blockIdx.y;
+  lut[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int c = classes[n * K + threadIdx.x];
+    if (c >= 0 && c < 256) lut[c] = 1;
+  }
+  __syncthreads();
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x)
+    mask[(i64)n * HW + i] = lut[gt[(i64)n * HW + i]];
+}
+
+// grid: (blocks over HW, N)
+__global__ void class_mix_kernel(const float* __restrict__ img, const float* __restrict__ trg, const unsigned char* __restrict__ gt,
+                                 const unsigned char* __restrict__ pseudo, const unsigned char* __restrict__ mask,
+                                 const unsigned long long* __restrict__ conf, float* __restrict__ mimg,
+                                 unsigned char* __restrict__ mlbl, long long* __restrict__ mlbl64, float* __restrict__ mw,
+                                 int Cimg, i64 HW, double numel) {
+  const int n = blockIdx.y;
+  // q exactly as the reference: python float (double) count/size, stored into a float32 tensor
+  const float q = (float)((double)conf[0] / numel);
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x) {
+    const i64 p = (i64)n * HW + i;
+    const int m = mask[p];
+    const float fm = (float)m, fi = (float)(1 - m);
+    for (int c = 0; c < Cimg; ++c) {
+      const i64 o = ((i64)n * Cimg + c) * HW + i;
+      mimg[o] = fm * img[o] + fi * trg[o];
+    }
+    const int l = m ? gt[p] : pseudo[p];
+    mlbl[p] = (unsigned char)l;
+    if (mlbl64) mlbl64[p] = l;
+    mw[p] = fm * 1.0f + fi * q;
+  }
+}
+
+__global__ void ce_finalize_kernel(const double* __restrict__ acc, double numel, float loss_weight, float* __restrict__ out) {
+  const double eps = 1.1920928955078125e-07;  // torch.finfo(float32).eps
+  out[0] = (float)((double)loss_weight * (acc[0] / numel));
+  out[1] = (float)((acc[1] + eps) * (100.0 / (acc[2] + eps)));
+}
+
+inline int px_blocks(i64 n) {
+  i64 g = (n + 1023) / 1024;
+  if (g > 4096) g = 4096;
+  return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+
+extern "C" int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
+                                    const float* class_weight, int H, int W, int ignore_index, float* lse, double* acc, pfst_stream_t stream) {
+  PFST_CHECK_ARG(logits && label && lse && acc && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+                     pix_weight, class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, acc);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
+                                    const float* class_weight, int H, int W, int ignore_index, const float* lse, float scale,
+                                    float* dlogits, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(logits && label && lse && dlogits && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
+  int gx = cdiv((i64)h * w, 256);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
+                     class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
+                                 long long* label_i64, unsigned char* label_u8, unsigned long long* count, pfst_stream_t stream) {
+  PFST_CHECK_ARG(logits && (label_i64 || label_u8) && count && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(count, 0, sizeof(unsigned long long), s) != hipSuccess) return PFST_ERR_LAUNCH;
+  hipLaunchKernelGGL(pseudo_label_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, logits, C, h, w, H, W,
+                     (float)h / (float)H, (float)w / (float)W, threshold, label_i64, label_u8, count);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_label_presence(const unsigned char* label, long long n, int* presence256, pfst_stream_t stream) {
+  PFST_CHECK_ARG(label && presence256 && n > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(presence256, 0, sizeof(int) * 256, s) != hipSuccess) return PFST_ERR_LAUNCH;
+  hipLaunchKernelGGL(label_presence_kernel, dim3(px_blocks(n)), dim3(256), 0, s, label, (i64)n, presence256);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_class_mask(const unsigned char* gt, const int* classes, int K, unsigned char* mask, int N, long long HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(gt && classes && mask && K > 0 && K <= 256 && N > 0 && N <= 65535 && HW > 0);
+  hipLaunchKernelGGL(class_mask_kernel, dim3(px_blocks(HW), N), dim3(256), 0, (hipStream_t)stream, gt, classes, K, mask, (i64)HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_class_mix(const float* img, const float* trg_img, const unsigned char* gt, const unsigned char* pseudo,
+                              const unsigned char* mask, const unsigned long long* conf_count, float* mixed_img,
+                              unsigned char* mixed_lbl, long long* mixed_lbl_i64, float* mixed_w, int N, int Cimg, long long HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(img && trg_img && gt && pseudo && mask && conf_count && mixed_img && mixed_lbl && mixed_w);
+  PFST_CHECK_ARG(N > 0 && N <= 65535 && Cimg > 0 && HW > 0);
+  hipLaunchKernelGGL(class_mix_kernel, dim3(px_blocks(HW), N), dim3(256), 0, (hipStream_t)stream, img, trg_img, gt, pseudo, mask,
+                     conf_count, mixed_img, mixed_lbl, mixed_lbl_i64, mixed_w, Cimg, (i64)HW, (double)N * (double)HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_ce_finalize(const double* acc, double numel, float loss_weight, float* out, pfst_stream_t stream) {
+  PFST_CHECK_ARG(acc && out && numel > 0);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, numel, loss_weight, out);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

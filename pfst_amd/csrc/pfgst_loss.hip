@@ -1,0 +1,436 @@
+// PFGSTLoss: local pseudo-feature similarity losses, fused so that the reference's unfold tensors
+// (b x 512 x 9 x H x W, 302 MB per image per call at S=1024) never exist.
+// Reference: rsiseg/models/losses/pfgst_loss.py:44-234 with the shipped options
+// (kernel 3, dilation d, sim_type 'cosine', cross_prob_type 'trg', detach_unfold=True,
+//  src_loss_type 'mean_std', top_k, downscale 0.5).
+// Neighbour index k = ty*3+tx, offset ((ty-1)*d, (tx-1)*d) -- the order nn.Unfold produces.
+#include "common.h"
+#include "../../include/pfst_hip.h"
+
+namespace {
+
+constexpr float COS_EPS = 1e-8f;
+
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+  // ATen nearest_neighbor_compute_source_index: min(floor(dst*scale), in-1)
+  int s = (int)floorf((float)dst * scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+// ---- cosine similarity to the 9 dilated neighbours.  One thread per pixel, loop over channels;
+// loads are coalesced along x and the 9 taps of a channel hit L1/L2 (feature map read once from HBM).
+// grid: (blocks over H*W, N)
+__global__ __launch_bounds__(256) void sim_map_kernel(const float* __restrict__ feat, int C, int H, int W, int dil,
+                                                      float* __restrict__ sim, float* __restrict__ norm) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const float* fp = feat + (i64)n * C * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
+      ok[k] = sy >= 0 && sy < H && sx >= 0 && sx < W;
+      off[k] = ok[k] ? sy * W + sx : p;
+    }
+    float dot[9], nn[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dot[k] = 0.f; nn[k] = 0.f; }
+    for (int c = 0; c < C; ++c) {
+      const float* ch = fp + (i64)c * HW;
+      const float a = ch[p];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float b = ok[k] ? ch[off[k]] : 0.f;
+        dot[k] = fmaf(a, b, dot[k]);
+        nn[k] = fmaf(b, b, nn[k]);
+      }
+    }
+    const float na = fmaxf(sqrtf(nn[4]), COS_EPS);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float nb = fmaxf(sqrtf(nn[k]), COS_EPS);
+      sim[((i64)n * 9 + k) * HW + p] = dot[k] / (na * nb);
+    }
+    norm[(i64)n * HW + p] = sqrtf(nn[4]);
+  }
+}
+
+// ---- adjoint: dF(r) = sum_k A_k(r) F(r+D_k) + B(r) F(r)   (PFGSTLoss backward)
+//   A_k = (G[k,r] + G[8-k, r+D_k]) / (n(r) n(r+D_k)),  B = -(sum_k G[k,r] s_k(r) + G[8-k,r+D_k] s_{8-k}(r+D_k)) / n(r)^2
+__global__ __launch_bounds__(256) void sim_map_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ sim,
+                                                          const float* __restrict__ norm, const float* __restrict__ gsim, int C,
+                                                          int H, int W, int dil, float* __restrict__ dfeat, int accumulate) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const float* fp = feat + (i64)n * C * HW;
+  float* dp = dfeat + (i64)n * C * HW;
+  const float* sp = sim + (i64)n * 9 * HW;
+  const float* gp = gsim + (i64)n * 9 * HW;
+  const float* np_ = norm + (i64)n * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const float nr = fmaxf(np_[p], COS_EPS);
+    float A[9];
+    int off[9];
+    float B = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
+      const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W && k != 4;
+      off[k] = ok ? sy * W + sx : p;
+      if (ok) {
+        const int q = off[k];
+        const float g1 = gp[(i64)k * HW + p], g2 = gp[(i64)(8 - k) * HW + q];
+        const float nq = fmaxf(np_[q], COS_EPS);
+        A[k] = (g1 + g2) / (nr * nq);
+        B -= g1 * sp[(i64)k * HW + p] + g2 * sp[(i64)(8 - k) * HW + q];
+      } else {
+        A[k] = 0.f;
+      }
+    }
+    B /= nr * nr;
+    for (int c = 0; c < C; ++c) {
+      const float* ch = fp + (i64)c * HW;
+      float v = B * ch[p];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v = fmaf(A[k], ch[off[k]], v);
+      const i64 o = (i64)c * HW + p;
+      dp[o] = accumulate ? dp[o] + v : v;
+    }
+  }
+}
+
+// ---- source statistics.  grid: (blocks over H*W, N)
+__device__ __forceinline__ int src_pair_class(const unsigned char* __restrict__ gt, int Hg, int Wg, float sgy, float sgx, int H, int W,
+                                               int y, int x, int k, int dil, int ctr) {
+  // returns 0 = skip, 1 = positive pair, 2 = negative pair
+  const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
+  int nb = 0;  // nn.Unfold zero padding: label 0 outside
+  if (sy >= 0 && sy < H && sx >= 0 && sx < W) nb = gt[(i64)nearest_src(sy, sgy, Hg) * Wg + nearest_src(sx, sgx, Wg)];
+  return nb == ctr ? 1 : 2;
+}
+
+__global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
+                                                        int Hg, int Wg, int dil, double* __restrict__ stats) {
+  __shared__ double sm[16];
+  const int n = blockIdx.y, HW = H * W;
+  const unsigned char* g = gt + (i64)n * Hg * Wg;
+  const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const int ctr = g[(i64)nearest_src(y, sgy, Hg) * Wg + nearest_src(x, sgx, Wg)];
+    if (ctr == 255) continue;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
+      const double s = (double)sim[((i64)n * 9 + k) * HW + p];
+      const int o = cls == 1 ? 0 : 3;
+      a[o] += 1.0; a[o + 1] += s; a[o + 2] += s * s;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const double r = block_sum_d(a[i], sm);
+    if (threadIdx.x == 0 && r != 0.0) atomicAdd(&stats[i], r);
+  }
+}
+
+struct SrcMoments { double n, mean, std; };
+__device__ __forceinline__ SrcMoments moments(const double* st) {
+  SrcMoments m;
+  m.n = st[0];
+  m.mean = st[0] > 0 ? st[1] / st[0] : 0.0;
+  const double var = st[0] > 1 ? (st[2] - st[1] * st[1] / st[0]) / (st[0] - 1.0) : 0.0;
+  m.std = var > 0 ? sqrt(var) : 0.0;
+  return m;
+}
+
+__global__ __launch_bounds__(256) void src_grad_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
+                                                       int Hg, int Wg, int dil, const double* __restrict__ stats, float w_pos,
+                                                       float w_neg, float w_pos_std, float w_neg_std, float* __restrict__ gsim,
+                                                       float* __restrict__ losses) {
+  const int n = blockIdx.y, HW = H * W;
+  const unsigned char* g = gt + (i64)n * Hg * Wg;
+  const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
+  const SrcMoments mp = moments(stats), mn = moments(stats + 3);
+  if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+    losses[0] = (float)(-mp.mean * w_pos);
+    losses[1] = (float)(mn.mean * w_neg);
+    losses[2] = (float)(mp.std * w_pos_std);
+    losses[3] = (float)(mn.std * w_neg_std);
+  }
+  // d(-w mean)/ds = -w/n ; d(w std)/ds = w (s-mean)/((n-1) std)
+  const double pa = mp.n > 0 ? -(double)w_pos / mp.n : 0.0;
+  const double pb = (mp.n > 1 && mp.std > 0) ? (double)w_pos_std / ((mp.n - 1.0) * mp.std) : 0.0;
+  const double na = mn.n > 0 ? (double)w_neg / mn.n : 0.0;
+  const double nb = (mn.n > 1 && mn.std > 0) ? (double)w_neg_std / ((mn.n - 1.0) * mn.std) : 0.0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const int ctr = g[(i64)nearest_src(y, sgy, Hg) * Wg + nearest_src(x, sgx, Wg)];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const i64 o = ((i64)n * 9 + k) * HW + p;
+      float gr = 0.f;
+      if (ctr != 255) {
+        const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
+        const double s = (double)sim[o];
+        gr = cls == 1 ? (float)(pa + pb * (s - mp.mean)) : (float)(na + nb * (s - mn.mean));
+      }
+      gsim[o] = gr;
+    }
+  }
+}
+
+// ---- softmax of the nearest-down-scaled student logits.  grid: (blocks over H*W, N)
+__global__ void softmax_down_kernel(const float* __restrict__ logits, int C, int h, int w, int ds, float* __restrict__ prob, int H, int W) {
+  const int n = blockIdx.y, HW = H * W;
+  const float* lp = logits + (i64)n * C * h * w;
+  float* pp = prob + (i64)n * C * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const int so = (y * ds) * w + x * ds;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(i64)c * h * w + so]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lp[(i64)c * h * w + so] - mx);
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) pp[(i64)c * HW + p] = expf(lp[(i64)c * h * w + so] - mx) * inv;
+  }
+}
+
+// ---- target validity: centre label != 255 and all nine dilated neighbours un-mixed (and inside the map)
+__global__ __launch_bounds__(256) void trg_valid_kernel(const unsigned char* __restrict__ gt, const unsigned char* __restrict__ mix,
+                                                        int H, int W, int Hg, int Wg, int dil, unsigned char* __restrict__ valid,
+                                                        unsigned char* __restrict__ all9, unsigned long long* __restrict__ count) {
+  __shared__ double sm[16];
+  const int n = blockIdx.y, HW = H * W;
+  const unsigned char* g = gt + (i64)n * Hg * Wg;
+  const unsigned char* m = mix + (i64)n * Hg * Wg;
+  const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
+  double cnt = 0.0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
+      const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+      all = all && in && (m[(i64)nearest_src(in ? sy : 0, sgy, Hg) * Wg + nearest_src(in ? sx : 0, sgx, Wg)] == 0);
+    }
+    const int ctr = g[(i64)nearest_src(y, sgy, Hg) * Wg + nearest_src(x, sgx, Wg)];
+    const bool v = all && ctr != 255;
+    valid[(i64)n * HW + p] = v;
+    if (all9) all9[(i64)n * HW + p] = all;
+    cnt += v ? 1.0 : 0.0;
+  }
+  cnt = block_sum_d(cnt, sm);
+  if (threadIdx.x == 0 && cnt > 0.0) atomicAdd(count, (unsigned long long)cnt);
+}
+
+// ---- top-k target losses.  One thread per pixel: 9-element sort in registers.
+__global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict__ ema_sim, const float* __restrict__ prob,
+                                                        const unsigned char* __restrict__ valid, const unsigned long long* __restrict__ count,
+                                                        int C, int H, int W, int dil, int top_k, float w_pos, float w_neg,
+                                                        float* __restrict__ gP, double* __restrict__ acc) {
+  __shared__ double sm[16];
+  const int n = blockIdx.y, HW = H * W;
+  const double cnt = (double)count[0];
+  const float cpos = cnt > 1.0 ? (float)((double)w_pos / (cnt * (top_k + 1))) : 0.f;
+  const float cneg = cnt > 1.0 ? (float)((double)w_neg / (cnt * top_k)) : 0.f;
+  const float* pp = prob + (i64)n * C * HW;
+  double spos = 0.0, sneg = 0.0;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const i64 base = (i64)n * 9 * HW + p;
+    if (!valid[(i64)n * HW + p]) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) gP[base + (i64)k * HW] = 0.f;
+      continue;
+    }
+    const int y = p / W, x = p - y * W;
+    float s[9], P[9];
+    int id[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      s[k] = ema_sim[base + (i64)k * HW];
+      id[k] = k;
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;  // always inside for valid pixels
+      const int q = sy * W + sx;
+      float d = 0.f;
+      for (int c = 0; c < C; ++c) d = fmaf(pp[(i64)c * HW + p], pp[(i64)c * HW + q], d);
+      P[k] = d;
+    }
+    // stable insertion sort, descending similarity (ties keep the lower index first)
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+#pragma unroll
+      for (int j = i; j > 0; --j) {
+        if (s[j] > s[j - 1]) {
+          const float ts = s[j]; s[j] = s[j - 1]; s[j - 1] = ts;
+          const float tp = P[j]; P[j] = P[j - 1]; P[j - 1] = tp;
+          const int ti = id[j]; id[j] = id[j - 1]; id[j - 1] = ti;
+        }
+      }
+    }
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      float gj = 0.f;
+      if (j <= top_k) {            // top-(k+1) largest: loc_pos = -sim * P
+        spos += (double)(-s[j] * P[j]);
+        gj = -s[j] * cpos;
+      } else if (j >= 9 - top_k) { // top-k smallest: loc_neg = -(1-sim) * (1-P)
+        sneg += (double)(-(1.f - s[j]) * (1.f - P[j]));
+        gj = (1.f - s[j]) * cneg;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (id[j] == k) g[k] = gj;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gP[base + (i64)k * HW] = g[k];
+  }
+  spos = block_sum_d(spos, sm);
+  sneg = block_sum_d(sneg, sm);
+  if (threadIdx.x == 0) {
+    if (spos != 0.0) atomicAdd(&acc[0], spos);
+    if (sneg != 0.0) atomicAdd(&acc[1], sneg);
+  }
+}
+
+// ---- gradient of the cross-probabilities into the (full 1/4-res) student logits (centre path only)
+__global__ __launch_bounds__(256) void cross_prob_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gP, int C, int H,
+                                                             int W, int dil, int ds, float* __restrict__ dlogits, int h, int w) {
+  const int n = blockIdx.y, HW = H * W;
+  const float* pp = prob + (i64)n * C * HW;
+  float* dl = dlogits + (i64)n * C * h * w;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    float g[9];
+    int off[9];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      g[k] = gP[((i64)n * 9 + k) * HW + p];
+      any = any || g[k] != 0.f;
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
+      const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+      off[k] = in ? sy * W + sx : -1;
+    }
+    if (!any) continue;
+    float dot = 0.f;  // sum_j p_j * dprob_j
+    for (int c = 0; c < C; ++c) {
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (off[k] >= 0) d = fmaf(g[k], pp[(i64)c * HW + off[k]], d);
+      dot = fmaf(pp[(i64)c * HW + p], d, dot);
+    }
+    const int so = (y * ds) * w + x * ds;
+    for (int c = 0; c < C; ++c) {
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) if (off[k] >= 0) d = fmaf(g[k], pp[(i64)c * HW + off[k]], d);
+      dl[(i64)c * h * w + so] += pp[(i64)c * HW + p] * (d - dot);
+    }
+  }
+}
+
+__global__ void sim_loss_finalize_kernel(const double* __restrict__ acc, const unsigned long long* __restrict__ count, int top_k,
+                                         float w_pos, float w_neg, float* __restrict__ out) {
+  const double cnt = (double)count[0];
+  out[0] = cnt > 1.0 ? (float)((double)w_pos * acc[0] / (cnt * (top_k + 1))) : 0.f;
+  out[1] = cnt > 1.0 ? (float)((double)w_neg * acc[1] / (cnt * top_k)) : 0.f;
+}
+
+inline int px_blocks(i64 n) {
+  i64 g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  return g < 1 ? 1 : (int)g;
+}
+
+}  // namespace
+
+extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, float* sim, float* norm, pfst_stream_t stream) {
+  PFST_CHECK_ARG(feat && sim && norm && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  hipLaunchKernelGGL(sim_map_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, sim, norm);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
+                                float* dfeat, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(feat && sim && norm && gsim && dfeat && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  hipLaunchKernelGGL(sim_map_bwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H,
+                     W, dil, dfeat, accumulate);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double* stats, pfst_stream_t stream) {
+  PFST_CHECK_ARG(sim && gt && stats && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stats, 0, 6 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
+  hipLaunchKernelGGL(src_stats_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, stats);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, const double* stats,
+                                 float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream) {
+  PFST_CHECK_ARG(sim && gt && stats && gsim && losses && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  hipLaunchKernelGGL(src_grad_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, sim, gt, H, W, Hg, Wg, dil,
+                     stats, w_pos, w_neg, w_pos_std, w_neg_std, gsim, losses);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_softmax_down(const float* logits, int N, int C, int h, int w, int ds, float* prob, int H, int W, pfst_stream_t stream) {
+  PFST_CHECK_ARG(logits && prob && N > 0 && N <= 65535 && C > 0 && h > 0 && w > 0 && ds >= 1 && H > 0 && W > 0);
+  PFST_CHECK_ARG((H - 1) * ds < h && (W - 1) * ds < w);
+  hipLaunchKernelGGL(softmax_down_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, ds, prob, H, W);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char* mix_mask, int N, int H, int W, int Hg, int Wg, int dil,
+                                   unsigned char* valid, unsigned char* all9, unsigned long long* count, pfst_stream_t stream) {
+  PFST_CHECK_ARG(gt && mix_mask && valid && count && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(count, 0, sizeof(unsigned long long), s) != hipSuccess) return PFST_ERR_LAUNCH;
+  hipLaunchKernelGGL(trg_valid_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, gt, mix_mask, H, W, Hg, Wg, dil, valid, all9, count);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
+                                  int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream) {
+  PFST_CHECK_ARG(ema_sim && prob && valid && count && gP && acc && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  PFST_CHECK_ARG(top_k >= 1 && 2 * top_k + 1 <= 9);
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(acc, 0, 2 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
+  hipLaunchKernelGGL(topk_loss_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, ema_sim, prob, valid, count, C, H, W, dil, top_k,
+                     w_pos, w_neg, gP, acc);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds,
+                                   float* dlogits, int h, int w, pfst_stream_t stream) {
+  PFST_CHECK_ARG(prob && gP && dlogits && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1 && ds >= 1);
+  PFST_CHECK_ARG((H - 1) * ds < h && (W - 1) * ds < w);
+  hipLaunchKernelGGL(cross_prob_bwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, prob, gP, C, H, W, dil, ds,
+                     dlogits, h, w);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_sim_loss_finalize(const double* acc, const unsigned long long* count, int top_k, float w_pos, float w_neg, float* out, pfst_stream_t stream) {
+  PFST_CHECK_ARG(acc && count && out && top_k >= 1);
+  hipLaunchKernelGGL(sim_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, top_k, w_pos, w_neg, out);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

