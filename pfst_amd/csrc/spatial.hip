@@ -10,7 +10,7 @@ namespace {
 __global__ void fill_kernel(float* __restrict__ p, i64 n, float v) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) p[i] = v;
 }
-__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, i64 n) {
+__global__ void axpy_kernel(float* y, const float* x, float a, i64 n) {   // x may alias y (in-place scaling)
   const i64 stride = (i64)gridDim.x * blockDim.x;
   i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
   if ((((uintptr_t)y | (uintptr_t)x) & 15) == 0) {

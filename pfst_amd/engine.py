@@ -1,0 +1,100 @@
+"""Minimal explicit autograd for the PFST train step: a reverse-ordered tape of closures over HIP ops.
+
+Why not torch.autograd: the graph is static, every backward op is one of our own kernels, gradients
+of branching activations are accumulated by the kernels themselves (`accumulate` epilogues), channel
+concatenations are never materialised (producers write into slices, consumers' data-gradients are
+read through slices), and both student graphs (source + mixed pass) run backward in one sweep like
+the reference's single `total_loss.backward()` (rsiseg/models/uda/pfgst.py:344)."""
+import torch
+
+from . import hip_ops as ops
+
+
+class Var:
+    """An activation (dense NCHW tensor, or a channel slice of a parent Var) with a gradient slot."""
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1')
+
+    def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
+        self.data = data
+        self._grad = None
+        self.requires_grad = requires_grad
+        self.parent, self.c0, self.c1 = parent, c0, c1
+
+    @property
+    def grad(self):
+        if self.parent is not None:
+            pg = self.parent.grad
+            return None if pg is None else pg[:, self.c0:self.c1]
+        return self._grad
+
+    def grad_target(self):
+        """-> (buffer, accumulate): where a backward kernel must write this Var's gradient."""
+        if self.parent is not None:
+            buf, acc = self.parent.grad_target_full()
+            return buf[:, self.c0:self.c1], acc
+        if self._grad is None:
+            self._grad = torch.empty(self.data.shape, dtype=self.data.dtype, device=self.data.device)
+            return self._grad, False
+        return self._grad, True
+
+    def grad_target_full(self):
+        # slices of a concat buffer are written by different producers' backward: zero once, accumulate after
+        if self._grad is None:
+            self._grad = torch.empty(self.data.shape, dtype=self.data.dtype, device=self.data.device)
+            ops.fill_(self._grad, 0.0)
+        return self._grad, True
+
+    def free_grad(self):
+        self._grad = None
+
+    def slice(self, c0, c1):
+        return Var(self.data[:, c0:c1], self.requires_grad, parent=self, c0=c0, c1=c1)
+
+
+class Tape:
+    """Closures recorded in forward order, executed in reverse; None tape = no-grad (teacher) mode."""
+
+    def __init__(self):
+        self.fns = []
+
+    def record(self, fn):
+        self.fns.append(fn)
+
+    def backward(self):
+        while self.fns:
+            self.fns.pop()()
+
+
+class ParamArena:
+    """All parameters of one network in ONE contiguous fp32 device buffer (+ an equally laid out
+    gradient buffer).  EMA, AdamW and the RCCL all-reduce each act on the flat buffer once."""
+
+    def __init__(self, named_params, device, with_grad=True):
+        self.names, self.offsets, self.shapes = [], {}, {}
+        off = 0
+        for name, p in named_params:
+            self.names.append(name)
+            self.offsets[name] = off
+            self.shapes[name] = tuple(p.shape)
+            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = off
+        self.data = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device) if with_grad else None
+        for name, p in named_params:
+            v = self.view(self.data, name)
+            v.copy_(p.data)
+            p.data = v
+            if with_grad:
+                p.grad = self.view(self.grad, name)
+            p._pfst_arena = self
+
+    def view(self, flat, name):
+        o = self.offsets[name]
+        shp = self.shapes[name]
+        n = 1
+        for s in shp:
+            n *= s
+        return flat[o:o + n].view(shp)
+
+    def zero_grad(self):
+        ops.fill_(self.grad, 0.0)

@@ -1,0 +1,153 @@
+"""Parameter holders with the reference's module/state_dict names and the fused layer forwards
+(conv -> train-mode BN -> ReLU [+ residual]) on the HIP ops, each recording its backward closure.
+
+Naming mirrors mmcv's ConvModule / DepthwiseSeparableConvModule (`.conv`, `.bn`, `.depthwise_conv`,
+`.pointwise_conv`) because checkpoints key on it (SURVEY.md §8b "Checkpoint layout")."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops as ops
+from .engine import Var
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Conv2dP(nn.Module):
+    """Weights of an nn.Conv2d (+ K-major packings for the implicit GEMM)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, bias=False):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        assert groups in (1, cin)
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        fan_out = cout * k * k // groups
+        nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))     # kaiming_normal_(fan_out, relu)
+        self.wf = self.wd = None        # packed copies, refreshed by repack()
+
+    @property
+    def depthwise(self):
+        return self.groups > 1
+
+    def repack(self, need_dgrad):
+        if self.depthwise:
+            return
+        if self.wf is None or self.wf.device != self.weight.device:
+            self.wf = torch.empty(self.k * self.k * self.cin, self.cout, device=self.weight.device)
+            self.wd = None
+        if need_dgrad and self.wd is None:
+            self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
+        ops.pack_weight(self.weight.data, True, need_dgrad, self.wf, self.wd if need_dgrad else None)
+
+
+class BatchNorm2dP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self._pending_batches = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending_batches:
+            self.num_batches_tracked += self._pending_batches
+            self._pending_batches = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+
+class ConvModule(nn.Module):
+    """conv -> BN(train) -> ReLU, `bias = not with_norm` (mmcv ConvModule semantics)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1):
+        super().__init__()
+        self.conv = Conv2dP(cin, cout, k, stride, padding, dilation, groups, bias=False)
+        self.bn = BatchNorm2dP(cout)
+
+    def forward(self, x, tape, relu=True, residual=None, out=None):
+        return conv_bn_act(x, self.conv, self.bn, tape, relu, residual, out)
+
+
+class DepthwiseSeparableConvModule(nn.Module):
+    def __init__(self, cin, cout, k, padding=0, dilation=1):
+        super().__init__()
+        self.depthwise_conv = ConvModule(cin, cin, k, 1, padding, dilation, groups=cin)
+        self.pointwise_conv = ConvModule(cin, cout, 1)
+
+    def forward(self, x, tape, out=None):
+        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out)
+
+
+def conv_forward(x, conv, tape, out=None):
+    """bare convolution (used by conv_seg); returns Var"""
+    xd = x.data
+    if conv.depthwise:
+        assert conv.k == 3 and conv.stride == 1 and conv.padding == conv.dilation
+        y = ops.dwconv(xd, conv.weight.data, conv.dilation, out=out)
+    else:
+        y = ops.conv_fprop(xd, conv.wf, conv.cout, conv.k, conv.stride, conv.dilation, conv.padding,
+                           bias=None if conv.bias is None else conv.bias.data, out=out)
+    yv = Var(y, tape is not None)
+    if tape is not None:
+        def bwd():
+            dy = yv.grad
+            conv_backward(x, conv, dy)
+            yv.free_grad()
+        tape.record(bwd)
+    return yv
+
+
+def conv_backward(x, conv, dy):
+    """accumulate weight/bias grads and propagate the data gradient into x"""
+    xd = x.data
+    if conv.depthwise:
+        ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
+        if x.requires_grad:
+            buf, acc = x.grad_target()
+            ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
+    else:
+        ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+        if conv.bias is not None:
+            ops.bias_grad_(conv.bias.grad, dy)
+        if x.requires_grad:
+            buf, acc = x.grad_target()
+            ops.conv_dgrad(dy, conv.wd, conv.cin, xd.shape[-2:], conv.k, conv.stride, conv.dilation, conv.padding,
+                           out=buf, accumulate=acc)
+
+
+def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
+    """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
+    (then the returned Var is expected to be obtained from the concat Var's .slice())."""
+    xd = x.data
+    if conv.depthwise:
+        pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
+    else:
+        pre = ops.conv_fprop(xd, conv.wf, conv.cout, conv.k, conv.stride, conv.dilation, conv.padding)
+    mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+    bn._pending_batches += 1
+    out_var = None
+    if isinstance(out, Var):                       # slice of a concat Var
+        out_var, out = out, out.data
+    y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
+                     None if residual is None else residual.data, out=out)
+    if tape is None:
+        return out_var if out_var is not None else Var(y, False)
+    yv = out_var if out_var is not None else Var(y, True)
+
+    def bwd():
+        dy = yv.grad
+        dres = dacc = None
+        if residual is not None and residual.requires_grad:
+            dres, dacc = residual.grad_target()
+        dpre = ops.bn_backward(dy, y if relu else None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
+                               relu, dres, bool(dacc))
+        conv_backward(x, conv, dpre)
+        if yv.parent is None:
+            yv.free_grad()
+    tape.record(bwd)
+    return yv

@@ -1,0 +1,367 @@
+"""ResNetV1c-50-d8 backbone, DepthwiseSeparableASPPHead, FCNHead, CrossEntropyLoss and EncoderDecoder on
+the HIP ops, registered under the reference's type names so `configs/pfst/*.py` build unchanged.
+
+Reference behaviour followed (file:line under /root/reference/rsiseg/models):
+  backbones/resnet.py:99-307,396-527,591-638,659-700  utils/res_layer.py:28-96
+  decode_heads/decode_head.py:55-108,188-283  aspp_head.py:53-126  sep_aspp_head.py:29-111  fcn_head.py:24-98
+  segmentors/encoder_decoder.py:65-217  losses/cross_entropy_loss.py:198-298
+Only what the PFST hot path uses is implemented; unsupported options raise instead of silently differing."""
+import torch
+import torch.nn as nn
+
+from . import hip_ops as ops
+from .engine import Var
+from .layers import BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, conv_bn_act, conv_forward
+from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
+
+
+def _check_norm(norm_cfg):
+    if norm_cfg is None or norm_cfg.get('type') != 'BN':
+        raise NotImplementedError(f'pfst_amd implements plain BN (the PFST configs); got norm_cfg={norm_cfg}')
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=False):
+        super().__init__()
+        self.conv1 = Conv2dP(inplanes, planes, 1)
+        self.bn1 = BatchNorm2dP(planes)
+        self.conv2 = Conv2dP(planes, planes, 3, stride, dilation, dilation)   # style='pytorch': stride on the 3x3
+        self.bn2 = BatchNorm2dP(planes)
+        self.conv3 = Conv2dP(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2dP(planes * 4)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(Conv2dP(inplanes, planes * 4, 1, stride), BatchNorm2dP(planes * 4))
+
+    def forward(self, x, tape):
+        o = conv_bn_act(x, self.conv1, self.bn1, tape)
+        o = conv_bn_act(o, self.conv2, self.bn2, tape)
+        idt = x
+        if self.downsample is not None:
+            idt = conv_bn_act(x, self.downsample[0], self.downsample[1], tape, relu=False)
+        return conv_bn_act(o, self.conv3, self.bn3, tape, relu=True, residual=idt)
+
+
+@BACKBONES.register_module()
+class ResNetV1c(nn.Module):
+    """ResNet-50 with the 3x(3x3) deep stem, strides (1,2,1,1), dilations (1,1,2,4), contract_dilation."""
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+    def __init__(self, depth=50, in_channels=3, stem_channels=64, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=False, contract_dilation=False,
+                 multi_grid=None, with_cp=False, zero_init_residual=True, pretrained=None, init_cfg=None,
+                 frozen_stages=-1, conv_cfg=None, dcn=None, plugins=None, avg_down=False, deep_stem=True,
+                 stage_with_dcn=(False, False, False, False)):
+        super().__init__()
+        _check_norm(norm_cfg)
+        if depth not in self.arch:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        unsupported = dict(style=style != 'pytorch', norm_eval=norm_eval, multi_grid=multi_grid is not None, with_cp=with_cp,
+                           frozen_stages=frozen_stages >= 0, conv_cfg=conv_cfg is not None, dcn=dcn is not None,
+                           plugins=plugins is not None, avg_down=avg_down, deep_stem=not deep_stem)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f'ResNetV1c options outside the PFST path: {bad}')
+        self.pretrained = pretrained
+        self.out_indices = tuple(out_indices)
+        self.zero_init_residual = zero_init_residual
+        c2 = stem_channels // 2
+        ident = nn.Identity
+        self.stem = nn.Sequential(Conv2dP(in_channels, c2, 3, 2, 1), BatchNorm2dP(c2), ident(),
+                                  Conv2dP(c2, c2, 3, 1, 1), BatchNorm2dP(c2), ident(),
+                                  Conv2dP(c2, stem_channels, 3, 1, 1), BatchNorm2dP(stem_channels), ident())
+        inplanes = stem_channels
+        self.res_layers = []
+        for i, nb in enumerate(self.arch[depth][:num_stages]):
+            planes = base_channels * 2 ** i
+            stride, dil = strides[i], dilations[i]
+            first_dil = dil // 2 if (dil > 1 and contract_dilation) else dil
+            blocks = [Bottleneck(inplanes, planes, stride, first_dil, downsample=(stride != 1 or inplanes != planes * 4))]
+            inplanes = planes * 4
+            for _ in range(1, nb):
+                blocks.append(Bottleneck(inplanes, planes, 1, dil))
+            name = f'layer{i + 1}'
+            self.add_module(name, nn.Sequential(*blocks))
+            self.res_layers.append(name)
+
+    def init_weights(self):
+        pass   # convs are kaiming-initialised at construction; pretrained weights come via load_state_dict
+
+    def forward(self, x, tape=None):
+        s = self.stem
+        x = conv_bn_act(x, s[0], s[1], tape)
+        x = conv_bn_act(x, s[3], s[4], tape)
+        x = conv_bn_act(x, s[6], s[7], tape)
+        xin = x
+        y, idx = ops.maxpool(xin.data)
+        x = Var(y, tape is not None)
+        if tape is not None:
+            pooled = x
+
+            def bwd_pool():
+                xin._grad = ops.maxpool_bwd(pooled.grad, idx, xin.data.shape[-2:])
+                pooled.free_grad()
+            tape.record(bwd_pool)
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            for blk in getattr(self, name):
+                x = blk(x, tape)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+@LOSSES.register_module()
+class CrossEntropyLoss(nn.Module):
+    """Softmax CE with pixel weights, optional class weights, ignore_index, mean over ALL pixels
+    (avg_non_ignore=False), fused with the bilinear up-sampling of the logits and the accuracy."""
+
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0,
+                 loss_name='loss_ce', avg_non_ignore=False):
+        super().__init__()
+        if use_sigmoid or use_mask or reduction != 'mean' or avg_non_ignore:
+            raise NotImplementedError('pfst_amd CrossEntropyLoss: softmax CE, reduction=mean, avg_non_ignore=False only')
+        if isinstance(class_weight, str):
+            import numpy as np
+            class_weight = np.load(class_weight).tolist() if class_weight.endswith('.npy') else None
+            if class_weight is None:
+                raise NotImplementedError('class_weight files: .npy only')
+        self.class_weight = class_weight
+        self.loss_weight = loss_weight
+        self._loss_name = loss_name
+        self._cw = None
+
+    @property
+    def loss_name(self):
+        return self._loss_name
+
+    def _cw_dev(self, dev):
+        if self.class_weight is None:
+            return None
+        if self._cw is None or self._cw.device != dev:
+            self._cw = torch.tensor(self.class_weight, dtype=torch.float32, device=dev)
+        return self._cw
+
+    def fused(self, logits, label_u8, weight, tape, ignore_index=255, grad_scale=1.0):
+        """logits: Var [N,C,h,w] (low res); label_u8 [N,1,H,W] or [N,H,W]; weight [N,H,W] or None.
+        -> device tensor [loss, acc_seg]"""
+        ld = logits.data
+        n = ld.shape[0]
+        H, W = label_u8.shape[-2:]
+        cw = self._cw_dev(ld.device)
+        lse, acc = ops.ce_upsample_fwd(ld, label_u8, weight, cw, ignore_index)
+        out = ops.ce_finalize(acc, n * H * W, self.loss_weight)
+        if tape is not None:
+            scale = grad_scale * self.loss_weight / float(n * H * W)
+
+            def bwd():
+                buf, accf = logits.grad_target()
+                ops.ce_upsample_bwd(ld, label_u8, lse, scale, weight, cw, ignore_index, out=buf, accumulate=accf)
+            tape.record(bwd)
+        return out
+
+
+class BaseDecodeHead(nn.Module):
+    def __init__(self, in_channels, channels, *, num_classes, dropout_ratio=0.1, conv_cfg=None, norm_cfg=None,
+                 act_cfg=dict(type='ReLU'), in_index=-1, input_transform=None,
+                 loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0), ignore_index=255,
+                 sampler=None, align_corners=False, init_cfg=None):
+        super().__init__()
+        _check_norm(norm_cfg)
+        if input_transform is not None or sampler is not None or align_corners or conv_cfg is not None:
+            raise NotImplementedError('decode head options outside the PFST path')
+        if not isinstance(loss_decode, dict):
+            raise NotImplementedError('a single loss_decode dict is supported')
+        self.in_channels, self.channels, self.num_classes = in_channels, channels, num_classes
+        self.dropout_ratio, self.in_index, self.ignore_index = dropout_ratio, in_index, ignore_index
+        self.align_corners = align_corners
+        self.loss_decode = build_loss(loss_decode)
+        self.conv_seg = Conv2dP(channels, num_classes, 1, bias=True)
+        nn.init.normal_(self.conv_seg.weight, 0, 0.01)
+        self.dropout_enabled = True            # the teacher switches this off (pfgst.py:247-251)
+        self.injected_dropout_mask = None      # parity tests inject the (n, C) keep/scale mask
+
+    def cls_seg(self, feat, tape, training):
+        p = self.dropout_ratio
+        if self.injected_dropout_mask is not None or (training and self.dropout_enabled and p > 0):
+            n, c = feat.data.shape[:2]
+            mask = self.injected_dropout_mask
+            if mask is None:
+                mask = (torch.rand(n, c, device=feat.data.device) >= p).float() / (1.0 - p)
+            src = feat
+            y = ops.channel_scale(src.data, mask)
+            feat = Var(y, tape is not None)
+            if tape is not None:
+                dropped = feat
+
+                def bwd():
+                    src._grad = ops.channel_scale(dropped.grad, mask)
+                    dropped.free_grad()
+                tape.record(bwd)
+        return conv_forward(feat, self.conv_seg, tape)
+
+    def losses(self, seg_logit, seg_label_u8, seg_weight, tape, grad_scale=1.0):
+        out = self.loss_decode.fused(seg_logit, seg_label_u8, seg_weight, tape, self.ignore_index, grad_scale)
+        return {self.loss_decode.loss_name: out[0:1], 'acc_seg': out[1:2]}
+
+    def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg, seg_weight=None, tape=None, grad_scale=1.0):
+        seg_logits, feats = self.forward(inputs, return_features=True, tape=tape, training=True)
+        losses = self.losses(seg_logits, gt_semantic_seg, seg_weight, tape, grad_scale)
+        return losses, {'seg_logits': seg_logits, 'decoded_features': feats}
+
+    def forward_test(self, inputs, img_metas, test_cfg, tape=None):
+        seg_logits, feats = self.forward(inputs, return_features=True, tape=None, training=False)
+        return seg_logits, {'decoded_features': feats}
+
+
+@HEADS.register_module()
+class DepthwiseSeparableASPPHead(BaseDecodeHead):
+    def __init__(self, c1_in_channels, c1_channels, dilations=(1, 6, 12, 18), **kwargs):
+        super().__init__(**kwargs)
+        assert c1_in_channels > 0 and dilations[0] == 1 and all(d > 1 for d in dilations[1:])
+        self.dilations = tuple(dilations)
+        ci, ch = self.in_channels, self.channels
+        self.image_pool = nn.Sequential(nn.Identity(), ConvModule(ci, ch, 1))
+        mods = [ConvModule(ci, ch, 1)]
+        mods += [DepthwiseSeparableConvModule(ci, ch, 3, padding=d, dilation=d) for d in dilations[1:]]
+        self.aspp_modules = nn.ModuleList(mods)
+        self.bottleneck = ConvModule((len(dilations) + 1) * ch, ch, 3, padding=1)
+        self.c1_bottleneck = ConvModule(c1_in_channels, c1_channels, 1)
+        self.c1_channels = c1_channels
+        self.sep_bottleneck = nn.Sequential(DepthwiseSeparableConvModule(ch + c1_channels, ch, 3, padding=1),
+                                            DepthwiseSeparableConvModule(ch, ch, 3, padding=1))
+
+    def forward(self, inputs, return_features=False, tape=None, training=True):
+        c1, x = inputs[0], inputs[self.in_index]
+        n, _, h, w = x.data.shape
+        ch, nb = self.channels, len(self.dilations) + 1
+        cat = Var(torch.empty(n, nb * ch, h, w, device=x.data.device), tape is not None)
+        # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)
+        pooled = Var(ops.global_avgpool(x.data), tape is not None)
+        pa = self.image_pool[1](pooled, tape)
+        ops.broadcast_hw(pa.data, cat.data[:, 0:ch])
+        if tape is not None:
+            hw = float(h * w)
+
+            def bwd_pool():
+                g = cat.grad
+                pa._grad = ops.reduce_hw(g[:, 0:ch])
+
+            def bwd_gap():
+                buf, acc = x.grad_target()
+                if not acc:
+                    ops.fill_(buf, 0.0)
+                ops.broadcast_hw(pooled.grad, buf, 1.0 / hw, True)
+                pooled.free_grad()
+            # order on the tape: gap-backward must run AFTER the image_pool conv's backward, pool-broadcast before it
+            self._reorder_pool(tape, bwd_gap, bwd_pool)
+        self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
+        for i in range(1, len(self.dilations)):
+            self.aspp_modules[i](x, tape, out=cat.slice((i + 1) * ch, (i + 2) * ch))
+        feats = self.bottleneck(cat, tape)
+        # decoder: upsample x2 to c1 size, concat with the 48-channel c1 projection
+        H, W = c1.data.shape[-2:]
+        cat2 = Var(torch.empty(n, ch + self.c1_channels, H, W, device=x.data.device), tape is not None)
+        ops.resize_bilinear(feats.data, (H, W), out=cat2.data[:, 0:ch])
+        if tape is not None:
+            def bwd_up():
+                buf, acc = feats.grad_target()
+                ops.resize_bilinear_bwd(cat2.grad[:, 0:ch], (h, w), out=buf, accumulate=acc)
+            tape.record(bwd_up)
+        self.c1_bottleneck(c1, tape, out=cat2.slice(ch, ch + self.c1_channels))
+        o = self.sep_bottleneck[0](cat2, tape)
+        o = self.sep_bottleneck[1](o, tape)
+        logits = self.cls_seg(o, tape, training)
+        return (logits, feats) if return_features else logits
+
+    @staticmethod
+    def _reorder_pool(tape, bwd_gap, bwd_pool):
+        # forward recorded: [..., image_pool ConvModule closure]; we need tape order
+        # [bwd_gap, conv closure, bwd_pool] so that reverse execution is pool -> conv -> gap.
+        conv_closure = tape.fns.pop()
+        tape.record(bwd_gap)
+        tape.record(conv_closure)
+        tape.record(bwd_pool)
+
+
+@HEADS.register_module()
+class FCNHead(BaseDecodeHead):
+    def __init__(self, num_convs=2, kernel_size=3, concat_input=True, dilation=1, **kwargs):
+        super().__init__(**kwargs)
+        if num_convs != 1 or concat_input or kernel_size != 3:
+            raise NotImplementedError('FCNHead: the PFST auxiliary head (num_convs=1, concat_input=False) only')
+        self.convs = nn.Sequential(ConvModule(self.in_channels, self.channels, 3, padding=dilation, dilation=dilation))
+
+    def forward(self, inputs, return_features=False, tape=None, training=True):
+        feats = self.convs[0](inputs[self.in_index], tape)
+        logits = self.cls_seg(feats, tape, training)
+        return (logits, feats) if return_features else logits
+
+
+@SEGMENTORS.register_module()
+class EncoderDecoder(nn.Module):
+    def __init__(self, backbone, decode_head, neck=None, auxiliary_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__()
+        if neck is not None or isinstance(auxiliary_head, (list, tuple)):
+            raise NotImplementedError('neck / multiple auxiliary heads are outside the PFST path')
+        if pretrained is not None:
+            backbone = dict(backbone)
+            backbone['pretrained'] = pretrained
+        self.backbone = build_backbone(backbone)
+        self.decode_head = build_head(decode_head)
+        self.auxiliary_head = build_head(auxiliary_head) if auxiliary_head is not None else None
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    @property
+    def with_auxiliary_head(self):
+        return self.auxiliary_head is not None
+
+    def init_weights(self):
+        self.backbone.init_weights()
+
+    def convs(self):
+        return [m for m in self.modules() if isinstance(m, Conv2dP)]
+
+    def repack_weights(self, need_dgrad=True):
+        for m in self.convs():
+            m.repack(need_dgrad)
+
+    def extract_feat(self, img, tape=None):
+        x = img if isinstance(img, Var) else Var(img, False)
+        return self.backbone(x, tape)
+
+    def encode_decode(self, img, img_metas=None):
+        """teacher-style forward: no tape, dropout off, BN still in train mode; returns the LOW-resolution
+        logits Var (the bilinear upsampling to the image size is fused into the consumers) + states."""
+        x = self.extract_feat(img, None)
+        logits, states = self.decode_head.forward_test(x, img_metas, self.test_cfg)
+        states.update({'feats': x, 'seg_logits': logits})
+        return logits, states
+
+    def forward_train(self, img, img_metas, gt_semantic_seg, seg_weight=None, return_feats=False,
+                      return_decoded_feats=False, return_logits=False, return_states=False, tape=None, grad_scale=1.0):
+        """gt_semantic_seg: uint8 [N,1,H,W]; returns the losses dict (device tensors) like the reference."""
+        x = self.extract_feat(img, tape)
+        losses, states = dict(), dict()
+        loss_decode, state = self.decode_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg, seg_weight,
+                                                            tape=tape, grad_scale=grad_scale)
+        losses.update(add_prefix(loss_decode, 'decode'))
+        states.update(state)
+        if self.with_auxiliary_head:
+            loss_aux, state_aux = self.auxiliary_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg,
+                                                                    seg_weight, tape=tape, grad_scale=grad_scale)
+            losses.update(add_prefix(loss_aux, 'aux'))
+            states.update(add_prefix(state_aux, 'aux'))
+        if return_feats:
+            losses['features'] = x
+        if return_logits:
+            losses['logits'] = state['seg_logits']
+        if return_decoded_feats:
+            losses['decoded_features'] = state['decoded_features']
+        return (losses, states) if return_states else losses

@@ -1,0 +1,328 @@
+"""PFGST self-training wrapper and PFGSTLoss on the HIP path, behind the reference's plugin API:
+`UDA.build(cfg.uda)` -> object with `train_step(data_batch, optimizer) -> {log_vars, num_samples, states}`.
+
+Reference: rsiseg/models/uda/pfgst.py:53-368, uda_decorator.py:13-103, losses/pfgst_loss.py:12-234,
+utils/dacs_transforms.py:12-144, segmentors/base.py:177-222.
+
+Differences from the reference that are deliberate:
+  * the EMA teacher's parameters are never part of the optimizer / gradient all-reduce;
+  * `local_iter` is part of state_dict (the reference loses it on resume);
+  * ~20 host syncs per step become one D2H read of a packed scalar vector (+ the 256-flag label
+    presence read that the NumPy class choice needs);
+  * labels travel as uint8 on the device, int64 only at the API boundary."""
+import random
+from collections import OrderedDict
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import hip_ops as ops
+from .engine import ParamArena, Tape, Var
+from .registry import LOSSES, UDA, build_loss, build_segmentor
+
+
+@LOSSES.register_module()
+class PFGSTLoss(nn.Module):
+    def __init__(self, top_k, dilation, kernel_size, weights, sigma=30, mean_sim=0.6, feat_level=2, sim_type='gaussian',
+                 num_bins=100, apply_ignore=False, src_perc=None, proj_net_cfg=None, src_loss_type='mean_std',
+                 margin=(0.5, 0.5), detach_unfold=False, cross_prob_type='trg', downscale=None):
+        super().__init__()
+        bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type != 'cosine', feat_level=feat_level is not None,
+                   src_perc=src_perc is not None, proj_net=proj_net_cfg is not None, src_loss_type=src_loss_type != 'mean_std',
+                   detach_unfold=not detach_unfold, cross_prob_type=cross_prob_type != 'trg',
+                   downscale=downscale not in (0.5,), top_k=top_k is None or not (1 <= top_k <= 4),
+                   weights=not isinstance(weights, dict))
+        bad = [k for k, v in bad.items() if v]
+        if bad:
+            raise NotImplementedError(f'PFGSTLoss options outside the shipped PFST configs: {bad}')
+        self.top_k, self.dilation, self.weights = top_k, dilation, dict(weights)
+        self.ds = int(round(1.0 / downscale))
+
+    def forward(self, tensors, tape=None):
+        """tensors: logits_trg (Var, student logits of the mixed pass), x_ema (Var), x_src (Var),
+        gt_src (uint8 [N,1,H,W]), mix_masks (uint8 [N,1,H,W]).  -> dict of 6 one-element device tensors."""
+        lt, x_ema, x_src = tensors['logits_trg'], tensors['x_ema'], tensors['x_src']
+        gt8, mm8 = tensors['gt_src'], tensors['mix_masks']
+        d, w = self.dilation, self.weights
+        n, c, h, wd = lt.data.shape
+        H, W = h // self.ds, wd // self.ds
+        assert x_ema.data.shape[-2:] == (H, W) and x_src.data.shape[-2:] == (H, W), \
+            'features must already be at the down-scaled logits resolution (nearest resize would be the identity)'
+        ema_sim, _ = ops.sim_map(x_ema.data, d)
+        src_sim, src_norm = ops.sim_map(x_src.data, d)
+        l4, gsim = ops.src_sim_losses(src_sim, gt8, d, w['src_pos'], w['src_neg'], w['src_pos_std'], w['src_neg_std'])
+        prob = ops.softmax_down(lt.data, self.ds)
+        valid, all9, cnt = ops.trg_valid_mask(gt8, mm8, (H, W), d)
+        l2, gP = ops.sim_topk_loss(ema_sim, prob, valid, cnt, d, self.top_k, w['sim_pos'], w['sim_neg'])
+        if tape is not None:
+            def bwd():
+                buf, acc = x_src.grad_target()
+                ops.sim_map_bwd(x_src.data, src_sim, src_norm, gsim, d, out=buf, accumulate=acc)
+                buf, acc = lt.grad_target()
+                if not acc:
+                    ops.fill_(buf, 0.0)
+                ops.cross_prob_bwd_(buf, prob, gP, d, self.ds)
+            tape.record(bwd)
+        out = OrderedDict(loss_src_pos_mean=l4[0:1], loss_src_neg_mean=l4[1:2], loss_src_pos_std=l4[2:3],
+                          loss_src_neg_std=l4[3:4], loss_sim_pos=l2[0:1], loss_sim_neg=l2[1:2])
+        out['vis|density_sim_feat'] = (ema_sim, all9)
+        return out
+
+
+def get_module(module):
+    return module.module if hasattr(module, 'module') and isinstance(getattr(module, 'module'), nn.Module) else module
+
+
+class UDADecorator(nn.Module):
+    """Owns the student `self.model`; test-time calls delegate to it (uda_decorator.py:29-103)."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        self.model = build_segmentor(deepcopy(cfg['model']))
+        self.train_cfg = cfg['model']['train_cfg']
+        self.test_cfg = cfg['model']['test_cfg']
+        self.num_classes = cfg['model']['decode_head']['num_classes']
+
+    def get_model(self):
+        return get_module(self.model)
+
+    def extract_feat(self, img):
+        return self.get_model().extract_feat(img)
+
+    def encode_decode(self, img, img_metas):
+        return self.get_model().encode_decode(img, img_metas)
+
+
+def parse_losses(losses):
+    """BaseSegmentor._parse_losses (base.py:177-222) on device scalars: returns (names, packed tensor, loss_mask).
+    Values stay on the device; ONE read-back happens at the end of the step."""
+    names = list(losses.keys())
+    return names, [losses[k] for k in names]
+
+
+@UDA.register_module()
+class PFGST(UDADecorator):
+    def __init__(self, **cfg):
+        super().__init__(**cfg)
+        self.local_iter = 0
+        self.max_iters = cfg['max_iters']
+        self.alpha = cfg['alpha']
+        self.pseudo_threshold = cfg['pseudo_threshold']
+        self.psweight_ignore_top = cfg['pseudo_weight_ignore_top']
+        self.psweight_ignore_bottom = cfg['pseudo_weight_ignore_bottom']
+        self.fdist_lambda = cfg['imnet_feature_dist_lambda']
+        self.mix = cfg['mix']
+        self.blur = cfg['blur']
+        self.color_jitter_s = cfg['color_jitter_strength']
+        self.color_jitter_p = cfg['color_jitter_probability']
+        self.print_grad_magnitude = cfg['print_grad_magnitude']
+        self.trg_loss_weight = cfg.get('trg_loss_weight', 1.)
+        self.use_decoded_feats = cfg.get('use_decoded_feats', False)
+        self.thre_type = cfg.get('thre_type', 'all')
+        self.strong_aug_denorm_type = cfg.get('strong_aug_denorm_type', 'mean_std')
+        self.apply_no_mix = cfg.get('apply_no_mix', False)
+        assert self.mix == 'class'
+        bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type != 'all', ps_top=self.psweight_ignore_top > 0,
+                   ps_bottom=self.psweight_ignore_bottom > 0, use_decoded_feats=not self.use_decoded_feats,
+                   apply_no_mix=self.apply_no_mix, print_grad=self.print_grad_magnitude)
+        bad = [k for k, v in bad.items() if v]
+        if bad:
+            raise NotImplementedError(f'PFGST options outside the shipped PFST configs: {bad}')
+        self.ema_model = build_segmentor(deepcopy(cfg['model']))
+        for p in self.ema_model.parameters():
+            p.requires_grad = False          # the teacher is never optimised / all-reduced
+        for m in self.ema_model.modules():
+            if hasattr(m, 'dropout_enabled'):
+                m.dropout_enabled = False    # pfgst.py:247-251
+        aux_losses = cfg.get('aux_losses', None)
+        self.apply_aux = aux_losses is not None
+        if self.apply_aux:
+            if not isinstance(aux_losses, (list, tuple)):
+                aux_losses = [aux_losses]
+            self.aux_losses = nn.ModuleList([build_loss(dict(l)) for l in aux_losses])
+        self.return_vis_states = False
+        self.debug = None                    # tests set this to a dict to capture intermediates
+        self._student_arena = self._teacher_arena = None
+        self.injected_mix_classes = None     # parity tests may inject the class choice
+
+    # ------------------------------------------------------------------ state
+    def get_extra_state(self):
+        return {'local_iter': self.local_iter}
+
+    def set_extra_state(self, state):
+        self.local_iter = int(state.get('local_iter', 0))
+
+    def init_weights(self):
+        self.model.init_weights()
+        self.ema_model.init_weights()
+
+    def get_ema_model(self):
+        return get_module(self.ema_model)
+
+    def _ensure_arenas(self, device):
+        a = self._student_arena
+        if a is not None and a.data.device == device:
+            return
+        model, ema = self.get_model(), self.get_ema_model()
+        model.to(device), ema.to(device)
+        for aux in (self.aux_losses if self.apply_aux else []):
+            aux.to(device)
+        self._student_arena = ParamArena(list(model.named_parameters()), device, with_grad=True)
+        self._teacher_arena = ParamArena(list(ema.named_parameters()), device, with_grad=False)
+        assert self._student_arena.numel == self._teacher_arena.numel
+
+    @property
+    def student_arena(self):
+        return self._student_arena
+
+    # ------------------------------------------------------------------ EMA (pfgst.py:105-127)
+    def _init_ema_weights(self):
+        self._teacher_arena.data.copy_(self._student_arena.data)
+
+    def _update_ema(self, it):
+        alpha_teacher = min(1 - 1 / (it + 1), self.alpha)
+        ops.ema_update_(self._teacher_arena.data, self._student_arena.data, alpha_teacher)
+
+    # ------------------------------------------------------------------ class mix (dacs_transforms.py:110-126)
+    def _choose_mix_classes(self, presence, batch_size):
+        """`torch.unique` over the whole batch + one NumPy `choice` per image (global RNG stream as the reference)."""
+        if self.injected_mix_classes is not None:
+            return self.injected_mix_classes
+        classes = np.nonzero(presence)[0]
+        n = classes.shape[0]
+        k = int((n + n % 2) / 2)
+        out = np.full((batch_size, max(k, 1)), -1, dtype=np.int32)
+        for i in range(batch_size):
+            out[i, :k] = classes[np.random.choice(n, k, replace=False)]
+        return out
+
+    # ------------------------------------------------------------------ the hot path
+    def train_step(self, data_batch, optimizer, **kwargs):
+        optimizer.zero_grad()
+        log_vars, vis_states = self(**data_batch)
+        optimizer.step()
+        log_vars.pop('loss', None)
+        return dict(log_vars=log_vars, num_samples=len(data_batch['img_metas']), states=vis_states)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        raise NotImplementedError('test-time forward is outside the round-1 hot path (SURVEY.md §8 f2)')
+
+    def forward_train(self, img, img_metas, gt_semantic_seg, target_img, target_img_metas, target_img_strong_aug):
+        if not img.is_cuda:
+            raise RuntimeError('PFGST.forward_train needs CUDA(HIP) tensors: pfst_amd has no CPU path')
+        dev = img.device
+        self._ensure_arenas(dev)
+        model, ema = self.get_model(), self.get_ema_model()
+        batch_size = img.shape[0]
+        S_hw = img.shape[-2:]
+        dbg = self.debug
+
+        # the optimizer's zero_grad() may have detached .grad views (set_to_none): re-attach + zero the arena
+        arena = self._student_arena
+        for name, p in model.named_parameters():
+            if p.grad is None or p.grad.data_ptr() != arena.view(arena.grad, name).data_ptr():
+                p.grad = arena.view(arena.grad, name)
+        arena.zero_grad()
+
+        if self.local_iter == 0:
+            self._init_ema_weights()
+        else:
+            self._update_ema(self.local_iter)
+        model.repack_weights(need_dgrad=True)
+        ema.repack_weights(need_dgrad=False)
+
+        # strong-augmentation parameters: same Python-RNG draws as the reference (pfgst.py:212-222)
+        jitter_draw = random.uniform(0, 1)
+        blur_draw = random.uniform(0, 1) if self.blur else 0
+        if img.shape[1] == 3 and (jitter_draw > self.color_jitter_p or blur_draw > 0.5):
+            from .strong_aug import apply_strong_aug
+        else:
+            apply_strong_aug = None
+
+        gt8 = ops.to_u8(gt_semantic_seg.contiguous())
+        presence = ops.label_presence(gt8)
+        if getattr(self, '_presence_host', None) is None:
+            self._presence_host = torch.empty(256, dtype=torch.int32, pin_memory=True)
+        presence_host = self._presence_host
+        presence_host.copy_(presence, non_blocking=True)
+        presence_evt = torch.cuda.Event()
+        presence_evt.record()
+
+        tape = Tape()
+        scalars = OrderedDict()
+
+        # ---- student on source
+        clean = model.forward_train(img.contiguous(), img_metas, gt8, None, return_feats=True, return_logits=True,
+                                    return_decoded_feats=True, tape=tape)
+        clean.pop('features')
+        src_dec = clean.pop('decoded_features')
+        src_logits = clean.pop('logits')
+        scalars.update(clean)
+
+        # ---- teacher on target -> pseudo labels (fused upsample + softmax + argmax + threshold count)
+        ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
+        ema_dec = ema_states['decoded_features']
+        pl64, pl8, conf_count = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None)
+
+        # ---- class mix
+        presence_evt.synchronize()
+        classes = self._choose_mix_classes(presence_host.numpy(), batch_size)
+        classes_dev = torch.from_numpy(np.ascontiguousarray(classes)).to(dev, non_blocking=True)
+        mix_masks = ops.class_mask(gt8, classes_dev)
+        mixed_img, mixed_lbl8, mixed_lbl64, mixed_w = ops.class_mix(
+            img.contiguous(), target_img_strong_aug.contiguous(), gt8, pl8, mix_masks, conf_count,
+            want_i64=self.return_vis_states or dbg is not None)
+        if apply_strong_aug is not None:
+            mixed_img = apply_strong_aug(mixed_img, img_metas, jitter_draw, self.color_jitter_p, self.color_jitter_s,
+                                         blur_draw, self.strong_aug_denorm_type)
+
+        # ---- student on mixed
+        mix = model.forward_train(mixed_img, img_metas, mixed_lbl8, mixed_w, return_feats=True, return_logits=True,
+                                  tape=tape, grad_scale=self.trg_loss_weight)
+        mix.pop('features')
+        mixed_logits = mix.pop('logits')
+        scalars.update({'mix.' + k: v for k, v in mix.items()})
+
+        # ---- auxiliary pseudo-feature losses
+        vis_states = {}
+        if self.apply_aux:
+            tensors = dict(gt_src=gt8, x_src=src_dec, x_ema=ema_dec, logits_trg=mixed_logits, mix_masks=mix_masks)
+            for loss_module in self.aux_losses:
+                aux = loss_module(tensors, tape=tape)
+                vis = {k: v for k, v in aux.items() if k.startswith('vis|')}
+                for k in vis:
+                    aux.pop(k)
+                scalars.update(aux)
+                if dbg is not None:
+                    dbg['aux_vis'] = vis
+
+        # ---- one backward over both student graphs + aux (pfgst.py:344)
+        tape.backward()
+
+        if dbg is not None:
+            dbg.update(pseudo_label=pl64, conf_count=conf_count, mix_masks=mix_masks, mixed_img=mixed_img,
+                       mixed_lbl=mixed_lbl64, mixed_w=mixed_w, src_logits=src_logits.data, mix_logits=mixed_logits.data,
+                       ema_logits=ema_logits.data, ema_dec=ema_dec.data, src_dec=src_dec.data, classes=classes)
+
+        # ---- gradient all-reduce (student only), log scalars packed into ONE vector
+        names = list(scalars.keys())
+        packed = torch.cat([scalars[k].reshape(1) for k in names])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            dist.all_reduce(arena.grad)
+            ops.axpy_(arena.grad, arena.grad, (1.0 / world) - 1.0)     # mean over ranks (DDP semantics)
+            dist.all_reduce(packed)
+            packed = packed / world
+        vals = packed.cpu().tolist()                                      # the step's single blocking read
+        log_vars = OrderedDict(zip(names, vals))
+        log_vars['loss'] = sum(v for k, v in log_vars.items() if 'loss' in k)
+
+        if self.return_vis_states:
+            vis_states['vis|seg_mask_mix'] = (mixed_img, mixed_lbl64)
+        self.local_iter += 1
+        return log_vars, vis_states
