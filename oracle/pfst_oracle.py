@@ -233,7 +233,7 @@ def encode_decode(sd, img, pre=''):
     BN in TRAIN mode (batch statistics), dropout off, no aux head; logits bilinear to image size."""
     feats = backbone_forward(sd, img, True, pre)
     logits, dec = decode_head_forward(sd, feats, True, None, pre)
-    return F.interpolate(logits, size=img.shape[2:], mode='bilinear', align_corners=False), dec
+    return F.interpolate(logits, size=img.shape[2:], mode='bilinear', align_corners=False), dec, logits
 
 
 def parse_losses(losses):
@@ -368,7 +368,7 @@ class OraclePFGST:
         self.blur = blur
         self.local_iter = 0
 
-    def train_step(self, batch, masks=None, drop_masks=None, return_extras=False):
+    def train_step(self, batch, masks=None, drop_masks=None, return_extras=False, pseudo_override=None):
         img, gt = batch['img'], batch['gt_semantic_seg']
         trg, trg_aug = batch['target_img'], batch['target_img_strong_aug']
         self.opt.zero_grad()
@@ -384,8 +384,11 @@ class OraclePFGST:
         clean_loss, lv = parse_losses(losses)
         lv.pop('loss'); log.update(lv)
         with torch.no_grad():
-            ema_logits, ema_dec = encode_decode(self.teacher, trg)
+            ema_logits, ema_dec, ema_low = encode_decode(self.teacher, trg)
         pl, pw, n_conf = pseudo_label(ema_logits, self.tau)
+        if pseudo_override is not None:        # (label map, #confident) injected by parity tests
+            pl, n_conf = pseudo_override
+            pw = (n_conf / pl.numel()) * torch.ones(pl.shape, dtype=ema_logits.dtype)
         if masks is None:
             masks = class_masks(gt)
         mixed_img, mixed_lbl, mixed_w = class_mix(masks, img, trg_aug, gt, pl, pw)
@@ -403,7 +406,7 @@ class OraclePFGST:
         if return_extras:
             extras.update(pseudo_label=pl, n_conf=n_conf, masks=masks, mixed_img=mixed_img, mixed_lbl=mixed_lbl,
                           mixed_w=mixed_w, src_logits=src_logits.detach(), mix_logits=mix_logits.detach(),
-                          ema_logits=ema_logits, ema_dec=ema_dec, src_dec=src_dec.detach(),
+                          ema_logits=ema_logits, ema_logits_low=ema_low, ema_dec=ema_dec, src_dec=src_dec.detach(),
                           grads=OrderedDict((k, self.student[k].grad.clone()) for k in self.pkeys))
             return log, extras
         return log

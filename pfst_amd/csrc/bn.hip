@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C, int HW, double inv_count, int relu, const double* __restrict__ ws) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mu = mean[c], is = invstd[c];
-  const float m1 = (float)(ws[2 * c] * inv_count), m2 = (float)(ws[2 * c + 1] * inv_count);
-  const float gs = gamma[c] * is;
+  // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
+  const double m1 = ws[2 * c] * inv_count, m2 = ws[2 * c + 1] * inv_count;
+  const double gs = (double)gamma[c] * (double)is;
   if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
     if (dgamma) dgamma[c] += (float)ws[2 * c + 1];
     if (dbeta) dbeta[c] += (float)ws[2 * c];
@@ -149,8 +150,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
     float dz = gp[i];
     if (relu && !(yp[i] > 0.f)) dz = 0.f;
-    const float xh = (xp[i] - mu) * is;
-    dxp[i] = gs * (dz - m1 - xh * m2);
+    const double xh = ((double)xp[i] - (double)mu) * (double)is;
+    dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
     if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
   }
 }

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
       if (c == lab) zl = z;
     }
     float se = 0.f;
-    for (int c = 0; c < C; ++c) se += __expf(interp(lp + (i64)c * hw, w, b) - mx);
-    const float l = mx + __logf(se);
+    for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
+    const float l = mx + logf(se);
     lse[(i64)n * H * W + p] = l;
     if (lab != ignore && lab < C) {
       float wgt = pw ? pw[(i64)n * H * W + p] : 1.f;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
         if (l == ignore || l >= C) continue;
         float g = pwp ? pwp[p] : 1.f;
         if (cw) g *= cw[l];
-        const float prob = __expf(interp(lp, w, b) - ls[p]);
+        const float prob = expf(interp(lp, w, b) - ls[p]);
         acc = fmaf(wy * wx * g, prob - (l == c ? 1.f : 0.f), acc);
       }
     }

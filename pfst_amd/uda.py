@@ -147,6 +147,8 @@ class PFGST(UDADecorator):
         self.debug = None                    # tests set this to a dict to capture intermediates
         self._student_arena = self._teacher_arena = None
         self.injected_mix_classes = None     # parity tests may inject the class choice
+        self.injected_pseudo = None          # ... and (uint8 label map, confident-pixel count) to decouple the
+                                             # student-gradient check from 1-ulp arg-max ties in the teacher logits
 
     # ------------------------------------------------------------------ state
     def get_extra_state(self):
@@ -268,6 +270,11 @@ class PFGST(UDADecorator):
         ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
         ema_dec = ema_states['decoded_features']
         pl64, pl8, conf_count = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None)
+        if self.injected_pseudo is not None:
+            if dbg is not None:
+                dbg['own_pseudo_label'], dbg['own_conf_count'] = pl64, conf_count
+            pl8, conf_count = self.injected_pseudo
+            pl64 = ops.to_i64(pl8) if dbg is not None else None
 
         # ---- class mix
         presence_evt.synchronize()
