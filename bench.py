@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""PFST train-step throughput on MI355X (BASELINE.json metric) + roofline of the dominant kernel + CPU baseline.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one full PFGST.train_step (student fwd/bwd on source + mixed batch, EMA-teacher forward, pseudo labels,
+class mix, PFGSTLoss, backward, gradient all-reduce, AdamW) on a synthetic batch of 8 x 1024x1024x3 tiles per GPU that
+is resident in HBM before the timed region.  value = global images / s (one image = one source+target pair).
+Rank 0 prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOAD = 'pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8'
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+PEAK_HBM_GBPS = 8000.0
+
+
+class KernelTimer:
+    """Brackets every C-ABI launch with HIP events on the launch stream (torch's current stream IS the stream the
+    kernels are enqueued on) and books algorithmic flops for the MFMA convolution kernels."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.records = []      # (key, start_evt, end_evt, flops)
+        self.enabled = False
+
+    @staticmethod
+    def _conv_variant(name, a):
+        if name == 'pfst_conv_igemm':
+            n, c, hi, wi, m, ho, wo, ks, mode = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[17]
+            bm = 128 if m > 64 else (64 if m > 32 else 32)
+            px = ho * wo if mode == 0 else hi * wi            # forward-output pixels = algorithmic work
+            return f'conv_igemm_kernel<{bm},{"true" if c % 16 else "false"}>', 2.0 * n * m * c * ks * ks * px
+        if name == 'pfst_conv_wgrad':
+            n, ci, co, ho, wo, ks = a[5], a[6], a[9], a[10], a[11], a[12]
+            bm = 128 if co > 64 else (64 if co > 32 else 32)
+            return f'conv_wgrad_kernel<{bm},{ks * ks}>', 2.0 * n * co * ci * ks * ks * ho * wo
+        return name, 0.0
+
+    def call(self, name, *args):
+        if not self.enabled:
+            return self.inner(name, *args)
+        key, flops = self._conv_variant(name, args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        self.inner(name, *args)
+        e.record()
+        self.records.append((key, s, e, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, s, e, flops in self.records:
+            d = agg.setdefault(key, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e)
+            d[2] += flops
+        return agg
+
+
+def cpu_baseline(num_classes, threads):
+    """The oracle (CPU restatement of the reference path) timed on this host: ONE PFGST.train_step on a bounded sample
+    (b=2, 512x512 crops = 1/4 of a 1024^2 tile each), reported in 1024^2-tile-equivalent images/s."""
+    from oracle import pfst_oracle as O
+    from pfst_amd.synthetic import fill_state_dict, synth_batch
+    torch.set_num_threads(threads)
+    sd = fill_state_dict(O.init_state_dict(num_classes, 3), 0)
+    m = O.OraclePFGST(sd)
+    b, S = 2, 512
+    batch = synth_batch(b, S, num_classes, seed=1234)
+    t0 = time.perf_counter()
+    m.train_step(batch)
+    dt = time.perf_counter() - t0
+    return dict(value=(b * (S * S) / (1024.0 * 1024.0)) / dt, unit='images/s', cores=threads, kind='port',
+                sample=f'1 PFGST.train_step, b={b}, {S}x{S} crops (={b * S * S / 1048576:.2f} 1024^2-tile equivalents), '
+                       f'{dt:.1f} s, torch-CPU fp32 oracle, no warm-up')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s 8)')
+    ap.add_argument('--size', type=int, default=None, help='tile size (default 1024)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    import pfst_amd  # noqa: F401
+    from pfst_amd import hip_ops, strong_aug  # noqa: F401
+    from pfst_amd.hostinfo import usable_cpus
+    from pfst_amd.optim import build_optimizer, poly_lr
+    from pfst_amd.presets import OPTIMIZER, workload_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import fill_state_dict, synth_batch
+
+    cfg, w = workload_cfg(WORKLOAD)
+    b = args.batch or w['per_gpu_batch']
+    S = args.size or w['size']
+    model = UDA.build(cfg)
+    fill_state_dict(model.state_dict(), 0)            # same seeded weights on every rank (DDP starts in sync)
+    model.to(dev)
+    opt = build_optimizer(model, OPTIMIZER)
+    batch = synth_batch(b, S, w['num_classes'], w['in_channels'], seed=1234 + rank, device=dev)
+
+    timer = KernelTimer(hip_ops.call)
+    hip_ops.call = timer.call
+
+    def step(it):
+        for g in opt.param_groups:
+            g['lr'] = poly_lr(OPTIMIZER['lr'], it, cfg['max_iters'])
+        return model.train_step(batch, opt)
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer.enabled = not args.no_kernel_timing
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(it)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        global_batch = b * world
+        value = global_batch * args.steps / elapsed
+        res = {
+            'metric': 'PFST train-step images/s on 1024^2 IRRG tiles', 'value': value, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': WORKLOAD, 'global_batch': global_batch, 'per_gpu_batch': b, 'tile': f'{S}x{S}x{w["in_channels"]}',
+                       'num_classes': w['num_classes'], 'parallelism': f'dp{world}', 'weights': 'seeded random init',
+                       'strong_aug': 'colour-jitter p=0.8 + gaussian-blur p=0.5 (HIP kernels)' if strong_aug.AVAILABLE else 'off (not implemented yet)',
+                       'dropout': 0.1},
+            'loss': out['log_vars'].get('decode.loss_ce'),
+        }
+        if not args.no_kernel_timing:
+            agg = timer.summary()
+            tot_ms = sum(v[1] for v in agg.values())
+            mfma = {k: v for k, v in agg.items() if v[2] > 0}
+            dom = max(mfma.items(), key=lambda kv: kv[1][1])
+            cnt, ms, fl = dom[1]
+            achieved = fl / (ms * 1e-3) / 1e12
+            res['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                               'launches': cnt, 'avg_launch_ms': ms / cnt,
+                               'algorithmic_flops_per_launch': fl / cnt}
+            all_fl = sum(v[2] for v in mfma.values())
+            all_ms = sum(v[1] for v in mfma.values())
+            res['mfma_all_convs'] = {'tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
+                                     'share_of_kernel_time': all_ms / tot_ms}
+            res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
+            res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(w['num_classes'], usable_cpus())
+        elif not args.no_cpu_baseline:
+            res['cpu_baseline'] = None   # measured at N=1 only
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

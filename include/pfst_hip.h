@@ -117,6 +117,14 @@ int pfst_class_mix(const float* img, const float* trg_img, const unsigned char* 
                    const unsigned char* mask, const unsigned long long* conf_count, float* mixed_img,
                    unsigned char* mixed_lbl, long long* mixed_lbl_i64, float* mixed_w, int N, int Cimg, long long HW, pfst_stream_t stream);
 
+/* ---- DACS strong augmentation of the mixed image (dacs_transforms.py:44-107; kornia arithmetic restated,
+ * parity unpinned).  params[n][8] = brightness, contrast, saturation, hue(rad), order[4] (0..3 = b,c,s,h) */
+int pfst_color_jitter(float* img, const float* params, const float* mean3, const float* std3, int N, long long HW,
+                      int denorm, pfst_stream_t stream);
+/* separable gaussian blur, reflect border; taps_*[n][K*] per image; taps farther than `reach` from the centre are skipped */
+int pfst_gaussian_blur(const float* x, float* tmp, float* y, const float* taps_y, int Ky, const float* taps_x, int Kx,
+                       int N, int C, int H, int W, int reach, pfst_stream_t stream);
+
 /* ---- PFGSTLoss (pfgst_loss.py:44-234), kernel 3x3, cosine similarity, top-k ------------------ */
 /* sim[n][k][y][x] = cos(f[n][:,y,x], f[n][:,y+dy_k,x+dx_k]) (0 outside); norm[n][y][x] = |f| */
 int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, float* sim, float* norm, pfst_stream_t stream);

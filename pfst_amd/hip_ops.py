@@ -420,3 +420,23 @@ def adamw_step_(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=1.0):
     assert g.numel() == n and m.numel() == n and v.numel() == n
     call('pfst_adamw_step', _dense(p).data_ptr(), _dense(g).data_ptr(), _dense(m).data_ptr(), _dense(v).data_ptr(), n, float(lr),
          float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+# ---------------------------------------------------------------- strong augmentation
+def color_jitter_(img, params, mean3, std3, denorm=True):
+    _dense(img)
+    n, c, h, w = img.shape
+    assert c == 3 and tuple(params.shape) == (n, 8)
+    call('pfst_color_jitter', img.data_ptr(), _dense(params).data_ptr(), _dense(mean3).data_ptr(), _dense(std3).data_ptr(),
+         n, h * w, int(denorm), _stream())
+    return img
+
+
+def gaussian_blur(img, taps_y, taps_x, reach):
+    _dense(img)
+    n, c, h, w = img.shape
+    assert taps_y.shape[0] == n and taps_x.shape[0] == n
+    tmp, out = torch.empty_like(img), torch.empty_like(img)
+    call('pfst_gaussian_blur', img.data_ptr(), tmp.data_ptr(), out.data_ptr(), _dense(taps_y).data_ptr(), taps_y.shape[1],
+         _dense(taps_x).data_ptr(), taps_x.shape[1], n, c, h, w, int(reach), _stream())
+    return out

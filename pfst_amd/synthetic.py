@@ -32,7 +32,11 @@ def fill_state_dict(sd, seed=0):
     depend only on (seed, position, shape): kaiming-like conv weights, N(0, .01) classifier,
     BN gamma in [.6, 1.4], beta ~ .2 N, running stats reset.  Used so the reference run that made
     the golden vectors, the oracle and the HIP product all start from bit-identical weights."""
-    for i, (k, v) in enumerate(sd.items()):
+    i = -1
+    for k, v in sd.items():
+        if not torch.is_tensor(v):          # e.g. PFGST's `_extra_state`: not a reference key, no position
+            continue
+        i += 1
         g = torch.Generator().manual_seed(seed * 100003 + i)
         with torch.no_grad():
             if k.endswith('num_batches_tracked'):
