@@ -87,6 +87,9 @@ int pfst_global_avgpool(const float* x, long long x_bs, float* y, int N, int C, 
 int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, pfst_stream_t stream);
 /* v[n][c] = sum_hw dy[n][c][hw]  (adjoint of the 1x1 -> HxW bilinear broadcast) */
 int pfst_reduce_hw(const float* dy, long long dy_bs, float* v, int N, int C, int HW, pfst_stream_t stream);
+/* F.interpolate(mode='nearest') by an integer factor on [NC][h][w] maps and its adjoint (pfgst_loss.py:57-58) */
+int pfst_upsample_nearest(const float* x, float* y, int NC, int h, int w, int factor, pfst_stream_t stream);
+int pfst_upsample_nearest_bwd(const float* dy, float* dx, int NC, int h, int w, int factor, pfst_stream_t stream);
 /* nn.Dropout2d (decode_head.py:103-107): y = x * mask[n][c] */
 int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream);
 

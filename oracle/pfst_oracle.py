@@ -288,7 +288,7 @@ def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2,
     unfold = lambda t: F.unfold(t, k, dilation=dil, padding=(k // 2) * dil)
     kk = k * k
     if downscale is not None:
-        logits_trg = F.interpolate(logits_trg, scale_factor=(downscale, downscale))
+        logits_trg = F.interpolate(logits_trg, scale_factor=(float(downscale), float(downscale)))
         x_ema = F.interpolate(x_ema, size=logits_trg.shape[2:])
         x_src = F.interpolate(x_src, size=logits_trg.shape[2:])
     B, C, H, W = logits_trg.shape
@@ -355,7 +355,7 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False):
+                 blur=False, downscale=0.5):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -366,6 +366,7 @@ class OraclePFGST:
         self.alpha, self.tau, self.trg_w = alpha, pseudo_threshold, trg_loss_weight
         self.aux_w = aux_weights or DEFAULT_LOSS_W
         self.blur = blur
+        self.downscale = downscale
         self.local_iter = 0
 
     def train_step(self, batch, masks=None, drop_masks=None, return_extras=False, pseudo_override=None):
@@ -396,7 +397,7 @@ class OraclePFGST:
             self.student, mixed_img, mixed_lbl, mixed_w, dm.get('mix', (None, None)))
         mix_loss, lv = parse_losses(OrderedDict(('mix.' + k, v) for k, v in mlosses.items()))
         lv.pop('loss'); log.update(lv)
-        aux, extras = pfgst_loss(mix_logits, ema_dec, src_dec, gt, masks, self.aux_w)
+        aux, extras = pfgst_loss(mix_logits, ema_dec, src_dec, gt, masks, self.aux_w, downscale=self.downscale)
         aux_loss, lv = parse_losses(aux)
         lv.pop('loss'); log.update(lv)
         total = clean_loss + self.trg_w * mix_loss + aux_loss

@@ -156,6 +156,26 @@ __global__ void channel_scale_kernel(const float* __restrict__ x, const float* _
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) y[base + i] = x[base + i] * m;
 }
 
+// ---- integer-factor nearest up-sampling of small maps and its adjoint (F.interpolate(mode='nearest'),
+// pfgst_loss.py:57-58 when downscale == 1: features at 1/8 are resized to the 1/4 logits grid)
+__global__ void upsample_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int u) {
+  const int nc = blockIdx.y, H = h * u, W = w * u;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < H * W; o += gridDim.x * blockDim.x) {
+    const int oy = o / W, ox = o - oy * W;
+    y[(i64)nc * H * W + o] = x[(i64)nc * h * w + (oy / u) * w + ox / u];
+  }
+}
+__global__ void upsample_nearest_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w, int u) {
+  const int nc = blockIdx.y, W = w * u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < h * w; i += gridDim.x * blockDim.x) {
+    const int iy = i / w, ix = i - iy * w;
+    float acc = 0.f;
+    for (int a = 0; a < u; ++a)
+      for (int b = 0; b < u; ++b) acc += dy[(i64)nc * h * u * W + (i64)(iy * u + a) * W + ix * u + b];
+    dx[(i64)nc * h * w + i] = acc;
+  }
+}
+
 inline int hw_blocks(int HW) {
   int g = cdiv(HW, 256 * 4);
   return g < 1 ? 1 : g;
@@ -241,6 +261,19 @@ extern "C" int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N
 extern "C" int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && mask && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   hipLaunchKernelGGL(channel_scale_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, x, mask, y, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_upsample_nearest(const float* x, float* y, int NC, int h, int w, int factor, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && NC > 0 && NC <= 65535 && h > 0 && w > 0 && factor >= 1);
+  hipLaunchKernelGGL(upsample_nearest_kernel, dim3(hw_blocks(h * w * factor * factor), NC), dim3(256), 0, (hipStream_t)stream, x, y, h, w, factor);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_upsample_nearest_bwd(const float* dy, float* dx, int NC, int h, int w, int factor, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && dx && NC > 0 && NC <= 65535 && h > 0 && w > 0 && factor >= 1);
+  hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(hw_blocks(h * w), NC), dim3(256), 0, (hipStream_t)stream, dy, dx, h, w, factor);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

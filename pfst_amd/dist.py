@@ -1,0 +1,50 @@
+"""Data-parallel exchange of the PFST step: ONE flat gradient arena + ONE packed log vector per step.
+
+Reference: mmcv MMDistributedDataParallel's bucketed gradient all-reduce fired from `total_loss.backward()`
+(rsiseg/apis/train.py:104-112, pfgst.py:344) and the 20 tiny all-reduces of `_parse_losses` (base.py:205-220).
+Here: the student gradient already lives in one contiguous 174.3 MB fp32 buffer, so the exchange is a few large
+RCCL all-reduces over xGMI (slices keep RCCL's staging bounded); the EMA teacher is rank-local and never reduced.
+Backend-agnostic on purpose (nccl == RCCL on the GPUs, gloo in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+SLICE_ELEMS = 16 * 1024 * 1024      # 64 MB per collective
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_mean_(flat, group=None, slice_elems=SLICE_ELEMS):
+    """In-place mean over ranks of a flat tensor (DDP gradient semantics)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    assert flat.dim() == 1 and flat.is_contiguous()
+    use_avg = dist.get_backend(group) == 'nccl'
+    op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+    n = flat.numel()
+    for beg in range(0, n, slice_elems):
+        dist.all_reduce(flat[beg:min(n, beg + slice_elems)], op=op, group=group)
+    if not use_avg:
+        flat.mul_(1.0 / world)
+    return flat
+
+
+def reduce_log_vector(packed, group=None):
+    """Mean over ranks of the packed per-step scalars (what `_parse_losses` does key by key)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return packed
+    dist.all_reduce(packed, group=group)
+    return packed / world
+
+
+def check_same_keys(names, group=None):
+    """The reference asserts that every rank logs the same number of variables (base.py:205-212) to avoid
+    hangs; here the check is folded into the packed vector's length via a single int all-reduce at start-up."""
+    t = torch.tensor([len(names)], dtype=torch.int64)
+    if dist.get_backend(group) == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, group=group)
+    assert int(t.item()) == len(names) * dist.get_world_size(group), 'loss log variables are different across GPUs!'

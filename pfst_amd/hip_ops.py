@@ -253,6 +253,22 @@ def broadcast_hw(v, out, scale=1.0, accumulate=False):
     return out
 
 
+def upsample_nearest(x, factor):
+    _dense(x)
+    n, c, h, w = x.shape
+    y = torch.empty(n, c, h * factor, w * factor, device=x.device)
+    call('pfst_upsample_nearest', x.data_ptr(), y.data_ptr(), n * c, h, w, factor, _stream())
+    return y
+
+
+def upsample_nearest_bwd(dy, factor):
+    _dense(dy)
+    n, c, H, W = dy.shape
+    dx = torch.empty(n, c, H // factor, W // factor, device=dy.device)
+    call('pfst_upsample_nearest_bwd', dy.data_ptr(), dx.data_ptr(), n * c, H // factor, W // factor, factor, _stream())
+    return dx
+
+
 def channel_scale(x, mask):
     _dense(x)
     n, c, h, w = x.shape

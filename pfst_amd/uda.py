@@ -16,9 +16,9 @@ from copy import deepcopy
 
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.nn as nn
 
+from . import dist as pdist
 from . import hip_ops as ops
 from .engine import ParamArena, Tape, Var
 from .registry import LOSSES, UDA, build_loss, build_segmentor
@@ -33,7 +33,7 @@ class PFGSTLoss(nn.Module):
         bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type != 'cosine', feat_level=feat_level is not None,
                    src_perc=src_perc is not None, proj_net=proj_net_cfg is not None, src_loss_type=src_loss_type != 'mean_std',
                    detach_unfold=not detach_unfold, cross_prob_type=cross_prob_type != 'trg',
-                   downscale=downscale not in (0.5,), top_k=top_k is None or not (1 <= top_k <= 4),
+                   downscale=downscale not in (0.5, 1, 1.0), top_k=top_k is None or not (1 <= top_k <= 4),
                    weights=not isinstance(weights, dict))
         bad = [k for k, v in bad.items() if v]
         if bad:
@@ -49,10 +49,21 @@ class PFGSTLoss(nn.Module):
         d, w = self.dilation, self.weights
         n, c, h, wd = lt.data.shape
         H, W = h // self.ds, wd // self.ds
-        assert x_ema.data.shape[-2:] == (H, W) and x_src.data.shape[-2:] == (H, W), \
-            'features must already be at the down-scaled logits resolution (nearest resize would be the identity)'
-        ema_sim, _ = ops.sim_map(x_ema.data, d)
-        src_sim, src_norm = ops.sim_map(x_src.data, d)
+        # F.interpolate(x, size=(H, W)) nearest (pfgst_loss.py:57-58): identity for downscale 0.5; for downscale 1 the
+        # 1/8 features are replicated u x u onto the 1/4 grid, where a dilation-d neighbourhood is EXACTLY the
+        # dilation-d/u neighbourhood of the source grid -- so the similarity is computed at the source resolution
+        # and only the tiny 9-channel map is replicated (its adjoint is a u x u sum).
+        hf, wf = x_src.data.shape[-2:]
+        assert x_ema.data.shape[-2:] == (hf, wf) and H % hf == 0 and H // hf == W // wf
+        u = H // hf
+        if d % u != 0:
+            raise NotImplementedError(f'PFGSTLoss: dilation {d} not divisible by the feature up-sampling factor {u}')
+        fd = d // u
+        ema_sim, _ = ops.sim_map(x_ema.data, fd)
+        src_sim_f, src_norm = ops.sim_map(x_src.data, fd)
+        src_sim = src_sim_f
+        if u > 1:
+            ema_sim, src_sim = ops.upsample_nearest(ema_sim, u), ops.upsample_nearest(src_sim_f, u)
         l4, gsim = ops.src_sim_losses(src_sim, gt8, d, w['src_pos'], w['src_neg'], w['src_pos_std'], w['src_neg_std'])
         prob = ops.softmax_down(lt.data, self.ds)
         valid, all9, cnt = ops.trg_valid_mask(gt8, mm8, (H, W), d)
@@ -60,7 +71,8 @@ class PFGSTLoss(nn.Module):
         if tape is not None:
             def bwd():
                 buf, acc = x_src.grad_target()
-                ops.sim_map_bwd(x_src.data, src_sim, src_norm, gsim, d, out=buf, accumulate=acc)
+                g_f = gsim if u == 1 else ops.upsample_nearest_bwd(gsim, u)
+                ops.sim_map_bwd(x_src.data, src_sim_f, src_norm, g_f, fd, out=buf, accumulate=acc)
                 buf, acc = lt.grad_target()
                 if not acc:
                     ops.fill_(buf, 0.0)
@@ -319,12 +331,11 @@ class PFGST(UDADecorator):
         # ---- gradient all-reduce (student only), log scalars packed into ONE vector
         names = list(scalars.keys())
         packed = torch.cat([scalars[k].reshape(1) for k in names])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            world = dist.get_world_size()
-            dist.all_reduce(arena.grad)
-            ops.axpy_(arena.grad, arena.grad, (1.0 / world) - 1.0)     # mean over ranks (DDP semantics)
-            dist.all_reduce(packed)
-            packed = packed / world
+        if pdist.is_distributed():
+            if self.local_iter == 0:
+                pdist.check_same_keys(names)
+            pdist.allreduce_mean_(arena.grad)          # student gradients only; the teacher stays rank-local
+            packed = pdist.reduce_log_vector(packed)
         vals = packed.cpu().tolist()                                      # the step's single blocking read
         log_vars = OrderedDict(zip(names, vals))
         log_vars['loss'] = sum(v for k, v in log_vars.items() if 'loss' in k)

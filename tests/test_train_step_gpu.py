@@ -144,3 +144,61 @@ def test_two_train_steps_match_reference_golden_and_oracle():
     assert rel(g, torch.from_numpy(gold['it0_grad|decode_head.conv_seg.weight'])) < 5 * TOL
     g = arena.view(arena.grad, 'backbone.stem.0.weight')
     assert rel(g, torch.from_numpy(gold['it0_grad|backbone.stem.0.weight'])) < 0.1   # fp32 conditioning, see above
+
+
+def test_pfgst_loss_downscale1_matches_oracle():
+    """SeasonNet setting (configs/pfst/pfst_season_net_sp2fa_*.py: downscale=1): 1/8 features resized to the 1/4 grid."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.engine import Tape, Var
+    from pfst_amd.registry import build_loss
+    from pfst_amd import hip_ops
+    g = torch.Generator().manual_seed(3)
+    B, C, S = 2, 33, 128
+    lt = (torch.randn(B, C, S // 4, S // 4, generator=g) * 2).requires_grad_()
+    xe = torch.randn(B, 24, S // 8, S // 8, generator=g)
+    xs = torch.randn(B, 24, S // 8, S // 8, generator=g).requires_grad_()
+    gts = torch.randint(0, C, (B, 1, 4, 4), generator=g).repeat_interleave(S // 4, 2).repeat_interleave(S // 4, 3)
+    gts[:, :, :8, :8] = 255
+    mm = (torch.rand(B, 1, 2, 2, generator=g) > 0.6).long().repeat_interleave(S // 2, 2).repeat_interleave(S // 2, 3)
+    ref, _ = O.pfgst_loss(lt, xe, xs, gts, mm, O.DEFAULT_LOSS_W, downscale=1)
+    sum(v.sum() for v in ref.values()).backward()
+    L = build_loss(dict(type='PFGSTLoss', kernel_size=3, dilation=2, top_k=3, weights=O.DEFAULT_LOSS_W, sim_type='cosine',
+                        feat_level=None, detach_unfold=True, downscale=1))
+    tape = Tape()
+    ltv, xsv = Var(lt.detach().cuda(), True), Var(xs.detach().cuda(), True)
+    out = L(dict(logits_trg=ltv, x_ema=Var(xe.cuda()), x_src=xsv, gt_src=hip_ops.to_u8(gts.cuda()),
+                 mix_masks=hip_ops.to_u8(mm.cuda())), tape=tape)
+    tape.backward()
+    for k, v in ref.items():
+        assert abs(float(out[k]) - float(v.sum())) <= 1e-4 * max(abs(float(v.sum())), 1e-3), k
+    assert rel(xsv.grad, xs.grad) < TOL
+    assert rel(ltv.grad, lt.grad) < TOL
+
+
+def test_seasonnet_like_step_10band_33class():
+    """BASELINE config #5 shape (C=33, 10 input bands, downscale=1) at reduced size: one step vs the oracle."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = preset_cfg(33, 10, dropout=0.0, blur=False, color_jitter_probability=2.0, downscale=1, pseudo_threshold=0.05)
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 4, 33, 10)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 33, cin=10, seed=77)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.05, teacher_sd=teacher, downscale=1)
+    random.seed(5); np.random.seed(5)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(5); np.random.seed(5)
+    model.debug = {}
+    model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    for k, v in olog.items():
+        assert abs(out['log_vars'][k] - v) <= TOL * max(abs(v), 1e-2), (k, out['log_vars'][k], v)
+    assert rel(model.debug['mix_logits'], ex['mix_logits']) < TOL
+    assert (model.debug['own_pseudo_label'].cpu() != ex['pseudo_label']).float().mean() < 5e-3
