@@ -199,6 +199,8 @@ def test_seasonnet_like_step_10band_33class():
     model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
     out = model.train_step(to_dev(batch, 'cuda'), opt)
     for k, v in olog.items():
-        assert abs(out['log_vars'][k] - v) <= TOL * max(abs(v), 1e-2), (k, out['log_vars'][k], v)
+        # acc_seg counts arg-max hits: a handful of near-tie pixels (of 32768) may flip -> absolute slack of 10 pixels
+        tol = 100.0 * 10 / (2 * 128 * 128) if k.endswith('acc_seg') else TOL * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
     assert rel(model.debug['mix_logits'], ex['mix_logits']) < TOL
     assert (model.debug['own_pseudo_label'].cpu() != ex['pseudo_label']).float().mean() < 5e-3
