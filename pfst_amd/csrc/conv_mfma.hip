@@ -15,13 +15,14 @@
 //   tile with register-staged prefetch (one barrier per step).
 #include "common.h"
 #include "../../include/pfst_hip.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr int BN = 128;  // pixels per block tile
-constexpr int BK = 16;   // K per step
+constexpr int BK_MIN = 16;  // K granularity of the wave-uniform-tap fast path (Cin % 16 == 0)
 
 __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, int div, int lim, int& s) {
   int v = o * a + t * b + c0;
@@ -33,7 +34,7 @@ __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, in
   return v >= 0 && v < lim;
 }
 
-template <int BM, bool GENERIC>
+template <int BM, bool GENERIC, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ in, i64 in_bs, const float* __restrict__ wk, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
       areg[i] = (amvalid && k < K) ? wk[(i64)k * M + m0 + am] : 0.f;
     }
     if (!GENERIC) {
-      // C % 16 == 0: the whole K-slice shares one tap (wave-uniform address arithmetic)
+      // C % BK == 0: the whole K-slice shares one tap (wave-uniform address arithmetic)
       const int tap = k0 / C, ci0 = k0 - tap * C;
       const int ty = tap / ks, tx = tap - ty * ks;
       int sy, sx;
@@ -184,6 +185,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   extern __shared__ float smem[];
   float(*As)[BM][WLD] = reinterpret_cast<float(*)[BM][WLD]>(smem);
   float(*Bs)[WBJ][WLD] = reinterpret_cast<float(*)[WBJ][WLD]>(smem + 2 * BM * WLD);
+  // per-column (j = ci*T + tap) gather descriptors, decoded ONCE per block: {channel offset, dy, dx}
+  int* jtab = reinterpret_cast<int*>(smem + 2 * (BM + WBJ) * WLD);   // [WBJ][2]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -196,6 +199,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   x += (i64)n * x_bs;
   dy += (i64)n * dy_bs;
 
+  if (tid < WBJ) {
+    const int j = j0 + tid;
+    int coff = -1, pk = 0;
+    if (j < J) {
+      const int ci = j / T, tap = j - ci * T;
+      const int ty = tap / KS, tx = tap - ty * KS;
+      coff = ci * HiWi;
+      pk = ((ty * dil - pad) << 16) | ((tx * dil - pad) & 0xffff);
+    }
+    jtab[2 * tid] = coff;
+    jtab[2 * tid + 1] = pk;
+  }
+  __syncthreads();
+
   const int kcol = tid & 31, r0 = tid >> 5;
   float areg[A_N], breg[B_N];
   f32x16 acc[TM][TN];
@@ -206,10 +223,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto load_tile = [&](int pk) {
-    const int p = pk + kcol;
+  auto load_tile = [&](int pk0) {
+    const int p = pk0 + kcol;
     const bool pv = p < pend;
     const int oy = pv ? p / Wo : 0, ox = pv ? p - oy * Wo : 0;
+    const int by = oy * stride, bx = ox * stride;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int m = m0 + r0 + 8 * i;
@@ -217,15 +235,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     }
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
-      const int j = j0 + r0 + 8 * i;
-      float v = 0.f;
-      if (pv && j < J) {
-        const int ci = j / T, tap = j - ci * T;
-        const int ty = tap / KS, tx = tap - ty * KS;
-        const int sy = oy * stride + ty * dil - pad, sx = ox * stride + tx * dil - pad;
-        if (sy >= 0 && sy < Hi && sx >= 0 && sx < Wi) v = x[(i64)ci * HiWi + sy * Wi + sx];
-      }
-      breg[i] = v;
+      const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
+      const int sy = by + (e.y >> 16), sx = bx + (int)(short)(e.y & 0xffff);
+      const bool ok = pv && e.x >= 0 && (unsigned)sy < (unsigned)Hi && (unsigned)sx < (unsigned)Wi;
+      breg[i] = ok ? x[(i64)e.x + sy * Wi + sx] : 0.f;
     }
   };
   auto store_tile = [&](int buf) {
@@ -309,8 +322,14 @@ template <int BM, bool G>
 int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
                  int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, BN), cdiv(M, BM), N);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, G>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                     Ho, Wo, ks, a, b, c, d, acc);
+  static const int bk_env = getenv("PFST_IGEMM_BK") ? atoi(getenv("PFST_IGEMM_BK")) : 0;   // tuning knob
+  const bool bk32 = !G && (C % 32 == 0) && bk_env == 32;   // measured: BK=16 (3 blocks/CU) beats BK=32 by ~2 %
+  if (bk32)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 32>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                       Ho, Wo, ks, a, b, c, d, acc);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                       Ho, Wo, ks, a, b, c, d, acc);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -326,7 +345,7 @@ int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
-  const size_t lds = (size_t)2 * (BM + WBJ) * WLD * sizeof(float);
+  const size_t lds = (size_t)2 * (BM + WBJ) * WLD * sizeof(float) + (size_t)WBJ * 2 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BM, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -363,7 +382,7 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   hipStream_t s = (hipStream_t)stream;
-  const bool generic = (C % BK) != 0;
+  const bool generic = (C % BK_MIN) != 0;
 #define PFST_IGEMM(BM_)                                                                                             \
   return generic ? launch_igemm<BM_, true>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s) \
                  : launch_igemm<BM_, false>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s)
