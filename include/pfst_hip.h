@@ -109,6 +109,11 @@ int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, int w, const 
 int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
                       long long* label_i64, unsigned char* label_u8, unsigned long long* count, pfst_stream_t stream);
 
+/* ---- evaluation: intersect_and_union (rsiseg/core/evaluation/metrics.py:26-86).  hist[3*C] (+)= per-class
+ * #intersect, #pred, #label over pixels whose label != ignore_index (caller zeroes hist once per evaluation) */
+int pfst_confusion_hist(const unsigned char* pred, const unsigned char* label, long long n, int C, int ignore_index,
+                        unsigned long long* hist, pfst_stream_t stream);
+
 /* ---- class mix (dacs_transforms.py:110-144, pfgst.py:281-300) ------------------------------- */
 /* presence[v] = 1 if label value v occurs (torch.unique over the batch) */
 int pfst_label_presence(const unsigned char* label, long long n, int* presence256, pfst_stream_t stream);

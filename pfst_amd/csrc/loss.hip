@@ -190,6 +190,26 @@ __global__ void class_mix_kernel(const float* __restrict__ img, const float* __r
   }
 }
 
+// confusion statistics of rsiseg/core/evaluation/metrics.py:26-86 (intersect_and_union):
+// hist[c] = #(pred==label==c), hist[C+c] = #(pred==c), hist[2C+c] = #(label==c), over pixels with label != ignore
+__global__ __launch_bounds__(256) void confusion_hist_kernel(const unsigned char* __restrict__ pred, const unsigned char* __restrict__ label,
+                                                             i64 n, int C, int ignore, unsigned long long* __restrict__ hist) {
+  extern __shared__ unsigned int sh[];   // [3*C]
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const int l = label[i];
+    if (l == ignore) continue;
+    const int p = pred[i];
+    if (p < C) atomicAdd(&sh[C + p], 1u);
+    if (l < C) atomicAdd(&sh[2 * C + l], 1u);
+    if (p == l && p < C) atomicAdd(&sh[p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x)
+    if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
 __global__ void ce_finalize_kernel(const double* __restrict__ acc, double numel, float loss_weight, float* __restrict__ out) {
   const double eps = 1.1920928955078125e-07;  // torch.finfo(float32).eps
   out[0] = (float)((double)loss_weight * (acc[0] / numel));
@@ -265,6 +285,15 @@ extern "C" int pfst_class_mix(const float* img, const float* trg_img, const unsi
 extern "C" int pfst_ce_finalize(const double* acc, double numel, float loss_weight, float* out, pfst_stream_t stream) {
   PFST_CHECK_ARG(acc && out && numel > 0);
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, numel, loss_weight, out);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_confusion_hist(const unsigned char* pred, const unsigned char* label, long long n, int C, int ignore_index,
+                                   unsigned long long* hist, pfst_stream_t stream) {
+  PFST_CHECK_ARG(pred && label && hist && n > 0 && C > 0 && C <= 255);
+  hipLaunchKernelGGL(confusion_hist_kernel, dim3(px_blocks(n)), dim3(256), 3 * C * sizeof(unsigned int), (hipStream_t)stream, pred,
+                     label, (i64)n, C, ignore_index, hist);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

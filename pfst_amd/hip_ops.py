@@ -456,3 +456,13 @@ def gaussian_blur(img, taps_y, taps_x, reach):
     call('pfst_gaussian_blur', img.data_ptr(), tmp.data_ptr(), out.data_ptr(), _dense(taps_y).data_ptr(), taps_y.shape[1],
          _dense(taps_x).data_ptr(), taps_x.shape[1], n, c, h, w, int(reach), _stream())
     return out
+
+
+# ---------------------------------------------------------------- evaluation
+def confusion_hist_(hist, pred_u8, label_u8, num_classes, ignore_index=255):
+    """hist: int64 [3*C] device tensor, accumulated in place."""
+    _dense(pred_u8, U8), _dense(label_u8, U8), _dense(hist, I64)
+    assert pred_u8.numel() == label_u8.numel() and hist.numel() == 3 * num_classes
+    call('pfst_confusion_hist', pred_u8.data_ptr(), label_u8.data_ptr(), pred_u8.numel(), num_classes, ignore_index,
+         hist.data_ptr(), _stream())
+    return hist

@@ -13,6 +13,19 @@ from .engine import Var
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+_BN_EVAL = False
+
+
+class bn_eval:
+    """`with bn_eval():` -- BatchNorm uses running statistics (model.eval() at test time, apis/test.py:60-116)."""
+
+    def __enter__(self):
+        global _BN_EVAL
+        self.prev, _BN_EVAL = _BN_EVAL, True
+
+    def __exit__(self, *a):
+        global _BN_EVAL
+        _BN_EVAL = self.prev
 
 
 class Conv2dP(nn.Module):
@@ -128,8 +141,12 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     else:
         pre = ops.conv_fprop(xd, conv.wf, conv.cout, conv.k, conv.stride, conv.dilation, conv.padding)
-    mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
-    bn._pending_batches += 1
+    if _BN_EVAL:
+        assert tape is None, 'eval-mode BN is inference only'
+        mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)
+    else:
+        mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+        bn._pending_batches += 1
     out_var = None
     if isinstance(out, Var):                       # slice of a concat Var
         out_var, out = out, out.data

@@ -11,7 +11,8 @@ import torch.nn as nn
 
 from . import hip_ops as ops
 from .engine import Var
-from .layers import BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, conv_bn_act, conv_forward
+from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, bn_eval, conv_bn_act,
+                     conv_forward)
 from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
 
 
@@ -343,6 +344,39 @@ class EncoderDecoder(nn.Module):
         logits, states = self.decode_head.forward_test(x, img_metas, self.test_cfg)
         states.update({'feats': x, 'seg_logits': logits})
         return logits, states
+
+    # ------------------------------------------------------------------ test time (encoder_decoder.py:265-353)
+    def inference(self, img, img_meta=None, rescale=True):
+        """whole-image inference in eval mode -> (argmax label map uint8 [N,H,W], low-res logits).  The softmax of the
+        reference (`F.softmax(seg_logit)` then `argmax`) does not change the arg-max, so the fused
+        upsample+softmax+argmax kernel is used."""
+        if self.test_cfg is not None and self.test_cfg.get('mode', 'whole') != 'whole':
+            raise NotImplementedError('slide inference is outside the PFST configs (test_cfg.mode="whole")')
+        self.repack_weights(need_dgrad=False)
+        with bn_eval():
+            x = self.extract_feat(img.contiguous(), None)
+            logits = self.decode_head(x, return_features=False, tape=None, training=False)
+        size = tuple(img.shape[2:])
+        if rescale and img_meta is not None and 'ori_shape' in img_meta[0]:
+            size = tuple(img_meta[0]['ori_shape'][:2])
+        _, lab8, _ = ops.pseudo_label(logits.data, size, 2.0, want_i64=False)
+        return lab8, logits.data
+
+    def simple_test(self, img, img_meta=None, rescale=True):
+        lab8, _ = self.inference(img, img_meta, rescale)
+        return list(lab8.cpu().numpy())
+
+    def forward_test(self, imgs, img_metas=None, **kwargs):
+        if isinstance(imgs, (list, tuple)):
+            if len(imgs) != 1:
+                raise NotImplementedError('aug_test (multi-scale / flip) is outside the PFST configs')
+            imgs, img_metas = imgs[0], (img_metas[0] if img_metas else None)
+        return self.simple_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_metas=None, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
 
     def forward_train(self, img, img_metas, gt_semantic_seg, seg_weight=None, return_feats=False,
                       return_decoded_feats=False, return_logits=False, return_states=False, tape=None, grad_scale=1.0):

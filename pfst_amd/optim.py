@@ -33,7 +33,14 @@ class AdamW(torch.optim.Optimizer):
                 if covered != a.numel:
                     loose.extend(plist)       # only part of the arena is optimised: per-tensor launches
                     continue
-                st = self._flat.setdefault(id(a), dict(m=torch.zeros_like(a.data), v=torch.zeros_like(a.data), step=0))
+                if id(a) not in self._flat:
+                    pend = getattr(self, '_pending_flat', None)
+                    if pend:
+                        p0 = pend.pop(0)
+                        self._flat[id(a)] = dict(m=p0['m'].to(a.data.device), v=p0['v'].to(a.data.device), step=p0['step'])
+                    else:
+                        self._flat[id(a)] = dict(m=torch.zeros_like(a.data), v=torch.zeros_like(a.data), step=0)
+                st = self._flat[id(a)]
                 st['step'] += 1
                 ops.adamw_step_(a.data, a.grad, st['m'], st['v'], group['lr'], group['betas'], group['eps'],
                                 group['weight_decay'], st['step'], self.grad_scale)
@@ -46,6 +53,18 @@ class AdamW(torch.optim.Optimizer):
                 st['step'] += 1
                 ops.adamw_step_(p.data, p.grad.contiguous(), st['m'], st['v'], group['lr'], group['betas'], group['eps'],
                                 group['weight_decay'], st['step'], self.grad_scale)
+
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd['pfst_flat'] = [dict(m=st['m'].cpu(), v=st['v'].cpu(), step=st['step']) for st in self._flat.values()]
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        flat = sd.pop('pfst_flat', [])
+        super().load_state_dict(sd)
+        self._pending_flat = flat       # attached to the arenas on the first step() after the model is on the GPU
 
 
 def build_optimizer(model, cfg):

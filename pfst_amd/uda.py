@@ -107,6 +107,15 @@ class UDADecorator(nn.Module):
     def encode_decode(self, img, img_metas):
         return self.get_model().encode_decode(img, img_metas)
 
+    def inference(self, img, img_meta=None, rescale=True):
+        return self.get_model().inference(img, img_meta, rescale)
+
+    def simple_test(self, img, img_meta=None, rescale=True):
+        return self.get_model().simple_test(img, img_meta, rescale)
+
+    def aug_test(self, imgs, img_metas, rescale=True):
+        raise NotImplementedError('aug_test is outside the PFST configs')
+
 
 def parse_losses(losses):
     """BaseSegmentor._parse_losses (base.py:177-222) on device scalars: returns (names, packed tensor, loss_mask).
@@ -224,7 +233,7 @@ class PFGST(UDADecorator):
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(img, img_metas, **kwargs)
-        raise NotImplementedError('test-time forward is outside the round-1 hot path (SURVEY.md §8 f2)')
+        return self.get_model().forward_test(img, img_metas, **kwargs)
 
     def forward_train(self, img, img_metas, gt_semantic_seg, target_img, target_img_metas, target_img_strong_aug):
         if not img.is_cuda:

@@ -1,0 +1,85 @@
+"""Test-time path and trainer glue (f1) on the GPU: whole-image inference in eval mode vs the oracle,
+confusion statistics / mIoU vs NumPy, checkpoint + resume of a short synthetic run."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import seeded_pfgst_state, uda_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_inference_eval_mode_and_miou():
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.evaluation import AreaAccumulator, evaluate, total_area_to_metrics
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    model = UDA.build(uda_cfg())
+    both, student, _ = seeded_pfgst_state(O, 9)
+    g = torch.Generator().manual_seed(1)
+    for k, v in both.items():                      # non-trivial running statistics
+        if k.endswith('running_mean'):
+            v.copy_(0.05 * torch.randn(v.shape, generator=g))
+        elif k.endswith('running_var'):
+            v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
+    student = {k[6:]: v for k, v in both.items() if k.startswith('model.')}
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    batch = synth_batch(2, 128, 6, seed=5)
+    with torch.no_grad():
+        feats = O.backbone_forward(student, batch['img'], train=False)
+        logits, _ = O.decode_head_forward(student, feats, train=False)
+        ref = F.interpolate(logits, size=(128, 128), mode='bilinear', align_corners=False).softmax(1).argmax(1)
+    out = model(batch['img'].cuda(), batch['img_metas'], return_loss=False)
+    pred = torch.from_numpy(np.stack(out)).long()
+    assert pred.shape == ref.shape
+    assert (pred != ref).float().mean() < 2e-3
+    lab8, low = model.inference(batch['img'].cuda())
+    assert float((low.cpu() - logits).abs().max() / logits.abs().max()) < 1e-3
+    # confusion statistics exact vs numpy on identical predictions
+    gt = batch['gt_semantic_seg'][:, 0]
+    acc = AreaAccumulator(6)
+    acc.update(lab8, gt.cuda())
+    inter, union, pa, la = acc.areas()
+    p, l = lab8.cpu().numpy().reshape(-1), gt.numpy().reshape(-1)
+    keep = l != 255
+    for c in range(6):
+        assert inter[c] == np.sum((p == c) & (l == c) & keep)
+        assert pa[c] == np.sum((p == c) & keep) and la[c] == np.sum((l == c) & keep)
+    m = total_area_to_metrics(inter, union, pa, la)
+    res = evaluate(model, [dict(img=batch['img'].cuda(), gt_semantic_seg=batch['gt_semantic_seg'].cuda())], 6)
+    assert abs(res['mIoU'] - 100 * np.nanmean(m['IoU'])) < 1e-9 and 0 <= res['aAcc'] <= 100
+
+
+def test_runner_checkpoint_resume(tmp_path):
+    import pfst_amd  # noqa: F401
+    from pfst_amd.config import Config
+    from pfst_amd.data import synthetic_loader
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import LR_CONFIG, OPTIMIZER
+    from pfst_amd.registry import UDA
+    from pfst_amd.runner import IterBasedRunner, find_latest_checkpoint
+
+    def make():
+        cfg = Config(dict(runner=dict(type='IterBasedRunner', max_iters=4), lr_config=dict(LR_CONFIG),
+                          log_config=dict(interval=2), checkpoint_config=dict(interval=2), optimizer=dict(OPTIMIZER)))
+        model = UDA.build(uda_cfg(threshold=0.3)).cuda()
+        opt = build_optimizer(model, cfg.optimizer)
+        return model, opt, IterBasedRunner(model, opt, cfg, str(tmp_path), log=lambda s: None)
+
+    model, opt, runner = make()
+    loader = synthetic_loader(2, 128, 6, device='cuda')
+    runner.run(loader, max_iters=2)
+    ck = find_latest_checkpoint(str(tmp_path))
+    assert ck and ck.endswith('latest.pth') and model.local_iter == 2
+    w_before = model.state_dict()['model.decode_head.conv_seg.weight'].cpu().clone()
+    model2, opt2, runner2 = make()
+    runner2.resume(ck)
+    assert runner2.iter == 2 and model2.local_iter == 2
+    assert torch.equal(model2.state_dict()['model.decode_head.conv_seg.weight'].cpu(), w_before)
+    runner2.run(loader, max_iters=4)
+    assert runner2.iter == 4 and model2.local_iter == 4
+    st = list(opt2._flat.values())[0]
+    assert st['step'] == 4            # Adam moments and step count survived the resume

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Train a PFST model on MI355X -- the flag surface of the reference's tools/train.py:23-107 on top of pfst_amd.
+
+  python tools/train.py configs/pfst/pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8.py --work-dir work_dirs/x
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
+
+The reference's dataset pipeline is out of scope: `--synthetic` trains on seeded synthetic tiles (benchmarks);
+otherwise `cfg.data.train.source/target` `img_dir`/`ann_dir` folders of converted ISPRS tiles are read by the
+minimal reader in pfst_amd/data.py."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description='Train a segmentor (pfst_amd)')
+    p.add_argument('config', help='train config file path (reference format) or a preset name from pfst_amd.presets')
+    p.add_argument('--work-dir')
+    p.add_argument('--load-from')
+    p.add_argument('--resume-from')
+    p.add_argument('--no-validate', action='store_true')
+    g = p.add_mutually_exclusive_group()
+    g.add_argument('--gpus', type=int)
+    g.add_argument('--gpu-ids', type=int, nargs='+')
+    g.add_argument('--gpu-id', type=int, default=0)
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--diff_seed', action='store_true')
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--options', nargs='+')
+    p.add_argument('--cfg-options', nargs='+')
+    p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none')
+    p.add_argument('--local_rank', '--local-rank', type=int, default=0)
+    p.add_argument('--auto-resume', action='store_true')
+    p.add_argument('--synthetic', action='store_true', help='seeded synthetic batches instead of cfg.data')
+    p.add_argument('--max-iters', type=int, default=None)
+    p.add_argument('--batch-size', type=int, default=None)
+    p.add_argument('--crop-size', type=int, default=None)
+    args = p.parse_args(argv)
+    if args.options and args.cfg_options:
+        raise ValueError('--options and --cfg-options cannot be both specified')
+    if args.options:
+        args.cfg_options = args.options
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['LOCAL_RANK'] = str(args.local_rank)
+    return args
+
+
+def load_cfg(args):
+    from pfst_amd.config import Config, parse_cfg_options
+    from pfst_amd.presets import LR_CONFIG, OPTIMIZER, WORKLOADS, workload_cfg
+    if os.path.exists(args.config):
+        cfg = Config.fromfile(args.config)
+    elif args.config in WORKLOADS:
+        uda, w = workload_cfg(args.config)
+        cfg = Config(dict(model=uda.pop('model'), uda=uda, optimizer=dict(OPTIMIZER), lr_config=dict(LR_CONFIG),
+                          runner=dict(type='IterBasedRunner', max_iters=40000), checkpoint_config=dict(by_epoch=False, interval=4000),
+                          evaluation=dict(interval=4000, metric='mIoU'), log_config=dict(interval=50),
+                          data=dict(samples_per_gpu=w['per_gpu_batch']), seed=0))
+    else:
+        raise FileNotFoundError(args.config)
+    if args.cfg_options:
+        cfg.merge_from_dict(parse_cfg_options(args.cfg_options))
+    if args.max_iters:
+        cfg.runner['max_iters'] = args.max_iters
+    return cfg
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    import torch
+    import torch.distributed as dist
+    import pfst_amd  # noqa: F401
+    from pfst_amd.data import ISPRSTiles, synthetic_loader, uda_loader
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.registry import build_train_model
+    from pfst_amd.runner import IterBasedRunner, find_latest_checkpoint, init_random_seed, set_random_seed
+
+    cfg = load_cfg(args)
+    distributed = args.launcher != 'none'
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local_rank if distributed else args.gpu_id)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group((cfg.get('dist_params') or {}).get('backend', 'nccl'), device_id=dev)
+    rank = dist.get_rank() if distributed else 0
+    world = dist.get_world_size() if distributed else 1
+    work_dir = args.work_dir or cfg.get('work_dir') or os.path.join('./work_dirs', os.path.splitext(os.path.basename(args.config))[0])
+    seed = init_random_seed(args.seed if args.seed is not None else cfg.get('seed'), dev)
+    seed = seed + rank if args.diff_seed else seed
+    set_random_seed(seed, args.deterministic)
+
+    if cfg.model.get('pretrained'):
+        print(f'note: pretrained={cfg.model.pretrained!r} is not downloadable here; use --load-from for a checkpoint')
+        cfg.model['pretrained'] = None
+    model = build_train_model(cfg)
+    model.init_weights()
+    model.to(dev)
+    optimizer = build_optimizer(model, cfg.optimizer)
+    runner = IterBasedRunner(model, optimizer, cfg, work_dir)
+    if args.load_from or cfg.get('load_from'):
+        runner.load_checkpoint(args.load_from or cfg.load_from)
+    resume = args.resume_from or cfg.get('resume_from')
+    if resume is None and args.auto_resume:
+        resume = find_latest_checkpoint(work_dir)
+    if resume:
+        runner.resume(resume)
+
+    nc = cfg.model.decode_head.num_classes
+    bs = args.batch_size or (cfg.get('data') or {}).get('samples_per_gpu', 2)
+    cin = cfg.model.backbone.get('in_channels', 3)
+    if args.synthetic or 'train' not in (cfg.get('data') or {}):
+        loader = synthetic_loader(bs, args.crop_size or 1024, nc, cin, seed=1234 + rank, device=dev)
+    else:
+        tr = cfg.data.train
+        crop = (args.crop_size,) * 2 if args.crop_size else (512, 512)
+        src = ISPRSTiles(os.path.join(tr.source.data_root, tr.source.img_dir), os.path.join(tr.source.data_root, tr.source.ann_dir), crop)
+        trg = ISPRSTiles(os.path.join(tr.target.data_root, tr.target.img_dir), None, crop)
+        loader = uda_loader(src, trg, bs, dev, seed, rank, world)
+    runner.run(iter(loader))
+    runner.save_checkpoint()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
