@@ -1,0 +1,58 @@
+"""Data-parallel train step rehearsed with 2 ranks sharing the one GPU of the test box (gloo backend moves the CUDA
+buffers; on the 8-GPU node the same code runs over RCCL): the reduced student gradient equals the mean of the
+per-rank single-process gradients, every rank ends the step with identical student weights, teachers stay local."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import seeded_pfgst_state, to_dev, uda_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _one_step(rank, seed_rng=True):
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    model = UDA.build(uda_cfg(threshold=0.30))
+    both, _, _ = seeded_pfgst_state(O, 9)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    random.seed(50 + rank); np.random.seed(50 + rank)
+    out = model.train_step(to_dev(synth_batch(2, 128, 6, seed=1234 + rank), 'cuda'), opt)
+    a = model.student_arena
+    return out, a.grad.clone().cpu(), a.data.clone().cpu(), model._teacher_arena.data.clone().cpu()
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out, grad, weights, teacher = _one_step(rank)
+    torch.save(dict(log=out['log_vars'], grad=grad, weights=weights, teacher=teacher), os.path.join(outdir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step(tmp_path):
+    port = 29600 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'r0.pt', weights_only=False)
+    r1 = torch.load(tmp_path / 'r1.pt', weights_only=False)
+    assert torch.equal(r0['grad'], r1['grad']), 'all ranks must hold the same reduced gradient'
+    assert torch.equal(r0['weights'], r1['weights']), 'all ranks must end the step with identical student weights'
+    assert r0['log'] == r1['log'], 'log_vars are averaged over ranks'
+    # single-process references for the two shards
+    (o0, g0, _, _), (o1, g1, _, _) = _one_step(0), _one_step(1)
+    mean = 0.5 * (g0 + g1)
+    err = float((r0['grad'].double() - mean.double()).norm() / mean.double().norm())
+    assert err < 1e-4, err
+    for k in o0['log_vars']:
+        assert abs(r0['log'][k] - 0.5 * (o0['log_vars'][k] + o1['log_vars'][k])) < 1e-4 * max(1.0, abs(r0['log'][k]))
