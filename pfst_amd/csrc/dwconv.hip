@@ -1,94 +1,201 @@
-// Depthwise 3x3 convolution, stride 1, padding = dilation (HBM-bound 9-tap stencil).
+// Depthwise 3x3 convolution, stride 1, padding = dilation: the HBM-bound dilated stencils of the ASPP head.
 // Reference: mmcv DepthwiseSeparableConvModule.depthwise_conv inside
 // rsiseg/models/decode_heads/sep_aspp_head.py:17-26 (ASPP, dilation 12/24/36) and :63-77 (sep_bottleneck).
 //
-// One workgroup owns a strip of rows of one (image, channel) plane.  The strip plus its two halo
-// row-bands is staged in LDS as three row-bands (top / middle / bottom taps) so each input element is
-// fetched from HBM/L2 once per band and every tap is an LDS read; rows are read with coalesced
-// 256-byte wave accesses.  The data gradient is the same stencil with mirrored taps.
+// Design (MI355X): one workgroup owns a strip of output rows of one (image, channel) plane and stages the strip
+// plus its +-dilation row halo in LDS with ONE contiguous, 16-byte-vectorised read (full rows are contiguous in NCHW,
+// so there is no index arithmetic in the copy).  With 160 KB of LDS per CU a 128x128 fp32 plane (64 KB) is staged
+// whole, which is what makes dilation 12/24/36 cheap: the halo (2d rows) would otherwise exceed the strip.  Every
+// input element is fetched from HBM exactly once; all 9 taps are LDS reads (ds_read_b128 when dilation % 4 == 0).
+// Algorithmic traffic = read plane + write plane = 8 B per output element.
+// The data gradient is the same stencil with mirrored taps; the weight gradient reuses the staging and reduces
+// 9 partial sums per block (wavefront shuffles, one atomic per tap per block).
 #include "common.h"
 #include "../../include/pfst_hip.h"
 
 namespace {
 
-constexpr int DW_ROWS = 8;  // output rows per workgroup
+constexpr int DW_LDS_BYTES = 64 * 1024;
 
-// LDS: 3 bands x DW_ROWS rows x W floats (W <= 1024 -> 96 KB max; typical 128/256 -> 12/24 KB)
-__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
-                                                        float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil,
+struct Strip { int y0, y1, lo, hi; };   // output rows [y0,y1), staged rows [lo,hi)
+
+__device__ __forceinline__ Strip make_strip(int strip_idx, int R, int H, int dil) {
+  Strip s;
+  s.y0 = strip_idx * R;
+  s.y1 = min(H, s.y0 + R);
+  s.lo = max(0, s.y0 - dil);
+  s.hi = min(H, s.y1 + dil);
+  return s;
+}
+
+// contiguous copy of rows [lo,hi) of one plane into LDS
+__device__ __forceinline__ void stage_rows(const float* __restrict__ plane, float* __restrict__ tile, int lo, int hi, int W) {
+  const int n = (hi - lo) * W;
+  const float* src = plane + (i64)lo * W;
+  if ((W & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) t4[i] = s4[i];
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = src[i];
+  }
+}
+
+// load 4 consecutive floats starting at column sx (any alignment, zero outside [0,W))
+template <bool ALIGNED>
+__device__ __forceinline__ float4 row4(const float* __restrict__ row, int sx, int W) {
+  if (ALIGNED) {
+    if (sx < 0 || sx >= W) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(row + sx);
+  }
+  float4 v;
+  v.x = (sx >= 0 && sx < W) ? row[sx] : 0.f;
+  v.y = (sx + 1 >= 0 && sx + 1 < W) ? row[sx + 1] : 0.f;
+  v.z = (sx + 2 >= 0 && sx + 2 < W) ? row[sx + 2] : 0.f;
+  v.w = (sx + 3 >= 0 && sx + 3 < W) ? row[sx + 3] : 0.f;
+  return v;
+}
+
+// MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation
+template <int MODE>
+__global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
+                                                        float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
                                                         int flip, int accumulate) {
-  extern __shared__ float tile[];  // [3][DW_ROWS][W]
+  extern __shared__ float tile[];
   const int c = blockIdx.y, n = blockIdx.z;
-  const int y0 = blockIdx.x * DW_ROWS;
+  const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
   float* yp = y + (i64)n * y_bs + (i64)c * H * W;
   float wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
-  const int rows = min(DW_ROWS, H - y0);
-  // stage the three row bands (zero-filled outside the image)
-  for (int band = 0; band < 3; ++band) {
-    const int dy = (band - 1) * dil;
-    for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
-      const int r = i / W, col = i - r * W;
-      const int sy = y0 + r + dy;
-      tile[(band * DW_ROWS + r) * W + col] = (sy >= 0 && sy < H) ? xp[(i64)sy * W + col] : 0.f;
-    }
-  }
+  stage_rows(xp, tile, s.lo, s.hi, W);
   __syncthreads();
-  for (int i = threadIdx.x; i < rows * W; i += blockDim.x) {
-    const int r = i / W, col = i - r * W;
-    float acc = 0.f;
+  if (MODE != 0) {
+    const int W4 = W >> 2;
+    const int total = (s.y1 - s.y0) * W4;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int r = i / W4, c4 = i - r * W4;
+      const int yy = s.y0 + r;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const float* row = tile + (ty * DW_ROWS + r) * W;
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + (sy - s.lo) * W;
 #pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        const int sx = col + (tx - 1) * dil;
-        const float v = (sx >= 0 && sx < W) ? row[sx] : 0.f;
-        acc = fmaf(wt[ty * 3 + tx], v, acc);
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 v = row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
+          const float k = wt[ty * 3 + tx];
+          acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
+        }
       }
+      float4* out = reinterpret_cast<float4*>(yp + (i64)yy * W) + c4;
+      if (accumulate) { const float4 o = *out; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+      *out = acc;
     }
-    const i64 o = (i64)(y0 + r) * W + col;
-    yp[o] = accumulate ? yp[o] + acc : acc;
+  } else {
+    const int total = (s.y1 - s.y0) * W;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int r = i / W, col = i - r * W;
+      const int yy = s.y0 + r;
+      float acc = 0.f;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + (sy - s.lo) * W;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int sx = col + (tx - 1) * dil;
+          if (sx >= 0 && sx < W) acc = fmaf(wt[ty * 3 + tx], row[sx], acc);
+        }
+      }
+      const i64 o = (i64)yy * W + col;
+      yp[o] = accumulate ? yp[o] + acc : acc;
+    }
   }
 }
 
-// dw[c][t] += sum_{n,p} dy[n][c][p] * x[n][c][p + off(t)]
-__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy,
-                                                              i64 dy_bs, float* __restrict__ dw, int C, int H, int W, int dil) {
-  __shared__ float red[4][9];
-  const int c = blockIdx.x, n = blockIdx.y;
+// dw[c][t] += sum_{n,p} dy[n][c][p] * x[n][c][p + off(t)]     VEC: W % 4 == 0 and 16-byte aligned planes
+template <bool VEC, bool ALIGNED>
+__global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy,
+                                                              i64 dy_bs, float* __restrict__ dw, int C, int H, int W, int dil, int R) {
+  extern __shared__ float tile[];
+  __shared__ float red[8][9];
+  const int c = blockIdx.y, n = blockIdx.z;
+  const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
   const float* gp = dy + (i64)n * dy_bs + (i64)c * H * W;
+  stage_rows(xp, tile, s.lo, s.hi, W);
+  __syncthreads();
   float acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = 0.f;
-  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
-    const int r = i / W, col = i - r * W;
-    const float g = gp[i];
+  if (VEC) {
+    const int W4 = W >> 2;
+    const int total = (s.y1 - s.y0) * W4;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int r = i / W4, c4 = i - r * W4;
+      const int yy = s.y0 + r;
+      const float4 g = *(reinterpret_cast<const float4*>(gp + (i64)yy * W) + c4);
 #pragma unroll
-    for (int ty = 0; ty < 3; ++ty) {
-      const int sy = r + (ty - 1) * dil;
-      if (sy < 0 || sy >= H) continue;
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + (sy - s.lo) * W;
 #pragma unroll
-      for (int tx = 0; tx < 3; ++tx) {
-        const int sx = col + (tx - 1) * dil;
-        if (sx >= 0 && sx < W) acc[ty * 3 + tx] = fmaf(g, xp[(i64)sy * W + sx], acc[ty * 3 + tx]);
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 v = row4<ALIGNED>(row, c4 * 4 + (tx - 1) * dil, W);
+          acc[ty * 3 + tx] += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+        }
+      }
+    }
+  } else {
+    const int total = (s.y1 - s.y0) * W;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+      const int r = i / W, col = i - r * W;
+      const int yy = s.y0 + r;
+      const float g = gp[(i64)yy * W + col];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + (sy - s.lo) * W;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int sx = col + (tx - 1) * dil;
+          if (sx >= 0 && sx < W) acc[ty * 3 + tx] = fmaf(g, row[sx], acc[ty * 3 + tx]);
+        }
       }
     }
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const float s = wave_sum(acc[t]);
-    if (lane == 0) red[wid][t] = s;
+    const float v = wave_sum(acc[t]);
+    if (lane == 0) red[wid][t] = v;
   }
   __syncthreads();
   if (threadIdx.x < 9) {
-    const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    atomicAdd(&dw[c * 9 + threadIdx.x], s);
+    float v = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += red[k][threadIdx.x];
+    atomicAdd(&dw[c * 9 + threadIdx.x], v);
   }
+}
+
+// rows per strip so that (R + 2*dil) * W floats fit the LDS budget; whole plane when it fits
+inline int strip_rows(int H, int W, int dil) {
+  if ((i64)H * W * 4 <= DW_LDS_BYTES) return H;
+  int rows = DW_LDS_BYTES / (W * 4) - 2 * dil;
+  if (rows < 1) rows = 1;
+  return rows < H ? rows : H;
+}
+
+inline size_t strip_lds(int R, int H, int W, int dil) {
+  i64 rows = (i64)R + 2 * dil;
+  if (rows > H) rows = H;
+  return (size_t)rows * W * sizeof(float);
 }
 
 }  // namespace
@@ -96,27 +203,55 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const float* __res
 extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
                               int N, int C, int H, int W, int dil, int flip, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
-  PFST_CHECK_ARG(x_bs >= (i64)C * H * W && y_bs >= (i64)C * H * W && C <= 65535 && N <= 65535 && W <= 4096);
-  const size_t lds = (size_t)3 * DW_ROWS * W * sizeof(float);
-  PFST_CHECK_ARG(lds <= 160 * 1024);
-  if (lds > 64 * 1024) {
-    static bool set = false;
-    if (!set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      set = true;
-    }
+  PFST_CHECK_ARG(x_bs >= (i64)C * H * W && y_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
+  const int R = strip_rows(H, W, dil);
+  const size_t lds = strip_lds(R, H, W, dil);
+  PFST_CHECK_ARG(lds <= 150 * 1024);
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    set = true;
   }
-  dim3 grid(cdiv(H, DW_ROWS), C, N);
-  hipLaunchKernelGGL(dwconv3x3_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, x_bs, w, y, y_bs, C, H, W, dil, flip, accumulate);
+  const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0) && (x_bs % 4 == 0) && (y_bs % 4 == 0) &&
+                   (((i64)H * W) % 4 == 0);
+  const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : 2);
+  dim3 grid(cdiv(H, R), C, N);
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1)
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
+  else if (mode == 2)
+    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
+  else
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 extern "C" int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
                                     int N, int C, int H, int W, int dil, pfst_stream_t stream) {
-  PFST_CHECK_ARG(x && dy && dw && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1 && N <= 65535);
-  dim3 grid(C, N);
-  hipLaunchKernelGGL(dwconv3x3_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, dy, dy_bs, dw, C, H, W, dil);
+  PFST_CHECK_ARG(x && dy && dw && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1 && N <= 65535 && C <= 65535);
+  const int R = strip_rows(H, W, dil);
+  const size_t lds = strip_lds(R, H, W, dil);
+  PFST_CHECK_ARG(lds <= 150 * 1024);
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    set = true;
+  }
+  const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0) && (x_bs % 4 == 0) && (dy_bs % 4 == 0) &&
+                   (((i64)H * W) % 4 == 0);
+  dim3 grid(cdiv(H, R), C, N);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec && dil % 4 == 0)
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+  else if (vec)
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+  else
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
