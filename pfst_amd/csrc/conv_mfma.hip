@@ -24,14 +24,12 @@ namespace {
 constexpr int BN = 128;  // pixels per block tile
 constexpr int BK_MIN = 16;  // K granularity of the wave-uniform-tap fast path (Cin % 16 == 0)
 
+// source coordinate of output index o for tap t: (o*a + t*b + c0) / div, div in {1,2}; branch-free validity
 __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, int div, int lim, int& s) {
-  int v = o * a + t * b + c0;
-  if (div == 2) {
-    if (v & 1) return false;
-    v >>= 1;
-  }
-  s = v;
-  return v >= 0 && v < lim;
+  const int v = o * a + t * b + c0;
+  const int odd = v & (div - 1);
+  s = v >> (div >> 1);
+  return (odd == 0) & (s >= 0) & (s < lim);
 }
 
 template <int BM, bool GENERIC, int BK>
@@ -77,43 +75,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // (tap, first channel) of the K-slice being prefetched, advanced incrementally (no divisions in the loop)
+  int ld_ty = 0, ld_tx = 0, ld_ci0 = 0;
+  const int amc = min(m0 + am, M - 1);
+  unsigned a_mask = 0, b_mask = 0;   // validity of the prefetched registers; applied when they are written to LDS so
+                                     // that nothing consumes a load result before the MFMA phase (latency overlap)
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
+    a_mask = GENERIC ? 0u : 0xffffffffu;
+    b_mask = 0;
+    // all loads are unconditional (clamped addresses): the 16 loads of a step stay in one basic block
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int k = k0 + ar0 + i * A_RPP;
-      areg[i] = (amvalid && k < K) ? wk[(i64)k * M + m0 + am] : 0.f;
+      const int kc = GENERIC ? min(k, K - 1) : k;
+      areg[i] = wk[(i64)kc * M + amc];
+      if (GENERIC) a_mask |= (unsigned)(k < K) << i;
     }
     if (!GENERIC) {
       // C % BK == 0: the whole K-slice shares one tap (wave-uniform address arithmetic)
-      const int tap = k0 / C, ci0 = k0 - tap * C;
-      const int ty = tap / ks, tx = tap - ty * ks;
       int sy, sx;
-      const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
-      const float* src = in + (i64)(ci0 + br0) * HiWi + (ok ? sy * Wi + sx : 0);
+      const bool ok = pvalid & src_coord(oy, ld_ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, ld_tx, ca, cb, cc, cdivv, Wi, sx);
+      const float* src = in + (i64)(ld_ci0 + br0) * HiWi + (ok ? sy * Wi + sx : 0);
 #pragma unroll
-      for (int i = 0; i < B_N; ++i) breg[i] = ok ? src[(i64)(2 * i) * HiWi] : 0.f;
+      for (int i = 0; i < B_N; ++i) breg[i] = src[(i64)(2 * i) * HiWi];
+      b_mask = ok ? 0xffffffffu : 0u;
+      ld_ci0 += BK;
+      if (ld_ci0 >= C) { ld_ci0 = 0; ld_tx += 1; if (ld_tx == ks) { ld_tx = 0; ld_ty += 1; } }
     } else {
 #pragma unroll
       for (int i = 0; i < B_N; ++i) {
         const int k = k0 + br0 + 2 * i;
-        float v = 0.f;
-        if (pvalid && k < K) {
-          const int tap = k / C, ci = k - tap * C;
-          const int ty = tap / ks, tx = tap - ty * ks;
-          int sy, sx;
-          if (src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) && src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx))
-            v = in[(i64)ci * HiWi + sy * Wi + sx];
-        }
-        breg[i] = v;
+        const int kc = min(k, K - 1);
+        const int tap = kc / C, ci = kc - tap * C;
+        const int ty = tap / ks, tx = tap - ty * ks;
+        int sy, sx;
+        const bool ok = pvalid & (k < K) & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+        breg[i] = in[(i64)ci * HiWi + (ok ? sy * Wi + sx : 0)];
+        b_mask |= (unsigned)ok << i;
       }
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = areg[i];
+    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = (amvalid && ((a_mask >> i) & 1u)) ? areg[i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + 2 * i][bj] = breg[i];
+    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + 2 * i][bj] = ((b_mask >> i) & 1u) ? breg[i] : 0.f;
   };
 
   load_tile(0);
@@ -223,29 +230,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  unsigned a_mask = 0, b_mask = 0;   // applied at the LDS store (see conv_igemm_kernel)
   auto load_tile = [&](int pk0) {
+    a_mask = 0; b_mask = 0;
     const int p = pk0 + kcol;
     const bool pv = p < pend;
-    const int oy = pv ? p / Wo : 0, ox = pv ? p - oy * Wo : 0;
+    const int pc = pv ? p : pend - 1;               // clamped: every load below is unconditional + select
+    const int oy = pc / Wo, ox = pc - oy * Wo;
     const int by = oy * stride, bx = ox * stride;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int m = m0 + r0 + 8 * i;
-      areg[i] = (pv && m < M) ? dy[(i64)m * P + p] : 0.f;
+      areg[i] = dy[(i64)min(m, M - 1) * P + pc];
+      a_mask |= (unsigned)(pv && m < M) << i;
     }
 #pragma unroll
     for (int i = 0; i < B_N; ++i) {
       const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
       const int sy = by + (e.y >> 16), sx = bx + (int)(short)(e.y & 0xffff);
-      const bool ok = pv && e.x >= 0 && (unsigned)sy < (unsigned)Hi && (unsigned)sx < (unsigned)Wi;
-      breg[i] = ok ? x[(i64)e.x + sy * Wi + sx] : 0.f;
+      const bool ok = pv & (e.x >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
+      breg[i] = x[(i64)max(e.x, 0) + (ok ? sy * Wi + sx : 0)];
+      b_mask |= (unsigned)ok << i;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = areg[i];
+    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = ((a_mask >> i) & 1u) ? areg[i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = breg[i];
+    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = ((b_mask >> i) & 1u) ? breg[i] : 0.f;
   };
 
   const int KT = (pend - pbeg + WBK - 1) / WBK;
