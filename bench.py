@@ -69,6 +69,21 @@ class KernelTimer:
         return agg
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_hbm_traffic_per_launch.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB units,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if no record matches."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic_per_launch.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    norm = lambda k: k.replace(' ', '').replace(',16>', '>').replace(',32>', '>')
+    for k, v in rec.items():
+        if isinstance(v, dict) and norm(k) == norm(kernel):
+            return (v['fetch_MB_corrected'] + v['write_MB']) * 1e6
+    return None
+
+
 def cpu_baseline(num_classes, threads):
     """The oracle (CPU restatement of the reference path) timed on this host: ONE PFGST.train_step on a bounded sample
     (b=2, 512x512 crops = 1/4 of a 1024^2 tile each), reported in 1024^2-tile-equivalent images/s."""
@@ -179,7 +194,7 @@ def main():
             cnt, ms, fl = dom[1]
             achieved = fl / (ms * 1e-3) / 1e12
             res['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom[0]),
                                'launches': cnt, 'avg_launch_ms': ms / cnt,
                                'algorithmic_flops_per_launch': fl / cnt}
             all_fl = sum(v[2] for v in mfma.values())
