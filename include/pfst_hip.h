@@ -68,9 +68,10 @@ int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long lo
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
                   int N, int C, int HW, int relu, pfst_stream_t stream);
 /* backward of the above: dz = dy * (y > 0 if relu); dres (+)= dz; dgamma += sum dz*xhat; dbeta += sum dz;
- * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles. */
+ * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles.  The ReLU mask comes from the saved
+ * output y; if y == NULL and beta != NULL (layer without residual) it is recomputed from x exactly as bn_apply did. */
 int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
-                     const float* mean, const float* invstd, const float* gamma,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta,
                      float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                      float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream);
 

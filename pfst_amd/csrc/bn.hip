@@ -97,10 +97,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
                                                             i64 y_bs, const float* __restrict__ x, i64 x_bs,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int HW, int chunk, int relu, double* __restrict__ ws) {
   __shared__ double sm[16];
   const int c = blockIdx.y, n = blockIdx.z;
   const float mu = mean[c], is = invstd[c];
+  // ReLU mask: from the saved output y, or (no residual) recomputed bit-identically to bn_apply from x -- saves the y read
+  const float sc = is * gamma[c], sh = (beta ? beta[c] : 0.f) - mu * sc;
   const i64 base = (i64)c * HW;
   const float* gp = dy + (i64)n * dy_bs + base;
   const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
@@ -110,8 +113,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   double s = 0.0, sx = 0.0;
   for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
     float dz = gp[i];
-    if (relu && !(yp[i] > 0.f)) dz = 0.f;
-    const float xh = (xp[i] - mu) * is;
+    const float xv = xp[i];
+    if (relu && !((yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f)) dz = 0.f;
+    const float xh = (xv - mu) * is;
     s += (double)dz;
     sx += (double)dz * (double)xh;
   }
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
                                                            i64 y_bs, const float* __restrict__ x, i64 x_bs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, float* __restrict__ dx, i64 dx_bs,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ dx, i64 dx_bs,
                                                            float* __restrict__ dres, i64 dres_bs, int dres_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int C, int HW, double inv_count, int relu, const double* __restrict__ ws) {
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
   const double m1 = ws[2 * c] * inv_count, m2 = ws[2 * c + 1] * inv_count;
   const double gs = (double)gamma[c] * (double)is;
+  const float sc = is * gamma[c], sh = (beta ? beta[c] : 0.f) - mu * sc;
   if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
     if (dgamma) dgamma[c] += (float)ws[2 * c + 1];
     if (dbeta) dbeta[c] += (float)ws[2 * c];
@@ -149,8 +155,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
     float dz = gp[i];
-    if (relu && !(yp[i] > 0.f)) dz = 0.f;
-    const double xh = ((double)xp[i] - (double)mu) * (double)is;
+    const float xv = xp[i];
+    if (relu && !((yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f)) dz = 0.f;
+    const double xh = ((double)xv - (double)mu) * (double)is;
     dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
     if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
   }
@@ -198,20 +205,20 @@ extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residu
 }
 
 extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
-                                const float* mean, const float* invstd, const float* gamma,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                                 float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
-  PFST_CHECK_ARG(!relu || y);
+  PFST_CHECK_ARG(!relu || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, HW,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, HW,
                      chunk, relu, ws);
   int gx = cdiv(HW, 256 * 4);
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, dx,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, dx,
                      dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, 1.0 / ((double)N * HW), relu, ws);
   PFST_CHECK_LAUNCH();
   return PFST_OK;

@@ -19,9 +19,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef PFST_CLOCK_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py): per-block shader-clock / real-time deltas, written to a buffer nothing reads.
+__device__ unsigned long long g_pfst_stamps[2 * 65536];
+extern "C" int pfst_debug_read_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pfst_stamps), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2;
+}
+#endif
+
 namespace {
 
-constexpr int BN = 128;  // pixels per block tile
 constexpr int BK_MIN = 16;  // K granularity of the wave-uniform-tap fast path (Cin % 16 == 0)
 
 // source coordinate of output index o for tap t: (o*a + t*b + c0) / div, div in {1,2}; branch-free validity
@@ -32,7 +39,7 @@ __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, in
   return (odd == 0) & (s >= 0) & (s < lim);
 }
 
-template <int BM, bool GENERIC, int BK>
+template <int BM, bool GENERIC, int BK, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ in, i64 in_bs, const float* __restrict__ wk, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -44,12 +51,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int A_RPP = 256 / BM;   // A rows loaded per pass
   constexpr int A_N = BK / A_RPP;   // A loads per thread per step
-  constexpr int B_N = BK / 2;       // B loads per thread per step
+  constexpr int B_RPP = 256 / BN;   // B rows loaded per pass
+  constexpr int B_N = BK / B_RPP;   // B loads per thread per step
 
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#ifdef PFST_CLOCK_STAMPS
+  const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi;
   const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM, n = blockIdx.z;
@@ -58,7 +69,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   in += (i64)n * in_bs;
   out += (i64)n * out_bs;
 
-  const int bj = tid & (BN - 1), br0 = tid >> 7;
+  const int bj = tid % BN, br0 = tid / BN;
   const int p = p0 + bj;
   const bool pvalid = p < P;
   const int oy = pvalid ? p / Wo : 0;
@@ -75,37 +86,55 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // (tap, first channel) of the K-slice being prefetched, advanced incrementally (no divisions in the loop)
-  int ld_ty = 0, ld_tx = 0, ld_ci0 = 0;
+  // Address generation is kept off the VALU.  Fast path (Cin % BK == 0): both operands are read with BUFFER loads
+  // (SRSRC descriptor built from kernel arguments / blockIdx only): the per-thread byte offsets live in VGPRs and stay
+  // constant while the tap does not change, the per-step advance is a scalar soffset, and out-of-tile elements use an
+  // out-of-range offset so the hardware range check returns 0 -- no address VALU, no masks, no branches in the loop.
+  int ld_ty = 0, ld_tx = 0, ld_ci0 = 0;          // (tap, first channel) of the K-slice being prefetched
   const int amc = min(m0 + am, M - 1);
-  unsigned a_mask = 0, b_mask = 0;   // validity of the prefetched registers; applied when they are written to LDS so
-                                     // that nothing consumes a load result before the MFMA phase (latency overlap)
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, K * M * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
+  unsigned a_voff[A_N], b_voff[B_N];
+#pragma unroll
+  for (int i = 0; i < A_N; ++i)
+    a_voff[i] = amvalid ? 4u * ((unsigned)(ar0 + i * A_RPP) * (unsigned)M + (unsigned)amc) : OOB;
+  auto set_tap = [&]() {
+    int sy, sx;
+    const bool ok = pvalid & src_coord(oy, ld_ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, ld_tx, ca, cb, cc, cdivv, Wi, sx);
+#pragma unroll
+    for (int i = 0; i < B_N; ++i)
+      b_voff[i] = ok ? 4u * ((unsigned)(br0 + i * B_RPP) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
+  };
+  if (!GENERIC) set_tap();
+  unsigned a_mask = 0, b_mask = 0;   // GENERIC path only: validity applied when the registers are written to LDS
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
-    a_mask = GENERIC ? 0u : 0xffffffffu;
-    b_mask = 0;
-    // all loads are unconditional (clamped addresses): the 16 loads of a step stay in one basic block
-#pragma unroll
-    for (int i = 0; i < A_N; ++i) {
-      const int k = k0 + ar0 + i * A_RPP;
-      const int kc = GENERIC ? min(k, K - 1) : k;
-      areg[i] = wk[(i64)kc * M + amc];
-      if (GENERIC) a_mask |= (unsigned)(k < K) << i;
-    }
     if (!GENERIC) {
-      // C % BK == 0: the whole K-slice shares one tap (wave-uniform address arithmetic)
-      int sy, sx;
-      const bool ok = pvalid & src_coord(oy, ld_ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, ld_tx, ca, cb, cc, cdivv, Wi, sx);
-      const float* src = in + (i64)(ld_ci0 + br0) * HiWi + (ok ? sy * Wi + sx : 0);
+      const int a_soff = k0 * M * 4, b_soff = ld_ci0 * HiWi * 4;
 #pragma unroll
-      for (int i = 0; i < B_N; ++i) breg[i] = src[(i64)(2 * i) * HiWi];
-      b_mask = ok ? 0xffffffffu : 0u;
+      for (int i = 0; i < A_N; ++i)
+        areg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, a_voff[i], a_soff, 0));
+#pragma unroll
+      for (int i = 0; i < B_N; ++i)
+        breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff[i], b_soff, 0));
       ld_ci0 += BK;
-      if (ld_ci0 >= C) { ld_ci0 = 0; ld_tx += 1; if (ld_tx == ks) { ld_tx = 0; ld_ty += 1; } }
+      if (ld_ci0 >= C) {
+        ld_ci0 = 0; ld_tx += 1;
+        if (ld_tx == ks) { ld_tx = 0; ld_ty += 1; }
+        set_tap();
+      }
     } else {
+      a_mask = 0; b_mask = 0;
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) {
+        const int k = k0 + ar0 + i * A_RPP;
+        areg[i] = wk[(i64)min(k, K - 1) * M + amc];
+        a_mask |= (unsigned)(amvalid && k < K) << i;
+      }
 #pragma unroll
       for (int i = 0; i < B_N; ++i) {
-        const int k = k0 + br0 + 2 * i;
+        const int k = k0 + br0 + B_RPP * i;
         const int kc = min(k, K - 1);
         const int tap = kc / C, ci = kc - tap * C;
         const int ty = tap / ks, tx = tap - ty * ks;
@@ -118,9 +147,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = (amvalid && ((a_mask >> i) & 1u)) ? areg[i] : 0.f;
+    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = (!GENERIC || ((a_mask >> i) & 1u)) ? areg[i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + 2 * i][bj] = ((b_mask >> i) & 1u) ? breg[i] : 0.f;
+    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + B_RPP * i][bj] = (!GENERIC || ((b_mask >> i) & 1u)) ? breg[i] : 0.f;
   };
 
   load_tile(0);
@@ -168,6 +197,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
       }
     }
   }
+#ifdef PFST_CLOCK_STAMPS
+  if (tid == 0) {
+    const unsigned b = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u;
+    g_pfst_stamps[2 * b] = __builtin_amdgcn_s_memtime() - t_clk0;
+    g_pfst_stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - t_rt0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,34 +266,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  unsigned a_mask = 0, b_mask = 0;   // applied at the LDS store (see conv_igemm_kernel)
+  // Buffer loads with hardware range check (see conv_igemm_kernel): rows / pixels / taps outside the problem use an
+  // out-of-range byte offset and read as 0; the K(pixel) advance is a scalar soffset wherever the mapping allows it.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
+  constexpr bool POINTWISE = (T == 1);
+  const bool unit = POINTWISE && stride == 1 && pad == 0;       // input pixel == output pixel: constant offsets
+  unsigned a_voff[A_N], b_voff[B_N];
+#pragma unroll
+  for (int i = 0; i < A_N; ++i) {
+    const int m = m0 + r0 + 8 * i;
+    a_voff[i] = m < M ? 4u * ((unsigned)m * (unsigned)P + (unsigned)kcol) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_N; ++i) {
+    const int j = j0 + r0 + 8 * i;
+    b_voff[i] = (unit && j < J) ? 4u * ((unsigned)j * (unsigned)HiWi + (unsigned)kcol) : OOB;
+  }
   auto load_tile = [&](int pk0) {
-    a_mask = 0; b_mask = 0;
     const int p = pk0 + kcol;
-    const bool pv = p < pend;
-    const int pc = pv ? p : pend - 1;               // clamped: every load below is unconditional + select
-    const int oy = pc / Wo, ox = pc - oy * Wo;
-    const int by = oy * stride, bx = ox * stride;
+    const bool tail = pk0 + WBK > pend;           // wave-uniform: only the last step of the last chunk
+    const int soff = pk0 * 4;
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
-      const int m = m0 + r0 + 8 * i;
-      areg[i] = dy[(i64)min(m, M - 1) * P + pc];
-      a_mask |= (unsigned)(pv && m < M) << i;
+      const unsigned vo = (tail && p >= pend) ? OOB : a_voff[i];
+      areg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, vo, soff, 0));
     }
+    if (unit) {
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) {
-      const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
-      const int sy = by + (e.y >> 16), sx = bx + (int)(short)(e.y & 0xffff);
-      const bool ok = pv & (e.x >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
-      breg[i] = x[(i64)max(e.x, 0) + (ok ? sy * Wi + sx : 0)];
-      b_mask |= (unsigned)ok << i;
+      for (int i = 0; i < B_N; ++i) {
+        const unsigned vo = (tail && p >= pend) ? OOB : b_voff[i];
+        breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, vo, soff, 0));
+      }
+    } else {
+      const bool pv = p < pend;
+      const int pc = pv ? p : pend - 1;
+      const int oy = pc / Wo, ox = pc - oy * Wo;
+      const int by = oy * stride, bx = ox * stride;
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) {
+        const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
+        const int sy = by + (e.y >> 16), sx = bx + (int)(short)(e.y & 0xffff);
+        const bool ok = pv & (e.x >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
+        const unsigned vo = ok ? 4u * (unsigned)(e.x + sy * Wi + sx) : OOB;
+        breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, vo, 0, 0));
+      }
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = ((a_mask >> i) & 1u) ? areg[i] : 0.f;
+    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = areg[i];
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = ((b_mask >> i) & 1u) ? breg[i] : 0.f;
+    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = breg[i];
   };
 
   const int KT = (pend - pbeg + WBK - 1) / WBK;
@@ -333,15 +394,25 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float*
 template <int BM, bool G>
 int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
                  int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
-  dim3 grid(cdiv((i64)Ho * Wo, BN), cdiv(M, BM), N);
-  static const int bk_env = getenv("PFST_IGEMM_BK") ? atoi(getenv("PFST_IGEMM_BK")) : 0;   // tuning knob
+  static const int bk_env = getenv("PFST_IGEMM_BK") ? atoi(getenv("PFST_IGEMM_BK")) : 0;   // tuning knobs
+  static const int bn_env = getenv("PFST_IGEMM_BN") ? atoi(getenv("PFST_IGEMM_BN")) : 0;
   const bool bk32 = !G && (C % 32 == 0) && bk_env == 32;   // measured: BK=16 (3 blocks/CU) beats BK=32 by ~2 %
-  if (bk32)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 32>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                       Ho, Wo, ks, a, b, c, d, acc);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                       Ho, Wo, ks, a, b, c, d, acc);
+  const bool bn256 = BM == 128 && !G && bn_env == 256 && (i64)Ho * Wo >= 4096;
+  if (bn256) {
+    if constexpr (BM == 128 && !G) {
+      dim3 grid(cdiv((i64)Ho * Wo, 256), cdiv(M, BM), N);
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 256>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                         Ho, Wo, ks, a, b, c, d, acc);
+    }
+  } else {
+    dim3 grid(cdiv((i64)Ho * Wo, 128), cdiv(M, BM), N);
+    if (bk32)
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 32, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                         Ho, Wo, ks, a, b, c, d, acc);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                         Ho, Wo, ks, a, b, c, d, acc);
+  }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

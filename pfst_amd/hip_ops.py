@@ -183,13 +183,13 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None):
     return out
 
 
-def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None):
+def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None):
     n, c, h, w = x.shape
     assert dy.shape == x.shape
     if dx is None:
         dx = torch.empty(n, c, h, w, device=x.device)
     call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
-         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), dx.data_ptr(), _bs(dx),
+         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _p(beta), dx.data_ptr(), _bs(dx),
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
          n, c, h * w, int(relu), _ws(x.device, 16 * c).data_ptr(), _stream())
     return dx

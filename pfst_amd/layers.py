@@ -161,8 +161,10 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         dres = dacc = None
         if residual is not None and residual.requires_grad:
             dres, dacc = residual.grad_target()
-        dpre = ops.bn_backward(dy, y if relu else None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc))
+        # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
+        ymask = y if (relu and residual is not None) else None
+        dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
+                               relu, dres, bool(dacc), beta=bn.bias.data)
         conv_backward(x, conv, dpre)
         if yv.parent is None:
             yv.free_grad()

@@ -75,7 +75,7 @@ def test_batchnorm_properties_full_size(ops):
     assert float((v / gamma.double() ** 2 - 1).abs().max()) < 1e-4
     dy = torch.randn(x.shape, device='cuda', generator=g)
     dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    dx = ops.bn_backward(dy, None, x, mean, invstd, gamma, dg, db, relu=False)
+    dx = ops.bn_backward(dy, None, x, mean, invstd, gamma, dg, db, relu=False, beta=beta)
     xhat = (x.double() - mean.double().view(1, C, 1, 1)) * invstd.double().view(1, C, 1, 1)
     scale = float(dx.double().abs().sum((0, 2, 3)).max())
     assert float(dx.double().sum((0, 2, 3)).abs().max()) < 1e-5 * scale

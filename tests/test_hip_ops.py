@@ -130,7 +130,8 @@ def test_batchnorm_train(ops, shape, relu, res):
     assert_close(y, y_ref, 1e-5, 'bn fwd')
     dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
     dres = torch.empty(shape, device=DEV) if res else None
-    dx = ops.bn_backward(dy.to(DEV), y, xd, mean, invstd, gamma.detach().to(DEV), dg, db, relu, dres)
+    dx = ops.bn_backward(dy.to(DEV), y if res else None, xd, mean, invstd, gamma.detach().to(DEV), dg, db, relu, dres,
+                         beta=beta.detach().to(DEV))
     assert_close(dx, x.grad, 1e-4, 'bn dx')
     assert_close(dg, gamma.grad, 1e-4, 'bn dgamma')
     assert_close(db, beta.grad, 1e-4, 'bn dbeta')
