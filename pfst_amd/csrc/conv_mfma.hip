@@ -284,6 +284,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int j = j0 + r0 + 8 * i;
     b_voff[i] = (unit && j < J) ? 4u * ((unsigned)j * (unsigned)HiWi + (unsigned)kcol) : OOB;
   }
+  // this thread's 16 gather descriptors, kept in registers for the whole K loop
+  int j_coff[B_N], j_dyx[B_N];
+#pragma unroll
+  for (int i = 0; i < B_N; ++i) {
+    const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
+    j_coff[i] = e.x;
+    j_dyx[i] = e.y;
+  }
   auto load_tile = [&](int pk0) {
     const int p = pk0 + kcol;
     const bool tail = pk0 + WBK > pend;           // wave-uniform: only the last step of the last chunk
@@ -306,10 +314,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       const int by = oy * stride, bx = ox * stride;
 #pragma unroll
       for (int i = 0; i < B_N; ++i) {
-        const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
-        const int sy = by + (e.y >> 16), sx = bx + (int)(short)(e.y & 0xffff);
-        const bool ok = pv & (e.x >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
-        const unsigned vo = ok ? 4u * (unsigned)(e.x + sy * Wi + sx) : OOB;
+        const int sy = by + (j_dyx[i] >> 16), sx = bx + (int)(short)(j_dyx[i] & 0xffff);
+        const bool ok = pv & (j_coff[i] >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
+        const unsigned vo = ok ? 4u * (unsigned)(j_coff[i] + sy * Wi + sx) : OOB;
         breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, vo, 0, 0));
       }
     }
