@@ -56,3 +56,24 @@ def test_two_rank_data_parallel_step(tmp_path):
     assert err < 1e-4, err
     for k in o0['log_vars']:
         assert abs(r0['log'][k] - 0.5 * (o0['log_vars'][k] + o1['log_vars'][k])) < 1e-4 * max(1.0, abs(r0['log'][k]))
+
+
+def _nccl_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    x = torch.arange(1000, dtype=torch.float32, device='cuda')
+    dist.all_reduce(x, op=dist.ReduceOp.AVG)            # the op pfst_amd.dist uses on RCCL
+    t = torch.tensor([3.5], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    ok = bool(torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))) and float(t) == 3.5
+    open(os.path.join(outdir, 'nccl_ok'), 'w').write(str(ok))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_ops_used_by_the_exchange(tmp_path):
+    """Single-rank RCCL group: the collectives / reduce ops the N>1 path relies on exist and run on this stack."""
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / 'nccl_ok').read() == 'True'
