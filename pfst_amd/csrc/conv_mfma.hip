@@ -211,9 +211,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // GEMM M = Cout, N = Cin*T, K = pixels (split over images and pixel chunks; fp32 atomics combine).
 // Both operands are K(pixel)-contiguous in memory: LDS tiles are [row][k] with a +1 pad.
 // ---------------------------------------------------------------------------------------------
-constexpr int WBJ = 128, WBK = 32, WLD = WBK + 1;
+constexpr int WBJ = 128;
 
-template <int BM, int T>
+template <int BM, int T, int WBK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
     int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len) {
@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int WN = WBJ / WAVES_N;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int A_N = BM / 8, B_N = WBJ / 8;
+  constexpr int WLD = WBK + 1;
+  constexpr int RPP = 256 / WBK;            // tile rows loaded per pass
+  constexpr int A_N = BM / RPP, B_N = WBJ / RPP;
   constexpr int KS = T == 9 ? 3 : 1;
 
   extern __shared__ float smem[];
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   }
   __syncthreads();
 
-  const int kcol = tid & 31, r0 = tid >> 5;
+  const int kcol = tid % WBK, r0 = tid / WBK;
   float areg[A_N], breg[B_N];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -276,19 +278,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   unsigned a_voff[A_N], b_voff[B_N];
 #pragma unroll
   for (int i = 0; i < A_N; ++i) {
-    const int m = m0 + r0 + 8 * i;
+    const int m = m0 + r0 + RPP * i;
     a_voff[i] = m < M ? 4u * ((unsigned)m * (unsigned)P + (unsigned)kcol) : OOB;
   }
 #pragma unroll
   for (int i = 0; i < B_N; ++i) {
-    const int j = j0 + r0 + 8 * i;
+    const int j = j0 + r0 + RPP * i;
     b_voff[i] = (unit && j < J) ? 4u * ((unsigned)j * (unsigned)HiWi + (unsigned)kcol) : OOB;
   }
   // this thread's 16 gather descriptors, kept in registers for the whole K loop
   int j_coff[B_N], j_dyx[B_N];
 #pragma unroll
   for (int i = 0; i < B_N; ++i) {
-    const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + 8 * i];
+    const int2 e = reinterpret_cast<const int2*>(jtab)[r0 + RPP * i];
     j_coff[i] = e.x;
     j_dyx[i] = e.y;
   }
@@ -323,9 +325,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][r0 + 8 * i][kcol] = areg[i];
+    for (int i = 0; i < A_N; ++i) As[buf][r0 + RPP * i][kcol] = areg[i];
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + 8 * i][kcol] = breg[i];
+    for (int i = 0; i < B_N; ++i) Bs[buf][r0 + RPP * i][kcol] = breg[i];
   };
 
   const int KT = (pend - pbeg + WBK - 1) / WBK;
@@ -424,9 +426,9 @@ int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias,
   return PFST_OK;
 }
 
-template <int BM, int T>
-int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
-                 int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+template <int BM, int T, int WBK>
+int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+                   int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, WBJ) * cdiv(M, BM);
   // split the pixel (K) range so that the launch has >= ~1024 blocks, chunks of >= 512 pixels
@@ -435,16 +437,26 @@ int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
-  const size_t lds = (size_t)2 * (BM + WBJ) * WLD * sizeof(float) + (size_t)WBJ * 2 * sizeof(int);
+  const size_t lds = (size_t)2 * (BM + WBJ) * (WBK + 1) * sizeof(float) + (size_t)WBJ * 2 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BM, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BM, T, WBK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, T>), grid, dim3(256), lds, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, T, WBK>), grid, dim3(256), lds, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
                      stride, dil, pad, chunks, chunk_len);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
+}
+
+template <int BM, int T>
+int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+                 int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+  static const int wbk_env = getenv("PFST_WGRAD_BK") ? atoi(getenv("PFST_WGRAD_BK")) : 0;   // tuning knob
+  // measured (tools/conv_microbench.py): 3x3 gathers prefer the shallower K tile (4 blocks/CU: +7-10 %), 1x1 the deeper one
+  const int wbk = wbk_env ? wbk_env : (T == 9 ? 16 : 32);
+  if (wbk == 16) return launch_wgrad_k<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
+  return launch_wgrad_k<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
 }
 
 }  // namespace
