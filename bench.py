@@ -111,6 +111,7 @@ def main():
     ap.add_argument('--size', type=int, default=None, help='tile size (default 1024)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-alt-math', action='store_true', help='skip the informational bf16x6 pass (N=1 only)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -203,6 +204,29 @@ def main():
                                      'share_of_kernel_time': all_ms / tot_ms}
             res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
             res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
+        if world == 1 and not args.no_alt_math:
+            # informational second pass: same step with the fp32-faithful 6-term bf16 split for fprop/dgrad
+            # (csrc/conv_split.hip).  `value` above is the fp32-MFMA number; this one is reported separately.
+            from pfst_amd import layers
+            hip_ops.call = timer.inner
+            del model, opt
+            torch.cuda.empty_cache()
+            layers.CONV_MATH = 'bf16x6'
+            model2 = UDA.build(cfg)
+            fill_state_dict(model2.state_dict(), 0)
+            model2.to(dev)
+            opt2 = build_optimizer(model2, OPTIMIZER)
+            for i in range(max(1, args.warmup)):
+                model2.train_step(batch, opt2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                model2.train_step(batch, opt2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            res['alt_math'] = {'mode': 'bf16x6 split for fprop+dgrad (fp32-faithful, opt-in via PFST_CONV_MATH=bf16x6)',
+                               'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
+            layers.CONV_MATH = 'f32'
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(w['num_classes'], usable_cpus())
         elif not args.no_cpu_baseline:

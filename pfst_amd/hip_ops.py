@@ -116,6 +116,40 @@ def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, ac
     return out
 
 
+def pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
+    """w [Cout][Cin][k][k] -> bf16x3-split K-major images (uint8 buffers of 6 bytes per weight)."""
+    _dense(w)
+    co, ci, kh, kw = w.shape
+    nbytes = 6 * co * ci * kh * kw
+    wf = (out_f if out_f is not None else torch.empty(nbytes, dtype=U8, device=w.device)) if want_fprop else None
+    wd = (out_d if out_d is not None else torch.empty(nbytes, dtype=U8, device=w.device)) if want_dgrad else None
+    call('pfst_conv_pack_weight_split', w.data_ptr(), _p(wf), _p(wd), co, ci, kh * kw, _stream())
+    return wf, wd
+
+
+def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None):
+    n, c, hi, wi = x.shape
+    ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
+    assert wk6.numel() == 6 * ksize * ksize * c * cout
+    if out is None:
+        out = torch.empty(n, cout, ho, wo, device=x.device)
+    call('pfst_conv_igemm_split', x.data_ptr(), _bs(x), wk6.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _stream())
+    return out
+
+
+def conv_dgrad_split(dy, wk6_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+    n, co, ho, wo = dy.shape
+    hi, wi = in_hw
+    assert wk6_d.numel() == 6 * ksize * ksize * co * cin
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, cin, hi, wi, device=dy.device)
+    call('pfst_conv_igemm_split', dy.data_ptr(), _bs(dy), wk6_d.data_ptr(), 0, out.data_ptr(), _bs(out),
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), _stream())
+    return out
+
+
 def conv_wgrad_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
     """dw += dL/dw (fp32 atomics)."""
     n, ci, hi, wi = x.shape

@@ -11,9 +11,15 @@ import torch.nn as nn
 from . import hip_ops as ops
 from .engine import Var
 
+import os
+
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 _BN_EVAL = False
+# Arithmetic of the dense convolutions' forward / data-gradient GEMMs:
+#   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32), the default and what every reported number uses;
+#   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores (csrc/conv_split.hip), opt-in.
+CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
 
 
 class bn_eval:
@@ -41,10 +47,25 @@ class Conv2dP(nn.Module):
         fan_out = cout * k * k // groups
         nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))     # kaiming_normal_(fan_out, relu)
         self.wf = self.wd = None        # packed copies, refreshed by repack()
+        self.w6f = self.w6d = None      # bf16x3-split packed copies (CONV_MATH == 'bf16x6')
+
+    split_f = split_d = False
 
     @property
     def depthwise(self):
         return self.groups > 1
+
+    def fprop(self, xd, out=None, bias=None):
+        if self.split_f:
+            return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out)
+        return ops.conv_fprop(xd, self.wf, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out)
+
+    def dgrad(self, dy, in_hw, out, accumulate):
+        if self.split_d:
+            return ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
+                                        out=out, accumulate=accumulate)
+        return ops.conv_dgrad(dy, self.wd, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
+                              out=out, accumulate=accumulate)
 
     def repack(self, need_dgrad):
         if self.depthwise:
@@ -55,6 +76,16 @@ class Conv2dP(nn.Module):
         if need_dgrad and self.wd is None:
             self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
         ops.pack_weight(self.weight.data, True, need_dgrad, self.wf, self.wd if need_dgrad else None)
+        self.split_f = CONV_MATH == 'bf16x6' and self.cin % 16 == 0
+        self.split_d = CONV_MATH == 'bf16x6' and self.cout % 16 == 0 and need_dgrad
+        if self.split_f or self.split_d:
+            nbytes = 6 * self.weight.numel()
+            if self.split_f and (self.w6f is None or self.w6f.device != self.weight.device):
+                self.w6f = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+            if self.split_d and (self.w6d is None or self.w6d.device != self.weight.device):
+                self.w6d = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+            ops.pack_weight_split(self.weight.data, self.split_f, self.split_d, self.w6f if self.split_f else None,
+                                  self.w6d if self.split_d else None)
 
 
 class BatchNorm2dP(nn.Module):
@@ -103,8 +134,7 @@ def conv_forward(x, conv, tape, out=None):
         assert conv.k == 3 and conv.stride == 1 and conv.padding == conv.dilation
         y = ops.dwconv(xd, conv.weight.data, conv.dilation, out=out)
     else:
-        y = ops.conv_fprop(xd, conv.wf, conv.cout, conv.k, conv.stride, conv.dilation, conv.padding,
-                           bias=None if conv.bias is None else conv.bias.data, out=out)
+        y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data)
     yv = Var(y, tape is not None)
     if tape is not None:
         def bwd():
@@ -129,8 +159,7 @@ def conv_backward(x, conv, dy):
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
             buf, acc = x.grad_target()
-            ops.conv_dgrad(dy, conv.wd, conv.cin, xd.shape[-2:], conv.k, conv.stride, conv.dilation, conv.padding,
-                           out=buf, accumulate=acc)
+            conv.dgrad(dy, xd.shape[-2:], buf, acc)
 
 
 def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
@@ -140,7 +169,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     if conv.depthwise:
         pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     else:
-        pre = ops.conv_fprop(xd, conv.wf, conv.cout, conv.k, conv.stride, conv.dilation, conv.padding)
+        pre = conv.fprop(xd)
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'
         mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)

@@ -76,6 +76,25 @@ def test_conv_fprop_dgrad_wgrad(ops, case):
         assert_close(db, dy.sum((0, 2, 3)), 1e-5, 'bias grad')
 
 
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[1] % 16 == 0])
+def test_conv_split_bf16x6_is_fp32_faithful(ops, case):
+    """6-term bf16 split on the bf16 matrix cores: as close to fp64 as fp32 arithmetic (1e-6), fprop + dgrad."""
+    n, ci, co, H, W, k, s, d, p = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, k, k, generator=g(2)) * 0.1
+    ref = F.conv2d(x.double(), w.double(), None, s, p, d)
+    w6f, w6d = ops.pack_weight_split(w.to(DEV), True, co % 16 == 0)
+    y = ops.conv_fprop_split(x.to(DEV), w6f, co, k, s, d, p)
+    assert_close(y, ref, 2e-6, 'split fprop')
+    if co % 16 == 0:
+        dy = torch.randn(ref.shape, generator=g(4))
+        dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, p, d)
+        dx = ops.conv_dgrad_split(dy.to(DEV), w6d, ci, (H, W), k, s, d, p)
+        assert_close(dx, dx_ref, 2e-6, 'split dgrad')
+        dx2 = ops.conv_dgrad_split(dy.to(DEV), w6d, ci, (H, W), k, s, d, p, out=dx.clone(), accumulate=True)
+        assert_close(dx2, 2 * dx_ref, 2e-6, 'split dgrad-acc')
+
+
 def test_conv_channel_slice_views(ops):
     """conv reading / writing channel slices of bigger tensors (concat elimination)."""
     n, ci, co, H, W = 2, 32, 64, 10, 12

@@ -35,7 +35,16 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def test_two_train_steps_match_reference_golden_and_oracle():
+@pytest.fixture(params=['f32', 'bf16x6'])
+def conv_math(request):
+    """run the end-to-end parity under both convolution arithmetics (fp32 MFMA default; fp32-faithful bf16 split)"""
+    from pfst_amd import layers
+    prev, layers.CONV_MATH = layers.CONV_MATH, request.param
+    yield request.param
+    layers.CONV_MATH = prev
+
+
+def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
     from oracle import pfst_oracle as O
     from pfst_amd.synthetic import synth_batch
     gold = np.load(os.path.join(G, 'train_step.npz'))
