@@ -115,7 +115,7 @@ int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, int w, const 
 /* ---- pseudo labels (pfgst.py:259-268 + encoder_decoder.py:77-81): bilinear upsample of the teacher
  * logits, softmax, (max prob, first arg-max), prob >= threshold counted into count[0] */
 int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
-                      long long* label_i64, unsigned char* label_u8, unsigned long long* count, pfst_stream_t stream);
+                      long long* label_i64, unsigned char* label_u8, unsigned long long* count, float* conf_mask, pfst_stream_t stream);
 
 /* ---- evaluation: intersect_and_union (rsiseg/core/evaluation/metrics.py:26-86).  hist[3*C] (+)= per-class
  * #intersect, #pred, #label over pixels whose label != ignore_index (caller zeroes hist once per evaluation) */
@@ -127,10 +127,11 @@ int pfst_confusion_hist(const unsigned char* pred, const unsigned char* label, l
 int pfst_label_presence(const unsigned char* label, long long n, int* presence256, pfst_stream_t stream);
 /* mask[n][p] = 1 if gt[n][p] is one of classes[n][0..K) (entries < 0 are padding) */
 int pfst_class_mask(const unsigned char* gt, const int* classes, int K, unsigned char* mask, int N, long long HW, pfst_stream_t stream);
-/* mixed = M*src + (1-M)*trg for image, label and pixel weight; the target weight is
- * q = conf_count[0] / (N*HW) (thre_type 'all').  mixed_lbl_i64 may be NULL. */
+/* mixed = M*src + (1-M)*trg for image, label and pixel weight; the target weight is the scalar
+ * q = conf_count[0] / (N*HW) (thre_type 'all') or, if trg_weight != NULL, the per-pixel map (thre_type 'part',
+ * conf_mask of pfst_pseudo_label).  mixed_lbl_i64 may be NULL. */
 int pfst_class_mix(const float* img, const float* trg_img, const unsigned char* gt, const unsigned char* pseudo,
-                   const unsigned char* mask, const unsigned long long* conf_count, float* mixed_img,
+                   const unsigned char* mask, const unsigned long long* conf_count, const float* trg_weight, float* mixed_img,
                    unsigned char* mixed_lbl, long long* mixed_lbl_i64, float* mixed_w, int N, int Cimg, long long HW, pfst_stream_t stream);
 
 /* ---- DACS strong augmentation of the mixed image (dacs_transforms.py:44-107; kornia arithmetic restated,

@@ -248,10 +248,14 @@ def parse_losses(losses):
 # ---------------------------------------------------------------------------
 # pseudo labels + class mix
 # ---------------------------------------------------------------------------
-def pseudo_label(ema_logits, threshold):
-    """pfgst.py:259-268 (thre_type='all'): softmax->max, prob>=tau count / numel -> scalar weight map."""
+def pseudo_label(ema_logits, threshold, thre_type='all'):
+    """pfgst.py:259-268: softmax->max; thre_type 'all': (#prob>=tau / numel) as a scalar weight map,
+    'part': the per-pixel 0/1 confidence mask."""
     prob, lab = torch.max(torch.softmax(ema_logits.detach(), dim=1), dim=1)
-    n_conf = int((prob >= threshold).sum())
+    conf = prob >= threshold
+    n_conf = int(conf.sum())
+    if thre_type == 'part':
+        return lab, conf.to(prob.dtype), n_conf
     q = n_conf / lab.numel()
     return lab, q * torch.ones_like(prob), n_conf
 
@@ -355,7 +359,7 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False, downscale=0.5):
+                 blur=False, downscale=0.5, thre_type='all'):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -367,6 +371,7 @@ class OraclePFGST:
         self.aux_w = aux_weights or DEFAULT_LOSS_W
         self.blur = blur
         self.downscale = downscale
+        self.thre_type = thre_type
         self.local_iter = 0
 
     def train_step(self, batch, masks=None, drop_masks=None, return_extras=False, pseudo_override=None):
@@ -386,10 +391,11 @@ class OraclePFGST:
         lv.pop('loss'); log.update(lv)
         with torch.no_grad():
             ema_logits, ema_dec, ema_low = encode_decode(self.teacher, trg)
-        pl, pw, n_conf = pseudo_label(ema_logits, self.tau)
+        pl, pw, n_conf = pseudo_label(ema_logits, self.tau, self.thre_type)
         if pseudo_override is not None:        # (label map, #confident) injected by parity tests
             pl, n_conf = pseudo_override
-            pw = (n_conf / pl.numel()) * torch.ones(pl.shape, dtype=ema_logits.dtype)
+            if self.thre_type == 'all':
+                pw = (n_conf / pl.numel()) * torch.ones(pl.shape, dtype=ema_logits.dtype)
         if masks is None:
             masks = class_masks(gt)
         mixed_img, mixed_lbl, mixed_w = class_mix(masks, img, trg_aug, gt, pl, pw)

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 // grid: (blocks over H*W, N)
 __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, int C, int h, int w, int H, int W,
                                                            float sh, float sw, float thr, long long* __restrict__ l64,
-                                                           unsigned char* __restrict__ l8, unsigned long long* __restrict__ count) {
+                                                           unsigned char* __restrict__ l8, unsigned long long* __restrict__ count,
+                                                           float* __restrict__ conf) {
   __shared__ double sm[16];
   const int n = blockIdx.y;
   const float* lp = logits + (i64)n * C * h * w;
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
     for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
     const float pmax = 1.f / se;         // softmax value of the arg-max class
     if (pmax >= thr) cnt += 1.0;
+    if (conf) conf[(i64)n * H * W + p] = pmax >= thr ? 1.f : 0.f;     // thre_type='part' (pfgst.py:267-268)
     if (l64) l64[(i64)n * H * W + p] = arg;
     if (l8) l8[(i64)n * H * W + p] = (unsigned char)arg;
   }
@@ -169,12 +171,12 @@ __global__ void class_mask_kernel(const unsigned char* __restrict__ gt, const in
 // grid: (blocks over HW, N)
 __global__ void class_mix_kernel(const float* __restrict__ img, const float* __restrict__ trg, const unsigned char* __restrict__ gt,
                                  const unsigned char* __restrict__ pseudo, const unsigned char* __restrict__ mask,
-                                 const unsigned long long* __restrict__ conf, float* __restrict__ mimg,
+                                 const unsigned long long* __restrict__ conf, const float* __restrict__ trg_w, float* __restrict__ mimg,
                                  unsigned char* __restrict__ mlbl, long long* __restrict__ mlbl64, float* __restrict__ mw,
                                  int Cimg, i64 HW, double numel) {
   const int n = blockIdx.y;
   // q exactly as the reference: python float (double) count/size, stored into a float32 tensor
-  const float q = (float)((double)conf[0] / numel);
+  const float q = trg_w ? 0.f : (float)((double)conf[0] / numel);
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x) {
     const i64 p = (i64)n * HW + i;
     const int m = mask[p];
@@ -186,7 +188,7 @@ __global__ void class_mix_kernel(const float* __restrict__ img, const float* __r
     const int l = m ? gt[p] : pseudo[p];
     mlbl[p] = (unsigned char)l;
     if (mlbl64) mlbl64[p] = l;
-    mw[p] = fm * 1.0f + fi * q;
+    mw[p] = fm * 1.0f + fi * (trg_w ? trg_w[p] : q);
   }
 }
 
@@ -245,12 +247,13 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
 }
 
 extern "C" int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
-                                 long long* label_i64, unsigned char* label_u8, unsigned long long* count, pfst_stream_t stream) {
+                                 long long* label_i64, unsigned char* label_u8, unsigned long long* count, float* conf_mask,
+                                 pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && (label_i64 || label_u8) && count && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, sizeof(unsigned long long), s) != hipSuccess) return PFST_ERR_LAUNCH;
   hipLaunchKernelGGL(pseudo_label_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, logits, C, h, w, H, W,
-                     (float)h / (float)H, (float)w / (float)W, threshold, label_i64, label_u8, count);
+                     (float)h / (float)H, (float)w / (float)W, threshold, label_i64, label_u8, count, conf_mask);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -272,12 +275,12 @@ extern "C" int pfst_class_mask(const unsigned char* gt, const int* classes, int 
 }
 
 extern "C" int pfst_class_mix(const float* img, const float* trg_img, const unsigned char* gt, const unsigned char* pseudo,
-                              const unsigned char* mask, const unsigned long long* conf_count, float* mixed_img,
+                              const unsigned char* mask, const unsigned long long* conf_count, const float* trg_weight, float* mixed_img,
                               unsigned char* mixed_lbl, long long* mixed_lbl_i64, float* mixed_w, int N, int Cimg, long long HW, pfst_stream_t stream) {
-  PFST_CHECK_ARG(img && trg_img && gt && pseudo && mask && conf_count && mixed_img && mixed_lbl && mixed_w);
+  PFST_CHECK_ARG(img && trg_img && gt && pseudo && mask && (conf_count || trg_weight) && mixed_img && mixed_lbl && mixed_w);
   PFST_CHECK_ARG(N > 0 && N <= 65535 && Cimg > 0 && HW > 0);
   hipLaunchKernelGGL(class_mix_kernel, dim3(px_blocks(HW), N), dim3(256), 0, (hipStream_t)stream, img, trg_img, gt, pseudo, mask,
-                     conf_count, mixed_img, mixed_lbl, mixed_lbl_i64, mixed_w, Cimg, (i64)HW, (double)N * (double)HW);
+                     conf_count, trg_weight, mixed_img, mixed_lbl, mixed_lbl_i64, mixed_w, Cimg, (i64)HW, (double)N * (double)HW);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

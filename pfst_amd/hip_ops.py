@@ -345,16 +345,17 @@ def ce_finalize(acc, numel, loss_weight):
     return out
 
 
-def pseudo_label(logits, size, threshold, want_i64=True):
-    """-> (label int64 [N,H,W] | None, label uint8 [N,H,W], count uint64-as-int64 [1])"""
+def pseudo_label(logits, size, threshold, want_i64=True, want_conf=False):
+    """-> (label int64 [N,H,W] | None, label uint8 [N,H,W], count uint64-as-int64 [1][, conf float [N,H,W]])"""
     _dense(logits)
     n, c, h, w = logits.shape
     H, W = size
     l64 = torch.empty(n, H, W, dtype=I64, device=logits.device) if want_i64 else None
     l8 = torch.empty(n, H, W, dtype=U8, device=logits.device)
     cnt = torch.empty(1, dtype=I64, device=logits.device)
-    call('pfst_pseudo_label', logits.data_ptr(), n, c, h, w, H, W, float(threshold), _p(l64), l8.data_ptr(), cnt.data_ptr(), _stream())
-    return l64, l8, cnt
+    conf = torch.empty(n, H, W, device=logits.device) if want_conf else None
+    call('pfst_pseudo_label', logits.data_ptr(), n, c, h, w, H, W, float(threshold), _p(l64), l8.data_ptr(), cnt.data_ptr(), _p(conf), _stream())
+    return (l64, l8, cnt, conf) if want_conf else (l64, l8, cnt)
 
 
 def label_presence(label_u8):
@@ -374,7 +375,7 @@ def class_mask(gt_u8, classes):
     return mask
 
 
-def class_mix(img, trg_img, gt_u8, pseudo_u8, mask_u8, conf_count, want_i64=False):
+def class_mix(img, trg_img, gt_u8, pseudo_u8, mask_u8, conf_count, want_i64=False, trg_weight=None):
     _dense(img), _dense(trg_img), _dense(gt_u8, U8), _dense(pseudo_u8, U8), _dense(mask_u8, U8), _dense(conf_count, I64)
     n, c, h, w = img.shape
     assert trg_img.shape == img.shape and gt_u8.numel() == n * h * w == pseudo_u8.numel() == mask_u8.numel()
@@ -383,7 +384,7 @@ def class_mix(img, trg_img, gt_u8, pseudo_u8, mask_u8, conf_count, want_i64=Fals
     mlbl64 = torch.empty(n, 1, h, w, dtype=I64, device=img.device) if want_i64 else None
     mw = torch.empty(n, h, w, device=img.device)
     call('pfst_class_mix', img.data_ptr(), trg_img.data_ptr(), gt_u8.data_ptr(), pseudo_u8.data_ptr(), mask_u8.data_ptr(),
-         conf_count.data_ptr(), mimg.data_ptr(), mlbl.data_ptr(), _p(mlbl64), mw.data_ptr(), n, c, h * w, _stream())
+         conf_count.data_ptr(), _p(trg_weight), mimg.data_ptr(), mlbl.data_ptr(), _p(mlbl64), mw.data_ptr(), n, c, h * w, _stream())
     return mimg, mlbl, mlbl64, mw
 
 

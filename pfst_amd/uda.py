@@ -146,7 +146,7 @@ class PFGST(UDADecorator):
         self.strong_aug_denorm_type = cfg.get('strong_aug_denorm_type', 'mean_std')
         self.apply_no_mix = cfg.get('apply_no_mix', False)
         assert self.mix == 'class'
-        bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type != 'all', ps_top=self.psweight_ignore_top > 0,
+        bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type not in ('all', 'part'), ps_top=self.psweight_ignore_top > 0,
                    ps_bottom=self.psweight_ignore_bottom > 0, use_decoded_feats=not self.use_decoded_feats,
                    apply_no_mix=self.apply_no_mix, print_grad=self.print_grad_magnitude)
         bad = [k for k, v in bad.items() if v]
@@ -290,7 +290,10 @@ class PFGST(UDADecorator):
         # ---- teacher on target -> pseudo labels (fused upsample + softmax + argmax + threshold count)
         ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
         ema_dec = ema_states['decoded_features']
-        pl64, pl8, conf_count = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None)
+        part = self.thre_type == 'part'
+        res = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None, want_conf=part)
+        pl64, pl8, conf_count = res[:3]
+        trg_weight = res[3] if part else None        # per-pixel 0/1 weights instead of the scalar fraction q
         if self.injected_pseudo is not None:
             if dbg is not None:
                 dbg['own_pseudo_label'], dbg['own_conf_count'] = pl64, conf_count
@@ -304,7 +307,7 @@ class PFGST(UDADecorator):
         mix_masks = ops.class_mask(gt8, classes_dev)
         mixed_img, mixed_lbl8, mixed_lbl64, mixed_w = ops.class_mix(
             img.contiguous(), target_img_strong_aug.contiguous(), gt8, pl8, mix_masks, conf_count,
-            want_i64=self.return_vis_states or dbg is not None)
+            want_i64=self.return_vis_states or dbg is not None, trg_weight=trg_weight)
         if apply_strong_aug is not None:
             mixed_img = apply_strong_aug(mixed_img, img_metas, jitter_draw, self.color_jitter_p, self.color_jitter_s,
                                          blur_draw, self.strong_aug_denorm_type)

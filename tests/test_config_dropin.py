@@ -47,7 +47,7 @@ def test_unknown_options_fail_loudly():
     from pfst_amd.presets import uda_cfg
     from pfst_amd.registry import UDA
     cfg = uda_cfg()
-    cfg['thre_type'] = 'part'
+    cfg['imnet_feature_dist_lambda'] = 0.005          # DAFormer feature distance: not part of the PFST configs
     with pytest.raises(NotImplementedError):
         UDA.build(cfg)
     with pytest.raises(KeyError):

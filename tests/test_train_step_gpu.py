@@ -213,3 +213,38 @@ def test_seasonnet_like_step_10band_33class():
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
     assert rel(model.debug['mix_logits'], ex['mix_logits']) < TOL
     assert (model.debug['own_pseudo_label'].cpu() != ex['pseudo_label']).float().mean() < 5e-3
+
+
+def test_inria_like_binary_step_with_part_threshold():
+    """BASELINE config #4 shape (C=2, binary building segmentation) at reduced size + thre_type='part' (SURVEY §8 f4):
+    per-pixel confidence weights instead of the scalar fraction."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = preset_cfg(2, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.52)
+    cfg['thre_type'] = 'part'
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 6, 2, 3)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 2, seed=99)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.52, teacher_sd=teacher, thre_type='part')
+    random.seed(8); np.random.seed(8)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(8); np.random.seed(8)
+    model.debug = {}
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    dbg = model.debug
+    same = dbg['pseudo_label'].cpu() == ex['pseudo_label']
+    assert 1 - same.float().mean() < 5e-3
+    # per-pixel weights: identical wherever the confidence decision is not within rounding of the threshold
+    wdiff = (dbg['mixed_w'].cpu() != ex['mixed_w']).float().mean()
+    assert wdiff < 5e-3, wdiff
+    assert 0.02 < float(ex['mixed_w'].mean()) < 0.999          # the mask is non-trivial
+    for k, v in olog.items():
+        tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
