@@ -66,7 +66,22 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi;
-  const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM, n = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so the m-tiles that share one pixel tile
+  // (= one activation tile) are given ids 8 apart: they run back to back on the SAME XCD and hit its L2.
+  int bx, by;
+  {
+    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int lin = blockIdx.x;
+    if ((gx & 7) == 0) {
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    } else {
+      by = lin / gx;
+      bx = lin - by * gx;
+    }
+  }
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.z;
   const int K = C * ks * ks;
   const int KT = K / 16;
   in += (i64)n * in_bs;
@@ -218,10 +233,157 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// weight gradient with the same 6-term split: dW[m][j] += sum_p dY[m][p] * X[ci(j)][src(p, tap(j))],  j = ci*T + tap.
+// Both operands are activations and pixel(K)-contiguous: each thread stages 8 consecutive pixels of one row
+// (dY: two 16-byte loads; X: eight range-checked buffer loads), splits them in registers and writes three 16-byte
+// pieces per operand into the [piece][k-half][row][8] LDS image.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int T>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len) {
+  constexpr int BJ = 128;
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BJ / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int KS = T == 9 ? 3 : 1;
+  constexpr unsigned OOB = 0x80000000u;
+
+  __shared__ uint4 As[2][2 * NP * BM];
+  __shared__ uint4 Bs[2][2 * NP * BJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
+  const int j0 = blockIdx.x * BJ, m0 = blockIdx.y * BM;
+  const int n = blockIdx.z / chunks, chunk = blockIdx.z - n * chunks;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)n * x_bs;
+  dy += (i64)n * dy_bs;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
+
+  // staging role: thread -> (row, k-half).  A rows only exist for tid < 2*BM.
+  const int srow = tid >> 1, half = tid & 1;
+  const bool a_thread = srow < BM;
+  const int am = m0 + srow;
+  const unsigned a_row_off = (a_thread && am < M) ? 4u * (unsigned)am * (unsigned)P : OOB;
+  const int bj = j0 + srow;                       // always < j0 + 128
+  int b_coff = -1, b_dy = 0, b_dx = 0;
+  if (bj < J) {
+    const int ci = bj / T, tap = bj - ci * T;
+    const int ty = tap / KS, tx = tap - ty * KS;
+    b_coff = ci * HiWi;
+    b_dy = ty * dil - pad;
+    b_dx = tx * dil - pad;
+  }
+
+  float areg[8], breg[8];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tile = [&](int pk0) {
+    const int pb = pk0 + half * 8;                 // first of this thread's 8 pixels
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = pb + e;
+      const bool pv = p < pend;
+      const unsigned va = (pv && a_row_off != OOB) ? a_row_off + 4u * (unsigned)p : OOB;
+      areg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, va, 0, 0));
+      const int pc = pv ? p : pend - 1;
+      const int oy = pc / Wo, ox = pc - oy * Wo;
+      const int sy = oy * stride + b_dy, sx = ox * stride + b_dx;
+      const bool ok = pv & (b_coff >= 0) & ((unsigned)sy < (unsigned)Hi) & ((unsigned)sx < (unsigned)Wi);
+      const unsigned vb = ok ? 4u * (unsigned)(b_coff + sy * Wi + sx) : OOB;
+      breg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, vb, 0, 0));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    uint4 q0, q1, q2;
+    if (a_thread) {
+      split8(areg, q0, q1, q2);
+      As[buf][(0 * 2 + half) * BM + srow] = q0;
+      As[buf][(1 * 2 + half) * BM + srow] = q1;
+      As[buf][(2 * 2 + half) * BM + srow] = q2;
+    }
+    split8(breg, q0, q1, q2);
+    Bs[buf][(0 * 2 + half) * BJ + srow] = q0;
+    Bs[buf][(1 * 2 + half) * BJ + srow] = q1;
+    Bs[buf][(2 * 2 + half) * BJ + srow] = q2;
+  };
+
+  const int KT = (pend - pbeg + 15) / 16;
+  load_tile(pbeg);
+  store_tile(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tile(pbeg + (kt + 1) * 16);
+    bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][pl] = __builtin_bit_cast(bf16x8, As[cur][(pl * 2 + lh) * BM + wm0 + i * 32 + l31]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[cur][(pl * 2 + lh) * BJ + wn0 + j * 32 + l31]);
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int BM, int T>
+int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+                       int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+  const int P = Ho * Wo, J = Cin * T;
+  const int tiles = cdiv(J, 128) * cdiv(M, BM);
+  int chunks = 1;
+  while ((i64)tiles * N * chunks < 1024 && P / (chunks * 2) >= 512) chunks *= 2;
+  int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
+  chunks = cdiv(P, chunk_len);
+  dim3 grid(cdiv(J, 128), cdiv(M, BM), N * chunks);
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<BM, T>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo, stride,
+                     dil, pad, chunks, chunk_len);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
 template <int BM>
 int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
                  int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
-  dim3 grid(cdiv((i64)Ho * Wo, BN), cdiv(M, BM), N);
+  dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), 1, N);
   hipLaunchKernelGGL((conv_igemm_split_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
                      Wi, M, Ho, Wo, ks, a, b, c, d, acc);
   PFST_CHECK_LAUNCH();
@@ -263,4 +425,22 @@ extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const voi
   if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
   if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
   return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
+}
+
+extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
+                                     int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
+                                     pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && dy && dw && N > 0 && Cin > 0 && Cout > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0);
+  const int span = (ksize - 1) * dil;
+  PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
+  PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo);
+  hipStream_t s = (hipStream_t)stream;
+#define PFST_WGS(BM_)                                                                                                  \
+  return ksize == 3 ? launch_wgrad_split<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s) \
+                    : launch_wgrad_split<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s)
+  if (Cout > 64) { PFST_WGS(128); }
+  if (Cout > 32) { PFST_WGS(64); }
+  PFST_WGS(32);
+#undef PFST_WGS
 }

@@ -160,6 +160,16 @@ def conv_wgrad_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
     return dw
 
 
+def conv_wgrad_split_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
+    """dw += dL/dw with the fp32-faithful bf16x6 split (fp32 atomics)."""
+    n, ci, hi, wi = x.shape
+    _, co, ho, wo = dy.shape
+    assert dy.shape[0] == n and dw.numel() == co * ci * ksize * ksize
+    call('pfst_conv_wgrad_split', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, ci, hi, wi, co, ho, wo,
+         ksize, stride, dil, pad, _stream())
+    return dw
+
+
 def bias_grad_(db, dy):
     n, c, h, w = dy.shape
     call('pfst_bias_grad', dy.data_ptr(), _bs(dy), _dense(db).data_ptr(), n, c, h * w, _stream())

@@ -20,6 +20,7 @@ _BN_EVAL = False
 #   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32), the default and what every reported number uses;
 #   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores (csrc/conv_split.hip), opt-in.
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
+WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
 
 
 class bn_eval:
@@ -154,7 +155,9 @@ def conv_backward(x, conv, dy):
             buf, acc = x.grad_target()
             ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
-        ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+        # the split wgrad kernel is correct but (first version) slower than the fp32-MFMA one: opt-in only
+        wgrad = ops.conv_wgrad_split_ if (CONV_MATH == 'bf16x6' and WGRAD_SPLIT) else ops.conv_wgrad_
+        wgrad(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:

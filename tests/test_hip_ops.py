@@ -95,6 +95,18 @@ def test_conv_split_bf16x6_is_fp32_faithful(ops, case):
         assert_close(dx2, 2 * dx_ref, 2e-6, 'split dgrad-acc')
 
 
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_wgrad_split(ops, case):
+    n, ci, co, H, W, k, s, d, p = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    ho, wo = (H + 2 * p - (k - 1) * d - 1) // s + 1, (W + 2 * p - (k - 1) * d - 1) // s + 1
+    dy = torch.randn(n, co, ho, wo, generator=g(4))
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, k, k), dy.double(), s, p, d)
+    dw = torch.zeros(co, ci, k, k, device=DEV)
+    ops.conv_wgrad_split_(dw, x.to(DEV), dy.to(DEV), k, s, d, p)
+    assert_close(dw, ref, 3e-6, 'split wgrad')
+
+
 def test_conv_channel_slice_views(ops):
     """conv reading / writing channel slices of bigger tensors (concat elimination)."""
     n, ci, co, H, W = 2, 32, 64, 10, 12

@@ -36,3 +36,12 @@ for name, ci, co, k, st, d, hin in [('l4.conv2', 512, 512, 3, 1, 4, 128), ('aspp
     t32 = timeit(lambda: ops.conv_fprop(x, wf, co, k, st, d, pad, out=y)); t6 = timeit(lambda: ops.conv_fprop_split(x, w6f, co, k, st, d, pad, out=y6))
     err = float((y6 - y).norm() / y.norm())
     print(f'{name:16s} fp32-MFMA {t32:7.3f} ms {fl/t32/1e9:6.1f} TF/s | bf16x6 {t6:7.3f} ms {fl/t6/1e9:6.1f} TF/s-equiv ({6*fl/t6/1e9:6.0f} bf16 TF/s) | diff {err:.1e}', flush=True)
+print('--- wgrad')
+for name, ci, co, k, st, d, hin in [('l4.conv2', 512, 512, 3, 1, 4, 128), ('aspp.pw', 2048, 512, 1, 1, 1, 128), ('head.bottleneck', 2560, 512, 3, 1, 1, 128),
+                                   ('l3.conv3', 256, 1024, 1, 1, 1, 128), ('l1.conv2', 64, 64, 3, 1, 1, 256), ('sep1.pw', 512, 512, 1, 1, 1, 256)]:
+    pad = d if k == 3 else 0
+    x = torch.randn(B, ci, hin, hin, device='cuda'); dy = torch.randn(B, co, hin, hin, device='cuda')
+    dw = torch.zeros(co, ci, k, k, device='cuda'); dw6 = torch.zeros_like(dw)
+    fl = 2.0 * dy.numel() * ci * k * k
+    t32 = timeit(lambda: ops.conv_wgrad_(dw, x, dy, k, st, d, pad)); t6 = timeit(lambda: ops.conv_wgrad_split_(dw6, x, dy, k, st, d, pad))
+    print(f'{name:16s} fp32-MFMA {t32:7.3f} ms {fl/t32/1e9:6.1f} TF/s | bf16x6 {t6:7.3f} ms {fl/t6/1e9:6.1f} TF/s-equiv', flush=True)
