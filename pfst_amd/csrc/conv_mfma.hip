@@ -388,16 +388,16 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
-__global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ db, int N, int C, int HW) {
+// grid: (splits over HW, C, N): one fp32 atomic per block
+__global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ db, int C, int HW, int chunk) {
   __shared__ double sm[16];
-  const int c = blockIdx.x;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* p = dy + (i64)n * dy_bs + (i64)c * HW;
+  const int beg = blockIdx.x * chunk, end = min(beg + chunk, HW);
   double s = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const float* p = dy + (i64)n * dy_bs + (i64)c * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += (double)p[i];
-  }
+  for (int i = beg + threadIdx.x; i < end; i += blockDim.x) s += (double)p[i];
   s = block_sum_d(s, sm);
-  if (threadIdx.x == 0) db[c] += (float)s;
+  if (threadIdx.x == 0) atomicAdd(&db[c], (float)s);
 }
 
 template <int BM, bool G>
@@ -513,8 +513,11 @@ extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, 
 }
 
 extern "C" int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream) {
-  PFST_CHECK_ARG(dy && db && N > 0 && C > 0 && HW > 0);
-  hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, db, N, C, HW);
+  PFST_CHECK_ARG(dy && db && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  int splits = cdiv(HW, 4096);
+  if (splits > 256) splits = 256;
+  const int chunk = cdiv(HW, splits);
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(cdiv(HW, chunk), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, db, C, HW, chunk);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
