@@ -41,31 +41,34 @@ class KernelTimer:
             n, c, hi, wi, m, ho, wo, ks, mode = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[17]
             bm = 128 if m > 64 else (64 if m > 32 else 32)
             px = ho * wo if mode == 0 else hi * wi            # forward-output pixels = algorithmic work
-            return f'conv_igemm_kernel<{bm},{"true" if c % 16 else "false"}>', 2.0 * n * m * c * ks * ks * px
+            nbytes = 4.0 * (n * c * hi * wi + n * m * ho * wo * (2 if a[18] else 1) + c * ks * ks * m)
+            return f'conv_igemm_kernel<{bm},{"true" if c % 16 else "false"}>', 2.0 * n * m * c * ks * ks * px, nbytes
         if name == 'pfst_conv_wgrad':
             n, ci, co, ho, wo, ks = a[5], a[6], a[9], a[10], a[11], a[12]
             bm = 128 if co > 64 else (64 if co > 32 else 32)
-            return f'conv_wgrad_kernel<{bm},{ks * ks}>', 2.0 * n * co * ci * ks * ks * ho * wo
-        return name, 0.0
+            nbytes = 4.0 * (n * ci * a[7] * a[8] + n * co * ho * wo + 2 * co * ci * ks * ks)
+            return f'conv_wgrad_kernel<{bm},{ks * ks}>', 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
+        return name, 0.0, 0.0
 
     def call(self, name, *args):
         if not self.enabled:
             return self.inner(name, *args)
-        key, flops = self._conv_variant(name, args)
+        key, flops, nbytes = self._conv_variant(name, args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         self.inner(name, *args)
         e.record()
-        self.records.append((key, s, e, flops))
+        self.records.append((key, s, e, flops, nbytes))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, s, e, flops in self.records:
-            d = agg.setdefault(key, [0, 0.0, 0.0])
+        for key, s, e, flops, nbytes in self.records:
+            d = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e)
             d[2] += flops
+            d[3] += nbytes
         return agg
 
 
@@ -192,12 +195,12 @@ def main():
             tot_ms = sum(v[1] for v in agg.values())
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             dom = max(mfma.items(), key=lambda kv: kv[1][1])
-            cnt, ms, fl = dom[1]
+            cnt, ms, fl, nb = dom[1]
             achieved = fl / (ms * 1e-3) / 1e12
             res['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom[0]),
                                'launches': cnt, 'avg_launch_ms': ms / cnt,
-                               'algorithmic_flops_per_launch': fl / cnt}
+                               'algorithmic_flops_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
             all_fl = sum(v[2] for v in mfma.values())
             all_ms = sum(v[1] for v in mfma.values())
             res['mfma_all_convs'] = {'tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
