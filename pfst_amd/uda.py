@@ -20,7 +20,7 @@ import torch.nn as nn
 
 from . import dist as pdist
 from . import hip_ops as ops
-from .engine import ParamArena, Tape, Var
+from .engine import ParamArena, Tape
 from .registry import LOSSES, UDA, build_loss, build_segmentor
 
 
@@ -115,13 +115,6 @@ class UDADecorator(nn.Module):
 
     def aug_test(self, imgs, img_metas, rescale=True):
         raise NotImplementedError('aug_test is outside the PFST configs')
-
-
-def parse_losses(losses):
-    """BaseSegmentor._parse_losses (base.py:177-222) on device scalars: returns (names, packed tensor, loss_mask).
-    Values stay on the device; ONE read-back happens at the end of the step."""
-    names = list(losses.keys())
-    return names, [losses[k] for k in names]
 
 
 @UDA.register_module()
