@@ -43,14 +43,18 @@ int pfst_conv_pack_weight(const float* w, float* wk_fprop, float* wk_dgrad, int 
  * ksize in {1,3}; accumulate != 0 adds into `out`. */
 int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
                     int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                    int mode, int accumulate, pfst_stream_t stream);
+                    int mode, int accumulate, float* stats, pfst_stream_t stream);
+/* Fused BatchNorm statistics: if `stats` != NULL the epilogue also writes per-channel partial (sum, sum of squares)
+ * pairs to stats[M][N * pfst_conv_stats_slots(M, Ho, Wo)][2] (fp32, no atomics); reduce them with
+ * pfst_bn_finalize_partials.  Saves the separate full-tensor read of pfst_bn_stats. */
+int pfst_conv_stats_slots(int M, int Ho, int Wo);
 /* The same convolution on the bf16 matrix cores with fp32-faithful arithmetic: operands are split exactly into three
  * bf16 pieces and the six piece-products >= 2^-16 are accumulated in fp32 (csrc/conv_split.hip).  Needs C % 16 == 0
  * (returns -3 otherwise).  wk6_*: pfst_conv_pack_weight_split images, 6*Cout*Cin*T bytes each. */
 int pfst_conv_pack_weight_split(const float* w, void* wk6_fprop, void* wk6_dgrad, int Cout, int Cin, int T, pfst_stream_t stream);
 int pfst_conv_igemm_split(const float* in, long long in_bs, const void* wk6, const float* bias, float* out, long long out_bs,
                           int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                          int mode, int accumulate, pfst_stream_t stream);
+                          int mode, int accumulate, float* stats, pfst_stream_t stream);
 int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
                           int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
                           pfst_stream_t stream);
@@ -73,6 +77,9 @@ int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long l
  * running_mean != NULL.  ws: >= 2*C doubles of scratch. */
 int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
                   float* running_mean, float* running_var, float momentum, float eps, double* ws, pfst_stream_t stream);
+/* the same from the conv epilogue's partials[C][T][2] (count = N*H*W elements per channel) */
+int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
+                              float* running_mean, float* running_var, float momentum, float eps, pfst_stream_t stream);
 /* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
 int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -58,6 +58,36 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double 
   }
 }
 
+// statistics from the conv epilogue's partials: part[c][T][2] (sum, sum of squares per slot)   grid: C blocks
+__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ part, int T, double count,
+                                                                    float* __restrict__ mean, float* __restrict__ invstd,
+                                                                    float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                    float momentum, float eps) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x;
+  const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    const float2 v = p[i];
+    s += (double)v.x;
+    ss += (double)v.y;
+  }
+  s = block_sum_d(s, sm);
+  ss = block_sum_d(ss, sm);
+  if (threadIdx.x == 0) {
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  }
+}
+
 // grid: (blocks over HW, C, N)
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ res,
                                                        i64 res_bs, float* __restrict__ y, i64 y_bs,
@@ -188,6 +218,16 @@ extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int H
   hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C, N), dim3(256), 0, s, x, x_bs, HW, chunk, ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, C, (double)N * HW, mean, invstd, running_mean,
                      running_var, momentum, eps);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
+                                         float* running_mean, float* running_var, float momentum, float eps, pfst_stream_t stream) {
+  PFST_CHECK_ARG(partials && mean && invstd && T > 0 && C > 0 && count > 0);
+  PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
+                     running_mean, running_var, momentum, eps);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -43,7 +43,7 @@ template <int BM, bool GENERIC, int BK, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ in, i64 in_bs, const float* __restrict__ wk, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate) {
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -195,6 +195,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
+  // the 32 lanes of each half-wave with shuffles and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
+  // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
+  if (stats) {
+    const int gx = (P + BN - 1) / BN;
+    const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pp = p0 + wn0 + j * 32 + l31;
+          const float v = pp < P ? acc[i][j][r] : 0.f;
+          sv += v;
+          sq = fmaf(v, v, sq);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sv += __shfl_xor(sv, o, 64);
+          sq += __shfl_xor(sq, o, 64);
+        }
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 == 0 && m < M) {
+          float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
+          *dst = make_float2(sv, sq);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -418,25 +449,25 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float*
 
 template <int BM, bool G>
 int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
-                 int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
+                 int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
   static const int bk_env = getenv("PFST_IGEMM_BK") ? atoi(getenv("PFST_IGEMM_BK")) : 0;   // tuning knobs
   static const int bn_env = getenv("PFST_IGEMM_BN") ? atoi(getenv("PFST_IGEMM_BN")) : 0;
   const bool bk32 = !G && (C % 32 == 0) && bk_env == 32;   // measured: BK=16 (3 blocks/CU) beats BK=32 by ~2 %
-  const bool bn256 = BM == 128 && !G && bn_env == 256 && (i64)Ho * Wo >= 4096;
+  const bool bn256 = BM == 128 && !G && bn_env == 256 && (i64)Ho * Wo >= 4096 && !stats;
   if (bn256) {
     if constexpr (BM == 128 && !G) {
       dim3 grid(cdiv((i64)Ho * Wo, 256) * cdiv(M, BM), 1, N);
       hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 256>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc);
+                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
     }
   } else {
     dim3 grid(cdiv((i64)Ho * Wo, 128) * cdiv(M, BM), 1, N);
     if (bk32)
       hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 32, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc);
+                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
     else
       hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc);
+                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
@@ -485,9 +516,14 @@ extern "C" int pfst_conv_pack_weight(const float* w, float* wk_fprop, float* wk_
   return PFST_OK;
 }
 
+extern "C" int pfst_conv_stats_slots(int M, int Ho, int Wo) {
+  const int waves_n = M > 64 ? 2 : 4;             // WAVES_N of the BM = 128 / 64 / 32 tile variants
+  return cdiv((i64)Ho * Wo, 128) * waves_n;
+}
+
 extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
                                int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                               int mode, int accumulate, pfst_stream_t stream) {
+                               int mode, int accumulate, float* stats, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
@@ -500,10 +536,11 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   hipStream_t s = (hipStream_t)stream;
+  const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   const bool generic = (C % BK_MIN) != 0;
 #define PFST_IGEMM(BM_)                                                                                             \
-  return generic ? launch_igemm<BM_, true>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s) \
-                 : launch_igemm<BM_, false>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s)
+  return generic ? launch_igemm<BM_, true>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s) \
+                 : launch_igemm<BM_, false>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s)
   if (M > 64) { PFST_IGEMM(128); }
   if (M > 32) { PFST_IGEMM(64); }
   PFST_IGEMM(32);

@@ -51,7 +51,7 @@ template <int BM>
 __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate) {
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -181,6 +181,37 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     __syncthreads();
   }
 
+  // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
+  // the 32 lanes of each half-wave with shuffles and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
+  // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
+  if (stats) {
+    const int gx = (P + BN - 1) / BN;
+    const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int pp = p0 + wn0 + j * 32 + l31;
+          const float v = pp < P ? acc[i][j][r] : 0.f;
+          sv += v;
+          sq = fmaf(v, v, sq);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sv += __shfl_xor(sv, o, 64);
+          sq += __shfl_xor(sq, o, 64);
+        }
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 == 0 && m < M) {
+          float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
+          *dst = make_float2(sv, sq);
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -382,10 +413,10 @@ int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, flo
 
 template <int BM>
 int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
-                 int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, hipStream_t s) {
+                 int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), 1, N);
   hipLaunchKernelGGL((conv_igemm_split_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
-                     Wi, M, Ho, Wo, ks, a, b, c, d, acc);
+                     Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -405,7 +436,7 @@ extern "C" int pfst_conv_pack_weight_split(const float* w, void* wk6_fprop, void
 
 extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const void* wk6, const float* bias, float* out, long long out_bs,
                                      int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                                     int mode, int accumulate, pfst_stream_t stream) {
+                                     int mode, int accumulate, float* stats, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk6 && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
@@ -422,9 +453,10 @@ extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const voi
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   hipStream_t s = (hipStream_t)stream;
-  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
-  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
-  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, s);
+  const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
+  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
 }
 
 extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,

@@ -91,16 +91,45 @@ def pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
     return wf, wd
 
 
-def conv_fprop(x, wk, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None):
+_stats_cache = {}
+
+
+def _stats_ws(dev, nfloat):
+    """per-stream scratch for the conv epilogue's BN partials (consumed by bn_finalize_partials on the same stream)"""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _stats_cache.get(key)
+    if t is None or t.numel() < nfloat:
+        t = torch.empty(max(nfloat, 1 << 20), dtype=F32, device=dev)
+        _stats_cache[key] = t
+    return t
+
+
+def conv_stats_slots(n, cout, ho, wo):
+    from ._lib import lib
+    return n * lib().pfst_conv_stats_slots(cout, ho, wo)
+
+
+def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    mean = torch.empty(c, device=stats.device)
+    invstd = torch.empty(c, device=stats.device)
+    call('pfst_bn_finalize_partials', stats.data_ptr(), slots, c, float(count), mean.data_ptr(), invstd.data_ptr(),
+         _p(running_mean), _p(running_var), momentum, eps, _stream())
+    return mean, invstd
+
+
+def conv_fprop(x, wk, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
+    """want_stats: also return (stats_ws, slots), the epilogue's per-channel BN partial sums"""
     n, c, hi, wi = x.shape
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
     assert wk.numel() == ksize * ksize * c * cout, (wk.shape, c, cout, ksize)
     if out is None:
         out = torch.empty(n, cout, ho, wo, device=x.device)
     assert tuple(out.shape) == (n, cout, ho, wo)
+    slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
+    st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm', x.data_ptr(), _bs(x), _dense(wk).data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _stream())
-    return out
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+    return (out, st, slots) if want_stats else out
 
 
 def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
@@ -112,7 +141,7 @@ def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, ac
         out = torch.empty(n, cin, hi, wi, device=dy.device)
     assert tuple(out.shape) == (n, cin, hi, wi)
     call('pfst_conv_igemm', dy.data_ptr(), _bs(dy), _dense(wk_d).data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), _stream())
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
     return out
 
 
@@ -127,15 +156,17 @@ def pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=Non
     return wf, wd
 
 
-def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None):
+def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
     n, c, hi, wi = x.shape
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
     assert wk6.numel() == 6 * ksize * ksize * c * cout
     if out is None:
         out = torch.empty(n, cout, ho, wo, device=x.device)
+    slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
+    st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm_split', x.data_ptr(), _bs(x), wk6.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _stream())
-    return out
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+    return (out, st, slots) if want_stats else out
 
 
 def conv_dgrad_split(dy, wk6_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
@@ -146,7 +177,7 @@ def conv_dgrad_split(dy, wk6_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=N
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)
     call('pfst_conv_igemm_split', dy.data_ptr(), _bs(dy), wk6_d.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), _stream())
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
     return out
 
 

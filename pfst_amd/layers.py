@@ -21,6 +21,7 @@ _BN_EVAL = False
 #   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores (csrc/conv_split.hip), opt-in.
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
+FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
 
 
 class bn_eval:
@@ -56,10 +57,12 @@ class Conv2dP(nn.Module):
     def depthwise(self):
         return self.groups > 1
 
-    def fprop(self, xd, out=None, bias=None):
+    def fprop(self, xd, out=None, bias=None, want_stats=False):
         if self.split_f:
-            return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out)
-        return ops.conv_fprop(xd, self.wf, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out)
+            return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
+                                        want_stats=want_stats)
+        return ops.conv_fprop(xd, self.wf, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
+                              want_stats=want_stats)
 
     def dgrad(self, dy, in_hw, out, accumulate):
         if self.split_d:
@@ -169,15 +172,22 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
     (then the returned Var is expected to be obtained from the concat Var's .slice())."""
     xd = x.data
+    fused_stats = FUSE_BN_STATS and not _BN_EVAL and not conv.depthwise
     if conv.depthwise:
         pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
+    elif fused_stats:                              # batch statistics come out of the GEMM epilogue
+        pre, st, slots = conv.fprop(xd, want_stats=True)
     else:
         pre = conv.fprop(xd)
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'
         mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)
     else:
-        mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+        if fused_stats:
+            n, c, h, w = pre.shape
+            mean, invstd = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+        else:
+            mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
         bn._pending_batches += 1
     out_var = None
     if isinstance(out, Var):                       # slice of a concat Var

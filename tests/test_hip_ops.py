@@ -107,6 +107,39 @@ def test_conv_wgrad_split(ops, case):
     assert_close(dw, ref, 3e-6, 'split wgrad')
 
 
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[2] != 6])
+def test_conv_fused_bn_statistics(ops, case, split):
+    """BN batch statistics from the conv epilogue's partial sums == statistics of the conv output (torch, fp64),
+    including the running-stat update (momentum 0.1, unbiased variance)."""
+    n, ci, co, H, W, k, s, d, p = case
+    if split and ci % 16:
+        pytest.skip('split kernel needs Cin % 16 == 0')
+    x = torch.randn(n, ci, H, W, generator=g(1)) + 0.3
+    w = torch.randn(co, ci, k, k, generator=g(2)) * 0.1
+    ref = F.conv2d(x.double(), w.double(), None, s, p, d)
+    if split:
+        w6f, _ = ops.pack_weight_split(w.to(DEV), True, False)
+        y, st, slots = ops.conv_fprop_split(x.to(DEV), w6f, co, k, s, d, p, want_stats=True)
+    else:
+        wf, _ = ops.pack_weight(w.to(DEV), want_dgrad=False)
+        y, st, slots = ops.conv_fprop(x.to(DEV), wf, co, k, s, d, p, want_stats=True)
+    assert_close(y, ref, 2e-5, 'fprop with stats')
+    rm, rv = torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+    cnt = ref.numel() // co
+    mean, invstd = ops.bn_finalize_partials(st, slots, co, cnt, rm, rv, 0.1, 1e-5)
+    m_ref = ref.mean((0, 2, 3))
+    v_ref = ref.var((0, 2, 3), unbiased=False)
+    assert_close(mean, m_ref, 2e-5, 'mean')
+    assert_close(invstd, 1.0 / torch.sqrt(v_ref + 1e-5), 2e-5, 'invstd')
+    assert_close(rm, 0.1 * m_ref, 2e-5, 'running mean')
+    assert_close(rv, 0.9 + 0.1 * v_ref * cnt / (cnt - 1), 2e-5, 'running var')
+    # and identical (to fp32 rounding of the partials) to the stand-alone statistics kernel
+    m2, i2 = ops.bn_stats(y)
+    assert_close(mean, m2, 1e-5, 'mean vs bn_stats')
+    assert_close(invstd, i2, 1e-5, 'invstd vs bn_stats')
+
+
 def test_conv_channel_slice_views(ops):
     """conv reading / writing channel slices of bigger tensors (concat elimination)."""
     n, ci, co, H, W = 2, 32, 64, 10, 12

@@ -17,7 +17,7 @@ vp = ctypes.c_void_p
 L.pfst_conv_pack_weight(vp(w.data_ptr()), vp(wf.data_ptr()), None, M, C, 1, None)
 def run():
     L.pfst_conv_igemm(vp(x.data_ptr()), ctypes.c_longlong(C * H * H), vp(wf.data_ptr()), None, vp(y.data_ptr()), ctypes.c_longlong(M * H * H),
-                      B, C, H, H, M, H, H, 1, 1, 1, 0, 0, 0, None)
+                      B, C, H, H, M, H, H, 1, 1, 1, 0, 0, 0, None, None)
 t0 = time.time()
 while time.time() - t0 < 3.0:       # >= 2 s of back-to-back launches on random data before reading the stamps
     for _ in range(50): run()
