@@ -80,7 +80,12 @@ def pmc_traffic(kernel):
     if not os.path.exists(path):
         return None
     rec = json.load(open(path))
-    norm = lambda k: k.replace(' ', '').replace(',16>', '>').replace(',32>', '>')
+    def norm(k):               # 'conv_igemm_kernel<128, false, 16, 128>' -> 'conv_igemm_kernel<128,false>' (first two template args)
+        k = k.replace(' ', '')
+        if '<' not in k:
+            return k
+        base, args = k.split('<', 1)
+        return base + '<' + ','.join(args.rstrip('>').split(',')[:2]) + '>'
     for k, v in rec.items():
         if isinstance(v, dict) and norm(k) == norm(kernel):
             return (v['fetch_MB_corrected'] + v['write_MB']) * 1e6
