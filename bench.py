@@ -48,6 +48,21 @@ class KernelTimer:
             bm = 128 if co > 64 else (64 if co > 32 else 32)
             nbytes = 4.0 * (n * ci * a[7] * a[8] + n * co * ho * wo + 2 * co * ci * ks * ks)
             return f'conv_wgrad_kernel<{bm},{ks * ks}>', 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
+        # HBM-bound kernels: read-once / write-once algorithmic bytes, fp32
+        if name == 'pfst_dwconv3x3':
+            n, c, h, w_, acc = a[5], a[6], a[7], a[8], a[11]
+            return name, 0.0, 4.0 * n * c * h * w_ * (3 if acc else 2) + 36.0 * c
+        if name == 'pfst_dwconv3x3_wgrad':
+            return name, 0.0, 4.0 * a[5] * a[6] * a[7] * a[8] * 2
+        if name == 'pfst_bn_stats':
+            return name, 0.0, 4.0 * a[2] * a[3] * a[4]
+        if name == 'pfst_bn_apply':                       # read x (+ residual), write y
+            return name, 0.0, 4.0 * a[10] * a[11] * a[12] * (3 if a[2] else 2)
+        if name == 'pfst_bn_backward':                    # minimum: read dy, x (+ y for the residual form), write dx (+ dres)
+            nel = 4.0 * a[17] * a[18] * a[19]
+            return name, 0.0, nel * (3 + (1 if a[2] else 0) + (1 if a[12] else 0))
+        if name == 'pfst_adamw_step':
+            return name, 0.0, 0.0
         return name, 0.0, 0.0
 
     def call(self, name, *args):
@@ -210,6 +225,11 @@ def main():
             all_ms = sum(v[1] for v in mfma.values())
             res['mfma_all_convs'] = {'tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
                                      'share_of_kernel_time': all_ms / tot_ms}
+            # the memory-bound kernels against the HBM roofline: algorithmic bytes (read-once / write-once) / kernel time.
+            # bn_backward is two passes (reduce + apply) over a 3-tensor minimum, so its ceiling is 3/5 of the peak.
+            res['hbm_kernels'] = {k: {'GBps': round(v[3] / (v[1] * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(v[3] / (v[1] * 1e-3) / 8e12, 3),
+                                      'ms_per_step': round(v[1] / args.steps, 3)}
+                                  for k, v in agg.items() if v[2] == 0 and v[3] > 0}
             res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
             res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
         if world == 1 and not args.no_alt_math:

@@ -1,0 +1,187 @@
+// Implicit-GEMM convolution on the fp32-input MFMA, "K-quad" main loop (Cin % 16 == 0; fprop and dgrad):
+//   out[n][m][p] (+)= sum_k W[m][k] * in[n][ci(k)][src(p, tap(k))],  k = tap*C + ci,   GEMM M = Cout, N = pixels, K = taps*C.
+// v_mfma_f32_32x32x2_f32 executes at the fp32 VECTOR rate on the SIMD's vector pipe: every VALU instruction in the main
+// loop takes ~4 cycles away from the matrix instructions (measured with SQ_INSTS_VALU / SQ_VALU_MFMA_BUSY_CYCLES: MFMA
+// utilisation = 64 N_mfma / (64 N_mfma + 4 N_valu) on all our fp32 kernels).  So the loop is built to need almost none:
+//   * both operands are staged as 16-byte quads of 4 consecutive k: LDS image [quad][row] of float4, one ds_write_b128 per
+//     quad and one ds_read_b128 per MFMA fragment of FOUR k-steps, every LDS address = per-thread base + immediate
+//     (the double-buffer flip costs one add per base pointer and K-step);
+//   * weights are pre-packed [K/4][M][4] (pfst_conv_pack_weight), read with one buffer_load_dwordx4 per quad;
+//   * activations are read with buffer_load_dword, voffsets constant while the tap is unchanged, channel advance as a
+//     scalar soffset, padding / ragged tiles as out-of-range offsets (hardware returns 0);
+//   * lane (l31, lh) holds quad 2g+lh of its row; MFMA #e of group g consumes element e of both operands
+//     (k = 8g + 4 lh + e) -- the K sum is order-free, A and B only have to agree.
+// Tiling, XCD-aware tile order and the epilogue (bias / accumulate / fused BN statistics) are those of conv_mfma.hip,
+// which keeps the generic path (Cin % 16 != 0: the 3- and 10-band stems).
+#include "conv_epilogue.h"
+#include "../../include/pfst_hip.h"
+
+namespace {
+
+constexpr int QBN = 128, QBK = 16, QNQ = 4;
+
+__device__ __forceinline__ bool src_coord_q(int o, int t, int a, int b, int c0, int div, int lim, int& s) {
+  const int v = o * a + t * b + c0;
+  const int odd = v & (div - 1);
+  s = v >> (div >> 1);
+  return (odd == 0) & (s >= 0) & (s < lim);
+}
+
+template <int BM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_igemm_q_kernel(
+    const float* __restrict__ in, i64 in_bs, const float4* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+  constexpr int BN = QBN, BK = QBK, NQ = QNQ;
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_CH = NQ * BM;                       // weight quads per K-step
+  constexpr int A_N = (A_CH + 255) / 256;
+  constexpr unsigned OOB = 0x80000000u;
+
+  __shared__ float4 As[2][NQ * BM];
+  __shared__ float4 Bs[2][NQ * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi;
+  int bx, by;   // XCD-aware tile order: the m-tiles of one pixel tile get ids 8 apart (same XCD, shared L2 copy of the activations)
+  {
+    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int lin = blockIdx.x;
+    if ((gx & 7) == 0) {
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    } else {
+      by = lin / gx;
+      bx = lin - by * gx;
+    }
+  }
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.z;
+  const int K = C * ks * ks;
+  const int KT = K / BK;
+  in += (i64)n * in_bs;
+  out += (i64)n * out_bs;
+
+  // B staging role: one pixel, one k-half (8 channels = 2 quads);  A staging role: quads tid + 256 i of the [quad][row] image
+  const int pix = tid & (BN - 1), kh = tid >> 7;
+  const int p = p0 + pix;
+  const bool pvalid = p < P;
+  const int oy = pvalid ? p / Wo : 0;
+  const int ox = pvalid ? p - oy * Wo : 0;
+
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wq), 0, K * M * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
+  unsigned a_voff[A_N], b_voff[8];
+#pragma unroll
+  for (int i = 0; i < A_N; ++i) {
+    const int c = tid + 256 * i;
+    const int kq = c / BM, row = c - kq * BM;
+    a_voff[i] = (c < A_CH && m0 + row < M) ? 16u * ((unsigned)kq * (unsigned)M + (unsigned)(m0 + row)) : OOB;
+  }
+  int ld_ty = 0, ld_tx = 0, ld_ci0 = 0;              // (tap, first channel) of the K-slice being prefetched
+  auto set_tap = [&]() {
+    int sy, sx;
+    const bool ok = pvalid & src_coord_q(oy, ld_ty, ca, cb, cc, cdivv, Hi, sy) & src_coord_q(ox, ld_tx, ca, cb, cc, cdivv, Wi, sx);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      b_voff[i] = ok ? 4u * ((unsigned)(kh * 8 + i) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
+  };
+  set_tap();
+
+  float4 areg[A_N];
+  float breg[8];
+  pfst_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load_tile = [&](int kt) {
+    const int a_soff = kt * (BK / 4) * M * 16, b_soff = ld_ci0 * HiWi * 4;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i)
+      areg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff[i], a_soff, 0));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff[i], b_soff, 0));
+    ld_ci0 += BK;
+    if (ld_ci0 >= C) {
+      ld_ci0 = 0; ld_tx += 1;
+      if (ld_tx == ks) { ld_tx = 0; ld_ty += 1; }
+      set_tap();
+    }
+  };
+  const int l31 = lane & 31, lh = lane >> 5;
+  // LDS pointers of this thread; the double-buffer flip is one add per pointer and K-step, everything else is immediates
+  const float4* a_rd = &As[0][lh * BM + wm0 + l31];     // + 2g * BM + 32 i
+  const float4* b_rd = &Bs[0][lh * BN + wn0 + l31];     // + 2g * BN + 32 j
+  float4* a_wr = &As[0][tid];                           // + 256 i
+  float4* b_wr = &Bs[0][(2 * kh) * BN + pix];           // + BN for the second quad
+  int da = NQ * BM, db = NQ * BN;
+
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i)
+      if (A_CH % 256 == 0 || tid + 256 * i < A_CH) a_wr[256 * i] = areg[i];
+    b_wr[0] = make_float4(breg[0], breg[1], breg[2], breg[3]);
+    b_wr[BN] = make_float4(breg[4], breg[5], breg[6], breg[7]);
+  };
+
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  a_wr += da; b_wr += db;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) load_tile(kt + 1);
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = a_rd[2 * g * BM + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = b_rd[2 * g * BN + 32 * j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float a = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+            const float b = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+    if (more) store_tile();
+    __syncthreads();
+    a_rd += da; b_rd += db; a_wr -= da; b_wr -= db;
+    da = -da; db = -db;
+  }
+  conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+}
+
+template <int BM>
+int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
+             int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
+  dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), 1, N);
+  hipLaunchKernelGGL((conv_igemm_q_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
+                     out_bs, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+}  // namespace
+
+int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
+                        int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
+  if (M > 64) return launch_q<128>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
+  if (M > 32) return launch_q<64>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
+  return launch_q<32>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
+}

@@ -13,7 +13,7 @@
 //   One 256-thread block (4 waves) computes a BM x 128 tile; each wave owns a 64x64 (or 32x32)
 //   sub-tile as 32x32 MFMA accumulators; K advances 16 per step through a double-buffered LDS
 //   tile with register-staged prefetch (one barrier per step).
-#include "common.h"
+#include "conv_epilogue.h"
 #include "../../include/pfst_hip.h"
 #include <stdlib.h>
 
@@ -194,56 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
-  // the 32 lanes of each half-wave with shuffles and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
-  // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
-  if (stats) {
-    const int gx = (P + BN - 1) / BN;
-    const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sv = 0.f, sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int pp = p0 + wn0 + j * 32 + l31;
-          const float v = pp < P ? acc[i][j][r] : 0.f;
-          sv += v;
-          sq = fmaf(v, v, sq);
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          sv += __shfl_xor(sv, o, 64);
-          sq += __shfl_xor(sq, o, 64);
-        }
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (l31 == 0 && m < M) {
-          float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
-          *dst = make_float2(sv, sq);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int pp = p0 + wn0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && pp < P) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          const i64 idx = (i64)m * P + pp;
-          if (accumulate) v += out[idx];
-          out[idx] = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
 #ifdef PFST_CLOCK_STAMPS
   if (tid == 0) {
     const unsigned b = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u;
@@ -416,21 +367,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   }
 }
 
+// K-major packings for the implicit GEMM.  Plain [k][m] when the channels per tap are not a multiple of 16 (generic kernel);
+// otherwise the K-quad image [k/4][m][4] that conv_igemm_q.hip reads with one 16-byte load per (quad, row).
+__device__ __forceinline__ i64 packed_index(i64 k, int m, int M, bool quad) {
+  return quad ? (((k >> 2) * M + m) << 2) + (k & 3) : k * M + m;
+}
+
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
                                    int Cout, int Cin, int T) {
   const i64 total = (i64)Cout * Cin * T;
+  const bool qf = (Cin % 16) == 0, qd = (Cout % 16) == 0;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
-    if (wf) {  // i = (t*Cin + ci)*Cout + co
+    if (wf) {  // i = (t*Cin + ci)*Cout + co : k = t*Cin + ci, row m = co
       const int co = (int)(i % Cout);
-      const i64 r = i / Cout;
-      const int ci = (int)(r % Cin), t = (int)(r / Cin);
-      wf[i] = w[((i64)co * Cin + ci) * T + t];
+      const i64 k = i / Cout;
+      const int ci = (int)(k % Cin), t = (int)(k / Cin);
+      wf[packed_index(k, co, Cout, qf)] = w[((i64)co * Cin + ci) * T + t];
     }
-    if (wd) {  // i = (t*Cout + co)*Cin + ci
+    if (wd) {  // i = (t*Cout + co)*Cin + ci : k = t*Cout + co, row m = ci
       const int ci = (int)(i % Cin);
-      const i64 r = i / Cin;
-      const int co = (int)(r % Cout), t = (int)(r / Cout);
-      wd[i] = w[((i64)co * Cin + ci) * T + t];
+      const i64 k = i / Cin;
+      const int co = (int)(k % Cout), t = (int)(k / Cout);
+      wd[packed_index(k, ci, Cin, qd)] = w[((i64)co * Cin + ci) * T + t];
     }
   }
 }
@@ -447,28 +405,12 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, i64 dy_bs, float*
   if (threadIdx.x == 0) atomicAdd(&db[c], (float)s);
 }
 
-template <int BM, bool G>
-int launch_igemm(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
-                 int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
-  static const int bk_env = getenv("PFST_IGEMM_BK") ? atoi(getenv("PFST_IGEMM_BK")) : 0;   // tuning knobs
-  static const int bn_env = getenv("PFST_IGEMM_BN") ? atoi(getenv("PFST_IGEMM_BN")) : 0;
-  const bool bk32 = !G && (C % 32 == 0) && bk_env == 32;   // measured: BK=16 (3 blocks/CU) beats BK=32 by ~2 %
-  const bool bn256 = BM == 128 && !G && bn_env == 256 && (i64)Ho * Wo >= 4096 && !stats;
-  if (bn256) {
-    if constexpr (BM == 128 && !G) {
-      dim3 grid(cdiv((i64)Ho * Wo, 256) * cdiv(M, BM), 1, N);
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 256>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-    }
-  } else {
-    dim3 grid(cdiv((i64)Ho * Wo, 128) * cdiv(M, BM), 1, N);
-    if (bk32)
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 32, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-    else
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, G, 16, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
-                         Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-  }
+template <int BM>
+int launch_igemm_generic(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
+                         int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
+  dim3 grid(cdiv((i64)Ho * Wo, 128) * cdiv(M, BM), 1, N);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, true, 16, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+                     Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -550,13 +492,11 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   hipStream_t s = (hipStream_t)stream;
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   const bool generic = (C % BK_MIN) != 0;
-#define PFST_IGEMM(BM_)                                                                                             \
-  return generic ? launch_igemm<BM_, true>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s) \
-                 : launch_igemm<BM_, false>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s)
-  if (M > 64) { PFST_IGEMM(128); }
-  if (M > 32) { PFST_IGEMM(64); }
-  PFST_IGEMM(32);
-#undef PFST_IGEMM
+  if (!generic)      // Cin % 16 == 0: K-quad kernel (conv_igemm_q.hip), weights packed [K/4][M][4]
+    return pfst_igemm_q_launch(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  if (M > 64) return launch_igemm_generic<128>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  if (M > 32) return launch_igemm_generic<64>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  return launch_igemm_generic<32>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
 }
 
 extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
@@ -568,6 +508,8 @@ extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, 
   PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
   PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo);
   hipStream_t s = (hipStream_t)stream;
+  if (pfst_wgrad_q_eligible(x, x_bs, dy, dy_bs, Hi, Wi, Ho, Wo, ksize, stride, dil))       // K-quad fast path (conv_wgrad_q.hip)
+    return pfst_wgrad_q_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, ksize, dil, pad, s);
 #define PFST_WGRAD(BM_)                                                                                          \
   return ksize == 3 ? launch_wgrad<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s) \
                     : launch_wgrad<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s)

@@ -10,7 +10,7 @@
 // whose Cin is not a multiple of 16 stay on the fp32-MFMA kernel).  Weights are pre-split once per step by
 // pfst_conv_pack_weight_split into the exact LDS image [k16-group][piece][k-half][row][8 x bf16]; activations are split
 // in registers on their way from HBM to LDS (fp32 NCHW stays the storage format everywhere).
-#include "common.h"
+#include "conv_epilogue.h"
 #include "../../include/pfst_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -181,55 +181,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     __syncthreads();
   }
 
-  // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
-  // the 32 lanes of each half-wave with shuffles and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
-  // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
-  if (stats) {
-    const int gx = (P + BN - 1) / BN;
-    const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sv = 0.f, sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int pp = p0 + wn0 + j * 32 + l31;
-          const float v = pp < P ? acc[i][j][r] : 0.f;
-          sv += v;
-          sq = fmaf(v, v, sq);
-        }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          sv += __shfl_xor(sv, o, 64);
-          sq += __shfl_xor(sq, o, 64);
-        }
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (l31 == 0 && m < M) {
-          float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
-          *dst = make_float2(sv, sq);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int pp = p0 + wn0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && pp < P) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          const i64 idx = (i64)m * P + pp;
-          if (accumulate) v += out[idx];
-          out[idx] = v;
-        }
-      }
-    }
-  }
+  conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
 }
 
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.

@@ -1,0 +1,259 @@
+// Weight gradient, "K-quad" fast path (stride 1, rows of 4-pixel quads):
+//   dW[m][j] += sum_{n,p} dY[n][m][p] * X[n][ci(j)][src(p, tap(j))],  j = ci*T + tap        GEMM M = Cout, N = Cin*T, K = pixels
+// Both operands are K(pixel)-contiguous in memory, so the whole staging path moves 16-byte quads of 4 consecutive pixels:
+//   global  : one buffer_load_dwordx4 per (row, quad)          (4x fewer VMEM instructions and address VALU than dword gathers)
+//   LDS     : image [quad][row] of float4, row XOR-swizzled by the quad index -> conflict-free ds_write_b128 / ds_read_b128
+//   MFMA    : v_mfma_f32_32x32x2_f32; lane (row l31, half lh) holds quad 2g+lh of its row, and MFMA #e of group g consumes
+//             element e of both operands: k = 8g + 4*lh + e.  The K sum is order-free, so A and B only have to agree.
+// 3x3 taps shift the source quad by dx = tx*dil - pad (4-byte-aligned dwordx4 loads).  A K-step is 16 pixels of one output
+// row, walked on the scalar unit: interior steps use constant voffsets + a scalar soffset (no per-lane arithmetic); the
+// first/last step of a row and the top/bottom `dil` rows load element-wise with out-of-range offsets for the padding.
+// Split-K over images and pixel chunks, fp32 atomics into the flat gradient arena -- as conv_wgrad_kernel (conv_mfma.hip),
+// which remains the generic path (stride 2, ragged widths).
+#include "common.h"
+#include "../../include/pfst_hip.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int QBJ = 128;
+
+template <int BM, int T, int WBK>
+__global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil, int pad, int chunks, int chunk_len) {
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = QBJ / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NQ = WBK / 4;                 // quads per K-step
+  constexpr int RPP = 256 / NQ;               // tile rows staged per pass
+  constexpr int A_N = (BM + RPP - 1) / RPP, B_N = QBJ / RPP;
+  constexpr int SW = 8 / NQ;                  // swizzle step: the 8 lanes of a ds_write_b128 group hit 8 distinct 16-B slots
+  constexpr int KS = T == 9 ? 3 : 1;
+  constexpr unsigned OOB = 0x80000000u;
+
+  __shared__ float4 As[2][NQ * BM];
+  __shared__ float4 Bs[2][NQ * QBJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
+  const int j0 = blockIdx.x * QBJ, m0 = blockIdx.y * BM;
+  const int n = blockIdx.z / chunks, chunk = blockIdx.z - n * chunks;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)n * x_bs;
+  dy += (i64)n * dy_bs;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
+
+  // staging role: quad q of rows r0 + RPP*i (4 x NQ consecutive lanes read one row's WBK*4 contiguous bytes)
+  const int q = tid % NQ, r0 = tid / NQ;
+  const int sw = (q * SW) & 7;
+  unsigned a_voff[A_N], b_voff[B_N];
+  int j_coff[B_N], j_dy[B_N], j_dx[B_N];
+#pragma unroll
+  for (int i = 0; i < A_N; ++i) {
+    const int r = r0 + RPP * i;
+    const int m = m0 + r;
+    a_voff[i] = (r < BM && m < M) ? 4u * ((unsigned)m * (unsigned)P + 4u * q) : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < B_N; ++i) {
+    const int j = j0 + r0 + RPP * i;
+    j_coff[i] = -1; j_dy[i] = 0; j_dx[i] = 0;
+    b_voff[i] = OOB;
+    if (j < J) {
+      if (T == 1) {
+        b_voff[i] = 4u * ((unsigned)j * (unsigned)HiWi + 4u * q);
+      } else {
+        const int ci = j / T, tap = j - ci * T;
+        const int ty = tap / KS, tx = tap - ty * KS;
+        j_coff[i] = ci * HiWi;
+        j_dy[i] = ty * dil - pad;
+        j_dx[i] = tx * dil - pad;
+      }
+    }
+  }
+
+  float4 areg[A_N], breg[B_N];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // 3x3: a K-step is 16 consecutive pixels of ONE output row (Wo % 16 == 0), so (oy0, ox0) are wave-uniform and advance
+  // on the scalar unit.  Interior steps (not the first/last step of a row, not within `dil` rows of the top/bottom) need no
+  // per-lane address or validity arithmetic at all: constant voffsets (biased by +dil rows/cols so they are never negative:
+  // the hardware range check looks at the voffset alone) plus a scalar soffset.  Edge steps take the general path.
+  int oy0 = 0, ox0 = 0;
+  if (T != 1) {
+    oy0 = pbeg / Wo;
+    ox0 = pbeg - oy0 * Wo;
+#pragma unroll
+    for (int i = 0; i < B_N; ++i)
+      b_voff[i] = j_coff[i] >= 0 ? 4u * (unsigned)(j_coff[i] + (j_dy[i] + dil) * Wi + (j_dx[i] + dil) + 4 * q) : OOB;
+  }
+  const int bias_px = dil * Wi + dil;
+
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, int so) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+  };
+  auto load_tile = [&](int pk0) {
+    const int p = pk0 + 4 * q;                 // P % 4 == 0 and chunk_len % WBK == 0: a quad is entirely in or out
+    const bool pv = p < pend;
+    const int soff = pk0 * 4;
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) areg[i] = ld4(a_rsrc, pv ? a_voff[i] : OOB, soff);
+    if (T == 1) {
+#pragma unroll
+      for (int i = 0; i < B_N; ++i) breg[i] = ld4(b_rsrc, pv ? b_voff[i] : OOB, soff);
+    } else {
+      const bool interior = (ox0 >= 16) & (ox0 + 32 <= Wo) & (oy0 >= dil) & (oy0 + dil < Hi) & (pk0 + WBK <= pend);
+      if (interior) {
+        const int so = (oy0 * Wi + ox0 - bias_px) * 4;
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) breg[i] = ld4(b_rsrc, b_voff[i], so);
+      } else {                                 // edge step: element-wise dword loads, padding / ragged ends via OOB offsets
+        const int ox = ox0 + 4 * q;
+#pragma unroll
+        for (int i = 0; i < B_N; ++i) {
+          const int sy = oy0 + j_dy[i], sx0 = ox + j_dx[i];
+          const bool rowok = pv & (j_coff[i] >= 0) & ((unsigned)sy < (unsigned)Hi);
+          const int base = j_coff[i] + sy * Wi + sx0;
+          float e[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool ok = rowok & ((unsigned)(sx0 + k) < (unsigned)Wi);
+            e[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, ok ? 4u * (unsigned)(base + k) : OOB, 0, 0));
+          }
+          breg[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      ox0 += WBK;                              // scalar walk over the output rows
+      if (ox0 >= Wo) { ox0 = 0; oy0 += 1; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) {
+      const int r = r0 + RPP * i;
+      if (A_N * RPP == BM || r < BM) As[buf][q * BM + (r ^ sw)] = areg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) {
+      const float4 v = breg[i];
+      Bs[buf][q * QBJ + ((r0 + RPP * i) ^ sw)] = v;
+    }
+  };
+
+  const int KT = (pend - pbeg + WBK - 1) / WBK;
+  load_tile(pbeg);
+  store_tile(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tile(pbeg + (kt + 1) * WBK);
+#pragma unroll
+    for (int g = 0; g < WBK / 8; ++g) {
+      const int qq = 2 * g + lh;
+      const int qs = (qq * SW) & 7;
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[cur][qq * BM + ((wm0 + i * 32 + l31) ^ qs)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][qq * QBJ + ((wn0 + j * 32 + l31) ^ qs)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float a = e == 0 ? af[i].x : e == 1 ? af[i].y : e == 2 ? af[i].z : af[i].w;
+            const float b = e == 0 ? bf[j].x : e == 1 ? bf[j].y : e == 2 ? bf[j].z : bf[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
+          }
+    }
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int BM, int T, int WBK>
+int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+             int Ho, int Wo, int dil, int pad, hipStream_t s) {
+  const int P = Ho * Wo, J = Cin * T;
+  const int tiles = cdiv(J, QBJ) * cdiv(M, BM);
+  // split-K chunking: whole rounds of resident blocks (see launch_wgrad_k in conv_mfma.hip); 32 KB LDS at WBK = 16, 64 KB at 32
+  static const int chunks_env = getenv("PFST_WGRAD_CHUNKS") ? atoi(getenv("PFST_WGRAD_CHUNKS")) : 0;
+  const double slots = 256.0 * (WBK == 16 ? 4 : 2);
+  int chunks = 1;
+  double best = -1.0;
+  for (int c = 1; c <= 64 && (c == 1 || P / c >= 512); ++c) {
+    const double rounds = (double)tiles * N * c / slots;
+    const double eff = rounds < 2.0 ? 0.45 * rounds : rounds / ceil(rounds);
+    if (eff > best + 0.02) { best = eff; chunks = c; }
+    if (eff >= 0.93) break;
+  }
+  if (chunks_env > 0) chunks = chunks_env;
+  int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
+  chunks = cdiv(P, chunk_len);
+  dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * chunks);
+  hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
+                     dil, pad, chunks, chunk_len);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+template <int BM, int T>
+int launch_q_bk(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
+                int Ho, int Wo, int dil, int pad, hipStream_t s) {
+  static const int wbk_env = getenv("PFST_WGRADQ_BK") ? atoi(getenv("PFST_WGRADQ_BK")) : 0;   // tuning knob
+  const int wbk = (wbk_env && T == 1) ? wbk_env : 16;        // the 3x3 row walk assumes 16-pixel K-steps
+  if (wbk == 32) return launch_q<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, s);
+  return launch_q<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, s);
+}
+
+}  // namespace
+
+// true if the quad path applies (the caller has validated the geometry already)
+bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, int dil) {
+  static const bool off = getenv("PFST_WGRAD_QUAD") && atoi(getenv("PFST_WGRAD_QUAD")) == 0;
+  if (off || stride != 1) return false;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) return false;
+  if ((x_bs | dy_bs) & 3) return false;
+  if (ksize == 1) return ((i64)Ho * Wo) % 4 == 0 && Hi == Ho && Wi == Wo;
+  return Wo % 16 == 0 && Hi == Ho && Wi == Wo && dil <= 8;    // 'same' 3x3 (pad == dil); 16-pixel K-steps walk whole rows
+}
+
+int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int Cout,
+                        int Ho, int Wo, int ksize, int dil, int pad, hipStream_t s) {
+#define PFST_WGQ(BM_)                                                                                            \
+  return ksize == 3 ? launch_q_bk<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, s)      \
+                    : launch_q_bk<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, s)
+  if (Cout > 64) { PFST_WGQ(128); }
+  if (Cout > 32) { PFST_WGQ(64); }
+  PFST_WGQ(32);
+#undef PFST_WGQ
+}

@@ -44,6 +44,16 @@ CONV_CASES = [
     (2, 512, 6, 16, 16, 1, 1, 1, 0),     # conv_seg (tiny M, bias)
     (2, 10, 32, 16, 16, 3, 2, 1, 1),     # 10-band stem
     (1, 160, 48, 9, 130, 1, 1, 1, 0),    # c1_bottleneck-like, P not multiple of 128
+    # shapes on the K-quad weight-gradient path (stride 1, width % 4 == 0): border quads, minimum width, ragged J / M
+    (2, 24, 40, 12, 16, 3, 1, 2, 2),
+    (1, 16, 96, 8, 4, 3, 1, 1, 1),
+    (2, 8, 16, 10, 12, 3, 1, 4, 4),
+    (1, 72, 200, 6, 20, 1, 1, 1, 0),
+    (2, 32, 64, 40, 36, 3, 1, 1, 1),     # > 512 pixels: split-K chunks
+    (2, 16, 48, 12, 64, 3, 1, 1, 1),     # 3x3 row-walk path (width % 16 == 0): interior + edge steps, dil 1 / 2 / 4
+    (1, 40, 72, 20, 48, 3, 1, 2, 2),
+    (2, 24, 136, 18, 80, 3, 1, 4, 4),
+    (1, 16, 32, 9, 16, 3, 1, 1, 1),      # one K-step per row: every step is an edge step
 ]
 
 
