@@ -34,6 +34,7 @@ class KernelTimer:
         self.inner = inner
         self.records = []      # (key, start_evt, end_evt, flops)
         self.enabled = False
+        self.per_layer = False
 
     @staticmethod
     def _conv_variant(name, a):
@@ -42,12 +43,15 @@ class KernelTimer:
             bm = 128 if m > 64 else (64 if m > 32 else 32)
             px = ho * wo if mode == 0 else hi * wi            # forward-output pixels = algorithmic work
             nbytes = 4.0 * (n * c * hi * wi + n * m * ho * wo * (2 if a[18] else 1) + c * ks * ks * m)
-            return f'conv_igemm_kernel<{bm},{"true" if c % 16 else "false"}>', 2.0 * n * m * c * ks * ks * px, nbytes
+            kern = f'conv_igemm_q_kernel<{bm}>' if c % 16 == 0 else f'conv_igemm_kernel<{bm},true>'   # dispatch of pfst_conv_igemm
+            return kern, 2.0 * n * m * c * ks * ks * px, nbytes
         if name == 'pfst_conv_wgrad':
-            n, ci, co, ho, wo, ks = a[5], a[6], a[9], a[10], a[11], a[12]
+            n, ci, co, ho, wo, ks, stride, dil = a[5], a[6], a[9], a[10], a[11], a[12], a[13], a[14]
             bm = 128 if co > 64 else (64 if co > 32 else 32)
             nbytes = 4.0 * (n * ci * a[7] * a[8] + n * co * ho * wo + 2 * co * ci * ks * ks)
-            return f'conv_wgrad_kernel<{bm},{ks * ks}>', 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
+            quad = stride == 1 and ((ks == 1 and (ho * wo) % 4 == 0) or (ks == 3 and wo % 16 == 0 and dil <= 8))   # pfst_wgrad_q_eligible
+            kern = f'conv_wgrad_q_kernel<{bm},{ks * ks}>' if quad else f'conv_wgrad_kernel<{bm},{ks * ks}>'
+            return kern, 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
         # HBM-bound kernels: read-once / write-once algorithmic bytes, fp32
         if name == 'pfst_dwconv3x3':
             n, c, h, w_, acc = a[5], a[6], a[7], a[8], a[11]
@@ -69,6 +73,8 @@ class KernelTimer:
         if not self.enabled:
             return self.inner(name, *args)
         key, flops, nbytes = self._conv_variant(name, args)
+        if self.per_layer and flops > 0:
+            key = key + ' ' + ' '.join(str(args[i]) for i in ((6, 7, 8, 10, 13, 15, 17, 18) if name == 'pfst_conv_igemm' else (5, 6, 7, 9, 12, 14)))
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         self.inner(name, *args)
@@ -134,6 +140,7 @@ def main():
     ap.add_argument('--size', type=int, default=None, help='tile size (default 1024)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--per-layer', action='store_true', help='debug: per-layer conv timing table on stderr')
     ap.add_argument('--no-alt-math', action='store_true', help='skip the informational bf16x6 pass (N=1 only)')
     args = ap.parse_args()
 
@@ -182,6 +189,7 @@ def main():
     if world > 1:
         dist.barrier()
     timer.enabled = not args.no_kernel_timing
+    timer.per_layer = args.per_layer
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -212,6 +220,16 @@ def main():
         }
         if not args.no_kernel_timing:
             agg = timer.summary()
+            if args.per_layer:       # debug table, then fold back to per-kernel keys for the JSON line
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    if v[2] > 0:
+                        sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/call {v[1] / v[0]:7.3f}  TF/s {v[2] / v[1] / 1e9:6.1f}\n')
+                folded = {}
+                for k, v in agg.items():
+                    d = folded.setdefault(k.split(' ')[0] if v[2] > 0 else k, [0, 0.0, 0.0, 0.0])
+                    for i in range(4):
+                        d[i] += v[i]
+                agg = folded
             tot_ms = sum(v[1] for v in agg.values())
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             dom = max(mfma.items(), key=lambda kv: kv[1][1])

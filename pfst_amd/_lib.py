@@ -6,7 +6,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, '..', 'include', 'pfst_hip.h')
-LIB_PATH = os.path.join(HERE, 'libpfst_hip.so')
+LIB_PATH = os.environ.get('PFST_HIP_LIB') or os.path.join(HERE, 'libpfst_hip.so')   # override: A/B builds of the kernels
 
 _SCALARS = {'int': ctypes.c_int, 'long long': ctypes.c_longlong, 'float': ctypes.c_float, 'double': ctypes.c_double}
 

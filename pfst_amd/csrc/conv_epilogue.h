@@ -6,13 +6,27 @@
 
 typedef float pfst_f32x16 __attribute__((ext_vector_type(16)));
 
+// sum over each 32-lane half of the wave, result in every lane: four DPP-fused adds (quad swaps, half-row and row mirrors)
+// and one ds_swizzle for the 16 <-> 16 exchange -- a tenth of the LDS traffic of five ds_bpermute shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float half_wave_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  v = dpp_add<0x140>(v);    // row_mirror
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+}
+
 template <int TM, int TN, int WAVES_N, int BN>
 __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
                                               int wm0, int wn0, int bx, int n, int wid, int lane) {
   const int l31 = lane & 31, lh = lane >> 5;
   // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
-  // the 32 lanes of each half-wave with shuffles and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
+  // the 32 lanes of each half-wave (half_wave_sum) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
   // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
   if (stats) {
     const int gx = (P + BN - 1) / BN;
@@ -29,11 +43,8 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
           sv += v;
           sq = fmaf(v, v, sq);
         }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          sv += __shfl_xor(sv, o, 64);
-          sq += __shfl_xor(sq, o, 64);
-        }
+        sv = half_wave_sum(sv);
+        sq = half_wave_sum(sq);
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (l31 == 0 && m < M) {
           float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
