@@ -2,7 +2,8 @@
 //   dW[m][j] += sum_{n,p} dY[n][m][p] * X[n][ci(j)][src(p, tap(j))],  j = ci*T + tap        GEMM M = Cout, N = Cin*T, K = pixels
 // Both operands are K(pixel)-contiguous in memory, so the whole staging path moves 16-byte quads of 4 consecutive pixels:
 //   global  : one buffer_load_dwordx4 per (row, quad)          (4x fewer VMEM instructions and address VALU than dword gathers)
-//   LDS     : image [quad][row] of float4, row XOR-swizzled by the quad index -> conflict-free ds_write_b128 / ds_read_b128
+//   LDS     : image [quad][row (+ pad)] of float4, planes padded by 8/NQ rows -> conflict-free ds_write_b128 / ds_read_b128,
+//             every address = per-thread base + immediate
 //   MFMA    : v_mfma_f32_32x32x2_f32; lane (row l31, half lh) holds quad 2g+lh of its row, and MFMA #e of group g consumes
 //             element e of both operands: k = 8g + 4*lh + e.  The K sum is order-free, so A and B only have to agree.
 // 3x3 taps shift the source quad by dx = tx*dil - pad (4-byte-aligned dwordx4 loads).  A K-step is 16 pixels of one output
@@ -32,12 +33,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
   constexpr int NQ = WBK / 4;                 // quads per K-step
   constexpr int RPP = 256 / NQ;               // tile rows staged per pass
   constexpr int A_N = (BM + RPP - 1) / RPP, B_N = QBJ / RPP;
-  constexpr int SW = 8 / NQ;                  // swizzle step: the 8 lanes of a ds_write_b128 group hit 8 distinct 16-B slots
+  constexpr int SW = 8 / NQ;                  // plane padding: the 8 lanes of a ds_write_b128 group hit 8 distinct 16-B slots
+  constexpr int PA = BM + SW, PB = QBJ + SW;  // rows per quad plane of the A / B image
   constexpr int KS = T == 9 ? 3 : 1;
   constexpr unsigned OOB = 0x80000000u;
 
-  __shared__ float4 As[2][NQ * BM];
-  __shared__ float4 Bs[2][NQ * QBJ];
+  __shared__ float4 As[2][NQ * PA];
+  __shared__ float4 Bs[2][NQ * PB];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
 
   // staging role: quad q of rows r0 + RPP*i (4 x NQ consecutive lanes read one row's WBK*4 contiguous bytes)
   const int q = tid % NQ, r0 = tid / NQ;
-  const int sw = (q * SW) & 7;
   unsigned a_voff[A_N], b_voff[B_N];
   int j_coff[B_N], j_dy[B_N], j_dx[B_N];
 #pragma unroll
@@ -142,36 +143,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
       if (ox0 >= Wo) { ox0 = 0; oy0 += 1; }
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_N; ++i) {
-      const int r = r0 + RPP * i;
-      if (A_N * RPP == BM || r < BM) As[buf][q * BM + (r ^ sw)] = areg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_N; ++i) {
-      const float4 v = breg[i];
-      Bs[buf][q * QBJ + ((r0 + RPP * i) ^ sw)] = v;
-    }
-  };
-
-  const int KT = (pend - pbeg + WBK - 1) / WBK;
-  load_tile(pbeg);
-  store_tile(0);
-  __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile(pbeg + (kt + 1) * WBK);
+  // LDS pointers of this thread: every access is base + immediate; the double-buffer flip is one add per pointer and K-step
+  const float4* a_rd = &As[0][lh * PA + wm0 + l31];     // + 2g * PA + 32 i
+  const float4* b_rd = &Bs[0][lh * PB + wn0 + l31];     // + 2g * PB + 32 j
+  float4* a_wr = &As[0][q * PA + r0];                   // + RPP i
+  float4* b_wr = &Bs[0][q * PB + r0];
+  int da = NQ * PA, db = NQ * PB;
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i)
+      if (A_N * RPP == BM || r0 + RPP * i < BM) a_wr[RPP * i] = areg[i];
+#pragma unroll
+    for (int i = 0; i < B_N; ++i) b_wr[RPP * i] = breg[i];
+  };
+  auto mma_step = [&]() {
 #pragma unroll
     for (int g = 0; g < WBK / 8; ++g) {
-      const int qq = 2 * g + lh;
-      const int qs = (qq * SW) & 7;
       float4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[cur][qq * BM + ((wm0 + i * 32 + l31) ^ qs)];
+      for (int i = 0; i < TM; ++i) af[i] = a_rd[2 * g * PA + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][qq * QBJ + ((wn0 + j * 32 + l31) ^ qs)];
+      for (int j = 0; j < TN; ++j) bf[j] = b_rd[2 * g * PB + 32 * j];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -183,9 +176,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i][j], 0, 0, 0);
           }
     }
-    if (kt + 1 < KT) store_tile(cur ^ 1);
+  };
+
+  const int KT = (pend - pbeg + WBK - 1) / WBK;
+  load_tile(pbeg);
+  store_tile();
+  __syncthreads();
+  a_wr += da; b_wr += db;
+  for (int kt = 0; kt + 1 < KT; ++kt) {             // steady state: prefetch K-step kt+1, multiply step kt
+    load_tile(pbeg + (kt + 1) * WBK);
+    mma_step();
+    store_tile();
     __syncthreads();
+    a_rd += da; b_rd += db; a_wr -= da; b_wr -= db;
+    da = -da; db = -db;
   }
+  mma_step();                                       // last K-step
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
