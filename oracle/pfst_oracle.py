@@ -286,27 +286,35 @@ def class_mix(masks, img, trg_img, gt, pseudo_lbl, pseudo_w):
 # ---------------------------------------------------------------------------
 # PFGSTLoss
 # ---------------------------------------------------------------------------
-def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2, top_k=3, downscale=0.5):
-    """PFGSTLoss.forward with sim_type='cosine', cross_prob_type='trg', detach_unfold=True,
-    src_loss_type='mean_std', feat_level=None (pfgst_loss.py:44-234).  Returns (losses, extras)."""
+def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2, top_k=3, downscale=0.5,
+               sim_type='cosine', sigma=30.0, src_loss_type='mean_std', margin=(0.5, 0.5), detach_unfold=True):
+    """PFGSTLoss.forward with cross_prob_type='trg', feat_level=None (pfgst_loss.py:44-234); options:
+    sim_type 'cosine' | 'gaussian' (:199-208), src_loss_type 'mean_std' | 'margin' | 'margin2' (:107-131),
+    detach_unfold (:151-152), top_k None = all k*k pairs (:229-231), downscale None (:54-57).  Returns (losses, extras)."""
     unfold = lambda t: F.unfold(t, k, dilation=dil, padding=(k // 2) * dil)
     kk = k * k
     if downscale is not None:
         logits_trg = F.interpolate(logits_trg, scale_factor=(float(downscale), float(downscale)))
-        x_ema = F.interpolate(x_ema, size=logits_trg.shape[2:])
-        x_src = F.interpolate(x_src, size=logits_trg.shape[2:])
     B, C, H, W = logits_trg.shape
+    x_ema = F.interpolate(x_ema, size=(H, W))              # nearest (get_sim_feat :193-194; the :56-57 resize is the same map)
+    x_src = F.interpolate(x_src, size=(H, W))
     gt_ = F.interpolate(gt_src.float(), size=(H, W), mode='nearest')
     valid_src = gt_ != 255
     trg_region = F.interpolate((1 - mix_masks).float(), size=(H, W), mode='nearest') > 0.5
     all9 = unfold(trg_region.float()).view(B, kk, H, W).long().sum(1, keepdim=True) == kk
 
     prob = F.softmax(logits_trg, 1)
-    q = unfold(prob).detach().view(B, C, kk, H, W)
+    q = unfold(prob)
+    if detach_unfold:
+        q = q.detach()
+    q = q.view(B, C, kk, H, W)
     cross_pos = (prob.unsqueeze(2) * q).sum(1)                 # (B, kk, H, W)
 
     def sim_of(x):
         u = unfold(x).view(B, x.shape[1], kk, H, W)
+        if sim_type == 'gaussian':
+            return torch.exp(-((u - x.unsqueeze(2)) ** 2).sum(1) / sigma ** 2)
+        assert sim_type == 'cosine'
         return F.cosine_similarity(u, x.unsqueeze(2), dim=1)   # (B, kk, H, W)
 
     ema_sim, src_sim = sim_of(x_ema), sim_of(x_src)
@@ -316,20 +324,30 @@ def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2,
     pos, neg = src_sim[(nb == ctr) & vs], src_sim[(nb != ctr) & vs]
 
     mask = valid_src & all9
-    _, imax = torch.topk(ema_sim, top_k + 1, dim=1)
-    _, imin = torch.topk(ema_sim, top_k, dim=1, largest=False)
-    loc_pos = torch.gather(ema_sim, 1, imax) * (-torch.gather(cross_pos, 1, imax))
-    loc_neg = (1 - torch.gather(ema_sim, 1, imin)) * (-torch.gather(1 - cross_pos, 1, imin))
+    if top_k is not None:
+        _, imax = torch.topk(ema_sim, top_k + 1, dim=1)
+        _, imin = torch.topk(ema_sim, top_k, dim=1, largest=False)
+        loc_pos = torch.gather(ema_sim, 1, imax) * (-torch.gather(cross_pos, 1, imax))
+        loc_neg = (1 - torch.gather(ema_sim, 1, imin)) * (-torch.gather(1 - cross_pos, 1, imin))
+    else:
+        loc_pos = ema_sim * (-cross_pos)
+        loc_neg = (1 - ema_sim) * (-(1 - cross_pos))
     if mask.sum() > 1:
         l_pos = loc_pos[mask.expand_as(loc_pos)].mean()
         l_neg = loc_neg[mask.expand_as(loc_neg)].mean()
     else:
         l_pos, l_neg = torch.zeros(1), torch.zeros(1)
     w = weights
-    losses = OrderedDict(
-        loss_src_pos_mean=-pos.mean() * w['src_pos'], loss_src_neg_mean=neg.mean() * w['src_neg'],
-        loss_src_pos_std=pos.std() * w['src_pos_std'], loss_src_neg_std=neg.std() * w['src_neg_std'],
-        loss_sim_pos=l_pos * w['sim_pos'], loss_sim_neg=l_neg * w['sim_neg'])
+    if src_loss_type == 'mean_std':
+        losses = OrderedDict(
+            loss_src_pos_mean=-pos.mean() * w['src_pos'], loss_src_neg_mean=neg.mean() * w['src_neg'],
+            loss_src_pos_std=pos.std() * w['src_pos_std'], loss_src_neg_std=neg.std() * w['src_neg_std'])
+    else:
+        assert src_loss_type in ('margin', 'margin2')
+        e = 1 if src_loss_type == 'margin' else 2
+        losses = OrderedDict(loss_src_pos=(F.relu(margin[0] - pos) ** e).mean() * w['src_pos'],
+                             loss_src_neg=(F.relu(neg - margin[1]) ** e).mean() * w['src_neg'])
+    losses.update(loss_sim_pos=l_pos * w['sim_pos'], loss_sim_neg=l_neg * w['sim_neg'])
     extras = dict(density=1 - ema_sim.mean(1, keepdim=True).detach(), trg_mask=all9, ema_sim=ema_sim.detach(),
                   src_sim=src_sim.detach(), cross_pos=cross_pos.detach(), mask=mask)
     return losses, extras

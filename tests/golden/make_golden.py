@@ -339,6 +339,49 @@ def gen_small_ops(ref):
     print('small_ops.npz', {k: v.shape for k, v in out.items()})
 
 
+PFGST_OPTION_VARIANTS = {
+    # name -> overrides of the PFGSTLoss config (options reachable from the same configs)
+    'gaussian': dict(sim_type='gaussian', sigma=8.0),
+    'margin': dict(src_loss_type='margin', margin=[0.5, 0.1]),
+    'margin2': dict(src_loss_type='margin2', margin=[0.6, 0.0]),
+    'unfold_grad': dict(detach_unfold=False),
+    'all_pairs': dict(top_k=None),
+    'full_res': dict(downscale=None),
+    'gaussian_all_unfold': dict(sim_type='gaussian', sigma=6.0, top_k=None, detach_unfold=False, src_loss_type='margin2',
+                                margin=[0.7, 0.2]),
+}
+
+
+def gen_pfgst_options(ref):
+    """PFGSTLoss (pfgst_loss.py:12-234) under the option variants above: loss values + gradients on one seeded input set."""
+    g = torch.Generator().manual_seed(21)
+    B, C, S = 2, 6, 128
+    lt0 = torch.randn(B, C, S // 4, S // 4, generator=g) * 2
+    xe = torch.randn(B, 32, S // 8, S // 8, generator=g)
+    xs0 = torch.randn(B, 32, S // 8, S // 8, generator=g)
+    gts = torch.randint(0, C, (B, 1, 4, 4), generator=g).repeat_interleave(S // 4, 2).repeat_interleave(S // 4, 3)
+    gts[:, :, :8, :8] = 255
+    mm = (torch.rand(B, 1, 2, 2, generator=g) > 0.6).long().repeat_interleave(S // 2, 2).repeat_interleave(S // 2, 3)
+    out = dict(logits_trg=lt0.numpy(), x_ema=xe.numpy(), x_src=xs0.numpy(), gt_src=gts.numpy(), mix_masks=mm.numpy(),
+               variants=np.array(list(PFGST_OPTION_VARIANTS)))
+    for name, over in PFGST_OPTION_VARIANTS.items():
+        cfg = dict(uda_cfg()['aux_losses'][0])
+        cfg.update(over)
+        PL = ref.builder.build_loss(cfg)
+        lt, xs = lt0.clone().requires_grad_(), xs0.clone().requires_grad_()
+        res = PL(dict(logits_trg=lt, logits_ema=None, gt_src=gts, x_ema=xe, x_src=xs, img_trg=None, mix_masks=mm))
+        names = [k for k in res if not k.startswith('vis|')]
+        tot = sum(res[n].sum() for n in names)
+        tot.backward()
+        out[name + '|names'] = np.array(names)
+        out[name + '|losses'] = np.array([float(res[n].sum()) for n in names], dtype=np.float64)
+        out[name + '|grad_logits'] = lt.grad.numpy().copy()
+        out[name + '|grad_xsrc'] = xs.grad.numpy().copy()
+        out[name + '|density'] = res['vis|density_sim_feat'][1].numpy().copy()
+        print(name, dict(zip(names, out[name + '|losses'])))
+    np.savez_compressed(os.path.join(OUT, 'pfgst_options.npz'), **out)
+
+
 def gen_segmentor(ref):
     """EncoderDecoder.forward_train + backward (BASELINE config #1 shape, reduced) and the
     teacher-style encode_decode.  Weights = pfst_amd.synthetic.fill_state_dict(seed=5), which the tests rebuild bit-identically."""
@@ -431,9 +474,11 @@ def gen_train_step(ref):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'seg', 'step']
     if 'small' in which:
         gen_small_ops(ref)
+    if 'options' in which:
+        gen_pfgst_options(ref)
     if 'seg' in which:
         gen_segmentor(ref)
     if 'step' in which:
