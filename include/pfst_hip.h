@@ -152,31 +152,40 @@ int pfst_color_jitter(float* img, const float* params, const float* mean3, const
 int pfst_gaussian_blur(const float* x, float* tmp, float* y, const float* taps_y, int Ky, const float* taps_x, int Kx,
                        int N, int C, int H, int W, int reach, pfst_stream_t stream);
 
-/* ---- PFGSTLoss (pfgst_loss.py:44-234), kernel 3x3, cosine similarity, top-k ------------------ */
-/* sim[n][k][y][x] = cos(f[n][:,y,x], f[n][:,y+dy_k,x+dx_k]) (0 outside); norm[n][y][x] = |f| */
-int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, float* sim, float* norm, pfst_stream_t stream);
+/* ---- PFGSTLoss (pfgst_loss.py:44-234), kernel 3x3 ------------------------------------------------ */
+/* sim_type 0: sim[n][k][y][x] = cos(f[n][:,y,x], f[n][:,y+dy_k,x+dx_k]) (0 outside); norm[n][y][x] = |f|
+ * sim_type 1: sim = exp(-|f(neighbour) - f(centre)|^2 / sigma^2), the zero padding counting as f = 0 (pfgst_loss.py:199-201) */
+int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, int sim_type, float sigma, float* sim, float* norm,
+                 pfst_stream_t stream);
 /* d feat (+)= adjoint of pfst_sim_map for upstream gradient gsim[n][9][H][W] */
 int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
-                     float* dfeat, int accumulate, pfst_stream_t stream);
+                     int sim_type, float sigma, float* dfeat, int accumulate, pfst_stream_t stream);
 /* source statistics: sets (neighbour label == / != centre label, centre != 255) of src sims.
- * gt is full resolution [N][Hg][Wg] uint8, nearest-sampled to HxW.  stats[0..5] = n_pos, sum_pos, sumsq_pos, n_neg, sum_neg, sumsq_neg */
-int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double* stats, pfst_stream_t stream);
-/* losses[0..3] = -w*mean_pos, w*mean_neg, w*std_pos, w*std_neg and gsim = d(sum of the four)/d sim */
-int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, const double* stats,
+ * gt is full resolution [N][Hg][Wg] uint8, nearest-sampled to HxW.
+ * loss_type 0 (mean_std): stats[0..5] = n_pos, sum_pos, sumsq_pos, n_neg, sum_neg, sumsq_neg
+ * loss_type 1 / 2 (margin / margin2, pfgst_loss.py:116-131): stats[1] = sum relu(margin_pos - s)^e over positive pairs,
+ *   stats[4] = sum relu(s - margin_neg)^e over negative pairs, e = loss_type */
+int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
+                       float margin_pos, float margin_neg, double* stats, pfst_stream_t stream);
+/* loss_type 0: losses[0..3] = -w*mean_pos, w*mean_neg, w*std_pos, w*std_neg; 1 / 2: losses[0..1] = w_pos*mean hinge_pos,
+ * w_neg*mean hinge_neg (losses[2..3] = 0); gsim = d(sum of the losses)/d sim */
+int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
+                      float margin_pos, float margin_neg, const double* stats,
                       float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream);
 /* prob[n][c][y][x] = softmax_c(logits[n][c][y*ds][x*ds]) (nearest down-scaling by ds) */
 int pfst_softmax_down(const float* logits, int N, int C, int h, int w, int ds, float* prob, int H, int W, pfst_stream_t stream);
 /* valid[n][y][x] = (gt != 255) && all 9 dilated neighbours un-mixed; count[0] = #valid */
 int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char* mix_mask, int N, int H, int W, int Hg, int Wg, int dil,
                         unsigned char* valid, unsigned char* all9, unsigned long long* count, pfst_stream_t stream);
-/* top-k target losses; acc[0] += sum loc_pos, acc[1] += sum loc_neg over valid pixels;
- * gP[n][9][y][x] = d(w_pos*mean loc_pos + w_neg*mean loc_neg)/d cross_prob (0 when count <= 1) */
+/* top-k target losses (top_k = 0: all nine pairs, the reference's top_k=None); acc[0] += sum loc_pos, acc[1] += sum loc_neg
+ * over valid pixels; gP[n][9][y][x] = d(w_pos*mean loc_pos + w_neg*mean loc_neg)/d cross_prob (0 when count <= 1) */
 int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
                        int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream);
-/* d logits[n][c][y*ds][x*ds] += softmax-backward( sum_k gP[k] * prob_c(neighbour k) ) */
-int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds,
+/* d logits[n][c][y*ds][x*ds] += softmax-backward( sum_k gP[k] * prob_c(neighbour k) ); unfold_grad != 0 (detach_unfold=False)
+ * adds the gradient through the unfolded factor: coefficient gP[k][r] + gP[8-k][r+D_k] */
+int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds, int unfold_grad,
                         float* dlogits, int h, int w, pfst_stream_t stream);
-/* out[0] = w_pos*acc[0]/(4*count), out[1] = w_neg*acc[1]/(3*count)  (zeros when count <= 1) */
+/* out[0] = w_pos*acc[0]/((top_k+1)*count), out[1] = w_neg*acc[1]/(top_k*count); top_k = 0: both /(9*count)  (zeros when count <= 1) */
 int pfst_sim_loss_finalize(const double* acc, const unsigned long long* count, int top_k, float w_pos, float w_neg, float* out, pfst_stream_t stream);
 
 /* ---- EMA teacher + AdamW on flat parameter arenas (pfgst.py:105-127, torch.optim.AdamW) ------ */

@@ -377,7 +377,7 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False, downscale=0.5, thre_type='all'):
+                 blur=False, downscale=0.5, thre_type='all', loss_opts=None):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -389,6 +389,7 @@ class OraclePFGST:
         self.aux_w = aux_weights or DEFAULT_LOSS_W
         self.blur = blur
         self.downscale = downscale
+        self.loss_opts = dict(loss_opts or {})       # PFGSTLoss option variants (sim_type, sigma, src_loss_type, margin, detach_unfold, top_k)
         self.thre_type = thre_type
         self.local_iter = 0
 
@@ -421,7 +422,7 @@ class OraclePFGST:
             self.student, mixed_img, mixed_lbl, mixed_w, dm.get('mix', (None, None)))
         mix_loss, lv = parse_losses(OrderedDict(('mix.' + k, v) for k, v in mlosses.items()))
         lv.pop('loss'); log.update(lv)
-        aux, extras = pfgst_loss(mix_logits, ema_dec, src_dec, gt, masks, self.aux_w, downscale=self.downscale)
+        aux, extras = pfgst_loss(mix_logits, ema_dec, src_dec, gt, masks, self.aux_w, downscale=self.downscale, **self.loss_opts)
         aux_loss, lv = parse_losses(aux)
         lv.pop('loss'); log.update(lv)
         total = clean_loss + self.trg_w * mix_loss + aux_loss

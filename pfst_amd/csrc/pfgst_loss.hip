@@ -1,8 +1,9 @@
 // PFGSTLoss: local pseudo-feature similarity losses, fused so that the reference's unfold tensors
 // (b x 512 x 9 x H x W, 302 MB per image per call at S=1024) never exist.
-// Reference: rsiseg/models/losses/pfgst_loss.py:44-234 with the shipped options
-// (kernel 3, dilation d, sim_type 'cosine', cross_prob_type 'trg', detach_unfold=True,
-//  src_loss_type 'mean_std', top_k, downscale 0.5).
+// Reference: rsiseg/models/losses/pfgst_loss.py:44-234: kernel 3, dilation d, cross_prob_type 'trg'; the shipped options
+// (sim_type 'cosine', detach_unfold=True, src_loss_type 'mean_std', top_k, downscale 0.5) and the variants reachable from
+// the same configs: sim_type 'gaussian' (:199-201), src_loss_type 'margin' / 'margin2' (:116-131), detach_unfold=False
+// (:151-152), top_k=None (:229-231), downscale None / 1.
 // Neighbour index k = ty*3+tx, offset ((ty-1)*d, (tx-1)*d) -- the order nn.Unfold produces.
 #include "common.h"
 #include "../../include/pfst_hip.h"
@@ -20,7 +21,9 @@ __device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
 // ---- cosine similarity to the 9 dilated neighbours.  One thread per pixel, loop over channels;
 // loads are coalesced along x and the 9 taps of a channel hit L1/L2 (feature map read once from HBM).
 // grid: (blocks over H*W, N)
-__global__ __launch_bounds__(256) void sim_map_kernel(const float* __restrict__ feat, int C, int H, int W, int dil,
+// GAUSS: sim_k = exp(-|F(r+D_k) - F(r)|^2 / sigma^2), the zero padding of nn.Unfold taking part as F = 0 (:199-201).
+template <bool GAUSS>
+__global__ __launch_bounds__(256) void sim_map_kernel(const float* __restrict__ feat, int C, int H, int W, int dil, float inv_sigma2,
                                                       float* __restrict__ sim, float* __restrict__ norm) {
   const int n = blockIdx.y;
   const int HW = H * W;
@@ -44,9 +47,20 @@ __global__ __launch_bounds__(256) void sim_map_kernel(const float* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         const float b = ok[k] ? ch[off[k]] : 0.f;
-        dot[k] = fmaf(a, b, dot[k]);
-        nn[k] = fmaf(b, b, nn[k]);
+        if (GAUSS) {
+          const float d = b - a;
+          dot[k] = fmaf(d, d, dot[k]);
+        } else {
+          dot[k] = fmaf(a, b, dot[k]);
+          nn[k] = fmaf(b, b, nn[k]);
+        }
       }
+    }
+    if (GAUSS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sim[((i64)n * 9 + k) * HW + p] = expf(-dot[k] * inv_sigma2);
+      if (norm) norm[(i64)n * HW + p] = 0.f;
+      continue;
     }
     const float na = fmaxf(sqrtf(nn[4]), COS_EPS);
 #pragma unroll
@@ -60,9 +74,13 @@ __global__ __launch_bounds__(256) void sim_map_kernel(const float* __restrict__ 
 
 // ---- adjoint: dF(r) = sum_k A_k(r) F(r+D_k) + B(r) F(r)   (PFGSTLoss backward)
 //   A_k = (G[k,r] + G[8-k, r+D_k]) / (n(r) n(r+D_k)),  B = -(sum_k G[k,r] s_k(r) + G[8-k,r+D_k] s_{8-k}(r+D_k)) / n(r)^2
+// GAUSS: d s_k(r) / dF(r) = -2/sigma^2 s_k(r) (F(r) - F(r+D_k)) and symmetrically for the neighbour, so with
+//   c_k = -2/sigma^2 (G[k,r] s_k(r) + G[8-k,r+D_k] s_{8-k}(r+D_k)):  A_k = -c_k,  B = sum_k c_k  (+ the padded taps, whose
+//   neighbour is the constant 0: c = -2/sigma^2 G[k,r] s_k(r) goes to B only).  Same final loop.
+template <bool GAUSS>
 __global__ __launch_bounds__(256) void sim_map_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ sim,
                                                           const float* __restrict__ norm, const float* __restrict__ gsim, int C,
-                                                          int H, int W, int dil, float* __restrict__ dfeat, int accumulate) {
+                                                          int H, int W, int dil, float inv_sigma2, float* __restrict__ dfeat, int accumulate) {
   const int n = blockIdx.y;
   const int HW = H * W;
   const float* fp = feat + (i64)n * C * HW;
@@ -72,26 +90,35 @@ __global__ __launch_bounds__(256) void sim_map_bwd_kernel(const float* __restric
   const float* np_ = norm + (i64)n * HW;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
     const int y = p / W, x = p - y * W;
-    const float nr = fmaxf(np_[p], COS_EPS);
+    const float nr = GAUSS ? 1.f : fmaxf(np_[p], COS_EPS);
     float A[9];
     int off[9];
     float B = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
-      const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W && k != 4;
+      const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
+      const bool ok = in && k != 4;
       off[k] = ok ? sy * W + sx : p;
-      if (ok) {
+      A[k] = 0.f;
+      if (GAUSS) {
+        if (ok) {
+          const int q = off[k];
+          const float c = -2.f * inv_sigma2 * (gp[(i64)k * HW + p] * sp[(i64)k * HW + p] + gp[(i64)(8 - k) * HW + q] * sp[(i64)(8 - k) * HW + q]);
+          A[k] = -c;
+          B += c;
+        } else if (!in) {
+          B += -2.f * inv_sigma2 * gp[(i64)k * HW + p] * sp[(i64)k * HW + p];
+        }
+      } else if (ok) {
         const int q = off[k];
         const float g1 = gp[(i64)k * HW + p], g2 = gp[(i64)(8 - k) * HW + q];
         const float nq = fmaxf(np_[q], COS_EPS);
         A[k] = (g1 + g2) / (nr * nq);
         B -= g1 * sp[(i64)k * HW + p] + g2 * sp[(i64)(8 - k) * HW + q];
-      } else {
-        A[k] = 0.f;
       }
     }
-    B /= nr * nr;
+    if (!GAUSS) B /= nr * nr;
     for (int c = 0; c < C; ++c) {
       const float* ch = fp + (i64)c * HW;
       float v = B * ch[p];
@@ -113,8 +140,11 @@ __device__ __forceinline__ int src_pair_class(const unsigned char* __restrict__ 
   return nb == ctr ? 1 : 2;
 }
 
+// loss_type 0: count / sum / sum of squares (mean & unbiased std, :107-115); 1 / 2: count / sum of relu(m0 - s)^e for positive
+// pairs and relu(s - m1)^e for negative pairs, e = loss_type (:116-131).
 __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
-                                                        int Hg, int Wg, int dil, double* __restrict__ stats) {
+                                                        int Hg, int Wg, int dil, int loss_type, float m0, float m1,
+                                                        double* __restrict__ stats) {
   __shared__ double sm[16];
   const int n = blockIdx.y, HW = H * W;
   const unsigned char* g = gt + (i64)n * Hg * Wg;
@@ -129,7 +159,12 @@ __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict_
       const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
       const double s = (double)sim[((i64)n * 9 + k) * HW + p];
       const int o = cls == 1 ? 0 : 3;
-      a[o] += 1.0; a[o + 1] += s; a[o + 2] += s * s;
+      if (loss_type == 0) {
+        a[o] += 1.0; a[o + 1] += s; a[o + 2] += s * s;
+      } else {
+        const double h = cls == 1 ? fmax((double)m0 - s, 0.0) : fmax(s - (double)m1, 0.0);
+        a[o] += 1.0; a[o + 1] += loss_type == 1 ? h : h * h;
+      }
     }
   }
 #pragma unroll
@@ -150,12 +185,40 @@ __device__ __forceinline__ SrcMoments moments(const double* st) {
 }
 
 __global__ __launch_bounds__(256) void src_grad_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
-                                                       int Hg, int Wg, int dil, const double* __restrict__ stats, float w_pos,
+                                                       int Hg, int Wg, int dil, int loss_type, float m0, float m1,
+                                                       const double* __restrict__ stats, float w_pos,
                                                        float w_neg, float w_pos_std, float w_neg_std, float* __restrict__ gsim,
                                                        float* __restrict__ losses) {
   const int n = blockIdx.y, HW = H * W;
   const unsigned char* g = gt + (i64)n * Hg * Wg;
   const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
+  if (loss_type != 0) {       // hinge losses: mean over the pairs of relu(.)^e; d/ds = -/+ e relu(.)^(e-1) w / n
+    const double np = stats[0], nn = stats[3];
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+      losses[0] = np > 0 ? (float)((double)w_pos * stats[1] / np) : 0.f;     // (an empty set gives NaN in the reference)
+      losses[1] = nn > 0 ? (float)((double)w_neg * stats[4] / nn) : 0.f;
+      losses[2] = 0.f;
+      losses[3] = 0.f;
+    }
+    const double cp = np > 0 ? (double)w_pos / np : 0.0, cn = nn > 0 ? (double)w_neg / nn : 0.0;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+      const int y = p / W, x = p - y * W;
+      const int ctr = g[(i64)nearest_src(y, sgy, Hg) * Wg + nearest_src(x, sgx, Wg)];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const i64 o = ((i64)n * 9 + k) * HW + p;
+        float gr = 0.f;
+        if (ctr != 255) {
+          const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
+          const double s = (double)sim[o];
+          const double h = cls == 1 ? (double)m0 - s : s - (double)m1;
+          if (h > 0.0) gr = (float)((cls == 1 ? -cp : cn) * (loss_type == 1 ? 1.0 : 2.0 * h));
+        }
+        gsim[o] = gr;
+      }
+    }
+    return;
+  }
   const SrcMoments mp = moments(stats), mn = moments(stats + 3);
   if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
     losses[0] = (float)(-mp.mean * w_pos);
@@ -239,8 +302,9 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
   __shared__ double sm[16];
   const int n = blockIdx.y, HW = H * W;
   const double cnt = (double)count[0];
-  const float cpos = cnt > 1.0 ? (float)((double)w_pos / (cnt * (top_k + 1))) : 0.f;
-  const float cneg = cnt > 1.0 ? (float)((double)w_neg / (cnt * top_k)) : 0.f;
+  const bool all_pairs = top_k == 0;          // top_k=None in the reference: every one of the 9 pairs, both losses (:229-231)
+  const float cpos = cnt > 1.0 ? (float)((double)w_pos / (cnt * (all_pairs ? 9 : top_k + 1))) : 0.f;
+  const float cneg = cnt > 1.0 ? (float)((double)w_neg / (cnt * (all_pairs ? 9 : top_k))) : 0.f;
   const float* pp = prob + (i64)n * C * HW;
   double spos = 0.0, sneg = 0.0;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
@@ -262,6 +326,15 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
       float d = 0.f;
       for (int c = 0; c < C; ++c) d = fmaf(pp[(i64)c * HW + p], pp[(i64)c * HW + q], d);
       P[k] = d;
+    }
+    if (all_pairs) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        spos += (double)(-s[k] * P[k]);
+        sneg += (double)(-(1.f - s[k]) * (1.f - P[k]));
+        gP[base + (i64)k * HW] = -s[k] * cpos + (1.f - s[k]) * cneg;
+      }
+      continue;
     }
     // stable insertion sort, descending similarity (ties keep the lower index first)
 #pragma unroll
@@ -302,9 +375,11 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
   }
 }
 
-// ---- gradient of the cross-probabilities into the (full 1/4-res) student logits (centre path only)
+// ---- gradient of the cross-probabilities P_k(r) = sum_c p_c(r) p_c(r+D_k) into the (full 1/4-res) student logits.
+// detach_unfold=True: only the centre factor p_c(r) carries gradient.  unfold_grad (detach_unfold=False): the unfolded
+// factor does too -- pixel r is the k-neighbour of r+D_{8-k}, so its coefficient gains gP[8-k, r+D_k] (gather form, no atomics).
 __global__ __launch_bounds__(256) void cross_prob_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gP, int C, int H,
-                                                             int W, int dil, int ds, float* __restrict__ dlogits, int h, int w) {
+                                                             int W, int dil, int ds, int unfold_grad, float* __restrict__ dlogits, int h, int w) {
   const int n = blockIdx.y, HW = H * W;
   const float* pp = prob + (i64)n * C * HW;
   float* dl = dlogits + (i64)n * C * h * w;
@@ -316,10 +391,11 @@ __global__ __launch_bounds__(256) void cross_prob_bwd_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       g[k] = gP[((i64)n * 9 + k) * HW + p];
-      any = any || g[k] != 0.f;
       const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
       const bool in = sy >= 0 && sy < H && sx >= 0 && sx < W;
       off[k] = in ? sy * W + sx : -1;
+      if (unfold_grad && in) g[k] += gP[((i64)n * 9 + (8 - k)) * HW + off[k]];
+      any = any || g[k] != 0.f;
     }
     if (!any) continue;
     float dot = 0.f;  // sum_j p_j * dprob_j
@@ -342,8 +418,8 @@ __global__ __launch_bounds__(256) void cross_prob_bwd_kernel(const float* __rest
 __global__ void sim_loss_finalize_kernel(const double* __restrict__ acc, const unsigned long long* __restrict__ count, int top_k,
                                          float w_pos, float w_neg, float* __restrict__ out) {
   const double cnt = (double)count[0];
-  out[0] = cnt > 1.0 ? (float)((double)w_pos * acc[0] / (cnt * (top_k + 1))) : 0.f;
-  out[1] = cnt > 1.0 ? (float)((double)w_neg * acc[1] / (cnt * top_k)) : 0.f;
+  out[0] = cnt > 1.0 ? (float)((double)w_pos * acc[0] / (cnt * (top_k == 0 ? 9 : top_k + 1))) : 0.f;
+  out[1] = cnt > 1.0 ? (float)((double)w_neg * acc[1] / (cnt * (top_k == 0 ? 9 : top_k))) : 0.f;
 }
 
 inline int px_blocks(i64 n) {
@@ -354,36 +430,53 @@ inline int px_blocks(i64 n) {
 
 }  // namespace
 
-extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, float* sim, float* norm, pfst_stream_t stream) {
+extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, int sim_type, float sigma, float* sim, float* norm,
+                            pfst_stream_t stream) {
   PFST_CHECK_ARG(feat && sim && norm && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
-  hipLaunchKernelGGL(sim_map_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, sim, norm);
+  PFST_CHECK_ARG(sim_type == 0 || (sim_type == 1 && sigma > 0.f));
+  const dim3 grid(px_blocks((i64)H * W), N);
+  if (sim_type == 1)
+    hipLaunchKernelGGL(sim_map_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, 1.f / (sigma * sigma), sim, norm);
+  else
+    hipLaunchKernelGGL(sim_map_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, 0.f, sim, norm);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 extern "C" int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
-                                float* dfeat, int accumulate, pfst_stream_t stream) {
+                                int sim_type, float sigma, float* dfeat, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(feat && sim && norm && gsim && dfeat && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
-  hipLaunchKernelGGL(sim_map_bwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H,
-                     W, dil, dfeat, accumulate);
+  PFST_CHECK_ARG(sim_type == 0 || (sim_type == 1 && sigma > 0.f));
+  const dim3 grid(px_blocks((i64)H * W), N);
+  if (sim_type == 1)
+    hipLaunchKernelGGL(sim_map_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, dil,
+                       1.f / (sigma * sigma), dfeat, accumulate);
+  else
+    hipLaunchKernelGGL(sim_map_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, dil, 0.f, dfeat,
+                       accumulate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-extern "C" int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double* stats, pfst_stream_t stream) {
+extern "C" int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
+                                  float margin_pos, float margin_neg, double* stats, pfst_stream_t stream) {
   PFST_CHECK_ARG(sim && gt && stats && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  PFST_CHECK_ARG(loss_type >= 0 && loss_type <= 2);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, 6 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
-  hipLaunchKernelGGL(src_stats_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, stats);
+  hipLaunchKernelGGL(src_stats_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, loss_type, margin_pos,
+                     margin_neg, stats);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-extern "C" int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, const double* stats,
+extern "C" int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
+                                 float margin_pos, float margin_neg, const double* stats,
                                  float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream) {
   PFST_CHECK_ARG(sim && gt && stats && gsim && losses && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  PFST_CHECK_ARG(loss_type >= 0 && loss_type <= 2);
   hipLaunchKernelGGL(src_grad_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, sim, gt, H, W, Hg, Wg, dil,
-                     stats, w_pos, w_neg, w_pos_std, w_neg_std, gsim, losses);
+                     loss_type, margin_pos, margin_neg, stats, w_pos, w_neg, w_pos_std, w_neg_std, gsim, losses);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -409,7 +502,7 @@ extern "C" int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char*
 extern "C" int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
                                   int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream) {
   PFST_CHECK_ARG(ema_sim && prob && valid && count && gP && acc && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
-  PFST_CHECK_ARG(top_k >= 1 && 2 * top_k + 1 <= 9);
+  PFST_CHECK_ARG(top_k >= 0 && 2 * top_k + 1 <= 9);    // 0 = all nine pairs (top_k=None)
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(acc, 0, 2 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
   hipLaunchKernelGGL(topk_loss_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, ema_sim, prob, valid, count, C, H, W, dil, top_k,
@@ -418,18 +511,18 @@ extern "C" int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const
   return PFST_OK;
 }
 
-extern "C" int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds,
+extern "C" int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds, int unfold_grad,
                                    float* dlogits, int h, int w, pfst_stream_t stream) {
   PFST_CHECK_ARG(prob && gP && dlogits && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1 && ds >= 1);
   PFST_CHECK_ARG((H - 1) * ds < h && (W - 1) * ds < w);
   hipLaunchKernelGGL(cross_prob_bwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, prob, gP, C, H, W, dil, ds,
-                     dlogits, h, w);
+                     unfold_grad, dlogits, h, w);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 extern "C" int pfst_sim_loss_finalize(const double* acc, const unsigned long long* count, int top_k, float w_pos, float w_neg, float* out, pfst_stream_t stream) {
-  PFST_CHECK_ARG(acc && count && out && top_k >= 1);
+  PFST_CHECK_ARG(acc && count && out && top_k >= 0);
   hipLaunchKernelGGL(sim_loss_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, count, top_k, w_pos, w_neg, out);
   PFST_CHECK_LAUNCH();
   return PFST_OK;

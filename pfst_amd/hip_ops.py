@@ -430,35 +430,41 @@ def class_mix(img, trg_img, gt_u8, pseudo_u8, mask_u8, conf_count, want_i64=Fals
 
 
 # ---------------------------------------------------------------- PFGSTLoss pieces
-def sim_map(feat, dil):
+SIM_TYPES = {'cosine': 0, 'gaussian': 1}
+SRC_LOSS_TYPES = {'mean_std': 0, 'margin': 1, 'margin2': 2}
+
+
+def sim_map(feat, dil, sim_type='cosine', sigma=30.0):
     _dense(feat)
     n, c, h, w = feat.shape
     sim = torch.empty(n, 9, h, w, device=feat.device)
     norm = torch.empty(n, h, w, device=feat.device)
-    call('pfst_sim_map', feat.data_ptr(), n, c, h, w, dil, sim.data_ptr(), norm.data_ptr(), _stream())
+    call('pfst_sim_map', feat.data_ptr(), n, c, h, w, dil, SIM_TYPES[sim_type], float(sigma), sim.data_ptr(), norm.data_ptr(), _stream())
     return sim, norm
 
 
-def sim_map_bwd(feat, sim, norm, gsim, dil, out=None, accumulate=False):
+def sim_map_bwd(feat, sim, norm, gsim, dil, out=None, accumulate=False, sim_type='cosine', sigma=30.0):
     n, c, h, w = feat.shape
     if out is None:
         assert not accumulate
         out = torch.empty_like(feat)
     call('pfst_sim_map_bwd', _dense(feat).data_ptr(), _dense(sim).data_ptr(), _dense(norm).data_ptr(), _dense(gsim).data_ptr(),
-         n, c, h, w, dil, _dense(out).data_ptr(), int(accumulate), _stream())
+         n, c, h, w, dil, SIM_TYPES[sim_type], float(sigma), _dense(out).data_ptr(), int(accumulate), _stream())
     return out
 
 
-def src_sim_losses(sim, gt_u8, dil, w_pos, w_neg, w_pos_std, w_neg_std):
-    """-> (losses float32[4], gsim [N,9,H,W])"""
+def src_sim_losses(sim, gt_u8, dil, w_pos, w_neg, w_pos_std=0.0, w_neg_std=0.0, loss_type='mean_std', margin=(0.5, 0.5)):
+    """-> (losses float32[4] (mean_std) or [2] used of 4 (margin / margin2), gsim [N,9,H,W])"""
     n, _, h, w = sim.shape
     hg, wg = gt_u8.shape[-2:]
+    lt = SRC_LOSS_TYPES[loss_type]
     stats = torch.empty(6, dtype=F64, device=sim.device)
-    call('pfst_src_sim_stats', _dense(sim).data_ptr(), _dense(gt_u8, U8).data_ptr(), n, h, w, hg, wg, dil, stats.data_ptr(), _stream())
+    call('pfst_src_sim_stats', _dense(sim).data_ptr(), _dense(gt_u8, U8).data_ptr(), n, h, w, hg, wg, dil, lt, float(margin[0]),
+         float(margin[1]), stats.data_ptr(), _stream())
     gsim = torch.empty_like(sim)
     losses = torch.empty(4, device=sim.device)
-    call('pfst_src_sim_grad', sim.data_ptr(), gt_u8.data_ptr(), n, h, w, hg, wg, dil, stats.data_ptr(), float(w_pos), float(w_neg),
-         float(w_pos_std), float(w_neg_std), gsim.data_ptr(), losses.data_ptr(), _stream())
+    call('pfst_src_sim_grad', sim.data_ptr(), gt_u8.data_ptr(), n, h, w, hg, wg, dil, lt, float(margin[0]), float(margin[1]),
+         stats.data_ptr(), float(w_pos), float(w_neg), float(w_pos_std), float(w_neg_std), gsim.data_ptr(), losses.data_ptr(), _stream())
     return losses, gsim
 
 
@@ -483,7 +489,8 @@ def trg_valid_mask(gt_u8, mix_mask_u8, hw, dil):
 
 
 def sim_topk_loss(ema_sim, prob, valid, count, dil, top_k, w_pos, w_neg):
-    """-> (losses float32[2], gP [N,9,H,W])"""
+    """top_k None / 0 = all nine pairs.  -> (losses float32[2], gP [N,9,H,W])"""
+    top_k = int(top_k or 0)
     n, c, h, w = prob.shape
     gP = torch.empty(n, 9, h, w, device=prob.device)
     acc = torch.empty(2, dtype=F64, device=prob.device)
@@ -494,10 +501,11 @@ def sim_topk_loss(ema_sim, prob, valid, count, dil, top_k, w_pos, w_neg):
     return out, gP
 
 
-def cross_prob_bwd_(dlogits, prob, gP, dil, ds):
+def cross_prob_bwd_(dlogits, prob, gP, dil, ds, unfold_grad=False):
     n, c, H, W = prob.shape
     h, w = dlogits.shape[-2:]
-    call('pfst_cross_prob_bwd', _dense(prob).data_ptr(), _dense(gP).data_ptr(), n, c, H, W, dil, ds, _dense(dlogits).data_ptr(), h, w, _stream())
+    call('pfst_cross_prob_bwd', _dense(prob).data_ptr(), _dense(gP).data_ptr(), n, c, H, W, dil, ds, int(unfold_grad),
+         _dense(dlogits).data_ptr(), h, w, _stream())
     return dlogits
 
 

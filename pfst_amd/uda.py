@@ -30,16 +30,22 @@ class PFGSTLoss(nn.Module):
                  num_bins=100, apply_ignore=False, src_perc=None, proj_net_cfg=None, src_loss_type='mean_std',
                  margin=(0.5, 0.5), detach_unfold=False, cross_prob_type='trg', downscale=None):
         super().__init__()
-        bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type != 'cosine', feat_level=feat_level is not None,
-                   src_perc=src_perc is not None, proj_net=proj_net_cfg is not None, src_loss_type=src_loss_type != 'mean_std',
-                   detach_unfold=not detach_unfold, cross_prob_type=cross_prob_type != 'trg',
-                   downscale=downscale not in (0.5, 1, 1.0), top_k=top_k is None or not (1 <= top_k <= 4),
-                   weights=not isinstance(weights, dict))
+        # Implemented: the shipped options plus the variants reachable from the same configs: sim_type
+        # 'cosine' | 'gaussian' (sigma), src_loss_type 'mean_std' | 'margin' | 'margin2' (margin), detach_unfold True | False,
+        # top_k 1..4 | None, downscale 0.5 | 1 | None.  Everything else fails loudly.
+        bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type not in ('cosine', 'gaussian'), feat_level=feat_level is not None,
+                   src_perc=src_perc is not None, proj_net=proj_net_cfg is not None,
+                   src_loss_type=src_loss_type not in ('mean_std', 'margin', 'margin2'), cross_prob_type=cross_prob_type != 'trg',
+                   downscale=downscale not in (None, 0.5, 1, 1.0), top_k=top_k is not None and not (1 <= top_k <= 4),
+                   weights=not isinstance(weights, dict), sigma=not sigma > 0)
         bad = [k for k, v in bad.items() if v]
         if bad:
-            raise NotImplementedError(f'PFGSTLoss options outside the shipped PFST configs: {bad}')
+            raise NotImplementedError(f'PFGSTLoss options outside the implemented set: {bad}')
         self.top_k, self.dilation, self.weights = top_k, dilation, dict(weights)
-        self.ds = int(round(1.0 / downscale))
+        self.sim_type, self.sigma = sim_type, float(sigma)
+        self.src_loss_type, self.margin = src_loss_type, tuple(margin)
+        self.unfold_grad = not detach_unfold
+        self.ds = 1 if downscale is None else int(round(1.0 / downscale))
 
     def forward(self, tensors, tape=None):
         """tensors: logits_trg (Var, student logits of the mixed pass), x_ema (Var), x_src (Var),
@@ -59,12 +65,13 @@ class PFGSTLoss(nn.Module):
         if d % u != 0:
             raise NotImplementedError(f'PFGSTLoss: dilation {d} not divisible by the feature up-sampling factor {u}')
         fd = d // u
-        ema_sim, _ = ops.sim_map(x_ema.data, fd)
-        src_sim_f, src_norm = ops.sim_map(x_src.data, fd)
+        ema_sim, _ = ops.sim_map(x_ema.data, fd, self.sim_type, self.sigma)
+        src_sim_f, src_norm = ops.sim_map(x_src.data, fd, self.sim_type, self.sigma)
         src_sim = src_sim_f
         if u > 1:
             ema_sim, src_sim = ops.upsample_nearest(ema_sim, u), ops.upsample_nearest(src_sim_f, u)
-        l4, gsim = ops.src_sim_losses(src_sim, gt8, d, w['src_pos'], w['src_neg'], w['src_pos_std'], w['src_neg_std'])
+        l4, gsim = ops.src_sim_losses(src_sim, gt8, d, w['src_pos'], w['src_neg'], w.get('src_pos_std', 0.0), w.get('src_neg_std', 0.0),
+                                      self.src_loss_type, self.margin)
         prob = ops.softmax_down(lt.data, self.ds)
         valid, all9, cnt = ops.trg_valid_mask(gt8, mm8, (H, W), d)
         l2, gP = ops.sim_topk_loss(ema_sim, prob, valid, cnt, d, self.top_k, w['sim_pos'], w['sim_neg'])
@@ -72,14 +79,18 @@ class PFGSTLoss(nn.Module):
             def bwd():
                 buf, acc = x_src.grad_target()
                 g_f = gsim if u == 1 else ops.upsample_nearest_bwd(gsim, u)
-                ops.sim_map_bwd(x_src.data, src_sim_f, src_norm, g_f, fd, out=buf, accumulate=acc)
+                ops.sim_map_bwd(x_src.data, src_sim_f, src_norm, g_f, fd, out=buf, accumulate=acc, sim_type=self.sim_type,
+                                sigma=self.sigma)
                 buf, acc = lt.grad_target()
                 if not acc:
                     ops.fill_(buf, 0.0)
-                ops.cross_prob_bwd_(buf, prob, gP, d, self.ds)
+                ops.cross_prob_bwd_(buf, prob, gP, d, self.ds, self.unfold_grad)
             tape.record(bwd)
-        out = OrderedDict(loss_src_pos_mean=l4[0:1], loss_src_neg_mean=l4[1:2], loss_src_pos_std=l4[2:3],
-                          loss_src_neg_std=l4[3:4], loss_sim_pos=l2[0:1], loss_sim_neg=l2[1:2])
+        if self.src_loss_type == 'mean_std':
+            out = OrderedDict(loss_src_pos_mean=l4[0:1], loss_src_neg_mean=l4[1:2], loss_src_pos_std=l4[2:3], loss_src_neg_std=l4[3:4])
+        else:                                           # pfgst_loss.py:116-131
+            out = OrderedDict(loss_src_pos=l4[0:1], loss_src_neg=l4[1:2])
+        out.update(loss_sim_pos=l2[0:1], loss_sim_neg=l2[1:2])
         out['vis|density_sim_feat'] = (ema_sim, all9)
         return out
 

@@ -364,3 +364,45 @@ def test_ema_adamw_flat(ops):
     assert_close(pd, p, 1e-6, 'adamw')
     ops.ema_update_(td, pd, 0.999)
     assert_close(td, 0.999 * t + (1 - 0.999) * p.detach(), 1e-6, 'ema')
+
+
+PFGST_VARIANTS = {          # the same table as tests/test_oracle_golden.py / tests/golden/make_golden.py
+    'gaussian': dict(sim_type='gaussian', sigma=8.0),
+    'margin': dict(src_loss_type='margin', margin=(0.5, 0.1)),
+    'margin2': dict(src_loss_type='margin2', margin=(0.6, 0.0)),
+    'unfold_grad': dict(detach_unfold=False),
+    'all_pairs': dict(top_k=None),
+    'full_res': dict(downscale=None),
+    'gaussian_all_unfold': dict(sim_type='gaussian', sigma=6.0, top_k=None, detach_unfold=False, src_loss_type='margin2',
+                                margin=(0.7, 0.2)),
+}
+
+
+@pytest.mark.parametrize('name', list(PFGST_VARIANTS))
+def test_pfgst_loss_option_variants_against_golden(ops, golden_dir, name):
+    """The PFGSTLoss MODULE (host mirror + HIP kernels) under the option variants of the reference, values and both
+    gradients against vectors produced by the executed reference (tests/golden/pfgst_options.npz)."""
+    import os
+    import pfst_amd  # noqa: F401
+    from pfst_amd.engine import Tape, Var
+    from pfst_amd.uda import PFGSTLoss
+    z = np.load(os.path.join(golden_dir, 'pfgst_options.npz'))
+    cfg = dict(kernel_size=3, dilation=2, top_k=3, weights={k: 0.1 for k in ('src_pos', 'src_neg', 'sim_pos', 'sim_neg', 'src_pos_std', 'src_neg_std')},
+               sim_type='cosine', feat_level=None, detach_unfold=True, downscale=0.5)
+    cfg.update(PFGST_VARIANTS[name])
+    loss = PFGSTLoss(**cfg)
+    lt = Var(torch.from_numpy(z['logits_trg']).to(DEV), True)
+    xs = Var(torch.from_numpy(z['x_src']).to(DEV), True)
+    xe = Var(torch.from_numpy(z['x_ema']).to(DEV), False)
+    tape = Tape()
+    out = loss(dict(logits_trg=lt, x_ema=xe, x_src=xs, gt_src=ops.to_u8(torch.from_numpy(z['gt_src']).to(DEV)),
+                    mix_masks=ops.to_u8(torch.from_numpy(z['mix_masks']).to(DEV))), tape)
+    names = [k for k in out if not k.startswith('vis|')]
+    assert names == list(z[name + '|names'])
+    got = np.array([float(out[k].sum()) for k in names])
+    assert np.allclose(got, z[name + '|losses'], rtol=1e-4, atol=1e-7), (got, z[name + '|losses'])
+    tape.backward()
+    assert_close(lt.grad, torch.from_numpy(z[name + '|grad_logits']), 1e-3, 'd logits_trg')
+    assert_close(xs.grad, torch.from_numpy(z[name + '|grad_xsrc']), 1e-3, 'd x_src')
+    dens = 1 - out['vis|density_sim_feat'][0].mean(1, keepdim=True)
+    assert_close(dens, torch.from_numpy(z[name + '|density']), 1e-4, 'density')

@@ -248,3 +248,32 @@ def test_inria_like_binary_step_with_part_threshold():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+
+
+def test_step_with_pfgst_loss_option_variants():
+    """One full train step with the non-default PFGSTLoss options (gaussian similarity, squared-hinge source
+    losses, gradient through the unfolded probabilities, all nine pairs) against the oracle."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    opts = dict(sim_type='gaussian', sigma=20.0, top_k=None, detach_unfold=False, src_loss_type='margin2', margin=(0.7, 0.2))
+    cfg = preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.3)
+    cfg['aux_losses'][0].update(opts)
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 9)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 6, seed=77)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.3, teacher_sd=teacher, loss_opts=opts)
+    random.seed(3); np.random.seed(3)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(3); np.random.seed(3)
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    assert set(olog) == set(out['log_vars']) and 'loss_src_pos' in olog and 'loss_src_pos_mean' not in olog
+    for k, v in olog.items():
+        tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
