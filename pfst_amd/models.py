@@ -115,6 +115,30 @@ class ResNetV1c(nn.Module):
         return tuple(outs)
 
 
+def get_class_weight(class_weight):
+    """losses/utils.py:10-25: a list is taken as is; a str is a file -- .npy via NumPy, otherwise what mmcv.load reads by
+    extension (.json, .yaml / .yml, .pkl / .pickle)."""
+    if not isinstance(class_weight, str):
+        return class_weight
+    import numpy as np
+    ext = class_weight.rsplit('.', 1)[-1].lower()
+    if ext == 'npy':
+        return np.load(class_weight).tolist()
+    if ext == 'json':
+        import json
+        with open(class_weight) as f:
+            return json.load(f)
+    if ext in ('yaml', 'yml'):
+        import yaml
+        with open(class_weight) as f:
+            return yaml.safe_load(f)
+    if ext in ('pkl', 'pickle'):
+        import pickle
+        with open(class_weight, 'rb') as f:
+            return pickle.load(f)
+    raise TypeError(f'Unsupported class_weight file format: {ext}')
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
     """Softmax CE with pixel weights, optional class weights, ignore_index, mean over ALL pixels
@@ -125,12 +149,7 @@ class CrossEntropyLoss(nn.Module):
         super().__init__()
         if use_sigmoid or use_mask or reduction != 'mean' or avg_non_ignore:
             raise NotImplementedError('pfst_amd CrossEntropyLoss: softmax CE, reduction=mean, avg_non_ignore=False only')
-        if isinstance(class_weight, str):
-            import numpy as np
-            class_weight = np.load(class_weight).tolist() if class_weight.endswith('.npy') else None
-            if class_weight is None:
-                raise NotImplementedError('class_weight files: .npy only')
-        self.class_weight = class_weight
+        self.class_weight = get_class_weight(class_weight)
         self.loss_weight = loss_weight
         self._loss_name = loss_name
         self._cw = None

@@ -112,3 +112,22 @@ def test_fscore_definition():
     p, r = inter / pa, inter / la
     assert np.allclose(m['Fscore'], (1 + 4) * p * r / (4 * p + r))
     assert np.allclose(m['Precision'], p) and np.allclose(m['Recall'], r)
+
+
+def test_class_weight_files(tmp_path):
+    # rsiseg/models/losses/utils.py:10-25 get_class_weight: list | .npy | whatever mmcv.load reads (json / yaml / pkl)
+    import json
+    import pickle
+    import pfst_amd  # noqa: F401
+    from pfst_amd.models import CrossEntropyLoss, get_class_weight
+    w = [0.5, 1.0, 1.5, 2.0, 0.7, 1.2]
+    np.save(tmp_path / 'w.npy', np.array(w))
+    (tmp_path / 'w.json').write_text(json.dumps(w))
+    (tmp_path / 'w.yaml').write_text('\n'.join(f'- {v}' for v in w))
+    (tmp_path / 'w.pkl').write_bytes(pickle.dumps(w))
+    assert get_class_weight(w) is w and get_class_weight(None) is None
+    for name in ('w.npy', 'w.json', 'w.yaml', 'w.pkl'):
+        assert np.allclose(get_class_weight(str(tmp_path / name)), w), name
+    assert np.allclose(CrossEntropyLoss(class_weight=str(tmp_path / 'w.json')).class_weight, w)
+    with pytest.raises(TypeError):
+        get_class_weight(str(tmp_path / 'w.txt'))
