@@ -83,6 +83,83 @@ class ISPRSTiles:
         return t(im), torch.from_numpy(np.ascontiguousarray(lab))[None], (t(aug) if aug is not None else None)
 
 
+def get_rcs_class_probs(data_root, temperature):
+    """Rare-class-sampling distribution (rsiseg/datasets/uda_dataset.py:17-40): classes sorted by total pixel count,
+    p = softmax((1 - freq) / T) in float32 as torch computes it."""
+    import json
+    with open(os.path.join(data_root, 'sample_class_stats.json')) as f:
+        sample_class_stats = json.load(f)
+    overall = {}
+    for s in sample_class_stats:
+        s.pop('file')
+        for c, n in s.items():
+            overall[int(c)] = overall.get(int(c), 0) + n
+    overall = dict(sorted(overall.items(), key=lambda item: item[1]))
+    freq = torch.tensor(list(overall.values()))
+    freq = freq / torch.sum(freq)
+    freq = torch.softmax((1 - freq) / temperature, dim=-1)
+    return list(overall.keys()), freq.numpy()
+
+
+class UDADataset:
+    """Source/target pairing of the reference (uda_dataset.py:43-135): sample idx = (source[idx // len(target)],
+    target[idx % len(target)]); with `rare_class_sampling` a class is drawn from get_rcs_class_probs, then a source file
+    containing it, re-cropped up to 10 times until it holds enough pixels of that class, then a uniform target -- the
+    same NumPy RNG calls in the same order, so a seeded run picks the same samples as the reference."""
+
+    def __init__(self, source, target, cfg):
+        import json
+        self.source, self.target = source, target
+        self.ignore_index = target.ignore_index
+        self.CLASSES, self.PALETTE = target.CLASSES, target.PALETTE
+        self.path2name = cfg.get('path2name', False)
+        assert target.ignore_index == source.ignore_index and target.CLASSES == source.CLASSES and target.PALETTE == source.PALETTE
+        rcs = cfg.get('rare_class_sampling')
+        self.rcs_enabled = rcs is not None
+        if self.rcs_enabled:
+            self.rcs_class_temp, self.rcs_min_crop_ratio, self.rcs_min_pixels = rcs['class_temp'], rcs['min_crop_ratio'], rcs['min_pixels']
+            root = cfg['source'].get('rcs_root', cfg['source']['data_root'])
+            self.rcs_classes, self.rcs_classprob = get_rcs_class_probs(root, self.rcs_class_temp)
+            with open(os.path.join(root, 'samples_with_class.json')) as f:
+                swc = {int(k): v for k, v in json.load(f).items() if int(k) in self.rcs_classes}
+            self.samples_with_class = {}
+            for c in self.rcs_classes:
+                self.samples_with_class[c] = [file.split('/')[-1] for file, pixels in swc[c] if pixels > self.rcs_min_pixels]
+                assert len(self.samples_with_class[c]) > 0
+            self.file_to_idx = {}
+            for i, info in enumerate(self.source.img_infos):
+                file = info['ann']['seg_map']
+                self.file_to_idx[file.split('/')[-1] if self.path2name else file] = i
+
+    def get_rare_class_sample(self):
+        c = np.random.choice(self.rcs_classes, p=self.rcs_classprob)
+        f1 = np.random.choice(self.samples_with_class[c])
+        i1 = self.file_to_idx[f1]
+        s1 = self.source[i1]
+        if self.rcs_min_crop_ratio > 0:
+            for _ in range(10):
+                if torch.sum(s1['gt_semantic_seg'].data == c) > self.rcs_min_pixels * self.rcs_min_crop_ratio:
+                    break
+                s1 = self.source[i1]                  # a new random crop of the same source image
+        s2 = self.target[np.random.choice(range(len(self.target)))]
+        return {**s1, 'target_img_metas': s2['img_metas'], 'target_img': s2['img']}
+
+    def __getitem__(self, idx):
+        if self.rcs_enabled:
+            return self.get_rare_class_sample()
+        s1 = self.source[idx // len(self.target)]
+        s2 = self.target[idx % len(self.target)]
+        out = {**s1, 'target_img_metas': s2['img_metas'], 'target_img': s2['img']}
+        if 'img_strong_aug' in s2:
+            out['target_img_strong_aug'] = s2['img_strong_aug']
+        if 'ori_img' in s2:
+            out['target_img_ori'] = s2['ori_img']
+        return out
+
+    def __len__(self):
+        return len(self.source) * len(self.target)
+
+
 def uda_loader(source, target, batch_size, device='cuda', seed=0, rank=0, world=1):
     """UDADataset pairing (uda_dataset.py:116-135: idx // len(target), idx % len(target)) -> collated device batches."""
     rng = random.Random(seed + rank)

@@ -382,6 +382,79 @@ def gen_pfgst_options(ref):
     np.savez_compressed(os.path.join(OUT, 'pfgst_options.npz'), **out)
 
 
+def gen_uda_dataset(ref):
+    """UDADataset (rsiseg/datasets/uda_dataset.py:17-135): index pairing and rare-class sampling on toy datasets; records the
+    RCS class probabilities and the (source index, class-pixel count, target index) sequence drawn under a NumPy seed."""
+    import json
+    import tempfile
+    # the file needs `mmcv.print_log` and the DATASETS registry only
+    pkg = types.ModuleType('rsiseg.datasets')
+    pkg.__path__ = []
+    sys.modules['rsiseg.datasets'] = pkg
+    bmod = types.ModuleType('rsiseg.datasets.builder')
+    bmod.DATASETS = sys.modules['mmcv.utils'].Registry('dataset')
+    sys.modules['rsiseg.datasets.builder'] = bmod
+    sys.modules['mmcv'].print_log = lambda *a, **k: None
+    ud = _load('rsiseg.datasets.uda_dataset', 'rsiseg/datasets/uda_dataset.py')
+
+    rng = np.random.RandomState(5)
+    n_src, n_trg, C = 7, 4, 5
+
+    class Toy(list):
+        ignore_index, CLASSES, PALETTE = 255, tuple('abcde'), None
+
+    # every access of a source sample yields a new "crop": the count of class pixels cycles through a fixed list
+    crops = {i: [int(v) for v in rng.randint(0, 4000, size=6)] for i in range(n_src)}
+    calls = {i: 0 for i in range(n_src)}
+
+    class Source(Toy):
+        def __getitem__(self, i):
+            k = calls[i] % 6
+            calls[i] += 1
+            gt = torch.zeros(1, 64, 64, dtype=torch.long)
+            gt.view(-1)[:crops[i][k]] = self.want
+            return dict(img=i, crop=k, gt_semantic_seg=types.SimpleNamespace(data=gt))
+
+    src = Source(range(n_src))
+    src.want = 0
+    src.img_infos = [dict(ann=dict(seg_map=f'dir/src_{i}.png')) for i in range(n_src)]
+    trg = Toy(dict(img=100 + j, img_metas=dict(j=j), img_strong_aug=200 + j) for j in range(n_trg))
+    stats = [dict(file=f'dir/src_{i}.png', **{str(c): int(rng.randint(1, 10000)) for c in range(C) if (i + c) % 3}) for i in range(n_src)]
+    swc = {str(c): [[f'dir/src_{i}.png', int(st[str(c)])] for i, st in enumerate(stats) if str(c) in st] for c in range(C)}
+    out = dict(stats=json.dumps(stats), samples_with_class=json.dumps(swc), crops=json.dumps(crops), n_src=n_src, n_trg=n_trg)
+    with tempfile.TemporaryDirectory() as d:
+        json.dump(stats, open(os.path.join(d, 'sample_class_stats.json'), 'w'))
+        json.dump(swc, open(os.path.join(d, 'samples_with_class.json'), 'w'))
+        cfg = dict(source=dict(data_root=d), path2name=True,
+                   rare_class_sampling=dict(class_temp=0.5, min_crop_ratio=0.5, min_pixels=3000))
+        ds = ud.UDADataset(src, trg, cfg)
+        out['rcs_classes'] = np.array(ds.rcs_classes)
+        out['rcs_classprob'] = np.array(ds.rcs_classprob, dtype=np.float64)
+        seq = []
+        np.random.seed(13)
+        _choice = np.random.choice
+
+        def spy(a, *args, **kw):                     # record which class was drawn so that the toy source can count its pixels
+            r = _choice(a, *args, **kw)
+            if 'p' in kw:
+                src.want = int(r)
+            return r
+        np.random.choice = spy
+        try:
+            for _ in range(40):
+                s = ds[0]
+                seq.append((s['img'], s['crop'], s['target_img']))
+        finally:
+            np.random.choice = _choice
+        out['rcs_sequence'] = np.array(seq)
+        plain = ud.UDADataset(src, trg, dict(source=dict(data_root=d)))
+        out['plain_len'] = len(plain)
+        calls.update({i: 0 for i in range(n_src)})
+        out['plain_pairs'] = np.array([(plain[i]['img'], plain[i]['target_img'], plain[i]['target_img_strong_aug']) for i in range(len(plain))])
+    np.savez_compressed(os.path.join(OUT, 'uda_dataset.npz'), **out)
+    print('uda_dataset.npz', out['rcs_classes'], out['rcs_classprob'], out['rcs_sequence'][:5].tolist())
+
+
 def gen_segmentor(ref):
     """EncoderDecoder.forward_train + backward (BASELINE config #1 shape, reduced) and the
     teacher-style encode_decode.  Weights = pfst_amd.synthetic.fill_state_dict(seed=5), which the tests rebuild bit-identically."""
@@ -474,11 +547,13 @@ def gen_train_step(ref):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'dataset', 'seg', 'step']
     if 'small' in which:
         gen_small_ops(ref)
     if 'options' in which:
         gen_pfgst_options(ref)
+    if 'dataset' in which:
+        gen_uda_dataset(ref)
     if 'seg' in which:
         gen_segmentor(ref)
     if 'step' in which:
