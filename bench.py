@@ -222,6 +222,8 @@ def main():
             agg = timer.summary()
             if args.per_layer:       # debug table, then fold back to per-kernel keys for the JSON line
                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    if v[2] == 0:
+                        sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/step {v[1] / args.steps:7.3f}\n')
                     if v[2] > 0:
                         sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/call {v[1] / v[0]:7.3f}  TF/s {v[2] / v[1] / 1e9:6.1f}\n')
                 folded = {}

@@ -133,6 +133,33 @@ __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, i64 dy_
   }
 }
 
+// exact 2x up-sampling (align_corners=False): output o = 2k reads inputs (k-1: .25, k: .75), o = 2k+1 reads (k: .75, k+1: .25),
+// clamped at the borders -- so input i receives {2i-1: .25, 2i: .75, 2i+1: .75, 2i+2: .25}, with the missing border tap's weight
+// folded onto the edge output (weight 1).  A separable 4x4 gather, one thread per input pixel.   grid: (blocks over Hi*Wi, C, N)
+__global__ __launch_bounds__(256) void resize_bilinear2x_bwd_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dx,
+                                                                    i64 dx_bs, int C, int Hi, int Wi, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Wo = 2 * Wi;
+  const float* gp = dy + (i64)n * dy_bs + (i64)c * 4 * Hi * Wi;
+  float* dp = dx + (i64)n * dx_bs + (i64)c * Hi * Wi;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hi * Wi; i += gridDim.x * blockDim.x) {
+    const int iy = i / Wi, ix = i - iy * Wi;
+    float wy[4], wx[4];
+    wy[0] = iy > 0 ? 0.25f : 0.f;  wy[1] = iy > 0 ? 0.75f : 1.f;  wy[2] = iy < Hi - 1 ? 0.75f : 1.f;  wy[3] = iy < Hi - 1 ? 0.25f : 0.f;
+    wx[0] = ix > 0 ? 0.25f : 0.f;  wx[1] = ix > 0 ? 0.75f : 1.f;  wx[2] = ix < Wi - 1 ? 0.75f : 1.f;  wx[3] = ix < Wi - 1 ? 0.25f : 0.f;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int oy = min(max(2 * iy - 1 + a, 0), 2 * Hi - 1);          // clamped rows/cols carry weight 0
+      const float* row = gp + (i64)oy * Wo + 2 * ix;
+      const float2 mid = *reinterpret_cast<const float2*>(row);
+      const float lft = row[ix > 0 ? -1 : 0], rgt = row[ix < Wi - 1 ? 2 : 1];
+      acc = fmaf(wy[a], wx[0] * lft + wx[1] * mid.x + wx[2] * mid.y + wx[3] * rgt, acc);
+    }
+    dp[i] = accumulate ? dp[i] + acc : acc;
+  }
+}
+
 // ---- per-(n,c) plane reductions / broadcasts.   grid: (C, N)
 __global__ void plane_sum_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ v, int C, int HW, float scale) {
   __shared__ double sm[16];
@@ -234,6 +261,12 @@ extern "C" int pfst_resize_bilinear(const float* x, long long x_bs, float* y, lo
 }
 extern "C" int pfst_resize_bilinear_bwd(const float* dy, long long dy_bs, float* dx, long long dx_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && dx && N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C <= 65535 && N <= 65535);
+  if (Ho == 2 * Hi && Wo == 2 * Wi && Hi > 1 && Wi > 1 && (dy_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {   // decoder up-sampling
+    hipLaunchKernelGGL(resize_bilinear2x_bwd_kernel, dim3(hw_blocks(Hi * Wi), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dx,
+                       dx_bs, C, Hi, Wi, accumulate);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(hw_blocks(Hi * Wi), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dx, dx_bs,
                      C, Hi, Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, accumulate);
   PFST_CHECK_LAUNCH();

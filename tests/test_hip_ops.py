@@ -224,7 +224,8 @@ def test_maxpool(ops):
     assert_close(dx, x.grad, 1e-6)
 
 
-@pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128)])
+@pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128),
+                                         (6, 10, 12, 20), (2, 2, 4, 4), (33, 17, 66, 34)])   # the last three: exact-2x fast path
 def test_bilinear_resize(ops, hi, wi, ho, wo):
     x = torch.randn(2, 5, hi, wi, generator=g(1)).requires_grad_()
     y_ref = F.interpolate(x, size=(ho, wo), mode='bilinear', align_corners=False)
@@ -234,6 +235,8 @@ def test_bilinear_resize(ops, hi, wi, ho, wo):
     assert_close(y, y_ref, 1e-6, 'resize fwd')
     dx = ops.resize_bilinear_bwd(dy.to(DEV), (hi, wi))
     assert_close(dx, x.grad, 1e-5, 'resize bwd')
+    dx2 = ops.resize_bilinear_bwd(dy.to(DEV), (hi, wi), out=dx.clone(), accumulate=True)
+    assert_close(dx2, 2 * x.grad, 1e-5, 'resize bwd accumulate')
 
 
 def test_pool_broadcast_dropout(ops):
