@@ -435,6 +435,7 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
     if (eff >= 0.93) break;
   }
   if (chunks_env > 0) chunks = chunks_env;
+  while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
@@ -481,6 +482,8 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   PFST_CHECK_ARG(in && wk && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
+  // 32-bit byte offsets inside one image / one weight tensor (buffer descriptors): fail loudly beyond 2 GiB
+  PFST_CHECK_ARG((i64)C * Hi * Wi * 4 < (1ll << 31) && (i64)M * Ho * Wo * 4 < (1ll << 31) && (i64)C * ksize * ksize * M * 4 < (1ll << 31));
   const int span = (ksize - 1) * dil;
   if (mode == 0) {
     PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
@@ -506,7 +509,8 @@ extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, 
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0);
   const int span = (ksize - 1) * dil;
   PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
-  PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo);
+  PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo && N <= 65535);
+  PFST_CHECK_ARG((i64)Cin * Hi * Wi * 4 < (1ll << 31) && (i64)Cout * Ho * Wo * 4 < (1ll << 31));     // 32-bit offsets per image
   hipStream_t s = (hipStream_t)stream;
   if (pfst_wgrad_q_eligible(x, x_bs, dy, dy_bs, Hi, Wi, Ho, Wo, ksize, stride, dil))       // K-quad fast path (conv_wgrad_q.hip)
     return pfst_wgrad_q_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, ksize, dil, pad, s);

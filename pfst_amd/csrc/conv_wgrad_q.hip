@@ -223,6 +223,7 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff >= 0.93) break;
   }
   if (chunks_env > 0) chunks = chunks_env;
+  while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * chunks);
