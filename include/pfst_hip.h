@@ -65,6 +65,21 @@ int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long d
 /* db[c] += sum_{n,hw} dy[n][c][hw] */
 int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream);
 
+/* ---- Winograd F(2x2,3x3) for wide stride-1 'same' 3x3 convolutions (csrc/conv_winograd.hip): the same F.conv2d / autograd
+ * results with 2.25x fewer MACs.  Transform-domain tensors: V [16][N][C][T], U [16][K/4][M][4], Mbuf [16][N][M][T],
+ * T = pfst_wino_tiles(H, W, dil) tiles per image (dilation d = d*d interleaved sub-grids).
+ *   fprop : pfst_wino_input(x) -> V;   pfst_wino_gemm(V, U_fprop) -> Mbuf;   pfst_wino_output(Mbuf) -> y
+ *   dgrad : the same on dy with U_dgrad (flipped, transposed filter), pfst_wino_output(..., accumulate)
+ *   wgrad : pfst_wino_input(x) -> V;  pfst_wino_dy(dy) -> dM;  pfst_wino_wgrad(V, dM, scratch dU[16*Cout*Cin]) : dw += ... */
+int pfst_wino_tiles(int H, int W, int dil);
+int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, pfst_stream_t stream);
+int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, pfst_stream_t stream);
+int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream);
+int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
+                     pfst_stream_t stream);
+int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, pfst_stream_t stream);
+int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream);
+
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
 int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,

@@ -83,4 +83,5 @@ int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, fl
                         int Ho, int Wo, int ksize, int dil, int pad, hipStream_t s);
 // internal: K-quad implicit-GEMM convolution (Cin % 16 == 0), conv_igemm_q.hip
 int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
-                        int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s);
+                        int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
+                        hipStream_t s);

@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 
   // B staging role: one pixel, one k-half (8 channels = 2 quads);  A staging role: quads tid + 256 i of the [quad][row] image
   const int pix = tid & (BN - 1), kh = tid >> 7;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wq), 0, K * M * 4, 0x00020000);
+  // gridDim.y > 1: a batch of GEMMs that share shapes but not weights (the 16 transform-domain products of the Winograd
+  // path, conv_winograd.hip): group g = blockIdx.y uses weight set g and images g*N .. g*N+N-1.
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(wq) + (i64)blockIdx.y * (K / 4) * M, 0,
+                                                                         K * M * 4, 0x00020000);
 
   // ---- tile of this workgroup (grid: tiles x 1 x images).  XCD-aware order inside an image: workgroups are dealt
   // round-robin over the 8 XCDs, so the m-tiles that share one pixel tile (= one activation tile) get ids 8 apart: they run
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     b_voff = ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
   };
   auto setup_tile = [&](int tile) {
-    t_n = blockIdx.z;                               // image index straight from an SGPR: the buffer descriptors stay scalar
+    t_n = blockIdx.y * N + blockIdx.z;              // image index straight from SGPRs: the buffer descriptors stay scalar
     const int lin = tile;
     int by;
     if ((gx & 7) == 0) {
@@ -193,15 +196,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     if (t == 12345.678f) out_all[tid] = t;
     return;
   }
+  if (diag == -2) {   // DIAGNOSTIC (PFST_IGEMM_DIAG=-2): all stores issued, but every workgroup writes the SAME tile (L2-resident)
+    conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all, bias, nullptr, 0, 0, M, P, 0, 0, wm0, wn0, 0, 0, wid, lane);
+    return;
+  }
   conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
                                      t_bx, t_n, wid, lane);
 }
 
 template <int BM>
 int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
-             int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
+             int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
+             hipStream_t s) {
   static const int diag = getenv("PFST_IGEMM_DIAG") ? atoi(getenv("PFST_IGEMM_DIAG")) : 0;
-  dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), 1, N);
+  dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), groups, N);
   hipLaunchKernelGGL((conv_igemm_q_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
                      out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, diag);
   PFST_CHECK_LAUNCH();
@@ -211,8 +219,9 @@ int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, flo
 }  // namespace
 
 int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
-                        int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
-  if (M > 64) return launch_q<128>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
-  if (M > 32) return launch_q<64>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
-  return launch_q<32>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, s);
+                        int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
+                        hipStream_t s) {
+  if (M > 64) return launch_q<128>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
+  if (M > 32) return launch_q<64>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
+  return launch_q<32>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
 }

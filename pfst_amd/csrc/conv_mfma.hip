@@ -496,7 +496,7 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   const bool generic = (C % BK_MIN) != 0;
   if (!generic)      // Cin % 16 == 0: K-quad kernel (conv_igemm_q.hip), weights packed [K/4][M][4]
-    return pfst_igemm_q_launch(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+    return pfst_igemm_q_launch(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
   if (M > 64) return launch_igemm_generic<128>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
   if (M > 32) return launch_igemm_generic<64>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
   return launch_igemm_generic<32>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);

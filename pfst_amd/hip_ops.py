@@ -207,6 +207,67 @@ def bias_grad_(db, dy):
     return db
 
 
+# ---------------------------------------------------------------- Winograd F(2x2,3x3) (wide stride-1 3x3 convolutions)
+_wino_cache = {}
+
+
+def _wino_ws(dev, tag, nfloat):
+    """per-stream scratch for the transform-domain tensors (consumed on the same stream)"""
+    key = (dev, torch.cuda.current_stream().cuda_stream, tag)
+    t = _wino_cache.get(key)
+    if t is None or t.numel() < nfloat:
+        t = torch.empty(nfloat, dtype=F32, device=dev)
+        _wino_cache[key] = t
+    return t
+
+
+def wino_tiles(h, w, dil):
+    from ._lib import lib
+    return lib().pfst_wino_tiles(h, w, dil)
+
+
+def wino_pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
+    """w [Cout][Cin][3][3] -> transform-domain filters U[16][K/4][M][4] for fprop (K = Cin) and dgrad (K = Cout, flipped)."""
+    _dense(w)
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    uf = (out_f if out_f is not None else torch.empty(16 * co * ci, device=w.device)) if want_fprop else None
+    ud = (out_d if out_d is not None else torch.empty(16 * co * ci, device=w.device)) if want_dgrad else None
+    call('pfst_wino_pack_weight', w.data_ptr(), _p(uf), _p(ud), co, ci, _stream())
+    return uf, ud
+
+
+def wino_conv(x, u, cout, dil, out=None, accumulate=False):
+    """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain"""
+    n, c, h, w = x.shape
+    t = wino_tiles(h, w, dil)
+    v = _wino_ws(x.device, 'V', 16 * n * c * t)
+    m = _wino_ws(x.device, 'M', 16 * n * cout * t)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, cout, h, w, device=x.device)
+    assert tuple(out.shape) == (n, cout, h, w)
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, _stream())
+    call('pfst_wino_gemm', v.data_ptr(), _dense(u).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
+    call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _stream())
+    return out
+
+
+def wino_wgrad_(dw, x, dy, dil):
+    """dw += dL/dw of the 'same' 3x3 stride-1 convolution"""
+    n, ci, h, w = x.shape
+    co = dy.shape[1]
+    assert dy.shape == (n, co, h, w) and dw.numel() == co * ci * 9
+    t = wino_tiles(h, w, dil)
+    v = _wino_ws(x.device, 'V', 16 * n * ci * t)
+    dm = _wino_ws(x.device, 'M', 16 * n * co * t)
+    du = _wino_ws(x.device, 'U', 16 * co * ci)
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, _stream())
+    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, _stream())
+    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, _stream())
+    return dw
+
+
 # ---------------------------------------------------------------- depthwise
 def dwconv(x, w, dil, flip=False, out=None, accumulate=False):
     n, c, h, wd = x.shape

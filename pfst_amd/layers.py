@@ -22,6 +22,11 @@ _BN_EVAL = False
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
+# Winograd F(2x2,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 2.25x fewer MACs.
+# Thresholds on Cin*Cout from tools/wino_microbench.py: fprop/dgrad win from 256x256 up, wgrad from 512x512 up.
+WINOGRAD = os.environ.get('PFST_WINOGRAD', '1') == '1'
+WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', 256 * 256))
+WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', 512 * 512))
 
 
 class bn_eval:
@@ -50,14 +55,24 @@ class Conv2dP(nn.Module):
         nn.init.normal_(self.weight, 0.0, math.sqrt(2.0 / fan_out))     # kaiming_normal_(fan_out, relu)
         self.wf = self.wd = None        # packed copies, refreshed by repack()
         self.w6f = self.w6d = None      # bf16x3-split packed copies (CONV_MATH == 'bf16x6')
+        self.uf = self.ud = None        # Winograd transform-domain filters
 
     split_f = split_d = False
+    wino = False
+
+    def _wino_eligible(self):
+        return (WINOGRAD and CONV_MATH == 'f32' and self.k == 3 and self.stride == 1 and self.groups == 1
+                and self.padding == self.dilation and self.cin % 16 == 0 and self.cout % 16 == 0
+                and self.cin * self.cout >= WINO_MIN_CC)
 
     @property
     def depthwise(self):
         return self.groups > 1
 
     def fprop(self, xd, out=None, bias=None, want_stats=False):
+        if self.wino and bias is None:
+            y = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out)
+            return (y, None, 0) if want_stats else y       # no GEMM epilogue in the output domain: statistics by bn_stats
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                                         want_stats=want_stats)
@@ -65,6 +80,8 @@ class Conv2dP(nn.Module):
                               want_stats=want_stats)
 
     def dgrad(self, dy, in_hw, out, accumulate):
+        if self.wino:
+            return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate)
         if self.split_d:
             return ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                                         out=out, accumulate=accumulate)
@@ -74,6 +91,17 @@ class Conv2dP(nn.Module):
     def repack(self, need_dgrad):
         if self.depthwise:
             return
+        self.wino = self._wino_eligible()
+        if self.wino:
+            n = 16 * self.weight.numel()
+            if self.uf is None or self.uf.device != self.weight.device:
+                self.uf = torch.empty(n, device=self.weight.device)
+                self.ud = None
+            if need_dgrad and self.ud is None:
+                self.ud = torch.empty(n, device=self.weight.device)
+            ops.wino_pack_weight(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
+            if self.bias is None:
+                return                    # the direct-convolution packings are not needed
         if self.wf is None or self.wf.device != self.weight.device:
             self.wf = torch.empty(self.k * self.k * self.cin, self.cout, device=self.weight.device)
             self.wd = None
@@ -158,9 +186,12 @@ def conv_backward(x, conv, dy):
             buf, acc = x.grad_target()
             ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
-        # the split wgrad kernel is correct but (first version) slower than the fp32-MFMA one: opt-in only
-        wgrad = ops.conv_wgrad_split_ if (CONV_MATH == 'bf16x6' and WGRAD_SPLIT) else ops.conv_wgrad_
-        wgrad(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+        if conv.wino and conv.cin * conv.cout >= WINO_MIN_CC_WGRAD and ops.wino_tiles(xd.shape[2], xd.shape[3], conv.dilation) % 4 == 0:
+            ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
+        else:
+            # the split wgrad kernel is correct but (first version) slower than the fp32-MFMA one: opt-in only
+            wgrad = ops.conv_wgrad_split_ if (CONV_MATH == 'bf16x6' and WGRAD_SPLIT) else ops.conv_wgrad_
+            wgrad(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
@@ -177,6 +208,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     elif fused_stats:                              # batch statistics come out of the GEMM epilogue
         pre, st, slots = conv.fprop(xd, want_stats=True)
+        fused_stats = st is not None               # (the Winograd path has no output-domain GEMM epilogue)
     else:
         pre = conv.fprop(xd)
     if _BN_EVAL:

