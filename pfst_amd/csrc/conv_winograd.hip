@@ -8,7 +8,7 @@
 //   dU_xi[co][ci] = sum_{n,t} dM_xi[n][co][t] V_xi[n][ci][t]   (16 launches of the 1x1 K-quad wgrad kernel),  dM = A dY A^T,
 //   dW = G^T dU G.
 // Dilation d: a dilated 3x3 convolution is d*d independent dilation-1 convolutions on the interleaved sub-grids
-// (y mod d, x mod d); tiles are enumerated sub-grid by sub-grid, so the same kernels serve d = 1, 2, 4.
+// (y mod d, x mod d); the tile index enumerates them (column offset fastest), so the same kernels serve d = 1, 2, 4.
 // Transform matrices (Lavin & Gray 2016, correlation form):
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
 #include "common.h"
@@ -27,12 +27,13 @@ __host__ __device__ inline WinoGeom wino_geom(int H, int W, int d) {
   g.T = d * d * g.Th * g.Tw;
   return g;
 }
-// tile index -> (sub-grid offsets sy, sx; tile coordinates ty, tx)
+// tile index -> (sub-grid offsets sy, sx; tile coordinates ty, tx).  The sub-grid column offset sx runs fastest: consecutive
+// threads then touch x = sx + d*(2tx + const), i.e. runs of d contiguous pixels, instead of pixels 2d apart.
 __device__ __forceinline__ void tile_coord(const WinoGeom& g, int t, int& sy, int& sx, int& ty, int& tx) {
+  sx = t % g.d; t /= g.d;
   tx = t % g.Tw; t /= g.Tw;
-  ty = t % g.Th; t /= g.Th;
-  sx = t % g.d;
-  sy = t / g.d;
+  ty = t % g.Th;
+  sy = t / g.Th;
 }
 
 // ---- filter transform.  One thread per (co, ci): U = G g G^T (4x4), written into the K-quad packed layouts
@@ -143,6 +144,13 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       if (yy >= g.H) continue;
       const float o0 = r[i][0] + r[i][1] + r[i][2], o1 = r[i][1] - r[i][2] - r[i][3];
       const int x0 = sx + g.d * (2 * tx), x1 = x0 + g.d;
+      if (g.d == 1 && x1 < g.W && (g.W & 1) == 0) {           // the two outputs are adjacent: one 8-byte store
+        float2* q = reinterpret_cast<float2*>(yp + (i64)yy * g.W + x0);
+        float2 v = make_float2(o0, o1);
+        if (accumulate) { const float2 old = *q; v.x += old.x; v.y += old.y; }
+        *q = v;
+        continue;
+      }
       if (x0 < g.W) { float* q = yp + (i64)yy * g.W + x0; *q = accumulate ? *q + o0 : o0; }
       if (x1 < g.W) { float* q = yp + (i64)yy * g.W + x1; *q = accumulate ? *q + o1 : o1; }
     }

@@ -237,11 +237,13 @@ def wino_pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None
     return uf, ud
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False):
-    """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain"""
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False):
+    """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
+    keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
+    (288 GB of HBM: keeping ~11 GB per pass resident beats re-transforming the input in backward)."""
     n, c, h, w = x.shape
     t = wino_tiles(h, w, dil)
-    v = _wino_ws(x.device, 'V', 16 * n * c * t)
+    v = torch.empty(16 * n * c * t, dtype=F32, device=x.device) if keep_v else _wino_ws(x.device, 'V', 16 * n * c * t)
     m = _wino_ws(x.device, 'M', 16 * n * cout * t)
     if out is None:
         assert not accumulate
@@ -250,19 +252,21 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False):
     call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, _stream())
     call('pfst_wino_gemm', v.data_ptr(), _dense(u).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
     call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _stream())
-    return out
+    return (out, v) if keep_v else out
 
 
-def wino_wgrad_(dw, x, dy, dil):
-    """dw += dL/dw of the 'same' 3x3 stride-1 convolution"""
+def wino_wgrad_(dw, x, dy, dil, v=None):
+    """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass"""
     n, ci, h, w = x.shape
     co = dy.shape[1]
     assert dy.shape == (n, co, h, w) and dw.numel() == co * ci * 9
     t = wino_tiles(h, w, dil)
-    v = _wino_ws(x.device, 'V', 16 * n * ci * t)
     dm = _wino_ws(x.device, 'M', 16 * n * co * t)
     du = _wino_ws(x.device, 'U', 16 * co * ci)
-    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, _stream())
+    if v is None:
+        v = _wino_ws(x.device, 'V', 16 * n * ci * t)
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, _stream())
+    assert v.numel() >= 16 * n * ci * t
     call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, _stream())
     call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, _stream())
     return dw

@@ -59,6 +59,7 @@ class Conv2dP(nn.Module):
 
     split_f = split_d = False
     wino = False
+    saved_v = None
 
     def _wino_eligible(self):
         return (WINOGRAD and CONV_MATH == 'f32' and self.k == 3 and self.stride == 1 and self.groups == 1
@@ -69,9 +70,17 @@ class Conv2dP(nn.Module):
     def depthwise(self):
         return self.groups > 1
 
-    def fprop(self, xd, out=None, bias=None, want_stats=False):
+    def wino_wgrad_ok(self, h, w):
+        return self.wino and self.cin * self.cout >= WINO_MIN_CC_WGRAD and ops.wino_tiles(h, w, self.dilation) % 4 == 0
+
+    def fprop(self, xd, out=None, bias=None, want_stats=False, keep=False):
+        """keep: training forward -- the Winograd path keeps its transformed input for the weight gradient (self.saved_v)"""
+        self.saved_v = None
         if self.wino and bias is None:
-            y = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out)
+            if keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
+                y, self.saved_v = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=True)
+            else:
+                y = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out)
             return (y, None, 0) if want_stats else y       # no GEMM epilogue in the output domain: statistics by bn_stats
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
@@ -166,19 +175,20 @@ def conv_forward(x, conv, tape, out=None):
         assert conv.k == 3 and conv.stride == 1 and conv.padding == conv.dilation
         y = ops.dwconv(xd, conv.weight.data, conv.dilation, out=out)
     else:
-        y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data)
+        y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data, keep=tape is not None)
+    saved_v = None if conv.depthwise else conv.saved_v
     yv = Var(y, tape is not None)
     if tape is not None:
         def bwd():
             dy = yv.grad
-            conv_backward(x, conv, dy)
+            conv_backward(x, conv, dy, saved_v)
             yv.free_grad()
         tape.record(bwd)
     return yv
 
 
-def conv_backward(x, conv, dy):
-    """accumulate weight/bias grads and propagate the data gradient into x"""
+def conv_backward(x, conv, dy, saved_v=None):
+    """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward"""
     xd = x.data
     if conv.depthwise:
         ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
@@ -186,8 +196,8 @@ def conv_backward(x, conv, dy):
             buf, acc = x.grad_target()
             ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
-        if conv.wino and conv.cin * conv.cout >= WINO_MIN_CC_WGRAD and ops.wino_tiles(xd.shape[2], xd.shape[3], conv.dilation) % 4 == 0:
-            ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
+        if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
+            ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v)
         else:
             # the split wgrad kernel is correct but (first version) slower than the fp32-MFMA one: opt-in only
             wgrad = ops.conv_wgrad_split_ if (CONV_MATH == 'bf16x6' and WGRAD_SPLIT) else ops.conv_wgrad_
@@ -207,10 +217,11 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     if conv.depthwise:
         pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     elif fused_stats:                              # batch statistics come out of the GEMM epilogue
-        pre, st, slots = conv.fprop(xd, want_stats=True)
+        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None)
         fused_stats = st is not None               # (the Winograd path has no output-domain GEMM epilogue)
     else:
-        pre = conv.fprop(xd)
+        pre = conv.fprop(xd, keep=tape is not None)
+    saved_v = None if conv.depthwise else conv.saved_v
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'
         mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)
@@ -239,7 +250,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         ymask = y if (relu and residual is not None) else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
                                relu, dres, bool(dacc), beta=bn.bias.data)
-        conv_backward(x, conv, dpre)
+        conv_backward(x, conv, dpre, saved_v)
         if yv.parent is None:
             yv.free_grad()
     tape.record(bwd)
