@@ -6,18 +6,40 @@
 
 typedef float pfst_f32x16 __attribute__((ext_vector_type(16)));
 
-// sum over each 32-lane half of the wave, result in every lane: four DPP-fused adds (quad swaps, half-row and row mirrors)
-// and one ds_swizzle for the 16 <-> 16 exchange -- a tenth of the LDS traffic of five ds_bpermute shuffles.
+// Transposing butterfly over the 32 lanes of each half-wave: every lane enters with NV values (one per accumulator row) and
+// leaves with ONE fully reduced value, lane l holding value index l & (NV-1).  Each step exchanges half of the remaining
+// values with the partner lane l ^ mask and adds, so the whole reduction costs NV-1 exchanges instead of 5 NV.  The partner
+// permutations are XORs the DPP unit (or one ds_swizzle) provides: 16 | 15 = row mirror | 7 = half-row mirror | 2, 1 = quad
+// perms; they are independent over GF(2) and the kept half is chosen by the top bit of each mask, which the lower masks
+// leave alone, so partners always hold the same value subset and every lane's data is counted exactly once.
 template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+__device__ __forceinline__ float lane_xchg(float v) {
+  if (CTRL == 0) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);    // row_half_mirror
-  v = dpp_add<0x140>(v);    // row_mirror
-  return v + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
+template <int H, int CTRL>
+__device__ __forceinline__ void butterfly_step(float* a, bool upper) {   // 2H values -> H values
+#pragma unroll
+  for (int k = 0; k < H; ++k) {
+    const float send = upper ? a[k] : a[k + H];
+    const float keep = upper ? a[k + H] : a[k];
+    a[k] = keep + lane_xchg<CTRL>(send);
+  }
+}
+template <int NV>
+__device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31) {
+  static_assert(NV == 32 || NV == 16, "one value per accumulator row of a 64- or 32-row wave tile");
+  if (NV == 32) {
+    butterfly_step<16, 0>(a, (l31 & 16) != 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a[k] += lane_xchg<0>(a[k]);          // both 16-lane rows need all 16 values: plain add
+  }
+  butterfly_step<8, 0x140>(a, (l31 & 8) != 0);     // row_mirror      (lane ^ 15)
+  butterfly_step<4, 0x141>(a, (l31 & 4) != 0);     // row_half_mirror (lane ^ 7)
+  butterfly_step<2, 0x4E>(a, (l31 & 2) != 0);      // quad_perm [2,3,0,1]
+  butterfly_step<1, 0xB1>(a, (l31 & 1) != 0);      // quad_perm [1,0,3,2]
+  return a[0];
 }
 
 template <int TM, int TN, int WAVES_N, int BN>
@@ -26,31 +48,37 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
                                               int wm0, int wn0, int bx, int n, int wid, int lane) {
   const int l31 = lane & 31, lh = lane >> 5;
   // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
-  // the 32 lanes of each half-wave (half_wave_sum) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
+  // the 32 lanes of each half-wave (transposing butterfly) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
   // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
   if (stats) {
     const int gx = (P + BN - 1) / BN;
     const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
+    constexpr int NV = TM * 16;
+    float sv[NV], sq[NV];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float sv = 0.f, sq = 0.f;
+        float a = 0.f, b = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int pp = p0 + wn0 + j * 32 + l31;
           const float v = pp < P ? acc[i][j][r] : 0.f;
-          sv += v;
-          sq = fmaf(v, v, sq);
+          a += v;
+          b = fmaf(v, v, b);
         }
-        sv = half_wave_sum(sv);
-        sq = half_wave_sum(sq);
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (l31 == 0 && m < M) {
-          float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
-          *dst = make_float2(sv, sq);
-        }
+        sv[i * 16 + r] = a;
+        sq[i * 16 + r] = b;
       }
+    }
+    const float ts = half_wave_transpose_sum<NV>(sv, l31);
+    const float tq = half_wave_transpose_sum<NV>(sq, l31);
+    // lane l31 now owns value index e = l31 & (NV-1) = i*16 + r of its half-wave: one 8-byte store per lane
+    const int e = l31 & (NV - 1), r = e & 15;
+    const int m = m0 + wm0 + (e >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (l31 < NV && m < M) {
+      float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
+      *dst = make_float2(ts, tq);
     }
   }
   // Store.  fp32 MFMA and VALU share the vector pipe, so per-element address arithmetic and bounds checks in a 64-store
