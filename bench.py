@@ -43,7 +43,7 @@ class KernelTimer:
             bm = 128 if m > 64 else (64 if m > 32 else 32)
             px = ho * wo if mode == 0 else hi * wi            # forward-output pixels = algorithmic work
             nbytes = 4.0 * (n * c * hi * wi + n * m * ho * wo * (2 if a[18] else 1) + c * ks * ks * m)
-            kern = f'conv_igemm_q_kernel<{bm}>' if c % 16 == 0 else f'conv_igemm_kernel<{bm},true>'   # dispatch of pfst_conv_igemm
+            kern = f'conv_igemm_q_kernel<{bm}>' if c % 16 == 0 else f'conv_igemm_kernel<{bm}>'   # dispatch of pfst_conv_igemm
             return kern, 2.0 * n * m * c * ks * ks * px, nbytes
         if name == 'pfst_conv_wgrad':
             n, ci, co, ho, wo, ks, stride, dil = a[5], a[6], a[9], a[10], a[11], a[12], a[13], a[14]
@@ -233,6 +233,7 @@ def main():
                        'strong_aug': 'colour-jitter p=0.8 + gaussian-blur p=0.5 (HIP kernels)' if strong_aug.AVAILABLE else 'off (not implemented yet)',
                        'dropout': 0.1},
             'loss': out['log_vars'].get('decode.loss_ce'),
+            'hbm_peak_allocated_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
         }
         if not args.no_kernel_timing:
             agg = timer.summary()

@@ -6,6 +6,10 @@
 // (rsiseg/models/backbones/resnet.py:169-209,593-624, decode_heads/aspp_head.py:32-42,85-92,
 // fcn_head.py:40-49, decode_head.py:242-247) and their autograd data / weight gradients.
 //
+// This file: the C entry points, weight packing, and the GENERIC kernels -- any channel count (the 3- / 10-band stems,
+// K steps that straddle taps), stride 2, ragged widths.  The fast paths live in conv_igemm_q.hip (fprop / dgrad with
+// Cin % 16 == 0), conv_wgrad_q.hip (stride-1 weight gradients) and conv_winograd.hip (wide 3x3 layers).
+//
 // Layout (NCHW fp32, per image):   OUT[m][p] = sum_k WK[k][m] * IN[c(k)][src(p, tap(k))]
 //   GEMM M = output channels, N = output pixels (contiguous in memory -> coalesced), K = (tap, c).
 //   WK is the weight re-packed K-major ([tap*C + c][M]) so both LDS tiles are filled by
@@ -39,11 +43,12 @@ __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, in
   return (odd == 0) & (s >= 0) & (s < lim);
 }
 
-template <int BM, bool GENERIC, int BK, int BN>
+template <int BM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ in, i64 in_bs, const float* __restrict__ wk, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+  constexpr int BK = 16, BN = 128;
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -102,70 +107,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Address generation is kept off the VALU.  Fast path (Cin % BK == 0): both operands are read with BUFFER loads
-  // (SRSRC descriptor built from kernel arguments / blockIdx only): the per-thread byte offsets live in VGPRs and stay
-  // constant while the tap does not change, the per-step advance is a scalar soffset, and out-of-tile elements use an
-  // out-of-range offset so the hardware range check returns 0 -- no address VALU, no masks, no branches in the loop.
-  int ld_ty = 0, ld_tx = 0, ld_ci0 = 0;          // (tap, first channel) of the K-slice being prefetched
+  // Generic loader: any (tap, channel) per K index, validity applied when the registers are written to LDS (clamped,
+  // branch-free loads).  The fast kernels for Cin % 16 == 0 keep all of this off the vector pipe (conv_igemm_q.hip).
   const int amc = min(m0 + am, M - 1);
-  constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wk), 0, K * M * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
-  unsigned a_voff[A_N], b_voff[B_N];
-#pragma unroll
-  for (int i = 0; i < A_N; ++i)
-    a_voff[i] = amvalid ? 4u * ((unsigned)(ar0 + i * A_RPP) * (unsigned)M + (unsigned)amc) : OOB;
-  auto set_tap = [&]() {
-    int sy, sx;
-    const bool ok = pvalid & src_coord(oy, ld_ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, ld_tx, ca, cb, cc, cdivv, Wi, sx);
-#pragma unroll
-    for (int i = 0; i < B_N; ++i)
-      b_voff[i] = ok ? 4u * ((unsigned)(br0 + i * B_RPP) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
-  };
-  if (!GENERIC) set_tap();
-  unsigned a_mask = 0, b_mask = 0;   // GENERIC path only: validity applied when the registers are written to LDS
+  unsigned a_mask = 0, b_mask = 0;
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
-    if (!GENERIC) {
-      const int a_soff = k0 * M * 4, b_soff = ld_ci0 * HiWi * 4;
+    a_mask = 0; b_mask = 0;
 #pragma unroll
-      for (int i = 0; i < A_N; ++i)
-        areg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, a_voff[i], a_soff, 0));
+    for (int i = 0; i < A_N; ++i) {
+      const int k = k0 + ar0 + i * A_RPP;
+      areg[i] = wk[(i64)min(k, K - 1) * M + amc];
+      a_mask |= (unsigned)(amvalid && k < K) << i;
+    }
 #pragma unroll
-      for (int i = 0; i < B_N; ++i)
-        breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff[i], b_soff, 0));
-      ld_ci0 += BK;
-      if (ld_ci0 >= C) {
-        ld_ci0 = 0; ld_tx += 1;
-        if (ld_tx == ks) { ld_tx = 0; ld_ty += 1; }
-        set_tap();
-      }
-    } else {
-      a_mask = 0; b_mask = 0;
-#pragma unroll
-      for (int i = 0; i < A_N; ++i) {
-        const int k = k0 + ar0 + i * A_RPP;
-        areg[i] = wk[(i64)min(k, K - 1) * M + amc];
-        a_mask |= (unsigned)(amvalid && k < K) << i;
-      }
-#pragma unroll
-      for (int i = 0; i < B_N; ++i) {
-        const int k = k0 + br0 + B_RPP * i;
-        const int kc = min(k, K - 1);
-        const int tap = kc / C, ci = kc - tap * C;
-        const int ty = tap / ks, tx = tap - ty * ks;
-        int sy, sx;
-        const bool ok = pvalid & (k < K) & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
-        breg[i] = in[(i64)ci * HiWi + (ok ? sy * Wi + sx : 0)];
-        b_mask |= (unsigned)ok << i;
-      }
+    for (int i = 0; i < B_N; ++i) {
+      const int k = k0 + br0 + B_RPP * i;
+      const int kc = min(k, K - 1);
+      const int tap = kc / C, ci = kc - tap * C;
+      const int ty = tap / ks, tx = tap - ty * ks;
+      int sy, sx;
+      const bool ok = pvalid & (k < K) & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+      breg[i] = in[(i64)ci * HiWi + (ok ? sy * Wi + sx : 0)];
+      b_mask |= (unsigned)ok << i;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = (!GENERIC || ((a_mask >> i) & 1u)) ? areg[i] : 0.f;
+    for (int i = 0; i < A_N; ++i) As[buf][ar0 + i * A_RPP][am] = ((a_mask >> i) & 1u) ? areg[i] : 0.f;
 #pragma unroll
-    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + B_RPP * i][bj] = (!GENERIC || ((b_mask >> i) & 1u)) ? breg[i] : 0.f;
+    for (int i = 0; i < B_N; ++i) Bs[buf][br0 + B_RPP * i][bj] = ((b_mask >> i) & 1u) ? breg[i] : 0.f;
   };
 
   load_tile(0);
@@ -409,7 +380,7 @@ template <int BM>
 int launch_igemm_generic(const float* in, i64 in_bs, const float* wk, const float* bias, float* out, i64 out_bs, int N, int C,
                          int Hi, int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, 128) * cdiv(M, BM), 1, N);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, true, 16, 128>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, wk, bias, out, out_bs, C, Hi, Wi, M,
                      Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
