@@ -270,7 +270,7 @@ def main():
             res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
             res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
         if world == 1 and not args.no_alt_math:
-            # informational second pass: same step with the fp32-faithful 6-term bf16 split for fprop/dgrad
+            # informational second pass: same step with the fp32-faithful 6-term bf16 split for the fprop/dgrad GEMMs (direct and Winograd)
             # (csrc/conv_split.hip).  `value` above is the fp32-MFMA number; this one is reported separately.
             from pfst_amd import layers
             hip_ops.call = timer.inner
@@ -289,7 +289,7 @@ def main():
                 model2.train_step(batch, opt2)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            res['alt_math'] = {'mode': 'bf16x6 split for fprop+dgrad (fp32-faithful, opt-in via PFST_CONV_MATH=bf16x6)',
+            res['alt_math'] = {'mode': 'bf16x6 split MFMA for fprop+dgrad GEMMs incl. the Winograd ones (fp32-faithful, opt-in via PFST_CONV_MATH=bf16x6)',
                                'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
             layers.CONV_MATH = 'f32'
         if not args.no_cpu_baseline and world == 1:

@@ -79,6 +79,12 @@ int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cou
                      pfst_stream_t stream);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream);
+/* the same GEMMs on the fp32-faithful bf16x6 path: plain [16][Cout][Cin] filter sets (normal / flipped) -> 16 split-packed sets of
+ * 6*Cout*Cin bytes each -> pfst_wino_gemm_split */
+int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, pfst_stream_t stream);
+int pfst_wino_pack_weight_split(const float* plain_f, const float* plain_d, void* U6_fprop, void* U6_dgrad, int Cout, int Cin,
+                                pfst_stream_t stream);
+int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */

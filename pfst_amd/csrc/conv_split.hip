@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
       bx = lin - by * gx;
     }
   }
-  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.z;
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;   // gridDim.y > 1: batched GEMMs (Winograd), group = blockIdx.y
   const int K = C * ks * ks;
   const int KT = K / 16;
   in += (i64)n * in_bs;
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   const int ox = pvalid ? p - oy * Wo : 0;
 
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk6), 0, KT * 2 * NP * M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk6) + (i64)blockIdx.y * KT * 2 * NP * M, 0,
+                                                                         KT * 2 * NP * M * 16, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
   unsigned a_voff[A_N], b_voff[8];
 #pragma unroll
@@ -365,8 +366,9 @@ int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, flo
 
 template <int BM>
 int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
-                 int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, hipStream_t s) {
-  dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), 1, N);
+                 int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
+                 hipStream_t s) {
+  dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), groups, N);
   hipLaunchKernelGGL((conv_igemm_split_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
                      Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   PFST_CHECK_LAUNCH();
@@ -406,9 +408,9 @@ extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const voi
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   hipStream_t s = (hipStream_t)stream;
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
-  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
-  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
-  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
+  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
+  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
+  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
 }
 
 extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
@@ -427,4 +429,36 @@ extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float
   if (Cout > 32) { PFST_WGS(64); }
   PFST_WGS(32);
 #undef PFST_WGS
+}
+
+// ---- Winograd on the bf16x6 GEMM (conv_winograd.hip supplies the transforms): the 16 transform-domain products as ONE
+// grouped launch of the split kernel, filter sets packed per transform index.
+extern "C" int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream) {
+  PFST_CHECK_ARG(V && U6 && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 16 == 0 && M > 0 && T > 0);
+  PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 6 < (1ll << 31));
+  hipStream_t s = (hipStream_t)stream;
+  if (M > 64) return launch_split<128>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
+  if (M > 32) return launch_split<64>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
+  return launch_split<32>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
+}
+
+// plain[16][Cout][Cin] transform-domain filters (pfst_wino_filter_plain: normal and flipped) -> 16 split-packed sets of 6*Cout*Cin bytes
+extern "C" int pfst_wino_pack_weight_split(const float* plain_f, const float* plain_d, void* U6_fprop, void* U6_dgrad, int Cout, int Cin,
+                                           pfst_stream_t stream) {
+  PFST_CHECK_ARG((plain_f && U6_fprop) || (plain_d && U6_dgrad));
+  PFST_CHECK_ARG(Cout > 0 && Cin > 0 && (!U6_fprop || Cin % 16 == 0) && (!U6_dgrad || Cout % 16 == 0));
+  const i64 n = (i64)Cout * Cin, set = 6 * n;
+  for (int xi = 0; xi < 16; ++xi) {
+    if (U6_fprop) {
+      hipLaunchKernelGGL(pack_weight_split_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, plain_f + xi * n,
+                         (uint4*)((char*)U6_fprop + xi * set), (uint4*)nullptr, Cout, Cin, 1);
+      PFST_CHECK_LAUNCH();
+    }
+    if (U6_dgrad) {
+      hipLaunchKernelGGL(pack_weight_split_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, plain_d + xi * n,
+                         (uint4*)nullptr, (uint4*)((char*)U6_dgrad + xi * set), Cout, Cin, 1);
+      PFST_CHECK_LAUNCH();
+    }
+  }
+  return PFST_OK;
 }

@@ -81,6 +81,31 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// plain [16][Cout][Cin] filter sets (normal and flipped), input of the bf16x6 packer (pfst_wino_pack_weight_split)
+__global__ void wino_filter_plain_kernel(const float* __restrict__ w, float* __restrict__ Pf, float* __restrict__ Pd, int Cout, int Cin) {
+  const i64 total = (i64)Cout * Cin;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    float g[3][3], gf[3][3], u[4][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        g[a][b] = w[i * 9 + a * 3 + b];
+        gf[2 - a][2 - b] = g[a][b];
+      }
+    if (Pf) {
+      filter_tf(g, u);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) Pf[(i64)xi * total + i] = u[xi >> 2][xi & 3];
+    }
+    if (Pd) {
+      filter_tf(gf, u);
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) Pd[(i64)xi * total + i] = u[xi >> 2][xi & 3];
+    }
+  }
+}
+
 // ---- input transform V = B^T d B.   grid: (blocks over T, C, N); one thread per tile
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
                                                          WinoGeom g) {
@@ -232,6 +257,13 @@ extern "C" int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dg
   PFST_CHECK_ARG(w && (U_fprop || U_dgrad) && Cout > 0 && Cin > 0);
   PFST_CHECK_ARG((!U_fprop || Cin % 16 == 0) && (!U_dgrad || Cout % 16 == 0));     // K-quad GEMM kernel: K % 16 == 0
   hipLaunchKernelGGL(wino_filter_kernel, dim3(ew_grid((i64)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, w, U_fprop, U_dgrad, Cout, Cin);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, pfst_stream_t stream) {
+  PFST_CHECK_ARG(w && (P_fprop || P_dgrad) && Cout > 0 && Cin > 0);
+  hipLaunchKernelGGL(wino_filter_plain_kernel, dim3(ew_grid((i64)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

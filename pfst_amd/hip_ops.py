@@ -237,6 +237,21 @@ def wino_pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None
     return uf, ud
 
 
+def wino_pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
+    """transform-domain filters for the bf16x6 GEMM: 16 split-packed sets (uint8 buffers of 16 * 6 * Cout * Cin bytes)"""
+    _dense(w)
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    n = co * ci
+    pf = _wino_ws(w.device, 'Pf', 16 * n) if want_fprop else None
+    pd = _wino_ws(w.device, 'Pd', 16 * n) if want_dgrad else None
+    call('pfst_wino_filter_plain', w.data_ptr(), _p(pf), _p(pd), co, ci, _stream())
+    uf = (out_f if out_f is not None else torch.empty(16 * 6 * n, dtype=U8, device=w.device)) if want_fprop else None
+    ud = (out_d if out_d is not None else torch.empty(16 * 6 * n, dtype=U8, device=w.device)) if want_dgrad else None
+    call('pfst_wino_pack_weight_split', _p(pf), _p(pd), _p(uf), _p(ud), co, ci, _stream())
+    return uf, ud
+
+
 def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
@@ -250,7 +265,8 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False):
         out = torch.empty(n, cout, h, w, device=x.device)
     assert tuple(out.shape) == (n, cout, h, w)
     call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, _stream())
-    call('pfst_wino_gemm', v.data_ptr(), _dense(u).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
+    gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
+    call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
     call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _stream())
     return (out, v) if keep_v else out
 

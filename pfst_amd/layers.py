@@ -62,7 +62,7 @@ class Conv2dP(nn.Module):
     saved_v = None
 
     def _wino_eligible(self):
-        return (WINOGRAD and CONV_MATH == 'f32' and self.k == 3 and self.stride == 1 and self.groups == 1
+        return (WINOGRAD and self.k == 3 and self.stride == 1 and self.groups == 1
                 and self.padding == self.dilation and self.cin % 16 == 0 and self.cout % 16 == 0
                 and self.cin * self.cout >= WINO_MIN_CC)
 
@@ -102,13 +102,16 @@ class Conv2dP(nn.Module):
             return
         self.wino = self._wino_eligible()
         if self.wino:
-            n = 16 * self.weight.numel()
-            if self.uf is None or self.uf.device != self.weight.device:
-                self.uf = torch.empty(n, device=self.weight.device)
+            split = CONV_MATH == 'bf16x6'           # transform-domain GEMMs on the bf16x6 kernel: split-packed filter sets
+            n = 16 * (self.weight.numel() // 9) * (6 if split else 1)
+            dt = torch.uint8 if split else torch.float32
+            if self.uf is None or self.uf.device != self.weight.device or self.uf.dtype != dt:
+                self.uf = torch.empty(n, dtype=dt, device=self.weight.device)
                 self.ud = None
             if need_dgrad and self.ud is None:
-                self.ud = torch.empty(n, device=self.weight.device)
-            ops.wino_pack_weight(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
+                self.ud = torch.empty(n, dtype=dt, device=self.weight.device)
+            pack = ops.wino_pack_weight_split if split else ops.wino_pack_weight
+            pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
             if self.bias is None:
                 return                    # the direct-convolution packings are not needed
         if self.wf is None or self.wf.device != self.weight.device:

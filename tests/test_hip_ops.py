@@ -185,6 +185,21 @@ def test_winograd_f2x2_3x3_matches_direct_convolution(ops, case):
         assert_close(dw, dw_ref, 5e-6, 'winograd wgrad')
 
 
+@pytest.mark.parametrize('case', [c for c in WINO_CASES if c[1] % 16 == 0 and c[2] % 16 == 0])
+def test_winograd_on_the_bf16x6_gemm(ops, case):
+    """The same Winograd pipeline with the 16 transform-domain GEMMs on the fp32-faithful bf16x6 kernel."""
+    n, ci, co, H, W, d = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1
+    dy = torch.randn(n, co, H, W, generator=g(4))
+    ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
+    uf, ud = ops.wino_pack_weight_split(w.to(DEV))
+    assert uf.dtype == torch.uint8
+    assert_close(ops.wino_conv(x.to(DEV), uf, co, d), ref, 3e-6, 'winograd/bf16x6 fprop')
+    assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d), dx_ref, 3e-6, 'winograd/bf16x6 dgrad')
+
+
 def test_conv_channel_slice_views(ops):
     """conv reading / writing channel slices of bigger tensors (concat elimination)."""
     n, ci, co, H, W = 2, 32, 64, 10, 12
