@@ -95,20 +95,41 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
       const int pp = p0 + wn0 + j * 32 + l31;
       voff[j] = pp < P ? 4u * ((unsigned)pp + 4u * (unsigned)lh * (unsigned)P) : OOB;
     }
+    // NOTE for callers: wm0 must be provably wave-uniform (derive the wave id with __builtin_amdgcn_readfirstlane(tid >> 6));
+    // otherwise every store below (and every accumulate load, each with its own vmcnt(0) wait) is wrapped in a waterfall
+    // loop over the 'divergent' soffset -- measured 120-300 k cycles per workgroup.
     const int row0 = m0 + wm0;
+    if (!accumulate) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int soff = 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2));     // wave-uniform
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          float v = acc[i][j][r];
-          if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], soff, 0));
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j], soff, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];       // (a float temporary: __builtin_bit_cast of the vector-element lvalue reads element 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
+                                                  4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
+          }
+        }
+      return;
+    }
+    // accumulate: the 16 loads of a 32x32 block are issued back to back, then added and stored (one latency per block, not 64)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+          const float v = acc[i][j][r] + old[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
+                                                4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
         }
       }
-    }
     return;
   }
 #pragma unroll

@@ -17,6 +17,15 @@
 #include "../../include/pfst_hip.h"
 #include <stdlib.h>
 
+#ifdef PFST_CLOCK_STAMPS
+// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py; the product library never contains this): per-workgroup shader-clock stamps
+// {prologue, main loop, epilogue} + real-time {lifetime, start}, written to a buffer that nothing else reads.
+__device__ unsigned long long g_pfst_stamps[5 * 65536];
+extern "C" int pfst_debug_read_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pfst_stamps), sizeof(unsigned long long) * 5 * n) == hipSuccess ? 0 : -2;
+}
+#endif
+
 namespace {
 
 constexpr int QBN = 128, QBK = 16, QNQ = 4;
@@ -46,7 +55,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   __shared__ float4 As[2][NQ * BM];
   __shared__ float4 Bs[2][NQ * BN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
+#ifdef PFST_CLOCK_STAMPS
+  const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi;
   const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
@@ -156,6 +168,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   __syncthreads();
   a_wr += da; b_wr += db;
   zero_acc();
+#ifdef PFST_CLOCK_STAMPS
+  const unsigned long long t_clk1 = __builtin_amdgcn_s_memtime();
+#endif
   auto mma_step = [&]() {
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
@@ -185,6 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     da = -da; db = -db;
   }
   mma_step();                                       // last K-slice
+#ifdef PFST_CLOCK_STAMPS
+  const unsigned long long t_clk2 = __builtin_amdgcn_s_memtime();
+#endif
   if (diag == -1) {   // DIAGNOSTIC (PFST_IGEMM_DIAG=-1): no epilogue traffic -- the store happens only for an impossible value
     float t = 0.f;
 #pragma unroll
@@ -202,6 +220,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   }
   conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
                                      t_bx, t_n, wid, lane);
+#ifdef PFST_CLOCK_STAMPS
+  if (tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);                  // the stores have left the wave
+    const unsigned long long t_clk3 = __builtin_amdgcn_s_memtime();
+    const unsigned b = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u;
+    g_pfst_stamps[5 * b + 0] = t_clk1 - t_clk0;
+    g_pfst_stamps[5 * b + 1] = t_clk2 - t_clk1;
+    g_pfst_stamps[5 * b + 2] = t_clk3 - t_clk2;
+    g_pfst_stamps[5 * b + 3] = __builtin_amdgcn_s_memrealtime() - t_rt0;
+    g_pfst_stamps[5 * b + 4] = t_rt0;
+  }
+#endif
 }
 
 template <int BM>

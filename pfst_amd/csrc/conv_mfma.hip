@@ -23,13 +23,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifdef PFST_CLOCK_STAMPS
-// DIAGNOSTIC BUILD ONLY (tools/clock_probe.py): per-block shader-clock / real-time deltas, written to a buffer nothing reads.
-__device__ unsigned long long g_pfst_stamps[2 * 65536];
-extern "C" int pfst_debug_read_stamps(unsigned long long* host, int n) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pfst_stamps), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2;
-}
-#endif
 
 namespace {
 
@@ -62,10 +55,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   __shared__ float As[2][BK][BM];
   __shared__ float Bs[2][BK][BN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#ifdef PFST_CLOCK_STAMPS
-  const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi;
   // XCD-aware tile order (1-D grid over tiles): workgroups are dealt round-robin over the 8 XCDs, so the m-tiles that
@@ -166,13 +156,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   }
 
   conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
-#ifdef PFST_CLOCK_STAMPS
-  if (tid == 0) {
-    const unsigned b = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 65535u;
-    g_pfst_stamps[2 * b] = __builtin_amdgcn_s_memtime() - t_clk0;
-    g_pfst_stamps[2 * b + 1] = __builtin_amdgcn_s_memrealtime() - t_rt0;
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   // per-column (j = ci*T + tap) gather descriptors, decoded ONCE per block: {channel offset, dy, dx}
   int* jtab = reinterpret_cast<int*>(smem + 2 * (BM + WBJ) * WLD);   // [WBJ][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
   const int j0 = blockIdx.x * WBJ, m0 = blockIdx.y * BM;

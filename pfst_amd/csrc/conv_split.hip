@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   __shared__ uint4 As[2][2 * NP * BM];
   __shared__ uint4 Bs[2][2 * NP * BN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi;
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so the m-tiles that share one pixel tile
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(
   __shared__ uint4 As[2][2 * NP * BM];
   __shared__ uint4 Bs[2][2 * NP * BJ];
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
   const int j0 = blockIdx.x * BJ, m0 = blockIdx.y * BM;

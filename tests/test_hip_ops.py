@@ -54,6 +54,8 @@ CONV_CASES = [
     (1, 40, 72, 20, 48, 3, 1, 2, 2),
     (2, 24, 136, 18, 80, 3, 1, 4, 4),
     (1, 16, 32, 9, 16, 3, 1, 1, 1),      # one K-step per row: every step is an edge step
+    (2, 64, 256, 32, 32, 1, 1, 1, 0),    # 8 pixel tiles: the XCD-aware tile order + the buffer-store epilogue on full tiles
+    (1, 32, 160, 32, 64, 3, 1, 2, 2),    # 16 pixel tiles, M = 128 + 32: fast and generic epilogue paths in one launch
 ]
 
 
