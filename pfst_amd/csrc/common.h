@@ -80,7 +80,7 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int
 // internal (not part of the C ABI): K-quad weight-gradient fast path, conv_wgrad_q.hip
 bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, int dil);
 int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int Cout,
-                        int Ho, int Wo, int ksize, int dil, int pad, hipStream_t s);
+                        int Ho, int Wo, int ksize, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s);
 // internal: K-quad implicit-GEMM convolution (Cin % 16 == 0), conv_igemm_q.hip
 int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
                         int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,

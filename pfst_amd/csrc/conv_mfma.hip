@@ -467,7 +467,7 @@ extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, 
   PFST_CHECK_ARG((i64)Cin * Hi * Wi * 4 < (1ll << 31) && (i64)Cout * Ho * Wo * 4 < (1ll << 31));     // 32-bit offsets per image
   hipStream_t s = (hipStream_t)stream;
   if (pfst_wgrad_q_eligible(x, x_bs, dy, dy_bs, Hi, Wi, Ho, Wo, ksize, stride, dil))       // K-quad fast path (conv_wgrad_q.hip)
-    return pfst_wgrad_q_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, ksize, dil, pad, s);
+    return pfst_wgrad_q_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, ksize, dil, pad, 1, 0, 0, 0, s);
 #define PFST_WGRAD(BM_)                                                                                          \
   return ksize == 3 ? launch_wgrad<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s) \
                     : launch_wgrad<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s)

@@ -24,7 +24,7 @@ constexpr int QBJ = 128;
 template <int BM, int T, int WBK>
 __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil, int pad, int chunks, int chunk_len) {
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil, int pad, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -45,12 +45,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
   const int j0 = blockIdx.x * QBJ, m0 = blockIdx.y * BM;
-  const int n = blockIdx.z / chunks, chunk = blockIdx.z - n * chunks;
+  // blockIdx.z = ((group * N) + image) * chunks + chunk; groups > 1: batched products that share shapes (the 16 transform
+  // indices of the Winograd weight gradient), each with its own x / dy / dw
+  const int ng = blockIdx.z / chunks, chunk = blockIdx.z - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
   const int pbeg = chunk * chunk_len;
   const int pend = min(P, pbeg + chunk_len);
   if (pbeg >= pend) return;
-  x += (i64)n * x_bs;
-  dy += (i64)n * dy_bs;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
 
@@ -208,9 +212,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
 
 template <int BM, int T, int WBK>
 int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
-             int Ho, int Wo, int dil, int pad, hipStream_t s) {
+             int Ho, int Wo, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
   const int P = Ho * Wo, J = Cin * T;
-  const int tiles = cdiv(J, QBJ) * cdiv(M, BM);
+  const int tiles = cdiv(J, QBJ) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident blocks (see launch_wgrad_k in conv_mfma.hip); 32 KB LDS at WBK = 16, 64 KB at 32
   static const int chunks_env = getenv("PFST_WGRAD_CHUNKS") ? atoi(getenv("PFST_WGRAD_CHUNKS")) : 0;
   const double slots = 256.0 * (WBK == 16 ? 4 : 2);
@@ -223,23 +227,23 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff >= 0.93) break;
   }
   if (chunks_env > 0) chunks = chunks_env;
-  while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
+  while ((i64)N * groups * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
-  dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * chunks);
+  dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * groups * chunks);
   hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
-                     dil, pad, chunks, chunk_len);
+                     dil, pad, chunks, chunk_len, N, x_gs, dy_gs, dw_gs);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 template <int BM, int T>
 int launch_q_bk(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
-                int Ho, int Wo, int dil, int pad, hipStream_t s) {
+                int Ho, int Wo, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
   static const int wbk_env = getenv("PFST_WGRADQ_BK") ? atoi(getenv("PFST_WGRADQ_BK")) : 0;   // tuning knob
   const int wbk = (wbk_env && T == 1) ? wbk_env : 16;        // the 3x3 row walk assumes 16-pixel K-steps
-  if (wbk == 32) return launch_q<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, s);
-  return launch_q<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, s);
+  if (wbk == 32) return launch_q<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
+  return launch_q<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
 }
 
 }  // namespace
@@ -255,10 +259,10 @@ bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs,
 }
 
 int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int Cout,
-                        int Ho, int Wo, int ksize, int dil, int pad, hipStream_t s) {
-#define PFST_WGQ(BM_)                                                                                            \
-  return ksize == 3 ? launch_q_bk<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, s)      \
-                    : launch_q_bk<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, s)
+                        int Ho, int Wo, int ksize, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
+#define PFST_WGQ(BM_)                                                                                                                        \
+  return ksize == 3 ? launch_q_bk<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s)      \
+                    : launch_q_bk<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s)
   if (Cout > 64) { PFST_WGQ(128); }
   if (Cout > 32) { PFST_WGQ(64); }
   PFST_WGQ(32);

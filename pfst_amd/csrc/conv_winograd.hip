@@ -5,7 +5,7 @@
 // ONE launch of the K-quad implicit-GEMM kernel (conv_igemm_q.hip, gridDim.y = 16, 1x1 mode) on transform-domain tensors
 //   V [16][N][C][T]   U [16][K/4][M][4] (the kernel's packed weight layout)   Mbuf [16][N][Cout][T].
 // Data gradient = the same pipeline on dY with the flipped / transposed filter.  Weight gradient:
-//   dU_xi[co][ci] = sum_{n,t} dM_xi[n][co][t] V_xi[n][ci][t]   (16 launches of the 1x1 K-quad wgrad kernel),  dM = A dY A^T,
+//   dU_xi[co][ci] = sum_{n,t} dM_xi[n][co][t] V_xi[n][ci][t]   (one grouped launch of the 1x1 K-quad wgrad kernel),  dM = A dY A^T,
 //   dW = G^T dU G.
 // Dilation d: a dilated 3x3 convolution is d*d independent dilation-1 convolutions on the interleaved sub-grids
 // (y mod d, x mod d); the tile index enumerates them (column offset fastest), so the same kernels serve d = 1, 2, 4.
@@ -302,18 +302,17 @@ extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, 
   return PFST_OK;
 }
 
-// dU[xi][Cout][Cin] = sum_{n,t} dM[xi][n][Cout][T] V[xi][n][Cin][T]  (16 launches of the 1x1 K-quad wgrad), then dW += G^T dU G.
+// dU[xi][Cout][Cin] = sum_{n,t} dM[xi][n][Cout][T] V[xi][n][Cin][T]  (one grouped launch of the 1x1 K-quad wgrad), then dW += G^T dU G.
 // dU is scratch of 16*Cout*Cin floats (zeroed here).
 extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && dM && dU && dw && N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && T % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const i64 uc = (i64)Cout * Cin;
   if (hipMemsetAsync(dU, 0, 16 * uc * sizeof(float), s) != hipSuccess) return PFST_ERR_LAUNCH;
-  for (int xi = 0; xi < 16; ++xi) {
-    const int rc = pfst_wgrad_q_launch(V + (i64)xi * N * Cin * T, (i64)Cin * T, dM + (i64)xi * N * Cout * T, (i64)Cout * T, dU + xi * uc, N,
-                                       Cin, 1, T, Cout, 1, T, 1, 1, 0, s);
-    if (rc != PFST_OK) return rc;
-  }
+  // the 16 per-transform-index products as ONE grouped launch: enough workgroups without splitting the tile range further
+  const int rc = pfst_wgrad_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, 1, T, Cout, 1, T, 1, 1, 0, 16, (i64)N * Cin * T,
+                                     (i64)N * Cout * T, uc, s);
+  if (rc != PFST_OK) return rc;
   hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid(uc)), dim3(256), 0, s, dU, dw, Cout, Cin);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
