@@ -52,3 +52,22 @@ def test_unknown_options_fail_loudly():
         UDA.build(cfg)
     with pytest.raises(KeyError):
         UDA.build(dict(type='DACS'))
+
+
+def test_winograd_dispatch_rules():
+    """Host-side dispatch of the wide stride-1 3x3 layers to the Winograd path (pfst_amd/layers.py): geometry and size rules."""
+    import pfst_amd  # noqa: F401
+    from pfst_amd import layers
+    from pfst_amd.layers import Conv2dP
+    assert layers.WINOGRAD                                            # on by default (PFST_WINOGRAD=0 disables it)
+    ok = Conv2dP(512, 512, 3, 1, 4, 4)                                # layer4 conv2: same-size dilated 3x3
+    assert ok._wino_eligible()
+    assert Conv2dP(2560, 512, 3, 1, 1, 1)._wino_eligible()            # head bottleneck
+    assert Conv2dP(256, 256, 3, 1, 2, 2)._wino_eligible()             # layer3 conv2 (fprop / dgrad only: below the wgrad threshold)
+    assert 256 * 256 < layers.WINO_MIN_CC_WGRAD <= 512 * 512
+    assert not Conv2dP(128, 128, 3, 1, 1, 1)._wino_eligible()         # transform-bound: stays direct
+    assert not Conv2dP(512, 512, 3, 2, 1, 1)._wino_eligible()         # stride 2
+    assert not Conv2dP(512, 512, 1)._wino_eligible()                  # 1x1
+    assert not Conv2dP(512, 512, 3, 1, 0, 1)._wino_eligible()         # not a 'same' convolution
+    assert not Conv2dP(2048, 2048, 3, 1, 12, 12, groups=2048)._wino_eligible()   # depthwise
+    assert not Conv2dP(520, 512, 3, 1, 1, 1)._wino_eligible()         # Cin not a multiple of 16: generic kernel
