@@ -86,6 +86,30 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
   }
 }
 
+// even H, W: one thread per 2x2 input block (a, b).  Only the windows (a,b), (a,b+1), (a+1,b), (a+1,b+1) reach it, each routing its
+// gradient to the ONE pixel its saved arg-max names: 4 index bytes + 4 gradients in, two 8-byte stores out.
+__global__ __launch_bounds__(256) void maxpool_bwd2x2_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                             float* __restrict__ dx, int H, int W) {
+  const int nc = blockIdx.y;
+  const int Ho = H >> 1, Wo = W >> 1;                 // (H + 2 - 3) / 2 + 1 for even H
+  const float* gp = dy + (i64)nc * Ho * Wo;
+  const unsigned char* ip = idx + (i64)nc * Ho * Wo;
+  float* xp = dx + (i64)nc * H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Ho * Wo; i += gridDim.x * blockDim.x) {
+    const int a = i / Wo, b = i - a * Wo;
+    const bool hb = b + 1 < Wo, ha = a + 1 < Ho;
+    const int k00 = ip[i], k01 = hb ? ip[i + 1] : -1, k10 = ha ? ip[i + Wo] : -1, k11 = (ha && hb) ? ip[i + Wo + 1] : -1;
+    const float g00 = gp[i], g01 = hb ? gp[i + 1] : 0.f, g10 = ha ? gp[i + Wo] : 0.f, g11 = (ha && hb) ? gp[i + Wo + 1] : 0.f;
+    // window (oy, ox) covers rows 2oy-1..2oy+1: tap index k = ty*3 + tx
+    const float o00 = k00 == 4 ? g00 : 0.f;                                                      // (2a,   2b)
+    const float o01 = (k00 == 5 ? g00 : 0.f) + (k01 == 3 ? g01 : 0.f);                           // (2a,   2b+1)
+    const float o10 = (k00 == 7 ? g00 : 0.f) + (k10 == 1 ? g10 : 0.f);                           // (2a+1, 2b)
+    const float o11 = (k00 == 8 ? g00 : 0.f) + (k01 == 6 ? g01 : 0.f) + (k10 == 2 ? g10 : 0.f) + (k11 == 0 ? g11 : 0.f);
+    *reinterpret_cast<float2*>(xp + (i64)(2 * a) * W + 2 * b) = make_float2(o00, o01);
+    *reinterpret_cast<float2*>(xp + (i64)(2 * a + 1) * W + 2 * b) = make_float2(o10, o11);
+  }
+}
+
 // ---- bilinear resize, align_corners=False.  grid: (blocks over Ho*Wo, C, N)
 __global__ void resize_bilinear_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ y, i64 y_bs, int C, int Hi, int Wi,
                                        int Ho, int Wo, float sh, float sw) {
@@ -247,6 +271,11 @@ extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, i
 extern "C" int pfst_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && idx && dx && NC > 0 && NC <= 65535 && H > 0 && W > 0);
   PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
+  if ((H & 1) == 0 && (W & 1) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {
+    hipLaunchKernelGGL(maxpool_bwd2x2_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, H, W);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(hw_blocks(H * W), NC), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, H, W, Ho, Wo);
   PFST_CHECK_LAUNCH();
   return PFST_OK;

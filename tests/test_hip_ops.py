@@ -265,14 +265,17 @@ def test_batchnorm_train(ops, shape, relu, res):
         assert_close(dres, r.grad, 1e-6, 'bn dres')
 
 
-def test_maxpool(ops):
-    x = torch.randn(2, 8, 17, 22, generator=g(1)).requires_grad_()
+@pytest.mark.parametrize('H,W', [(17, 22), (16, 24), (2, 2), (64, 64)])      # odd sizes: generic kernel; even: 2x2-block backward
+def test_maxpool(ops, H, W):
+    x = torch.randn(2, 8, H, W, generator=g(1)).requires_grad_()
+    with torch.no_grad():
+        x[0, 0, :4, :4] = 1.5                       # ties: the first maximum in scan order must win, as in torch
     y_ref = F.max_pool2d(x, 3, 2, 1)
     dy = torch.randn(y_ref.shape, generator=g(2))
     y_ref.backward(dy)
     y, idx = ops.maxpool(x.detach().to(DEV))
     assert torch.equal(y.cpu(), y_ref.detach())
-    dx = ops.maxpool_bwd(dy.to(DEV), idx, (17, 22))
+    dx = ops.maxpool_bwd(dy.to(DEV), idx, (H, W))
     assert_close(dx, x.grad, 1e-6)
 
 
