@@ -41,7 +41,7 @@ template <int BM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_igemm_q_kernel(
     const float* __restrict__ in_all, i64 in_bs, const float4* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ out_all, i64 out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, int diag) {
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
   constexpr int BN = QBN, BK = QBK, NQ = QNQ;
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
@@ -203,21 +203,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 #ifdef PFST_CLOCK_STAMPS
   const unsigned long long t_clk2 = __builtin_amdgcn_s_memtime();
 #endif
-  if (diag == -1) {   // DIAGNOSTIC (PFST_IGEMM_DIAG=-1): no epilogue traffic -- the store happens only for an impossible value
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
-    if (t == 12345.678f) out_all[tid] = t;
-    return;
-  }
-  if (diag == -2) {   // DIAGNOSTIC (PFST_IGEMM_DIAG=-2): all stores issued, but every workgroup writes the SAME tile (L2-resident)
-    conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all, bias, nullptr, 0, 0, M, P, 0, 0, wm0, wn0, 0, 0, wid, lane);
-    return;
-  }
   conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
                                      t_bx, t_n, wid, lane);
 #ifdef PFST_CLOCK_STAMPS
@@ -238,10 +223,9 @@ template <int BM>
 int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
              int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
              hipStream_t s) {
-  static const int diag = getenv("PFST_IGEMM_DIAG") ? atoi(getenv("PFST_IGEMM_DIAG")) : 0;
   dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), groups, N);
   hipLaunchKernelGGL((conv_igemm_q_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
-                     out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, diag);
+                     out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
