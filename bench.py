@@ -225,7 +225,7 @@ def main():
         global_batch = b * world
         value = global_batch * args.steps / elapsed
         res = {
-            'metric': 'PFST train-step images/s on 1024^2 IRRG tiles', 'value': value, 'unit': 'images/s',
+            'metric': 'PFST train-step images/s on 1024\u00b2 IRRG tiles', 'value': value, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': WORKLOAD, 'global_batch': global_batch, 'per_gpu_batch': b, 'tile': f'{S}x{S}x{w["in_channels"]}',
