@@ -23,10 +23,11 @@ CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
 # Winograd F(2x2,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 2.25x fewer MACs.
-# Thresholds on Cin*Cout from tools/wino_microbench.py: fprop/dgrad win from 256x256 up, wgrad from 512x512 up.
+# Threshold on Cin*Cout from tools/wino_microbench.py / bench.py: from 256x256 up Winograd wins for fprop, dgrad and (with the
+# transformed input kept from the forward pass and the grouped launch) the weight gradient.
 WINOGRAD = os.environ.get('PFST_WINOGRAD', '1') == '1'
 WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', 256 * 256))
-WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', 512 * 512))
+WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', 256 * 256))
 
 
 class bn_eval:

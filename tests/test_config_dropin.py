@@ -63,8 +63,8 @@ def test_winograd_dispatch_rules():
     ok = Conv2dP(512, 512, 3, 1, 4, 4)                                # layer4 conv2: same-size dilated 3x3
     assert ok._wino_eligible()
     assert Conv2dP(2560, 512, 3, 1, 1, 1)._wino_eligible()            # head bottleneck
-    assert Conv2dP(256, 256, 3, 1, 2, 2)._wino_eligible()             # layer3 conv2 (fprop / dgrad only: below the wgrad threshold)
-    assert 256 * 256 < layers.WINO_MIN_CC_WGRAD <= 512 * 512
+    assert Conv2dP(256, 256, 3, 1, 2, 2)._wino_eligible()             # layer3 conv2
+    assert layers.WINO_MIN_CC <= layers.WINO_MIN_CC_WGRAD <= 512 * 512
     assert not Conv2dP(128, 128, 3, 1, 1, 1)._wino_eligible()         # transform-bound: stays direct
     assert not Conv2dP(512, 512, 3, 2, 1, 1)._wino_eligible()         # stride 2
     assert not Conv2dP(512, 512, 1)._wino_eligible()                  # 1x1
