@@ -76,7 +76,9 @@ int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Co
 int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, pfst_stream_t stream);
 int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                     pfst_stream_t stream);
+                     float* stats, pfst_stream_t stream);
+/* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil)][2] */
+int pfst_wino_stats_slots(int H, int W, int dil);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream);
 /* the same GEMMs on the fp32-faithful bf16x6 path: plain [16][Cout][Cin] filter sets (normal / flipped) -> 16 split-packed sets of
@@ -89,7 +91,10 @@ int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
 int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                   int N, int C, int H, int W, int dil, int flip, int accumulate, pfst_stream_t stream);
+                   int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, pfst_stream_t stream);
+/* stats != NULL: per-channel partial (sum, sum of squares) of the outputs, stats[C][N * pfst_dwconv_stats_slots(H, W, dil)][2],
+ * for pfst_bn_finalize_partials (as the `stats` argument of pfst_conv_igemm) */
+int pfst_dwconv_stats_slots(int H, int W, int dil);
 int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
                          int N, int C, int H, int W, int dil, pfst_stream_t stream);
 

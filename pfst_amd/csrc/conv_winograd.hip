@@ -146,7 +146,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 
 // ---- output transform Y = A^T m A (2x2 per tile), optional accumulate.   grid: (blocks over T, Cout, N)
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, i64 y_bs, int N, int Cout,
-                                                          WinoGeom g, int accumulate) {
+                                                          WinoGeom g, int accumulate, float* __restrict__ stats) {
+  __shared__ double red[16];
+  float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of the outputs this block writes (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
   float* yp = y + (i64)n * y_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * Cout * g.T;
@@ -174,10 +176,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         float2 v = make_float2(o0, o1);
         if (accumulate) { const float2 old = *q; v.x += old.x; v.y += old.y; }
         *q = v;
+        st_s += v.x + v.y;
+        st_q = fmaf(v.x, v.x, fmaf(v.y, v.y, st_q));
         continue;
       }
-      if (x0 < g.W) { float* q = yp + (i64)yy * g.W + x0; *q = accumulate ? *q + o0 : o0; }
-      if (x1 < g.W) { float* q = yp + (i64)yy * g.W + x1; *q = accumulate ? *q + o1 : o1; }
+      if (x0 < g.W) { float* q = yp + (i64)yy * g.W + x0; const float v = accumulate ? *q + o0 : o0; *q = v; st_s += v; st_q = fmaf(v, v, st_q); }
+      if (x1 < g.W) { float* q = yp + (i64)yy * g.W + x1; const float v = accumulate ? *q + o1 : o1; *q = v; st_s += v; st_q = fmaf(v, v, st_q); }
+    }
+  }
+  if (stats) {                                       // stats[c][n * gridDim.x + blockIdx.x][2] for pfst_bn_finalize_partials
+    const double bs = block_sum_d((double)st_s, red);
+    const double bq = block_sum_d((double)st_q, red);
+    if (threadIdx.x == 0) {
+      const i64 T = (i64)gridDim.x * gridDim.z;
+      float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);
+      *dst = make_float2((float)bs, (float)bq);
     }
   }
 }
@@ -284,12 +297,17 @@ extern "C" int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N
                              (hipStream_t)stream);
 }
 
+extern "C" int pfst_wino_stats_slots(int H, int W, int dil) {
+  if (H <= 0 || W <= 0 || dil < 1) return 0;
+  return tile_blocks(wino_geom(H, W, dil).T);
+}
+
 extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                                pfst_stream_t stream) {
+                                float* stats, pfst_stream_t stream) {
   PFST_CHECK_ARG(Mbuf && y && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && y_bs >= (i64)Cout * H * W);
   const WinoGeom g = wino_geom(H, W, dil);
   hipLaunchKernelGGL(wino_output_kernel, dim3(tile_blocks(g.T), Cout, N), dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g,
-                     accumulate);
+                     accumulate, stats);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -60,8 +60,10 @@ __device__ __forceinline__ float4 row4(const float* __restrict__ row, int sx, in
 template <int MODE>
 __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
-                                                        int flip, int accumulate) {
+                                                        int flip, int accumulate, float* __restrict__ stats) {
   extern __shared__ float tile[];
+  __shared__ double red[16];
+  float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of this block's outputs (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
   const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       float4* out = reinterpret_cast<float4*>(yp + (i64)yy * W) + c4;
       if (accumulate) { const float4 o = *out; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
       *out = acc;
+      st_s += (acc.x + acc.y) + (acc.z + acc.w);
+      st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
     }
   } else {
     const int total = (s.y1 - s.y0) * W;
@@ -112,7 +116,21 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
         }
       }
       const i64 o = (i64)yy * W + col;
-      yp[o] = accumulate ? yp[o] + acc : acc;
+      acc = accumulate ? yp[o] + acc : acc;
+      yp[o] = acc;
+      st_s += acc;
+      st_q = fmaf(acc, acc, st_q);
+    }
+  }
+  // per-(channel, strip, image) partial sums for pfst_bn_finalize_partials: stats[c][n * gridDim.x + strip][2]  (the kernel is
+  // HBM-bound, the arithmetic is free; saves the separate bn_stats read of the depthwise output)
+  if (stats) {
+    const double bs = block_sum_d((double)st_s, red);
+    const double bq = block_sum_d((double)st_q, red);
+    if (threadIdx.x == 0) {
+      const i64 T = (i64)gridDim.x * gridDim.z;
+      float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);
+      *dst = make_float2((float)bs, (float)bq);
     }
   }
 }
@@ -200,8 +218,13 @@ inline size_t strip_lds(int R, int H, int W, int dil) {
 
 }  // namespace
 
+extern "C" int pfst_dwconv_stats_slots(int H, int W, int dil) {
+  if (H <= 0 || W <= 0 || dil < 1) return 0;
+  return cdiv(H, strip_rows(H, W, dil));
+}
+
 extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                              int N, int C, int H, int W, int dil, int flip, int accumulate, pfst_stream_t stream) {
+                              int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && y_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
   const int R = strip_rows(H, W, dil);
@@ -220,11 +243,11 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
   if (mode == 1)
-    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   else if (mode == 2)
-    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
+    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate);
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

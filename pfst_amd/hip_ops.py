@@ -252,7 +252,7 @@ def wino_pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_
     return uf, ud
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False):
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
     (288 GB of HBM: keeping ~11 GB per pass resident beats re-transforming the input in backward)."""
@@ -267,8 +267,16 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False):
     call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, _stream())
     gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
     call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
-    call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _stream())
-    return (out, v) if keep_v else out
+    slots, st = 0, None
+    if want_stats:                      # BN partial sums of the output come out of the output transform
+        from ._lib import lib
+        slots = n * lib().pfst_wino_stats_slots(h, w, dil)
+        st = _stats_ws(x.device, 2 * cout * slots)
+    call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), _stream())
+    res = (out, st, slots) if want_stats else (out,)
+    if keep_v:
+        res = res + (v,)
+    return res if len(res) > 1 else res[0]
 
 
 def wino_wgrad_(dw, x, dy, dil, v=None):
@@ -289,15 +297,21 @@ def wino_wgrad_(dw, x, dy, dil, v=None):
 
 
 # ---------------------------------------------------------------- depthwise
-def dwconv(x, w, dil, flip=False, out=None, accumulate=False):
+def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False):
+    """want_stats: also return (stats_ws, slots), per-channel BN partial sums of the output (as conv_fprop)"""
     n, c, h, wd = x.shape
     assert w.numel() == c * 9
     if out is None:
         assert not accumulate
         out = torch.empty(n, c, h, wd, device=x.device)
+    slots, st = 0, None
+    if want_stats:
+        from ._lib import lib
+        slots = n * lib().pfst_dwconv_stats_slots(h, wd, dil)
+        st = _stats_ws(x.device, 2 * c * slots)
     call('pfst_dwconv3x3', x.data_ptr(), _bs(x), _dense(w).data_ptr(), out.data_ptr(), _bs(out), n, c, h, wd, dil,
-         int(flip), int(accumulate), _stream())
-    return out
+         int(flip), int(accumulate), _p(st), _stream())
+    return (out, st, slots) if want_stats else out
 
 
 def dwconv_wgrad_(dw, x, dy, dil):

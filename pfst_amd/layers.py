@@ -78,11 +78,12 @@ class Conv2dP(nn.Module):
         """keep: training forward -- the Winograd path keeps its transformed input for the weight gradient (self.saved_v)"""
         self.saved_v = None
         if self.wino and bias is None:
-            if keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-                y, self.saved_v = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=True)
-            else:
-                y = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out)
-            return (y, None, 0) if want_stats else y       # no GEMM epilogue in the output domain: statistics by bn_stats
+            keep_v = keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3])
+            res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats)
+            if keep_v:
+                self.saved_v = res[-1]
+                res = res[:-1] if len(res) > 2 else res[0]
+            return res                                     # (y, stats, slots) with want_stats, else y
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                                         want_stats=want_stats)
@@ -217,12 +218,14 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
     (then the returned Var is expected to be obtained from the concat Var's .slice())."""
     xd = x.data
-    fused_stats = FUSE_BN_STATS and not _BN_EVAL and not conv.depthwise
+    fused_stats = FUSE_BN_STATS and not _BN_EVAL
     if conv.depthwise:
-        pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
-    elif fused_stats:                              # batch statistics come out of the GEMM epilogue
+        if fused_stats:                            # batch statistics come out of the producing kernel in every case
+            pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True)
+        else:
+            pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
+    elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
         pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None)
-        fused_stats = st is not None               # (the Winograd path has no output-domain GEMM epilogue)
     else:
         pre = conv.fprop(xd, keep=tape is not None)
     saved_v = None if conv.depthwise else conv.saved_v

@@ -177,6 +177,12 @@ def test_winograd_f2x2_3x3_matches_direct_convolution(ops, case):
     uf, ud = ops.wino_pack_weight(w.to(DEV))
     y = ops.wino_conv(x.to(DEV), uf, co, d)
     assert_close(y, ref, 3e-6, 'winograd fprop')
+    # fused BatchNorm statistics of the output transform
+    y2, st, slots = ops.wino_conv(x.to(DEV), uf, co, d, want_stats=True)
+    mean, invstd = ops.bn_finalize_partials(st, slots, co, n * H * W)
+    assert_close(y2, ref, 3e-6, 'winograd fprop with stats')
+    assert_close(mean, ref.mean((0, 2, 3)), 2e-5, 'winograd stats mean')
+    assert_close(invstd, 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5), 2e-5, 'winograd stats invstd')
     dx = ops.wino_conv(dy.to(DEV), ud, ci, d)
     assert_close(dx, dx_ref, 3e-6, 'winograd dgrad')
     dx2 = ops.wino_conv(dy.to(DEV), ud, ci, d, out=dx.clone(), accumulate=True)
@@ -225,6 +231,12 @@ def test_depthwise(ops, dil, H, W):
     y_ref.backward(dy)
     xd, wd, dyd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV)
     assert_close(ops.dwconv(xd, wd, dil), y_ref, 1e-5, 'dw fwd')
+    y2, st, slots = ops.dwconv(xd, wd, dil, want_stats=True)            # fused BatchNorm statistics of the output
+    mean, invstd = ops.bn_finalize_partials(st, slots, c, n * H * W)
+    assert_close(y2, y_ref, 1e-5, 'dw fwd with stats')
+    yr = y_ref.detach().double()
+    assert_close(mean, yr.mean((0, 2, 3)), 2e-5, 'dw stats mean')
+    assert_close(invstd, 1.0 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5), 2e-5, 'dw stats invstd')
     assert_close(ops.dwconv(dyd, wd, dil, flip=True), x.grad, 1e-5, 'dw dgrad')
     dw = torch.zeros_like(wd)
     ops.dwconv_wgrad_(dw, xd, dyd, dil)
