@@ -6,7 +6,7 @@ There is NO fallback: a missing libpfst_hip.so or a CPU tensor raises.
 Tensors may be channel slices of a bigger NCHW tensor (batch stride != C*H*W)."""
 import torch
 
-from ._lib import call
+from ._lib import call, lib
 
 F32, U8, I64, F64 = torch.float32, torch.uint8, torch.int64, torch.float64
 
@@ -105,7 +105,6 @@ def _stats_ws(dev, nfloat):
 
 
 def conv_stats_slots(n, cout, ho, wo):
-    from ._lib import lib
     return n * lib().pfst_conv_stats_slots(cout, ho, wo)
 
 
@@ -222,7 +221,6 @@ def _wino_ws(dev, tag, nfloat):
 
 
 def wino_tiles(h, w, dil):
-    from ._lib import lib
     return lib().pfst_wino_tiles(h, w, dil)
 
 
@@ -269,7 +267,6 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
     slots, st = 0, None
     if want_stats:                      # BN partial sums of the output come out of the output transform
-        from ._lib import lib
         slots = n * lib().pfst_wino_stats_slots(h, w, dil)
         st = _stats_ws(x.device, 2 * cout * slots)
     call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), _stream())
@@ -306,7 +303,6 @@ def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False):
         out = torch.empty(n, c, h, wd, device=x.device)
     slots, st = 0, None
     if want_stats:
-        from ._lib import lib
         slots = n * lib().pfst_dwconv_stats_slots(h, wd, dil)
         st = _stats_ws(x.device, 2 * c * slots)
     call('pfst_dwconv3x3', x.data_ptr(), _bs(x), _dense(w).data_ptr(), out.data_ptr(), _bs(out), n, c, h, wd, dil,
