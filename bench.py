@@ -52,20 +52,20 @@ class KernelTimer:
             quad = stride == 1 and ((ks == 1 and (ho * wo) % 4 == 0) or (ks == 3 and wo % 16 == 0 and dil <= 8))   # pfst_wgrad_q_eligible
             kern = f'conv_wgrad_q_kernel<{bm},{ks * ks}>' if quad else f'conv_wgrad_kernel<{bm},{ks * ks}>'
             return kern, 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
-        # Winograd path: the 16 transform-domain GEMMs are one launch of the same K-quad kernel (gridDim.y = 16); the flops
-        # booked are the GEMM's own (what the kernel executes), not the direct-convolution count it replaces
+        # Winograd path: the X = (m+2)^2 transform-domain GEMMs are one launch of the same K-quad kernel (gridDim.y = X); the
+        # flops booked are the GEMM's own (what the kernel executes), not the direct-convolution count it replaces
         if name == 'pfst_wino_gemm':
-            n, k, m, t = a[3], a[4], a[5], a[6]
+            n, k, m, t, nx = a[3], a[4], a[5], a[6], (a[7] + 2) ** 2
             bm = 128 if m > 64 else (64 if m > 32 else 32)
-            return f'conv_igemm_q_kernel<{bm}>', 2.0 * 16 * n * m * k * t, 4.0 * 16 * (n * k * t + n * m * t + k * m)
+            return f'conv_igemm_q_kernel<{bm}>', 2.0 * nx * n * m * k * t, 4.0 * nx * (n * k * t + n * m * t + k * m)
         if name == 'pfst_wino_wgrad':
-            n, ci, co, t = a[4], a[5], a[6], a[7]
+            n, ci, co, t, nx = a[4], a[5], a[6], a[7], (a[8] + 2) ** 2
             bm = 128 if co > 64 else (64 if co > 32 else 32)
-            return f'conv_wgrad_q_kernel<{bm},1>', 2.0 * 16 * n * co * ci * t, 4.0 * 16 * (n * ci * t + n * co * t + 2 * co * ci)
-        if name in ('pfst_wino_input', 'pfst_wino_dy'):          # read the image once, write 16 transform planes of T = HW/4 tiles
-            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * 5
+            return f'conv_wgrad_q_kernel<{bm},1>', 2.0 * nx * n * co * ci * t, 4.0 * nx * (n * ci * t + n * co * t + 2 * co * ci)
+        if name in ('pfst_wino_input', 'pfst_wino_dy'):          # read the image once, write X transform planes of T = HW/m^2 tiles
+            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * (1.0 + (a[8] + 2) ** 2 / a[8] ** 2)
         if name == 'pfst_wino_output':
-            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * (6 if a[8] else 5)
+            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * ((a[10] + 2) ** 2 / a[10] ** 2 + (2 if a[8] else 1))
         # HBM-bound kernels: read-once / write-once algorithmic bytes, fp32
         if name == 'pfst_dwconv3x3':
             n, c, h, w_, acc = a[5], a[6], a[7], a[8], a[11]

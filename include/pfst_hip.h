@@ -65,28 +65,30 @@ int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long d
 /* db[c] += sum_{n,hw} dy[n][c][hw] */
 int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream);
 
-/* ---- Winograd F(2x2,3x3) for wide stride-1 'same' 3x3 convolutions (csrc/conv_winograd.hip): the same F.conv2d / autograd
- * results with 2.25x fewer MACs.  Transform-domain tensors: V [16][N][C][T], U [16][K/4][M][4], Mbuf [16][N][M][T],
- * T = pfst_wino_tiles(H, W, dil) tiles per image (dilation d = d*d interleaved sub-grids).
+/* ---- Winograd F(m x m, 3x3), m = 2 or 4, for wide stride-1 'same' 3x3 convolutions (csrc/conv_winograd.hip): the same F.conv2d /
+ * autograd results with 2.25x (m = 2) or 4x (m = 4) fewer MACs.  X = (m+2)^2 transform indices; transform-domain tensors
+ * V [X][N][C][T], U [X][K/4][M][4], Mbuf [X][N][M][T], T = pfst_wino_tiles(H, W, dil, m) tiles per image (dilation d = d*d
+ * interleaved sub-grids).  fp32 error vs an fp64 direct convolution: 3e-6 (m = 2), 3e-5 (m = 4) of the mean |y|.
  *   fprop : pfst_wino_input(x) -> V;   pfst_wino_gemm(V, U_fprop) -> Mbuf;   pfst_wino_output(Mbuf) -> y
  *   dgrad : the same on dy with U_dgrad (flipped, transposed filter), pfst_wino_output(..., accumulate)
- *   wgrad : pfst_wino_input(x) -> V;  pfst_wino_dy(dy) -> dM;  pfst_wino_wgrad(V, dM, scratch dU[16*Cout*Cin]) : dw += ... */
-int pfst_wino_tiles(int H, int W, int dil);
-int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, pfst_stream_t stream);
-int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, pfst_stream_t stream);
-int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream);
+ *   wgrad : pfst_wino_input(x) -> V;  pfst_wino_dy(dy) -> dM;  pfst_wino_wgrad(V, dM, scratch dU[X*Cout*Cin]) : dw += ... */
+int pfst_wino_tiles(int H, int W, int dil, int m);
+int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
+int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, pfst_stream_t stream);
+int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                     float* stats, pfst_stream_t stream);
-/* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil)][2] */
-int pfst_wino_stats_slots(int H, int W, int dil);
-int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, pfst_stream_t stream);
-int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream);
-/* the same GEMMs on the fp32-faithful bf16x6 path: plain [16][Cout][Cin] filter sets (normal / flipped) -> 16 split-packed sets of
+                     float* stats, int m, pfst_stream_t stream);
+/* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2] */
+int pfst_wino_stats_slots(int H, int W, int dil, int m);
+int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, pfst_stream_t stream);
+int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
+                    pfst_stream_t stream);
+/* the same GEMMs on the fp32-faithful bf16x6 path: plain [X][Cout][Cin] filter sets (normal / flipped) -> X split-packed sets of
  * 6*Cout*Cin bytes each -> pfst_wino_gemm_split */
-int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, pfst_stream_t stream);
+int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
 int pfst_wino_pack_weight_split(const float* plain_f, const float* plain_d, void* U6_fprop, void* U6_dgrad, int Cout, int Cin,
-                                pfst_stream_t stream);
-int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream);
+                                int m, pfst_stream_t stream);
+int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */

@@ -431,24 +431,25 @@ extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float
 #undef PFST_WGS
 }
 
-// ---- Winograd on the bf16x6 GEMM (conv_winograd.hip supplies the transforms): the 16 transform-domain products as ONE
+// ---- Winograd on the bf16x6 GEMM (conv_winograd.hip supplies the transforms): the (m+2)^2 transform-domain products as ONE
 // grouped launch of the split kernel, filter sets packed per transform index.
-extern "C" int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream) {
-  PFST_CHECK_ARG(V && U6 && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 16 == 0 && M > 0 && T > 0);
+extern "C" int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream) {
+  PFST_CHECK_ARG(V && U6 && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 16 == 0 && M > 0 && T > 0 && (m == 2 || m == 4));
+  const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 6 < (1ll << 31));
   hipStream_t s = (hipStream_t)stream;
-  if (M > 64) return launch_split<128>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
-  if (M > 32) return launch_split<64>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
-  return launch_split<32>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16, s);
+  if (M > 64) return launch_split<128>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, nx, s);
+  if (M > 32) return launch_split<64>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, nx, s);
+  return launch_split<32>(V, (i64)K * T, U6, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, nx, s);
 }
 
-// plain[16][Cout][Cin] transform-domain filters (pfst_wino_filter_plain: normal and flipped) -> 16 split-packed sets of 6*Cout*Cin bytes
+// plain[(m+2)^2][Cout][Cin] transform-domain filters (pfst_wino_filter_plain: normal and flipped) -> split-packed sets of 6*Cout*Cin bytes
 extern "C" int pfst_wino_pack_weight_split(const float* plain_f, const float* plain_d, void* U6_fprop, void* U6_dgrad, int Cout, int Cin,
-                                           pfst_stream_t stream) {
-  PFST_CHECK_ARG((plain_f && U6_fprop) || (plain_d && U6_dgrad));
+                                           int m, pfst_stream_t stream) {
+  PFST_CHECK_ARG(((plain_f && U6_fprop) || (plain_d && U6_dgrad)) && (m == 2 || m == 4));
   PFST_CHECK_ARG(Cout > 0 && Cin > 0 && (!U6_fprop || Cin % 16 == 0) && (!U6_dgrad || Cout % 16 == 0));
   const i64 n = (i64)Cout * Cin, set = 6 * n;
-  for (int xi = 0; xi < 16; ++xi) {
+  for (int xi = 0; xi < (m + 2) * (m + 2); ++xi) {
     if (U6_fprop) {
       hipLaunchKernelGGL(pack_weight_split_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, plain_f + xi * n,
                          (uint4*)((char*)U6_fprop + xi * set), (uint4*)nullptr, Cout, Cin, 1);

@@ -1,34 +1,81 @@
-// Winograd F(2x2, 3x3) for the wide stride-1 3x3 convolutions (fp32 throughout).
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile / 4x4 input patch, summed over input channels
-// 16 multiplies instead of 36 per tile and channel pair: 2.25x fewer MACs on a path that is bound by the fp32 MFMA rate.
-// The channel sum is 16 independent GEMMs  M_xi[co][t] = sum_ci U_xi[co][ci] V_xi[ci][t]  (xi = transform index, t = tile), run as
-// ONE launch of the K-quad implicit-GEMM kernel (conv_igemm_q.hip, gridDim.y = 16, 1x1 mode) on transform-domain tensors
-//   V [16][N][C][T]   U [16][K/4][M][4] (the kernel's packed weight layout)   Mbuf [16][N][Cout][T].
+// Winograd F(m x m, 3x3), m = 2 or 4, for the wide stride-1 3x3 convolutions (fp32 throughout).
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per m x m output tile / (m+2) x (m+2) input patch, summed over input channels
+// R*R multiplies (R = m + 2) instead of 9 m*m per tile and channel pair: 2.25x (m = 2) or 4x (m = 4) fewer MACs on a path that is
+// bound by the fp32 MFMA rate; the transform-domain tensors shrink as well (R*R/m*m = 4x resp. 2.25x the plain tensor).
+// The channel sum is R*R independent GEMMs  M_xi[co][t] = sum_ci U_xi[co][ci] V_xi[ci][t]  (xi = transform index, t = tile), run as
+// ONE launch of the K-quad implicit-GEMM kernel (conv_igemm_q.hip, gridDim.y = R*R, 1x1 mode) on transform-domain tensors
+//   V [R*R][N][C][T]   U [R*R][K/4][M][4] (the kernel's packed weight layout)   Mbuf [R*R][N][Cout][T].
 // Data gradient = the same pipeline on dY with the flipped / transposed filter.  Weight gradient:
 //   dU_xi[co][ci] = sum_{n,t} dM_xi[n][co][t] V_xi[n][ci][t]   (one grouped launch of the 1x1 K-quad wgrad kernel),  dM = A dY A^T,
 //   dW = G^T dU G.
 // Dilation d: a dilated 3x3 convolution is d*d independent dilation-1 convolutions on the interleaved sub-grids
 // (y mod d, x mod d); the tile index enumerates them (column offset fastest), so the same kernels serve d = 1, 2, 4.
-// Transform matrices (Lavin & Gray 2016, correlation form):
-//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+// Transform matrices (Lavin & Gray 2016, correlation form; interpolation points 0, +-1 [, +-2], inf):
+//   m = 2:  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//   m = 4:  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//           G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//           A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 error against an fp64 direct convolution (512 channels): 3e-6 (m = 2), 3e-5 max / 5e-6 rms (m = 4) of the mean |y|.
 #include "common.h"
 #include "../../include/pfst_hip.h"
 
 namespace {
 
+// constant transform matrices; every use below has compile-time indices after unrolling, so zeros vanish and +-1 become adds
+template <int M> struct Wino;
+template <> struct Wino<2> {
+  static constexpr int R = 4;
+  static constexpr float bt(int i, int j) {
+    constexpr float m[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+    return m[i][j];
+  }
+  static constexpr float g(int i, int j) {
+    constexpr float m[4][3] = {{1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
+    return m[i][j];
+  }
+  static constexpr float at(int i, int j) {
+    constexpr float m[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+    return m[i][j];
+  }
+};
+template <> struct Wino<4> {
+  static constexpr int R = 6;
+  static constexpr float bt(int i, int j) {
+    constexpr float m[6][6] = {{4, 0, -5, 0, 1, 0}, {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                               {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+    return m[i][j];
+  }
+  static constexpr float g(int i, int j) {
+    constexpr float m[6][3] = {{1.f / 4, 0, 0}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6},
+                               {1.f / 24, 1.f / 12, 1.f / 6}, {1.f / 24, -1.f / 12, 1.f / 6}, {0, 0, 1}};
+    return m[i][j];
+  }
+  static constexpr float at(int i, int j) {
+    constexpr float m[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+    return m[i][j];
+  }
+};
+// acc += coef * v with the trivial coefficients folded
+__device__ __forceinline__ float cmac(float acc, float coef, float v) {
+  if (coef == 0.f) return acc;
+  if (coef == 1.f) return acc + v;
+  if (coef == -1.f) return acc - v;
+  return fmaf(coef, v, acc);
+}
+
 struct WinoGeom {
   int H, W, d, Hs, Ws, Th, Tw, T;   // image, dilation, sub-grid size, tiles per sub-grid, tiles per image
 };
-__host__ __device__ inline WinoGeom wino_geom(int H, int W, int d) {
+inline WinoGeom wino_geom(int H, int W, int d, int m) {
   WinoGeom g;
   g.H = H; g.W = W; g.d = d;
   g.Hs = (H + d - 1) / d; g.Ws = (W + d - 1) / d;
-  g.Th = (g.Hs + 1) / 2; g.Tw = (g.Ws + 1) / 2;
+  g.Th = (g.Hs + m - 1) / m; g.Tw = (g.Ws + m - 1) / m;
   g.T = d * d * g.Th * g.Tw;
   return g;
 }
 // tile index -> (sub-grid offsets sy, sx; tile coordinates ty, tx).  The sub-grid column offset sx runs fastest: consecutive
-// threads then touch x = sx + d*(2tx + const), i.e. runs of d contiguous pixels, instead of pixels 2d apart.
+// threads then touch x = sx + d*(m*tx + const), i.e. runs of d contiguous pixels, instead of pixels m*d apart.
 __device__ __forceinline__ void tile_coord(const WinoGeom& g, int t, int& sy, int& sx, int& ty, int& tx) {
   sx = t % g.d; t /= g.d;
   tx = t % g.Tw; t /= g.Tw;
@@ -36,31 +83,40 @@ __device__ __forceinline__ void tile_coord(const WinoGeom& g, int t, int& sy, in
   sy = t / g.Th;
 }
 
-// ---- filter transform.  One thread per (co, ci): U = G g G^T (4x4), written into the K-quad packed layouts
+// ---- filter transform U = G g G^T (R x R).  One thread per (co, ci); outputs in the K-quad packed layouts
 //   Uf[xi][(ci>>2)*Cout + co][ci&3]            (fprop:  K = Cin,  rows = Cout)
 //   Ud[xi][(co>>2)*Cin  + ci][co&3]  with g flipped (dgrad: K = Cout, rows = Cin)
-__device__ __forceinline__ void filter_tf(const float (&g)[3][3], float (&u)[4][4]) {
-  float t[4][3];
+// or (PLAIN) as [xi][Cout][Cin] sets, the input of the bf16x6 packer (pfst_wino_pack_weight_split).
+template <int M>
+__device__ __forceinline__ void filter_tf(const float (&g)[3][3], float (&u)[M + 2][M + 2]) {
+  constexpr int R = M + 2;
+  float t[R][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    t[0][j] = g[0][j];
-    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
-    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
-    t[3][j] = g[2][j];
-  }
+  for (int i = 0; i < R; ++i)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    u[i][0] = t[i][0];
-    u[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-    u[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-    u[i][3] = t[i][2];
-  }
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a = cmac(a, Wino<M>::g(i, k), g[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a = cmac(a, Wino<M>::g(j, k), t[i][k]);
+      u[i][j] = a;
+    }
 }
+template <int M, bool PLAIN>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ Uf, float* __restrict__ Ud, int Cout, int Cin) {
+  constexpr int R = M + 2;
   const i64 total = (i64)Cout * Cin;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
     const int ci = (int)(i % Cin), co = (int)(i / Cin);
-    float g[3][3], gf[3][3], u[4][4];
+    float g[3][3], gf[3][3], u[R][R];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -69,46 +125,25 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
         gf[2 - a][2 - b] = g[a][b];
       }
     if (Uf) {
-      filter_tf(g, u);
+      filter_tf<M>(g, u);
+      const i64 at = PLAIN ? i : ((i64)(ci >> 2) * Cout + co) * 4 + (ci & 3);
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) Uf[(i64)xi * total + ((i64)(ci >> 2) * Cout + co) * 4 + (ci & 3)] = u[xi >> 2][xi & 3];
+      for (int xi = 0; xi < R * R; ++xi) Uf[(i64)xi * total + at] = u[xi / R][xi % R];
     }
     if (Ud) {
-      filter_tf(gf, u);
+      filter_tf<M>(gf, u);
+      const i64 at = PLAIN ? i : ((i64)(co >> 2) * Cin + ci) * 4 + (co & 3);
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) Ud[(i64)xi * total + ((i64)(co >> 2) * Cin + ci) * 4 + (co & 3)] = u[xi >> 2][xi & 3];
-    }
-  }
-}
-
-// plain [16][Cout][Cin] filter sets (normal and flipped), input of the bf16x6 packer (pfst_wino_pack_weight_split)
-__global__ void wino_filter_plain_kernel(const float* __restrict__ w, float* __restrict__ Pf, float* __restrict__ Pd, int Cout, int Cin) {
-  const i64 total = (i64)Cout * Cin;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
-    float g[3][3], gf[3][3], u[4][4];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        g[a][b] = w[i * 9 + a * 3 + b];
-        gf[2 - a][2 - b] = g[a][b];
-      }
-    if (Pf) {
-      filter_tf(g, u);
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) Pf[(i64)xi * total + i] = u[xi >> 2][xi & 3];
-    }
-    if (Pd) {
-      filter_tf(gf, u);
-#pragma unroll
-      for (int xi = 0; xi < 16; ++xi) Pd[(i64)xi * total + i] = u[xi >> 2][xi & 3];
+      for (int xi = 0; xi < R * R; ++xi) Ud[(i64)xi * total + at] = u[xi / R][xi % R];
     }
   }
 }
 
 // ---- input transform V = B^T d B.   grid: (blocks over T, C, N); one thread per tile
+template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
                                                          WinoGeom g) {
+  constexpr int R = M + 2;
   const int c = blockIdx.y, n = blockIdx.z;
   const float* xp = x + (i64)n * x_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * C * g.T;                        // stride between transform indices
@@ -116,37 +151,45 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.T; t += gridDim.x * blockDim.x) {
     int sy, sx, ty, tx;
     tile_coord(g, t, sy, sx, ty, tx);
-    float d[4][4];
+    float d[R][R];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int y = sy + g.d * (2 * ty - 1 + a);
+    for (int a = 0; a < R; ++a) {
+      const int y = sy + g.d * (M * ty - 1 + a);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int xx = sx + g.d * (2 * tx - 1 + b);
+      for (int b = 0; b < R; ++b) {
+        const int xx = sx + g.d * (M * tx - 1 + b);
         d[a][b] = (y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? xp[(i64)y * g.W + xx] : 0.f;
       }
     }
-    float r[4][4];                                           // B^T d
+    float r[R][R];                                           // B^T d
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      r[0][b] = d[0][b] - d[2][b];
-      r[1][b] = d[1][b] + d[2][b];
-      r[2][b] = d[2][b] - d[1][b];
-      r[3][b] = d[1][b] - d[3][b];
-    }
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {                            // (B^T d) B
-      vp[(i64)(a * 4 + 0) * plane + t] = r[a][0] - r[a][2];
-      vp[(i64)(a * 4 + 1) * plane + t] = r[a][1] + r[a][2];
-      vp[(i64)(a * 4 + 2) * plane + t] = r[a][2] - r[a][1];
-      vp[(i64)(a * 4 + 3) * plane + t] = r[a][1] - r[a][3];
-    }
+      for (int b = 0; b < R; ++b) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::bt(i, k), d[k][b]);
+        r[i][b] = a;
+      }
+#pragma unroll
+    for (int i = 0; i < R; ++i)                              // (B^T d) B
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::bt(j, k), r[i][k]);
+        vp[(i64)(i * R + j) * plane + t] = a;
+      }
   }
 }
 
-// ---- output transform Y = A^T m A (2x2 per tile), optional accumulate.   grid: (blocks over T, Cout, N)
+// ---- output transform Y = A^T m A (M x M per tile), optional accumulate.   grid: (blocks over T, Cout, N)
+// vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M outputs of a tile row are adjacent -> one wide store
+template <int M>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, i64 y_bs, int N, int Cout,
-                                                          WinoGeom g, int accumulate, float* __restrict__ stats) {
+                                                          WinoGeom g, int accumulate, int vec, float* __restrict__ stats) {
+  constexpr int R = M + 2;
+  typedef float vecM __attribute__((ext_vector_type(M)));
   __shared__ double red[16];
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of the outputs this block writes (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
@@ -156,32 +199,58 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.T; t += gridDim.x * blockDim.x) {
     int sy, sx, ty, tx;
     tile_coord(g, t, sy, sx, ty, tx);
-    float m[4][4];
+    float m[R][R];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) m[i >> 2][i & 3] = mp[(i64)i * plane + t];
-    float r[2][4];                                           // A^T m
+    for (int i = 0; i < R * R; ++i) m[i / R][i % R] = mp[(i64)i * plane + t];
+    float r[M][R];                                           // A^T m
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      r[0][b] = m[0][b] + m[1][b] + m[2][b];
-      r[1][b] = m[1][b] - m[2][b] - m[3][b];
-    }
+    for (int i = 0; i < M; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int yy = sy + g.d * (2 * ty + i);
+      for (int b = 0; b < R; ++b) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::at(i, k), m[k][b]);
+        r[i][b] = a;
+      }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const int yy = sy + g.d * (M * ty + i);
       if (yy >= g.H) continue;
-      const float o0 = r[i][0] + r[i][1] + r[i][2], o1 = r[i][1] - r[i][2] - r[i][3];
-      const int x0 = sx + g.d * (2 * tx), x1 = x0 + g.d;
-      if (g.d == 1 && x1 < g.W && (g.W & 1) == 0) {           // the two outputs are adjacent: one 8-byte store
-        float2* q = reinterpret_cast<float2*>(yp + (i64)yy * g.W + x0);
-        float2 v = make_float2(o0, o1);
-        if (accumulate) { const float2 old = *q; v.x += old.x; v.y += old.y; }
+      float o[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::at(j, k), r[i][k]);
+        o[j] = a;
+      }
+      const int x0 = sx + g.d * (M * tx);
+      if (vec) {
+        vecM* q = reinterpret_cast<vecM*>(yp + (i64)yy * g.W + x0);
+        vecM v;
+#pragma unroll
+        for (int j = 0; j < M; ++j) v[j] = o[j];
+        if (accumulate) v += *q;
         *q = v;
-        st_s += v.x + v.y;
-        st_q = fmaf(v.x, v.x, fmaf(v.y, v.y, st_q));
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const float e = v[j];
+          st_s += e;
+          st_q = fmaf(e, e, st_q);
+        }
         continue;
       }
-      if (x0 < g.W) { float* q = yp + (i64)yy * g.W + x0; const float v = accumulate ? *q + o0 : o0; *q = v; st_s += v; st_q = fmaf(v, v, st_q); }
-      if (x1 < g.W) { float* q = yp + (i64)yy * g.W + x1; const float v = accumulate ? *q + o1 : o1; *q = v; st_s += v; st_q = fmaf(v, v, st_q); }
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const int xx = x0 + g.d * j;
+        if (xx < g.W) {
+          float* q = yp + (i64)yy * g.W + xx;
+          const float v = accumulate ? *q + o[j] : o[j];
+          *q = v;
+          st_s += v;
+          st_q = fmaf(v, v, st_q);
+        }
+      }
     }
   }
   if (stats) {                                       // stats[c][n * gridDim.x + blockIdx.x][2] for pfst_bn_finalize_partials
@@ -195,9 +264,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
-// ---- adjoint of the output transform: dM = A dY A^T (4x4 per tile) for the weight gradient.   grid: (blocks over T, Cout, N)
+// ---- adjoint of the output transform: dM = A dY A^T (R x R per tile) for the weight gradient.   grid: (blocks over T, Cout, N)
+template <int M>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dM, int N, int Cout,
                                                       WinoGeom g) {
+  constexpr int R = M + 2;
   const int c = blockIdx.y, n = blockIdx.z;
   const float* gp = dy + (i64)n * dy_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * Cout * g.T;
@@ -205,52 +276,64 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.T; t += gridDim.x * blockDim.x) {
     int sy, sx, ty, tx;
     tile_coord(g, t, sy, sx, ty, tx);
-    float e[2][2];
+    float e[M][M];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < M; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int yy = sy + g.d * (2 * ty + i), xx = sx + g.d * (2 * tx + j);
+      for (int j = 0; j < M; ++j) {
+        const int yy = sy + g.d * (M * ty + i), xx = sx + g.d * (M * tx + j);
         e[i][j] = (yy < g.H && xx < g.W) ? gp[(i64)yy * g.W + xx] : 0.f;
       }
-    float r[4][2];                                           // A e   (A = [1 0; 1 1; 1 -1; 0 -1])
+    float r[R][M];                                           // A e   (A = (A^T)^T)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      r[0][j] = e[0][j];
-      r[1][j] = e[0][j] + e[1][j];
-      r[2][j] = e[0][j] - e[1][j];
-      r[3][j] = -e[1][j];
-    }
+    for (int a = 0; a < R; ++a)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {                            // (A e) A^T
-      mp[(i64)(a * 4 + 0) * plane + t] = r[a][0];
-      mp[(i64)(a * 4 + 1) * plane + t] = r[a][0] + r[a][1];
-      mp[(i64)(a * 4 + 2) * plane + t] = r[a][0] - r[a][1];
-      mp[(i64)(a * 4 + 3) * plane + t] = -r[a][1];
-    }
+      for (int j = 0; j < M; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) s = cmac(s, Wino<M>::at(i, a), e[i][j]);
+        r[a][j] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < R; ++a)                              // (A e) A^T
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < M; ++j) s = cmac(s, Wino<M>::at(j, b), r[a][j]);
+        mp[(i64)(a * R + b) * plane + t] = s;
+      }
   }
 }
 
-// ---- dW += G^T dU G.   dU [16][Cout][Cin] (row-major as the 1x1 wgrad kernel writes it).  One thread per (co, ci)
+// ---- dW += G^T dU G.   dU [R*R][Cout][Cin] (row-major as the 1x1 wgrad kernel writes it).  One thread per (co, ci)
+template <int M>
 __global__ void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin) {
+  constexpr int R = M + 2;
   const i64 total = (i64)Cout * Cin;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
-    float u[4][4];
+    float u[R][R];
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) u[xi >> 2][xi & 3] = dU[(i64)xi * total + i];
-    float t[3][4];                                           // G^T u
+    for (int xi = 0; xi < R * R; ++xi) u[xi / R][xi % R] = dU[(i64)xi * total + i];
+    float t[3][R];                                           // G^T u
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-      t[1][b] = 0.5f * (u[1][b] - u[2][b]);
-      t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
-    }
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {                            // (G^T u) G
-      dw[i * 9 + a * 3 + 0] += t[a][0] + 0.5f * (t[a][1] + t[a][2]);
-      dw[i * 9 + a * 3 + 1] += 0.5f * (t[a][1] - t[a][2]);
-      dw[i * 9 + a * 3 + 2] += 0.5f * (t[a][1] + t[a][2]) + t[a][3];
-    }
+      for (int b = 0; b < R; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < R; ++a) s = cmac(s, Wino<M>::g(a, p), u[a][b]);
+        t[p][b] = s;
+      }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)                              // (G^T u) G
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < R; ++b) s = cmac(s, Wino<M>::g(b, q), t[p][b]);
+        dw[i * 9 + p * 3 + q] += s;
+      }
   }
 }
 
@@ -259,79 +342,106 @@ inline int tile_blocks(int T) {
   return b < 1 ? 1 : b;
 }
 
+#define PFST_WINO_M(m_, CALL2, CALL4) \
+  do {                                \
+    if ((m_) == 2) { CALL2; } else { CALL4; } \
+  } while (0)
+
 }  // namespace
 
-extern "C" int pfst_wino_tiles(int H, int W, int dil) {
-  if (H <= 0 || W <= 0 || dil < 1) return 0;
-  return wino_geom(H, W, dil).T;
+#define PFST_CHECK_TILE(m) PFST_CHECK_ARG((m) == 2 || (m) == 4)
+
+extern "C" int pfst_wino_tiles(int H, int W, int dil, int m) {
+  if (H <= 0 || W <= 0 || dil < 1 || (m != 2 && m != 4)) return 0;
+  return wino_geom(H, W, dil, m).T;
 }
 
-extern "C" int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, pfst_stream_t stream) {
+extern "C" int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(w && (U_fprop || U_dgrad) && Cout > 0 && Cin > 0);
+  PFST_CHECK_TILE(m);
   PFST_CHECK_ARG((!U_fprop || Cin % 16 == 0) && (!U_dgrad || Cout % 16 == 0));     // K-quad GEMM kernel: K % 16 == 0
-  hipLaunchKernelGGL(wino_filter_kernel, dim3(ew_grid((i64)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, w, U_fprop, U_dgrad, Cout, Cin);
+  const dim3 grid(ew_grid((i64)Cout * Cin));
+  PFST_WINO_M(m, hipLaunchKernelGGL((wino_filter_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, w, U_fprop, U_dgrad, Cout, Cin),
+              hipLaunchKernelGGL((wino_filter_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, w, U_fprop, U_dgrad, Cout, Cin));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, pfst_stream_t stream) {
+extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(w && (P_fprop || P_dgrad) && Cout > 0 && Cin > 0);
-  hipLaunchKernelGGL(wino_filter_plain_kernel, dim3(ew_grid((i64)Cout * Cin)), dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin);
+  PFST_CHECK_TILE(m);
+  const dim3 grid(ew_grid((i64)Cout * Cin));
+  PFST_WINO_M(m, hipLaunchKernelGGL((wino_filter_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin),
+              hipLaunchKernelGGL((wino_filter_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, pfst_stream_t stream) {
+extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && V && N > 0 && N <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0 && dil >= 1 && x_bs >= (i64)C * H * W);
-  const WinoGeom g = wino_geom(H, W, dil);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(tile_blocks(g.T), C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g);
+  PFST_CHECK_TILE(m);
+  const WinoGeom g = wino_geom(H, W, dil, m);
+  const dim3 grid(tile_blocks(g.T), C, N);
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g),
+              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-// the 16 transform-domain GEMMs: Mbuf[xi][n][M][T] = U[xi] (M x K) * V[xi][n] (K x T)
-extern "C" int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, pfst_stream_t stream) {
+// the R*R transform-domain GEMMs: Mbuf[xi][n][M][T] = U[xi] (M x K) * V[xi][n] (K x T)
+extern "C" int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && U && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 16 == 0 && M > 0 && T > 0);
+  PFST_CHECK_TILE(m);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
-  return pfst_igemm_q_launch(V, (i64)K * T, U, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0, 16,
-                             (hipStream_t)stream);
+  return pfst_igemm_q_launch(V, (i64)K * T, U, nullptr, Mbuf, (i64)M * T, N, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, nullptr, 0,
+                             (m + 2) * (m + 2), (hipStream_t)stream);
 }
 
-extern "C" int pfst_wino_stats_slots(int H, int W, int dil) {
-  if (H <= 0 || W <= 0 || dil < 1) return 0;
-  return tile_blocks(wino_geom(H, W, dil).T);
+extern "C" int pfst_wino_stats_slots(int H, int W, int dil, int m) {
+  if (H <= 0 || W <= 0 || dil < 1 || (m != 2 && m != 4)) return 0;
+  return tile_blocks(wino_geom(H, W, dil, m).T);
 }
 
 extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                                float* stats, pfst_stream_t stream) {
+                                float* stats, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(Mbuf && y && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && y_bs >= (i64)Cout * H * W);
-  const WinoGeom g = wino_geom(H, W, dil);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(tile_blocks(g.T), Cout, N), dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g,
-                     accumulate, stats);
+  PFST_CHECK_TILE(m);
+  const WinoGeom g = wino_geom(H, W, dil, m);
+  const int vec = dil == 1 && W % m == 0 && y_bs % m == 0 && ((uintptr_t)y & (4 * m - 1)) == 0;
+  const dim3 grid(tile_blocks(g.T), Cout, N);
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats),
+              hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
-extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, pfst_stream_t stream) {
+extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && dM && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && dy_bs >= (i64)Cout * H * W);
-  const WinoGeom g = wino_geom(H, W, dil);
-  hipLaunchKernelGGL(wino_dy_kernel, dim3(tile_blocks(g.T), Cout, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g);
+  PFST_CHECK_TILE(m);
+  const WinoGeom g = wino_geom(H, W, dil, m);
+  const dim3 grid(tile_blocks(g.T), Cout, N);
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g),
+              hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 // dU[xi][Cout][Cin] = sum_{n,t} dM[xi][n][Cout][T] V[xi][n][Cin][T]  (one grouped launch of the 1x1 K-quad wgrad), then dW += G^T dU G.
-// dU is scratch of 16*Cout*Cin floats (zeroed here).
-extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, pfst_stream_t stream) {
+// dU is scratch of (m+2)^2*Cout*Cin floats (zeroed here).
+extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
+                               pfst_stream_t stream) {
   PFST_CHECK_ARG(V && dM && dU && dw && N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && T % 4 == 0);
+  PFST_CHECK_TILE(m);
   hipStream_t s = (hipStream_t)stream;
   const i64 uc = (i64)Cout * Cin;
-  if (hipMemsetAsync(dU, 0, 16 * uc * sizeof(float), s) != hipSuccess) return PFST_ERR_LAUNCH;
-  // the 16 per-transform-index products as ONE grouped launch: enough workgroups without splitting the tile range further
-  const int rc = pfst_wgrad_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, 1, T, Cout, 1, T, 1, 1, 0, 16, (i64)N * Cin * T,
+  const int nx = (m + 2) * (m + 2);
+  if (hipMemsetAsync(dU, 0, nx * uc * sizeof(float), s) != hipSuccess) return PFST_ERR_LAUNCH;
+  // the per-transform-index products as ONE grouped launch: enough workgroups without splitting the tile range further
+  const int rc = pfst_wgrad_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, 1, T, Cout, 1, T, 1, 1, 0, nx, (i64)N * Cin * T,
                                      (i64)N * Cout * T, uc, s);
   if (rc != PFST_OK) return rc;
-  hipLaunchKernelGGL(wino_dw_kernel, dim3(ew_grid(uc)), dim3(256), 0, s, dU, dw, Cout, Cin);
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dw_kernel<2>, dim3(ew_grid(uc)), dim3(256), 0, s, dU, dw, Cout, Cin),
+              hipLaunchKernelGGL(wino_dw_kernel<4>, dim3(ew_grid(uc)), dim3(256), 0, s, dU, dw, Cout, Cin));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -4,6 +4,8 @@ Every function checks device / dtype / layout on the host (a wrong shape must ne
 passes raw device pointers + the current HIP stream, and returns torch tensors it allocated.
 There is NO fallback: a missing libpfst_hip.so or a CPU tensor raises.
 Tensors may be channel slices of a bigger NCHW tensor (batch stride != C*H*W)."""
+import os
+
 import torch
 
 from ._lib import call, lib
@@ -220,76 +222,94 @@ def _wino_ws(dev, tag, nfloat):
     return t
 
 
-def wino_tiles(h, w, dil):
-    return lib().pfst_wino_tiles(h, w, dil)
+# output tile edge m of the Winograd F(m x m, 3x3) transforms: 4 (4x fewer MACs, 36 transform indices) or 2 (2.25x, 16 indices)
+WINO_TILE = int(os.environ.get('PFST_WINO_TILE', '4'))
+assert WINO_TILE in (2, 4), 'PFST_WINO_TILE must be 2 or 4'
 
 
-def wino_pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
-    """w [Cout][Cin][3][3] -> transform-domain filters U[16][K/4][M][4] for fprop (K = Cin) and dgrad (K = Cout, flipped)."""
+def _wino_m(m):
+    m = WINO_TILE if m is None else int(m)
+    assert m in (2, 4)
+    return m, (m + 2) * (m + 2)
+
+
+def wino_tiles(h, w, dil, m=None):
+    return lib().pfst_wino_tiles(h, w, dil, _wino_m(m)[0])
+
+
+def wino_pack_weight(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, m=None):
+    """w [Cout][Cin][3][3] -> transform-domain filters U[X][K/4][M][4], X = (m+2)^2, for fprop (K = Cin) and dgrad (K = Cout, flipped)."""
     _dense(w)
+    m, nx = _wino_m(m)
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
-    uf = (out_f if out_f is not None else torch.empty(16 * co * ci, device=w.device)) if want_fprop else None
-    ud = (out_d if out_d is not None else torch.empty(16 * co * ci, device=w.device)) if want_dgrad else None
-    call('pfst_wino_pack_weight', w.data_ptr(), _p(uf), _p(ud), co, ci, _stream())
+    uf = (out_f if out_f is not None else torch.empty(nx * co * ci, device=w.device)) if want_fprop else None
+    ud = (out_d if out_d is not None else torch.empty(nx * co * ci, device=w.device)) if want_dgrad else None
+    assert (uf is None or uf.numel() == nx * co * ci) and (ud is None or ud.numel() == nx * co * ci)
+    call('pfst_wino_pack_weight', w.data_ptr(), _p(uf), _p(ud), co, ci, m, _stream())
     return uf, ud
 
 
-def wino_pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
-    """transform-domain filters for the bf16x6 GEMM: 16 split-packed sets (uint8 buffers of 16 * 6 * Cout * Cin bytes)"""
+def wino_pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, m=None):
+    """transform-domain filters for the bf16x6 GEMM: X split-packed sets (uint8 buffers of X * 6 * Cout * Cin bytes)"""
     _dense(w)
+    m, nx = _wino_m(m)
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
     n = co * ci
-    pf = _wino_ws(w.device, 'Pf', 16 * n) if want_fprop else None
-    pd = _wino_ws(w.device, 'Pd', 16 * n) if want_dgrad else None
-    call('pfst_wino_filter_plain', w.data_ptr(), _p(pf), _p(pd), co, ci, _stream())
-    uf = (out_f if out_f is not None else torch.empty(16 * 6 * n, dtype=U8, device=w.device)) if want_fprop else None
-    ud = (out_d if out_d is not None else torch.empty(16 * 6 * n, dtype=U8, device=w.device)) if want_dgrad else None
-    call('pfst_wino_pack_weight_split', _p(pf), _p(pd), _p(uf), _p(ud), co, ci, _stream())
+    pf = _wino_ws(w.device, 'Pf', nx * n) if want_fprop else None
+    pd = _wino_ws(w.device, 'Pd', nx * n) if want_dgrad else None
+    call('pfst_wino_filter_plain', w.data_ptr(), _p(pf), _p(pd), co, ci, m, _stream())
+    uf = (out_f if out_f is not None else torch.empty(nx * 6 * n, dtype=U8, device=w.device)) if want_fprop else None
+    ud = (out_d if out_d is not None else torch.empty(nx * 6 * n, dtype=U8, device=w.device)) if want_dgrad else None
+    assert (uf is None or uf.numel() == nx * 6 * n) and (ud is None or ud.numel() == nx * 6 * n)
+    call('pfst_wino_pack_weight_split', _p(pf), _p(pd), _p(uf), _p(ud), co, ci, m, _stream())
     return uf, ud
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False):
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
-    (288 GB of HBM: keeping ~11 GB per pass resident beats re-transforming the input in backward)."""
+    (288 GB of HBM: keeping it resident beats re-transforming the input in backward)."""
     n, c, h, w = x.shape
-    t = wino_tiles(h, w, dil)
-    v = torch.empty(16 * n * c * t, dtype=F32, device=x.device) if keep_v else _wino_ws(x.device, 'V', 16 * n * c * t)
-    m = _wino_ws(x.device, 'M', 16 * n * cout * t)
+    m, nx = _wino_m(m)
+    t = wino_tiles(h, w, dil, m)
+    assert u.numel() == nx * c * cout * (6 if u.dtype == U8 else 1), 'filter set was packed for another tile size'
+    v = torch.empty(nx * n * c * t, dtype=F32, device=x.device) if keep_v else _wino_ws(x.device, 'V', nx * n * c * t)
+    mb = _wino_ws(x.device, 'M', nx * n * cout * t)
     if out is None:
         assert not accumulate
         out = torch.empty(n, cout, h, w, device=x.device)
     assert tuple(out.shape) == (n, cout, h, w)
-    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, _stream())
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _stream())
     gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
-    call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), m.data_ptr(), n, c, cout, t, _stream())
+    call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
     slots, st = 0, None
     if want_stats:                      # BN partial sums of the output come out of the output transform
-        slots = n * lib().pfst_wino_stats_slots(h, w, dil)
+        slots = n * lib().pfst_wino_stats_slots(h, w, dil, m)
         st = _stats_ws(x.device, 2 * cout * slots)
-    call('pfst_wino_output', m.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), _stream())
+    call('pfst_wino_output', mb.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), m, _stream())
     res = (out, st, slots) if want_stats else (out,)
     if keep_v:
         res = res + (v,)
     return res if len(res) > 1 else res[0]
 
 
-def wino_wgrad_(dw, x, dy, dil, v=None):
-    """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass"""
+def wino_wgrad_(dw, x, dy, dil, v=None, m=None):
+    """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass (same m)"""
     n, ci, h, w = x.shape
     co = dy.shape[1]
+    m, nx = _wino_m(m)
     assert dy.shape == (n, co, h, w) and dw.numel() == co * ci * 9
-    t = wino_tiles(h, w, dil)
-    dm = _wino_ws(x.device, 'M', 16 * n * co * t)
-    du = _wino_ws(x.device, 'U', 16 * co * ci)
+    t = wino_tiles(h, w, dil, m)
+    dm = _wino_ws(x.device, 'M', nx * n * co * t)
+    du = _wino_ws(x.device, 'U', nx * co * ci)
     if v is None:
-        v = _wino_ws(x.device, 'V', 16 * n * ci * t)
-        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, _stream())
-    assert v.numel() >= 16 * n * ci * t
-    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, _stream())
-    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, _stream())
+        v = _wino_ws(x.device, 'V', nx * n * ci * t)
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _stream())
+    assert v.numel() >= nx * n * ci * t
+    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _stream())
+    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m, _stream())
     return dw
 
 

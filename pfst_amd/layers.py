@@ -22,12 +22,15 @@ _BN_EVAL = False
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
-# Winograd F(2x2,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 2.25x fewer MACs.
-# Threshold on Cin*Cout from tools/wino_microbench.py / bench.py: from 256x256 up Winograd wins for fprop, dgrad and (with the
-# transformed input kept from the forward pass and the grouped launch) the weight gradient.
+# Winograd F(m x m,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 4x (m = 4, default) or 2.25x
+# (PFST_WINO_TILE=2) fewer MACs.
+# Threshold on Cin*Cout from tools/wino_microbench.py / bench.py: Winograd wins for fprop, dgrad and (with the transformed input
+# kept from the forward pass and the grouped launch) the weight gradient from 128x128 channels up with F(4x4) (x1.4 at layer2,
+# x3.0 at the head bottleneck), from 256x256 up with F(2x2); 64x64 (layer1) stays direct (x0.9).
 WINOGRAD = os.environ.get('PFST_WINOGRAD', '1') == '1'
-WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', 256 * 256))
-WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', 256 * 256))
+_WINO_DEFAULT_CC = 128 * 128 if ops.WINO_TILE == 4 else 256 * 256
+WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', _WINO_DEFAULT_CC))
+WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', _WINO_DEFAULT_CC))
 
 
 class bn_eval:
@@ -105,9 +108,9 @@ class Conv2dP(nn.Module):
         self.wino = self._wino_eligible()
         if self.wino:
             split = CONV_MATH == 'bf16x6'           # transform-domain GEMMs on the bf16x6 kernel: split-packed filter sets
-            n = 16 * (self.weight.numel() // 9) * (6 if split else 1)
+            n = (ops.WINO_TILE + 2) ** 2 * (self.weight.numel() // 9) * (6 if split else 1)
             dt = torch.uint8 if split else torch.float32
-            if self.uf is None or self.uf.device != self.weight.device or self.uf.dtype != dt:
+            if self.uf is None or self.uf.device != self.weight.device or self.uf.dtype != dt or self.uf.numel() != n:
                 self.uf = torch.empty(n, dtype=dt, device=self.weight.device)
                 self.ud = None
             if need_dgrad and self.ud is None:

@@ -65,7 +65,8 @@ def test_winograd_dispatch_rules():
     assert Conv2dP(2560, 512, 3, 1, 1, 1)._wino_eligible()            # head bottleneck
     assert Conv2dP(256, 256, 3, 1, 2, 2)._wino_eligible()             # layer3 conv2
     assert layers.WINO_MIN_CC <= layers.WINO_MIN_CC_WGRAD <= 512 * 512
-    assert not Conv2dP(128, 128, 3, 1, 1, 1)._wino_eligible()         # transform-bound: stays direct
+    assert Conv2dP(128, 128, 3, 1, 1, 1)._wino_eligible() == (layers.ops.WINO_TILE == 4)   # layer2 conv2: pays off with F(4x4) only
+    assert not Conv2dP(64, 64, 3, 1, 1, 1)._wino_eligible()           # layer1 conv2, transform-bound: stays direct
     assert not Conv2dP(512, 512, 3, 2, 1, 1)._wino_eligible()         # stride 2
     assert not Conv2dP(512, 512, 1)._wino_eligible()                  # 1x1
     assert not Conv2dP(512, 512, 3, 1, 0, 1)._wino_eligible()         # not a 'same' convolution

@@ -163,49 +163,68 @@ WINO_CASES = [
 ]
 
 
+# fp32 Winograd against the fp64 direct convolution, relative to max |ref| (rel_err): F(2x2) is as good as the direct fp32
+# kernel; F(4x4) has transform entries up to 8 and 1/24, so its rounding error is ~10x larger -- still 30x inside the 1e-3 bar
+WINO_TOL = {2: 3e-6, 4: 3e-5}
+
+
+@pytest.mark.parametrize('m', [2, 4])
 @pytest.mark.parametrize('case', WINO_CASES)
-def test_winograd_f2x2_3x3_matches_direct_convolution(ops, case):
-    """Winograd F(2x2,3x3) forward, data gradient (incl. accumulate) and weight gradient == F.conv2d / autograd (fp64 ref)."""
+def test_winograd_matches_direct_convolution(ops, case, m):
+    """Winograd F(m x m,3x3) forward, data gradient (incl. accumulate) and weight gradient == F.conv2d / autograd (fp64 ref)."""
     n, ci, co, H, W, d = case
+    tol = WINO_TOL[m]
     x = torch.randn(n, ci, H, W, generator=g(1))
     w = torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1
     dy = torch.randn(n, co, H, W, generator=g(4))
     ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
     dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
     dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), 1, d, d)
-    assert ops.wino_tiles(H, W, d) % 4 == 0 or True
-    uf, ud = ops.wino_pack_weight(w.to(DEV))
-    y = ops.wino_conv(x.to(DEV), uf, co, d)
-    assert_close(y, ref, 3e-6, 'winograd fprop')
+    uf, ud = ops.wino_pack_weight(w.to(DEV), m=m)
+    y = ops.wino_conv(x.to(DEV), uf, co, d, m=m)
+    assert_close(y, ref, tol, 'winograd fprop')
     # fused BatchNorm statistics of the output transform
-    y2, st, slots = ops.wino_conv(x.to(DEV), uf, co, d, want_stats=True)
+    y2, st, slots = ops.wino_conv(x.to(DEV), uf, co, d, want_stats=True, m=m)
     mean, invstd = ops.bn_finalize_partials(st, slots, co, n * H * W)
-    assert_close(y2, ref, 3e-6, 'winograd fprop with stats')
+    assert_close(y2, ref, tol, 'winograd fprop with stats')
     assert_close(mean, ref.mean((0, 2, 3)), 2e-5, 'winograd stats mean')
     assert_close(invstd, 1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5), 2e-5, 'winograd stats invstd')
-    dx = ops.wino_conv(dy.to(DEV), ud, ci, d)
-    assert_close(dx, dx_ref, 3e-6, 'winograd dgrad')
-    dx2 = ops.wino_conv(dy.to(DEV), ud, ci, d, out=dx.clone(), accumulate=True)
-    assert_close(dx2, 2 * dx_ref, 3e-6, 'winograd dgrad accumulate')
-    if ops.wino_tiles(H, W, d) % 4 == 0:
+    dx = ops.wino_conv(dy.to(DEV), ud, ci, d, m=m)
+    assert_close(dx, dx_ref, tol, 'winograd dgrad')
+    dx2 = ops.wino_conv(dy.to(DEV), ud, ci, d, out=dx.clone(), accumulate=True, m=m)
+    assert_close(dx2, 2 * dx_ref, tol, 'winograd dgrad accumulate')
+    if ops.wino_tiles(H, W, d, m) % 4 == 0:
         dw = torch.zeros(co, ci, 3, 3, device=DEV)
-        ops.wino_wgrad_(dw, x.to(DEV), dy.to(DEV), d)
-        assert_close(dw, dw_ref, 5e-6, 'winograd wgrad')
+        ops.wino_wgrad_(dw, x.to(DEV), dy.to(DEV), d, m=m)
+        assert_close(dw, dw_ref, 2 * tol, 'winograd wgrad')
+        # with the transformed input kept from the forward pass, as the train step does
+        _, v = ops.wino_conv(x.to(DEV), uf, co, d, keep_v=True, m=m)
+        dw2 = torch.zeros(co, ci, 3, 3, device=DEV)
+        ops.wino_wgrad_(dw2, x.to(DEV), dy.to(DEV), d, v=v, m=m)
+        assert_close(dw2, dw_ref, 2 * tol, 'winograd wgrad from the kept V')
 
 
+def test_winograd_tile_counts(ops):
+    """tiles per image: d*d sub-grids of ceil(Hs/m) x ceil(Ws/m) tiles"""
+    assert ops.wino_tiles(128, 128, 1, 2) == 64 * 64 and ops.wino_tiles(128, 128, 1, 4) == 32 * 32
+    assert ops.wino_tiles(128, 128, 4, 4) == 16 * 8 * 8 and ops.wino_tiles(9, 13, 1, 4) == 3 * 4
+    assert ops.wino_tiles(10, 14, 2, 2) == 4 * 3 * 4 and ops.wino_tiles(10, 14, 2, 4) == 4 * 2 * 2
+
+
+@pytest.mark.parametrize('m', [2, 4])
 @pytest.mark.parametrize('case', [c for c in WINO_CASES if c[1] % 16 == 0 and c[2] % 16 == 0])
-def test_winograd_on_the_bf16x6_gemm(ops, case):
-    """The same Winograd pipeline with the 16 transform-domain GEMMs on the fp32-faithful bf16x6 kernel."""
+def test_winograd_on_the_bf16x6_gemm(ops, case, m):
+    """The same Winograd pipeline with the transform-domain GEMMs on the fp32-faithful bf16x6 kernel."""
     n, ci, co, H, W, d = case
     x = torch.randn(n, ci, H, W, generator=g(1))
     w = torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1
     dy = torch.randn(n, co, H, W, generator=g(4))
     ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
     dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
-    uf, ud = ops.wino_pack_weight_split(w.to(DEV))
+    uf, ud = ops.wino_pack_weight_split(w.to(DEV), m=m)
     assert uf.dtype == torch.uint8
-    assert_close(ops.wino_conv(x.to(DEV), uf, co, d), ref, 3e-6, 'winograd/bf16x6 fprop')
-    assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d), dx_ref, 3e-6, 'winograd/bf16x6 dgrad')
+    assert_close(ops.wino_conv(x.to(DEV), uf, co, d, m=m), ref, WINO_TOL[m], 'winograd/bf16x6 fprop')
+    assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d, m=m), dx_ref, WINO_TOL[m], 'winograd/bf16x6 dgrad')
 
 
 def test_conv_channel_slice_views(ops):
