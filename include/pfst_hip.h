@@ -108,17 +108,21 @@ int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* m
 /* the same from the conv epilogue's partials[C][T][2] (count = N*H*W elements per channel) */
 int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
                               float* running_mean, float* running_var, float momentum, float eps, pfst_stream_t stream);
-/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ) */
+/* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).  relu_mask != NULL (needs relu, HW % 256 == 0, 16-byte aligned planes):
+ * also writes the ReLU gate as a bitmask of N*C*HW/64 words for pfst_bn_backward -- the backward of a residual layer then reads
+ * 1 bit per element instead of the fp32 output y in both of its passes. */
 int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  int N, int C, int HW, int relu, pfst_stream_t stream);
+                  int N, int C, int HW, int relu, unsigned long long* relu_mask, pfst_stream_t stream);
 /* backward of the above: dz = dy * (y > 0 if relu); dres (+)= dz; dgamma += sum dz*xhat; dbeta += sum dz;
- * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles.  The ReLU mask comes from the saved
- * output y; if y == NULL and beta != NULL (layer without residual) it is recomputed from x exactly as bn_apply did. */
+ * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles.  The ReLU gate comes from relu_mask (as written by
+ * pfst_bn_apply), else from the saved output y; if both are NULL and beta != NULL (layer without residual) it is recomputed from
+ * x exactly as bn_apply did. */
 int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                      float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
-                     float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream);
+                     float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
+                     double* ws, pfst_stream_t stream);
 
 /* ---- pooling / resize ---------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:638); idx holds the winning tap 0..8 */

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        i64 res_bs, float* __restrict__ y, i64 y_bs,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int C, int HW, int relu) {
+                                                       int C, int HW, int relu, unsigned long long* __restrict__ mask) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float sc = invstd[c] * gamma[c];
   const float sh = beta[c] - mean[c] * sc;
@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const float4 r = reinterpret_cast<const float4*>(rp)[i];
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
+      if (mask) {
+        // ReLU bitmask for the backward pass (the host guarantees HW % 256 == 0, so all 64 lanes are here and hold 256
+        // consecutive elements): word [i >> 6][k] bit (lane) <-> component k of lane's float4, i.e. element 4*lane + k
+        const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
+        const int l = threadIdx.x & 63;
+        if (l < 4) mask[((i64)n * C + c) * (HW >> 6) + (i64)(i >> 6) * 4 + l] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
+      }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       reinterpret_cast<float4*>(yp)[i] = v;
     }
@@ -123,12 +130,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
+// ReLU gate of element i of a plane: from the bitmask bn_apply wrote (layout there), else from the saved output y, else
+// (no residual) recomputed from x exactly as bn_apply did
+__device__ __forceinline__ bool relu_on(const unsigned long long* __restrict__ mp, const float* __restrict__ yp, int i, float xv,
+                                        float sc, float sh) {
+  if (mp) return (mp[(i >> 8) * 4 + (i & 3)] >> ((i >> 2) & 63)) & 1ull;
+  return (yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f;
+}
+
 // backward pass 1: ws[2c] += sum dz, ws[2c+1] += sum dz*xhat     grid: (splits, C, N)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
                                                             i64 y_bs, const float* __restrict__ x, i64 x_bs,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            int HW, int chunk, int relu, double* __restrict__ ws) {
+                                                            int HW, int chunk, int relu, const unsigned long long* __restrict__ mask,
+                                                            double* __restrict__ ws) {
   __shared__ double sm[16];
   const int c = blockIdx.y, n = blockIdx.z;
   const float mu = mean[c], is = invstd[c];
@@ -137,6 +153,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const i64 base = (i64)c * HW;
   const float* gp = dy + (i64)n * dy_bs + base;
   const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
+  const unsigned long long* mp = mask ? mask + ((i64)n * gridDim.y + c) * (HW >> 6) : nullptr;
   const float* xp = x + (i64)n * x_bs + base;
   const int beg = blockIdx.x * chunk;
   const int end = min(beg + chunk, HW);
@@ -144,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
     float dz = gp[i];
     const float xv = xp[i];
-    if (relu && !((yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f)) dz = 0.f;
+    if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
     const float xh = (xv - mu) * is;
     s += (double)dz;
     sx += (double)dz * (double)xh;
@@ -165,7 +182,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, i64 dx_bs,
                                                            float* __restrict__ dres, i64 dres_bs, int dres_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int C, int HW, double inv_count, int relu, const double* __restrict__ ws) {
+                                                           int C, int HW, double inv_count, int relu,
+                                                           const unsigned long long* __restrict__ mask, const double* __restrict__ ws) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float mu = mean[c], is = invstd[c];
   // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const i64 base = (i64)c * HW;
   const float* gp = dy + (i64)n * dy_bs + base;
   const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
+  const unsigned long long* mp = mask ? mask + ((i64)n * gridDim.y + c) * (HW >> 6) : nullptr;
   const float* xp = x + (i64)n * x_bs + base;
   float* dxp = dx + (i64)n * dx_bs + base;
   float* drp = dres ? dres + (i64)n * dres_bs + base : nullptr;
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
     float dz = gp[i];
     const float xv = xp[i];
-    if (relu && !((yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f)) dz = 0.f;
+    if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
     const double xh = ((double)xv - (double)mu) * (double)is;
     dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
     if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
@@ -234,12 +253,15 @@ extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, do
 
 extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                             int N, int C, int HW, int relu, pfst_stream_t stream) {
+                             int N, int C, int HW, int relu, unsigned long long* relu_mask, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && y && mean && invstd && gamma && beta && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  // the bitmask comes out of the float4 path only: whole 256-element groups per wave, 16-byte aligned planes
+  PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0 && ((x_bs | y_bs | (residual ? res_bs : 0)) & 3) == 0 &&
+                                (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0));
   int gx = cdiv(HW, 256 * 4 * 4);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, residual, res_bs, y, y_bs, mean,
-                     invstd, gamma, beta, C, HW, relu);
+                     invstd, gamma, beta, C, HW, relu, relu_mask);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -247,19 +269,21 @@ extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residu
 extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long y_bs, const float* x, long long x_bs,
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
-                                float* dgamma, float* dbeta, int N, int C, int HW, int relu, double* ws, pfst_stream_t stream) {
+                                float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
+                                double* ws, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
-  PFST_CHECK_ARG(!relu || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
+  PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0));
+  PFST_CHECK_ARG(!relu || relu_mask || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, HW,
-                     chunk, relu, ws);
+                     chunk, relu, relu_mask, ws);
   int gx = cdiv(HW, 256 * 4);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, dx,
-                     dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, 1.0 / ((double)N * HW), relu, ws);
+                     dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, 1.0 / ((double)N * HW), relu, relu_mask, ws);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -359,25 +359,35 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
     return mean, invstd
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None):
+def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False):
+    """want_mask: also return the ReLU gate as a bitmask (int64 words) for bn_backward, or None where the kernel cannot
+    produce it (plane size not a multiple of 256, unaligned slices) -- the caller then keeps using y."""
     n, c, h, w = x.shape
     if out is None:
         out = torch.empty(n, c, h, w, device=x.device)
     assert out.shape == x.shape
+    mask = None
+    if want_mask and relu and (h * w) % 256 == 0 and all(
+            t is None or (_bs(t) % 4 == 0 and t.data_ptr() % 16 == 0) for t in (x, out, residual)):
+        mask = torch.empty(n * c * h * w // 64, dtype=torch.int64, device=x.device)
     call('pfst_bn_apply', x.data_ptr(), _bs(x), _p(residual), 0 if residual is None else _bs(residual), out.data_ptr(), _bs(out),
-         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _stream())
-    return out
+         mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _p(mask),
+         _stream())
+    return (out, mask) if want_mask else out
 
 
-def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None):
+def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None,
+                mask=None):
+    """mask: the bitmask bn_apply(..., want_mask=True) returned; replaces y as the source of the ReLU gate"""
     n, c, h, w = x.shape
     assert dy.shape == x.shape
+    assert mask is None or (mask.dtype == torch.int64 and mask.numel() == n * c * h * w // 64 and (h * w) % 256 == 0)
     if dx is None:
         dx = torch.empty(n, c, h, w, device=x.device)
     call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _p(beta), dx.data_ptr(), _bs(dx),
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
-         n, c, h * w, int(relu), _ws(x.device, 16 * c).data_ptr(), _stream())
+         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _stream())
     return dx
 
 

@@ -245,8 +245,13 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     out_var = None
     if isinstance(out, Var):                       # slice of a concat Var
         out_var, out = out, out.data
+    # residual layers: the ReLU gate goes to the backward pass as a bitmask (1 bit instead of 4 bytes per element, read twice)
+    want_mask = tape is not None and relu and residual is not None
     y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
-                     None if residual is None else residual.data, out=out)
+                     None if residual is None else residual.data, out=out, want_mask=want_mask)
+    gate = None
+    if want_mask:
+        y, gate = y
     if tape is None:
         return out_var if out_var is not None else Var(y, False)
     yv = out_var if out_var is not None else Var(y, True)
@@ -257,9 +262,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         if residual is not None and residual.requires_grad:
             dres, dacc = residual.grad_target()
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
-        ymask = y if (relu and residual is not None) else None
+        ymask = y if (relu and residual is not None and gate is None) else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc), beta=bn.bias.data)
+                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate)
         conv_backward(x, conv, dpre, saved_v)
         if yv.parent is None:
             yv.free_grad()

@@ -296,6 +296,43 @@ def test_batchnorm_train(ops, shape, relu, res):
         assert_close(dres, r.grad, 1e-6, 'bn dres')
 
 
+@pytest.mark.parametrize('shape', [(2, 24, 16, 16), (3, 8, 32, 24), (1, 5, 16, 48)])
+def test_batchnorm_relu_bitmask_equals_saved_output(ops, shape):
+    """Residual BN+ReLU: the backward pass fed with the 1-bit ReLU gate of bn_apply gives bit-identical results to the one fed
+    with the saved fp32 output (plane sizes are multiples of 256; a zero-crossing residual makes both gate values common),
+    and the mask words hold exactly the bits (y > 0) in the documented layout."""
+    n, c, h, w = shape
+    x = (torch.randn(shape, generator=g(1)) * 2 + 0.5).to(DEV)
+    r = torch.randn(shape, generator=g(2)).to(DEV)
+    r[0, 0, 0, :8] = 0.0
+    gamma, beta = (torch.rand(c, generator=g(3)) + 0.5).to(DEV), torch.randn(c, generator=g(4)).to(DEV)
+    dy = torch.randn(shape, generator=g(5)).to(DEV)
+    mean, invstd = ops.bn_stats(x)
+    y, mask = ops.bn_apply(x, mean, invstd, gamma, beta, True, r, want_mask=True)
+    assert mask is not None and mask.numel() == n * c * h * w // 64
+    assert torch.equal(y, ops.bn_apply(x, mean, invstd, gamma, beta, True, r))
+    # layout: 256-element chunk q of a plane -> 4 words; word k, bit l <-> element 256 q + 4 l + k
+    gate = (y > 0).reshape(n * c, h * w // 256, 64, 4).permute(0, 1, 3, 2).cpu().numpy()          # [plane][q][k][l]
+    words = mask.cpu().numpy().view(np.uint64).reshape(n * c, h * w // 256, 4)
+    bits = (words[..., None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)
+    assert np.array_equal(bits.astype(bool), gate)
+    out = []
+    for use_mask in (False, True):
+        dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        dres = torch.full(shape, 0.25, device=DEV)
+        dx = ops.bn_backward(dy, None if use_mask else y, x, mean, invstd, gamma, dg, db, True, dres, dres_accumulate=True, beta=beta,
+                             mask=mask if use_mask else None)
+        out.append((dx, dres, dg, db))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])        # dx, dres: element-wise, no reduction order
+    assert_close(out[1][2], out[0][2], 1e-6, 'dgamma')
+    assert_close(out[1][3], out[0][3], 1e-6, 'dbeta')
+    # planes that are not a multiple of 256: no mask, the caller keeps y
+    x2 = torch.randn(2, 4, 9, 13, generator=g(6)).to(DEV)
+    m2, i2 = ops.bn_stats(x2)
+    y2, none = ops.bn_apply(x2, m2, i2, gamma[:4], beta[:4], True, x2, want_mask=True)
+    assert none is None
+
+
 @pytest.mark.parametrize('H,W', [(17, 22), (16, 24), (2, 2), (64, 64)])      # odd sizes: generic kernel; even: 2x2-block backward
 def test_maxpool(ops, H, W):
     x = torch.randn(2, 8, H, W, generator=g(1)).requires_grad_()
