@@ -140,10 +140,12 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 }
 
 // ---- input transform V = B^T d B.   grid: (blocks over T, C, N); one thread per tile
+// vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M interior columns of a patch row are one wide load
 template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
-                                                         WinoGeom g) {
+                                                         WinoGeom g, int vec) {
   constexpr int R = M + 2;
+  typedef float vecM __attribute__((ext_vector_type(M)));
   const int c = blockIdx.y, n = blockIdx.z;
   const float* xp = x + (i64)n * x_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * C * g.T;                        // stride between transform indices
@@ -152,13 +154,31 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     int sy, sx, ty, tx;
     tile_coord(g, t, sy, sx, ty, tx);
     float d[R][R];
+    if (vec) {                                               // d == 1: columns M*tx - 1 | M*tx .. M*tx + M-1 | M*tx + M
+      const int x0 = M * tx;
 #pragma unroll
-    for (int a = 0; a < R; ++a) {
-      const int y = sy + g.d * (M * ty - 1 + a);
+      for (int a = 0; a < R; ++a) {
+        const int y = M * ty - 1 + a;
+        const bool in = y >= 0 && y < g.H;
+        const float* row = xp + (i64)y * g.W + x0;
+        vecM mid;
 #pragma unroll
-      for (int b = 0; b < R; ++b) {
-        const int xx = sx + g.d * (M * tx - 1 + b);
-        d[a][b] = (y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? xp[(i64)y * g.W + xx] : 0.f;
+        for (int b = 0; b < M; ++b) mid[b] = 0.f;
+        if (in) mid = *reinterpret_cast<const vecM*>(row);
+        d[a][0] = (in && x0 > 0) ? row[-1] : 0.f;
+#pragma unroll
+        for (int b = 0; b < M; ++b) d[a][1 + b] = mid[b];
+        d[a][R - 1] = (in && x0 + M < g.W) ? row[M] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        const int y = sy + g.d * (M * ty - 1 + a);
+#pragma unroll
+        for (int b = 0; b < R; ++b) {
+          const int xx = sx + g.d * (M * tx - 1 + b);
+          d[a][b] = (y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? xp[(i64)y * g.W + xx] : 0.f;
+        }
       }
     }
     float r[R][R];                                           // B^T d
@@ -381,9 +401,10 @@ extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, 
   PFST_CHECK_ARG(x && V && N > 0 && N <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0 && dil >= 1 && x_bs >= (i64)C * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
+  const int vec = dil == 1 && W % m == 0 && x_bs % m == 0 && ((uintptr_t)x & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), C, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g),
-              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec),
+              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
