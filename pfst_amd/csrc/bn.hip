@@ -138,7 +138,25 @@ __device__ __forceinline__ bool relu_on(const unsigned long long* __restrict__ m
   return (yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f;
 }
 
+// ReLU gates of the 4 elements of float4 number i4 of a plane (same sources as relu_on)
+__device__ __forceinline__ void relu_on4(const unsigned long long* __restrict__ mp, const float* __restrict__ yp, int i4, const float4& xv,
+                                         float sc, float sh, bool (&on)[4]) {
+  if (mp) {
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(mp + (i4 >> 6) * 4);       // wave-uniform address: broadcast loads
+    const ulonglong2 b = *reinterpret_cast<const ulonglong2*>(mp + (i4 >> 6) * 4 + 2);
+    const int l = i4 & 63;
+    on[0] = (a.x >> l) & 1ull; on[1] = (a.y >> l) & 1ull; on[2] = (b.x >> l) & 1ull; on[3] = (b.y >> l) & 1ull;
+  } else if (yp) {
+    const float4 yv = reinterpret_cast<const float4*>(yp)[i4];
+    on[0] = yv.x > 0.f; on[1] = yv.y > 0.f; on[2] = yv.z > 0.f; on[3] = yv.w > 0.f;
+  } else {
+    on[0] = fmaf(xv.x, sc, sh) > 0.f; on[1] = fmaf(xv.y, sc, sh) > 0.f; on[2] = fmaf(xv.z, sc, sh) > 0.f; on[3] = fmaf(xv.w, sc, sh) > 0.f;
+  }
+}
+
 // backward pass 1: ws[2c] += sum dz, ws[2c+1] += sum dz*xhat     grid: (splits, C, N)
+// VEC (host: HW % 4 == 0, 16-byte aligned planes): float4 streams
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
                                                             i64 y_bs, const float* __restrict__ x, i64 x_bs,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -158,13 +176,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int beg = blockIdx.x * chunk;
   const int end = min(beg + chunk, HW);
   double s = 0.0, sx = 0.0;
-  for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
-    float dz = gp[i];
-    const float xv = xp[i];
-    if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
-    const float xh = (xv - mu) * is;
-    s += (double)dz;
-    sx += (double)dz * (double)xh;
+  if (VEC) {
+    for (int i4 = (beg >> 2) + threadIdx.x; i4 < (end >> 2); i4 += blockDim.x) {
+      float4 g = reinterpret_cast<const float4*>(gp)[i4];
+      const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
+      if (relu) {
+        bool on[4];
+        relu_on4(mp, yp, i4, xv, sc, sh, on);
+        if (!on[0]) g.x = 0.f;
+        if (!on[1]) g.y = 0.f;
+        if (!on[2]) g.z = 0.f;
+        if (!on[3]) g.w = 0.f;
+      }
+      s += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+      sx += ((double)g.x * (double)((xv.x - mu) * is) + (double)g.y * (double)((xv.y - mu) * is)) +
+            ((double)g.z * (double)((xv.z - mu) * is) + (double)g.w * (double)((xv.w - mu) * is));
+    }
+  } else {
+    for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
+      float dz = gp[i];
+      const float xv = xp[i];
+      if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
+      const float xh = (xv - mu) * is;
+      s += (double)dz;
+      sx += (double)dz * (double)xh;
+    }
   }
   s = block_sum_d(s, sm);
   sx = block_sum_d(sx, sm);
@@ -175,6 +211,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // backward pass 2     grid: (blocks over HW, C, N)
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
                                                            i64 y_bs, const float* __restrict__ x, i64 x_bs,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -202,13 +239,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   float* dxp = dx + (i64)n * dx_bs + base;
   float* drp = dres ? dres + (i64)n * dres_bs + base : nullptr;
   const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
-    float dz = gp[i];
-    const float xv = xp[i];
-    if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
-    const double xh = ((double)xv - (double)mu) * (double)is;
-    dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
-    if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
+  if (VEC) {
+    for (int i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < (HW >> 2); i4 += stride) {
+      float4 g = reinterpret_cast<const float4*>(gp)[i4];
+      const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
+      if (relu) {
+        bool on[4];
+        relu_on4(mp, yp, i4, xv, sc, sh, on);
+        if (!on[0]) g.x = 0.f;
+        if (!on[1]) g.y = 0.f;
+        if (!on[2]) g.z = 0.f;
+        if (!on[3]) g.w = 0.f;
+      }
+      float4 o;
+      o.x = (float)(gs * ((double)g.x - m1 - (((double)xv.x - (double)mu) * (double)is) * m2));
+      o.y = (float)(gs * ((double)g.y - m1 - (((double)xv.y - (double)mu) * (double)is) * m2));
+      o.z = (float)(gs * ((double)g.z - m1 - (((double)xv.z - (double)mu) * (double)is) * m2));
+      o.w = (float)(gs * ((double)g.w - m1 - (((double)xv.w - (double)mu) * (double)is) * m2));
+      reinterpret_cast<float4*>(dxp)[i4] = o;
+      if (drp) {
+        if (dres_acc) {
+          const float4 old = reinterpret_cast<const float4*>(drp)[i4];
+          g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+        }
+        reinterpret_cast<float4*>(drp)[i4] = g;
+      }
+    }
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
+      float dz = gp[i];
+      const float xv = xp[i];
+      if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
+      const double xh = ((double)xv - (double)mu) * (double)is;
+      dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
+      if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
+    }
   }
 }
 
@@ -278,12 +343,22 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, HW,
-                     chunk, relu, relu_mask, ws);
+  const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs | dx_bs | (y ? y_bs : 0) | (dres ? dres_bs : 0)) & 3) == 0 &&
+                   (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)y | (uintptr_t)dres) & 15) == 0;
   int gx = cdiv(HW, 256 * 4);
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta, dx,
-                     dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, 1.0 / ((double)N * HW), relu, relu_mask, ws);
+  const double inv_count = 1.0 / ((double)N * HW);
+  if (vec) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
+                       beta, HW, chunk, relu, relu_mask, ws);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
+                       beta, HW, chunk, relu, relu_mask, ws);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws);
+  }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
