@@ -270,6 +270,28 @@ def main():
             res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
             res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
         if world == 1 and not args.no_alt_math:
+            # informational pass: the same fp32 step with stream-level overlap (weight gradients on a side stream beside the
+            # BatchNorm-backward / data-gradient chain, teacher forward forked beside the student's source pass).  Kept out of
+            # `value`: with kernels of several streams sharing the CUs, per-kernel event durations stop describing the kernel,
+            # and the roofline leg above is measured in the same timed region as `value`.
+            from pfst_amd import layers
+            hip_ops.call = timer.inner
+            layers.set_overlap(True, True)
+            for i in range(max(1, args.warmup)):
+                step(it)
+                it += 1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                step(it)
+                it += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            layers.set_overlap(False, False)
+            res['alt_streams'] = {'mode': 'fp32 MFMA, weight gradients on a side stream + teacher forward forked (opt-in via '
+                                          'PFST_WGRAD_STREAM=1 PFST_FORK_TEACHER=1)',
+                                  'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
+        if world == 1 and not args.no_alt_math:
             # informational second pass: same step with the fp32-faithful 6-term bf16 split for the fprop/dgrad GEMMs (direct and Winograd)
             # (csrc/conv_split.hip).  `value` above is the fp32-MFMA number; this one is reported separately.
             from pfst_amd import layers

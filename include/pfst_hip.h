@@ -62,6 +62,10 @@ int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long 
 int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
                     int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
                     pfst_stream_t stream);
+/* Occupancy cap of the K-quad weight-gradient kernels: `bytes` of unused dynamic LDS per workgroup (0 = off, the default).  With
+ * 24000 two instead of four workgroups fit per CU (the fp32-MFMA pipe stays saturated: -0.3 % on the step) and an HBM-bound kernel
+ * of ANOTHER stream -- the BatchNorm-backward chain, when the host runs weight gradients on a side stream -- can be co-resident. */
+int pfst_conv_wgrad_set_lds_pad(int bytes);
 /* db[c] += sum_{n,hw} dy[n][c][hw] */
 int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream);
 

@@ -19,6 +19,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+int g_wgrad_lds_pad = getenv("PFST_WGRAD_LDS_PAD") ? atoi(getenv("PFST_WGRAD_LDS_PAD")) : 0;
+
+
 constexpr int QBJ = 128;
 
 template <int BM, int T, int WBK>
@@ -231,7 +234,9 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * groups * chunks);
-  hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
+  // occupancy cap (pfst_conv_wgrad_set_lds_pad): unused dynamic LDS, so that fewer workgroups fit per CU and a concurrently running
+  // HBM-bound kernel of another stream finds registers and wave slots
+  hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
                      dil, pad, chunks, chunk_len, N, x_gs, dy_gs, dw_gs);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
@@ -267,4 +272,10 @@ int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, fl
   if (Cout > 32) { PFST_WGQ(64); }
   PFST_WGQ(32);
 #undef PFST_WGQ
+}
+
+extern "C" int pfst_conv_wgrad_set_lds_pad(int bytes) {
+  PFST_CHECK_ARG(bytes >= 0 && bytes <= 96 * 1024);
+  g_wgrad_lds_pad = bytes;
+  return PFST_OK;
 }

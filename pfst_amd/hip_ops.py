@@ -233,6 +233,11 @@ def _wino_m(m):
     return m, (m + 2) * (m + 2)
 
 
+def set_wgrad_lds_pad(nbytes):
+    """occupancy cap of the K-quad weight-gradient kernels (pfst_conv_wgrad_set_lds_pad)"""
+    call('pfst_conv_wgrad_set_lds_pad', int(nbytes))
+
+
 def wino_tiles(h, w, dil, m=None):
     return lib().pfst_wino_tiles(h, w, dil, _wino_m(m)[0])
 

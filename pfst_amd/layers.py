@@ -195,9 +195,70 @@ def conv_forward(x, conv, tape, out=None):
     return yv
 
 
+# Stream-level overlap (opt-in): weight gradients on a high-priority side stream beside the BatchNorm-backward /
+# data-gradient chain (with the wgrad kernels capped to 2 workgroups per CU so the chain's HBM-bound kernels find room), and the
+# teacher's forward pass forked beside the student's source pass.  +2.3 % step throughput, but per-kernel durations measured
+# with events then include time-sharing, so bench.py's roofline leg runs with both OFF (the default).
+WGRAD_STREAM = os.environ.get('PFST_WGRAD_STREAM', '0') == '1'
+FORK_TEACHER = os.environ.get('PFST_FORK_TEACHER', '0') == '1'
+WGRAD_STREAM_LDS_PAD = 24000
+_side_stream = None
+_teacher_stream = None
+
+
+def set_overlap(wgrad_stream, fork_teacher):
+    """switch the two overlap features at run time (bench.py's `alt_streams` leg, tests)"""
+    global WGRAD_STREAM, FORK_TEACHER
+    WGRAD_STREAM, FORK_TEACHER = bool(wgrad_stream), bool(fork_teacher)
+    if 'PFST_WGRAD_LDS_PAD' not in os.environ:
+        ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD if WGRAD_STREAM else 0)
+
+
+def teacher_stream():
+    global _teacher_stream
+    if _teacher_stream is None:
+        _teacher_stream = torch.cuda.Stream()
+    return _teacher_stream
+
+
+def _on_side_stream(fn, *tensors):
+    """run fn (weight-gradient launches) on the side stream, ordered after everything queued on the current stream so far"""
+    global _side_stream
+    main = torch.cuda.current_stream()
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream(priority=-1)      # high priority: the chain's kernels fill in around the wgrads
+        if 'PFST_WGRAD_LDS_PAD' not in os.environ:
+            ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD)
+    _side_stream.wait_stream(main)
+    with torch.cuda.stream(_side_stream):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(_side_stream)
+
+
+def join_side_stream():
+    """the current stream waits for the weight gradients queued on the side stream (before the optimizer / all-reduce)"""
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+
+
 def conv_backward(x, conv, dy, saved_v=None):
     """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward"""
     xd = x.data
+    if WGRAD_STREAM and not conv.depthwise:
+        def wg():
+            if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
+                ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v)
+            else:
+                ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+        _on_side_stream(wg, dy, xd, saved_v)
+        if conv.bias is not None:
+            ops.bias_grad_(conv.bias.grad, dy)
+        if x.requires_grad:
+            buf, acc = x.grad_target()
+            conv.dgrad(dy, xd.shape[-2:], buf, acc)
+        return
     if conv.depthwise:
         ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
         if x.requires_grad:

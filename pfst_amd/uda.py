@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import dist as pdist
 from . import hip_ops as ops
+from . import layers
 from .engine import ParamArena, Tape
 from .registry import LOSSES, UDA, build_loss, build_segmentor
 
@@ -283,6 +284,18 @@ class PFGST(UDADecorator):
         tape = Tape()
         scalars = OrderedDict()
 
+        # ---- teacher on target, optionally forked onto a second stream (layers.FORK_TEACHER): it is independent of the
+        # student's source pass, so its HBM-bound kernels can run beside the other pass's MFMA-bound ones.  The host order of
+        # RNG draws is unchanged (the teacher draws none: dropout is off)
+        fork = layers.FORK_TEACHER
+        if fork:
+            main_s = torch.cuda.current_stream()
+            side_s = layers.teacher_stream()
+            side_s.wait_stream(main_s)
+            with torch.cuda.stream(side_s):
+                ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
+            ema_dec = ema_states['decoded_features']
+
         # ---- student on source
         clean = model.forward_train(img.contiguous(), img_metas, gt8, None, return_feats=True, return_logits=True,
                                     return_decoded_feats=True, tape=tape)
@@ -292,8 +305,13 @@ class PFGST(UDADecorator):
         scalars.update(clean)
 
         # ---- teacher on target -> pseudo labels (fused upsample + softmax + argmax + threshold count)
-        ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
-        ema_dec = ema_states['decoded_features']
+        if fork:
+            main_s.wait_stream(side_s)
+            for t in (ema_logits.data, ema_dec.data):
+                t.record_stream(main_s)
+        else:
+            ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
+            ema_dec = ema_states['decoded_features']
         part = self.thre_type == 'part'
         res = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None, want_conf=part)
         pl64, pl8, conf_count = res[:3]
@@ -338,6 +356,7 @@ class PFGST(UDADecorator):
 
         # ---- one backward over both student graphs + aux (pfgst.py:344)
         tape.backward()
+        layers.join_side_stream()
 
         if dbg is not None:
             dbg.update(pseudo_label=pl64, conf_count=conf_count, mix_masks=mix_masks, mixed_img=mixed_img,

@@ -277,3 +277,38 @@ def test_step_with_pfgst_loss_option_variants():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+
+
+def test_stream_overlap_options_do_not_change_the_step():
+    """PFST_WGRAD_STREAM / PFST_FORK_TEACHER (layers.set_overlap): weight gradients on a side stream and the teacher's forward
+    forked beside the student's source pass are pure scheduling -- the step gives the same pseudo labels, losses and gradients
+    as the single-stream schedule (to the fp32 atomics' summation-order noise); a second step (after AdamW, which amplifies
+    that noise, see above) stays close."""
+    from pfst_amd import layers
+    from pfst_amd.synthetic import synth_batch
+    batch = to_dev(synth_batch(2, 128, 6, seed=77), 'cuda')
+    runs = []
+    for overlap in (False, True):
+        model, opt, _, _ = _build(0.30)
+        model.debug = {}
+        layers.set_overlap(overlap, overlap)
+        try:
+            random.seed(100); np.random.seed(100)
+            log0 = model.train_step(batch, opt)['log_vars']
+            grad0 = model.student_arena.grad.clone().cpu()
+            pl0 = model.debug['pseudo_label'].cpu()
+            random.seed(101); np.random.seed(101)
+            log1 = model.train_step(batch, opt)['log_vars']
+            torch.cuda.synchronize()
+        finally:
+            layers.set_overlap(False, False)
+        runs.append((log0, pl0, grad0, log1, model._teacher_arena.data.clone().cpu()))
+    assert layers._side_stream is not None and layers._teacher_stream is not None, 'the overlap streams were never used'
+    (a0, p0, g0, a1, t0), (b0, p1, g1, b1, t1) = runs
+    assert torch.equal(p0, p1), 'pseudo labels'
+    assert list(a0) == list(b0)
+    for k in a0:
+        assert abs(a0[k] - b0[k]) <= 1e-5 * max(abs(a0[k]), 1e-2), (k, a0[k], b0[k])
+        assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
+    assert rel(g1, g0) < 1e-4, rel(g1, g0)
+    assert rel(t1, t0) < 1e-5
