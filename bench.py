@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 WORKLOAD = 'pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 PEAK_HBM_GBPS = 8000.0
+DOMINANT_KERNEL = 'conv_igemm_q_kernel<128>'     # expected dominant kernel (checked against the full per-kernel pass)
 
 
 class KernelTimer:
@@ -35,6 +36,7 @@ class KernelTimer:
         self.records = []      # (key, start_evt, end_evt, flops)
         self.enabled = False
         self.per_layer = False
+        self.only = None       # kernel-name prefix: bracket only those launches (the timed region), None = all
 
     @staticmethod
     def _conv_variant(name, a):
@@ -87,6 +89,8 @@ class KernelTimer:
         if not self.enabled:
             return self.inner(name, *args)
         key, flops, nbytes = self._conv_variant(name, args)
+        if self.only is not None and not key.startswith(self.only):
+            return self.inner(name, *args)
         if self.per_layer and flops > 0:
             idx = {'pfst_conv_igemm': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad': (5, 6, 7, 9, 12, 14),
                    'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7)}[name]
@@ -204,8 +208,12 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    # Timed region: only the dominant kernel's launches are bracketed with events (its roofline figure must come from the very
+    # steps `value` is measured on, and 2700 event pairs per step would cost the step 1.5-2 %); the per-kernel tables
+    # (hbm_kernels, kernel_ms_per_step) come from a second, untimed pass of the same K steps with every launch bracketed.
     timer.enabled = not args.no_kernel_timing
     timer.per_layer = args.per_layer
+    timer.only = None if args.per_layer else DOMINANT_KERNEL
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -216,6 +224,17 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    dom_agg = None
+    if not args.no_kernel_timing and not args.per_layer:
+        dom_agg = timer.summary()
+        timer.records = []
+        timer.only = None
+        timer.enabled = True
+        for _ in range(args.steps):
+            step(it)
+            it += 1
+        torch.cuda.synchronize()
+        timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -252,11 +271,15 @@ def main():
             tot_ms = sum(v[1] for v in agg.values())
             mfma = {k: v for k, v in agg.items() if v[2] > 0}
             dom = max(mfma.items(), key=lambda kv: kv[1][1])
+            measured_in = 'second pass (all launches bracketed)'
+            if dom_agg and dom[0] in dom_agg:          # the expected dominant kernel: use its launches of the TIMED region
+                dom = (dom[0], dom_agg[dom[0]])
+                measured_in = 'timed region'
             cnt, ms, fl, nb = dom[1]
             achieved = fl / (ms * 1e-3) / 1e12
             res['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom[0]),
-                               'launches': cnt, 'avg_launch_ms': ms / cnt,
+                               'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
                                'algorithmic_flops_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
             all_fl = sum(v[2] for v in mfma.values())
             all_ms = sum(v[1] for v in mfma.values())
