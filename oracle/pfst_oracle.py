@@ -228,12 +228,13 @@ def segmentor_forward_train(sd, img, gt, seg_weight=None, drop_masks=(None, None
     return losses, feats, logits, dec, aux_logits
 
 
-def encode_decode(sd, img, pre=''):
+def encode_decode(sd, img, pre='', return_feats=False):
     """EncoderDecoder.encode_decode as the teacher runs it (encoder_decoder.py:72-84, pfgst.py:247-257):
     BN in TRAIN mode (batch statistics), dropout off, no aux head; logits bilinear to image size."""
     feats = backbone_forward(sd, img, True, pre)
     logits, dec = decode_head_forward(sd, feats, True, None, pre)
-    return F.interpolate(logits, size=img.shape[2:], mode='bilinear', align_corners=False), dec, logits
+    out = (F.interpolate(logits, size=img.shape[2:], mode='bilinear', align_corners=False), dec, logits)
+    return out + (feats,) if return_feats else out
 
 
 def parse_losses(losses):
@@ -377,7 +378,7 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False, downscale=0.5, thre_type='all', loss_opts=None):
+                 blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -390,6 +391,9 @@ class OraclePFGST:
         self.blur = blur
         self.downscale = downscale
         self.loss_opts = dict(loss_opts or {})       # PFGSTLoss option variants (sim_type, sigma, src_loss_type, margin, detach_unfold, top_k)
+        # feat_level k: use_decoded_feats=False + PFGSTLoss(feat_level=k) -- backbone feature map k instead of the decoded
+        # features (pfgst.py:229-231,255-257; pfgst_loss.py:50-51)
+        self.feat_level = feat_level
         self.thre_type = thre_type
         self.local_iter = 0
 
@@ -409,7 +413,7 @@ class OraclePFGST:
         clean_loss, lv = parse_losses(losses)
         lv.pop('loss'); log.update(lv)
         with torch.no_grad():
-            ema_logits, ema_dec, ema_low = encode_decode(self.teacher, trg)
+            ema_logits, ema_dec, ema_low, ema_feats = encode_decode(self.teacher, trg, return_feats=True)
         pl, pw, n_conf = pseudo_label(ema_logits, self.tau, self.thre_type)
         if pseudo_override is not None:        # (label map, #confident) injected by parity tests
             pl, n_conf = pseudo_override
@@ -422,7 +426,8 @@ class OraclePFGST:
             self.student, mixed_img, mixed_lbl, mixed_w, dm.get('mix', (None, None)))
         mix_loss, lv = parse_losses(OrderedDict(('mix.' + k, v) for k, v in mlosses.items()))
         lv.pop('loss'); log.update(lv)
-        aux, extras = pfgst_loss(mix_logits, ema_dec, src_dec, gt, masks, self.aux_w, downscale=self.downscale, **self.loss_opts)
+        x_ema, x_src = (ema_dec, src_dec) if self.feat_level is None else (ema_feats[self.feat_level], feats[self.feat_level])
+        aux, extras = pfgst_loss(mix_logits, x_ema, x_src, gt, masks, self.aux_w, downscale=self.downscale, **self.loss_opts)
         aux_loss, lv = parse_losses(aux)
         lv.pop('loss'); log.update(lv)
         total = clean_loss + self.trg_w * mix_loss + aux_loss

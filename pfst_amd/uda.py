@@ -33,8 +33,10 @@ class PFGSTLoss(nn.Module):
         super().__init__()
         # Implemented: the shipped options plus the variants reachable from the same configs: sim_type
         # 'cosine' | 'gaussian' (sigma), src_loss_type 'mean_std' | 'margin' | 'margin2' (margin), detach_unfold True | False,
-        # top_k 1..4 | None, downscale 0.5 | 1 | None.  Everything else fails loudly.
-        bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type not in ('cosine', 'gaussian'), feat_level=feat_level is not None,
+        # top_k 1..4 | None, downscale 0.5 | 1 | None, feat_level None | 0..3 (a backbone feature map instead of the decoded
+        # features, with PFGST(use_decoded_feats=False)).  Everything else fails loudly.
+        bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type not in ('cosine', 'gaussian'),
+                   feat_level=feat_level is not None and feat_level not in (0, 1, 2, 3),
                    src_perc=src_perc is not None, proj_net=proj_net_cfg is not None,
                    src_loss_type=src_loss_type not in ('mean_std', 'margin', 'margin2'), cross_prob_type=cross_prob_type != 'trg',
                    downscale=downscale not in (None, 0.5, 1, 1.0), top_k=top_k is not None and not (1 <= top_k <= 4),
@@ -47,11 +49,16 @@ class PFGSTLoss(nn.Module):
         self.src_loss_type, self.margin = src_loss_type, tuple(margin)
         self.unfold_grad = not detach_unfold
         self.ds = 1 if downscale is None else int(round(1.0 / downscale))
+        self.feat_level = feat_level
 
     def forward(self, tensors, tape=None):
         """tensors: logits_trg (Var, student logits of the mixed pass), x_ema (Var), x_src (Var),
         gt_src (uint8 [N,1,H,W]), mix_masks (uint8 [N,1,H,W]).  -> dict of 6 one-element device tensors."""
         lt, x_ema, x_src = tensors['logits_trg'], tensors['x_ema'], tensors['x_src']
+        if self.feat_level is not None:                   # pfgst_loss.py:50-51
+            x_ema, x_src = x_ema[self.feat_level], x_src[self.feat_level]
+        if isinstance(x_src, (tuple, list)) or isinstance(x_ema, (tuple, list)):
+            raise TypeError('PFGSTLoss: x_src / x_ema are feature tuples (use_decoded_feats=False) but feat_level is None')
         gt8, mm8 = tensors['gt_src'], tensors['mix_masks']
         d, w = self.dilation, self.weights
         n, c, h, wd = lt.data.shape
@@ -61,7 +68,8 @@ class PFGSTLoss(nn.Module):
         # dilation-d/u neighbourhood of the source grid -- so the similarity is computed at the source resolution
         # and only the tiny 9-channel map is replicated (its adjoint is a u x u sum).
         hf, wf = x_src.data.shape[-2:]
-        assert x_ema.data.shape[-2:] == (hf, wf) and H % hf == 0 and H // hf == W // wf
+        if x_ema.data.shape[-2:] != (hf, wf) or H % hf != 0 or H // hf != W // wf:
+            raise NotImplementedError(f'PFGSTLoss: feature grid {hf}x{wf} does not divide the logit grid {H}x{W}')
         u = H // hf
         if d % u != 0:
             raise NotImplementedError(f'PFGSTLoss: dilation {d} not divisible by the feature up-sampling factor {u}')
@@ -152,7 +160,7 @@ class PFGST(UDADecorator):
         self.apply_no_mix = cfg.get('apply_no_mix', False)
         assert self.mix == 'class'
         bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type not in ('all', 'part'), ps_top=self.psweight_ignore_top > 0,
-                   ps_bottom=self.psweight_ignore_bottom > 0, use_decoded_feats=not self.use_decoded_feats,
+                   ps_bottom=self.psweight_ignore_bottom > 0,
                    apply_no_mix=self.apply_no_mix, print_grad=self.print_grad_magnitude)
         bad = [k for k, v in bad.items() if v]
         if bad:
@@ -294,24 +302,25 @@ class PFGST(UDADecorator):
             side_s.wait_stream(main_s)
             with torch.cuda.stream(side_s):
                 ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
-            ema_dec = ema_states['decoded_features']
+            ema_dec = ema_states['decoded_features'] if self.use_decoded_feats else ema_states['feats']
 
         # ---- student on source
         clean = model.forward_train(img.contiguous(), img_metas, gt8, None, return_feats=True, return_logits=True,
-                                    return_decoded_feats=True, tape=tape)
-        clean.pop('features')
-        src_dec = clean.pop('decoded_features')
+                                    return_decoded_feats=self.use_decoded_feats, tape=tape)
+        src_dec = clean.pop('features')                       # pfgst.py:229-231: the backbone feature tuple, or ...
+        if self.use_decoded_feats:
+            src_dec = clean.pop('decoded_features')           # ... the decode head's 512-channel map (all shipped configs)
         src_logits = clean.pop('logits')
         scalars.update(clean)
 
         # ---- teacher on target -> pseudo labels (fused upsample + softmax + argmax + threshold count)
         if fork:
             main_s.wait_stream(side_s)
-            for t in (ema_logits.data, ema_dec.data):
-                t.record_stream(main_s)
+            for t in (ema_logits,) + (tuple(ema_dec) if isinstance(ema_dec, (tuple, list)) else (ema_dec,)):
+                t.data.record_stream(main_s)
         else:
             ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
-            ema_dec = ema_states['decoded_features']
+            ema_dec = ema_states['decoded_features'] if self.use_decoded_feats else ema_states['feats']
         part = self.thre_type == 'part'
         res = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None, want_conf=part)
         pl64, pl8, conf_count = res[:3]
@@ -361,7 +370,9 @@ class PFGST(UDADecorator):
         if dbg is not None:
             dbg.update(pseudo_label=pl64, conf_count=conf_count, mix_masks=mix_masks, mixed_img=mixed_img,
                        mixed_lbl=mixed_lbl64, mixed_w=mixed_w, src_logits=src_logits.data, mix_logits=mixed_logits.data,
-                       ema_logits=ema_logits.data, ema_dec=ema_dec.data, src_dec=src_dec.data, classes=classes)
+                       ema_logits=ema_logits.data, classes=classes)
+            if self.use_decoded_feats:
+                dbg.update(ema_dec=ema_dec.data, src_dec=src_dec.data)
 
         # ---- gradient all-reduce (student only), log scalars packed into ONE vector
         names = list(scalars.keys())

@@ -279,6 +279,59 @@ def test_step_with_pfgst_loss_option_variants():
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
 
 
+@pytest.mark.parametrize('level', [3, 1])
+def test_step_with_backbone_feature_level(level):
+    """use_decoded_feats=False + PFGSTLoss(feat_level=k) (pfgst.py:229-231,255-257; pfgst_loss.py:50-51): the similarity losses act
+    on backbone feature map k (2048 / 512 channels at 1/8) instead of the decoded features, and their gradient enters the
+    backbone there.  Losses and the gradient of the first backbone tensor upstream of that map against the oracle."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.3)
+    cfg['use_decoded_feats'] = False
+    cfg['aux_losses'][0]['feat_level'] = level
+    # 1000x the shipped loss weights: the similarity losses then dominate the gradient where they enter the backbone, one
+    # well-conditioned BN layer above the tensor checked below (through the heads' ~10 BN layers fp32 noise alone is 2-5 %)
+    aux_w = {k: 100.0 for k in cfg['aux_losses'][0]['weights']}
+    cfg['aux_losses'][0]['weights'] = dict(aux_w)
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 9)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 6, seed=78)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.3, teacher_sd=teacher, feat_level=level, aux_weights=aux_w)
+    random.seed(3); np.random.seed(3)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    o_dec = O.OraclePFGST(student, pseudo_threshold=0.3, teacher_sd=teacher, aux_weights=aux_w)    # decoded-feature losses differ
+    random.seed(3); np.random.seed(3)
+    dlog, dex = o_dec.train_step(batch, return_extras=True)
+    assert abs(dlog['loss_src_pos_mean'] - olog['loss_src_pos_mean']) > 1e-3 * abs(olog['loss_src_pos_mean'])
+    random.seed(3); np.random.seed(3)
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    assert set(olog) == set(out['log_vars'])
+    for k, v in olog.items():
+        tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    # backward: the loss gradient enters the backbone at feature map `level`; the tensor producing that map must carry it --
+    # the HIP gradient is far closer to the feature-level oracle than the decoded-feature oracle's gradient is
+    name = {3: 'backbone.layer4.2.bn3.weight', 1: 'backbone.layer2.3.bn3.weight'}[level]
+    a = model.student_arena
+    e_hip = rel(a.view(a.grad, name), ex['grads'][name])
+    e_other = rel(dex['grads'][name], ex['grads'][name])
+    assert e_hip < 3e-2 and e_other > 0.5, (name, e_hip, e_other)
+    # a tuple of features with feat_level=None is a type error in the reference too (F.unfold of a tuple)
+    cfg['aux_losses'][0]['feat_level'] = None
+    bad = UDA.build(cfg)
+    bad.load_state_dict(both, strict=False)
+    bad.cuda()
+    with pytest.raises(TypeError):
+        bad.train_step(to_dev(batch, 'cuda'), build_optimizer(bad, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)))
+
+
 def test_stream_overlap_options_do_not_change_the_step():
     """PFST_WGRAD_STREAM / PFST_FORK_TEACHER (layers.set_overlap): weight gradients on a side stream and the teacher's forward
     forked beside the student's source pass are pure scheduling -- the step gives the same pseudo labels, losses and gradients
