@@ -12,12 +12,28 @@ SOURCES = ['conv_mfma.hip', 'conv_igemm_q.hip', 'conv_wgrad_q.hip', 'conv_winogr
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
 
 
+def _deps(src, seen=None):
+    """src + every header it reaches through `#include "..."` (csrc/ and include/), so that editing a shared header
+    (conv_epilogue.h, common.h, pfst_hip.h) rebuilds all of its includers"""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    for inc in re.findall(r'^\s*#\s*include\s*"([^"]+)"', open(src).read(), flags=re.M):
+        for base in (os.path.dirname(src), CSRC, os.path.join(HERE, '..', 'include')):
+            cand = os.path.normpath(os.path.join(base, inc))
+            if os.path.exists(cand):
+                _deps(cand, seen)
+                break
+    return seen
+
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src, os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'pfst_hip.h')]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) > t for d in _deps(src))
 
 
 def build(force=False, verbose=True):
@@ -44,7 +60,7 @@ def build(force=False, verbose=True):
             print(out.decode())
     if failed:
         raise RuntimeError('hipcc failed')
-    if force or procs or not os.path.exists(LIB):
+    if force or procs or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
