@@ -159,9 +159,12 @@ int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, int w, const 
                          float* dlogits, int accumulate, pfst_stream_t stream);
 
 /* ---- pseudo labels (pfgst.py:259-268 + encoder_decoder.py:77-81): bilinear upsample of the teacher
- * logits, softmax, (max prob, first arg-max), prob >= threshold counted into count[0] */
+ * logits, softmax (exp(z - max) / sum as torch computes it), then torch.max over the PROBABILITIES: the first class whose
+ * rounded probability is maximal (not the arg-max of the logits: distinct logits may tie after rounding); prob >= threshold
+ * counted into count[0].  conf_mask (0/1 per pixel) and max_prob (the softmax value itself) may be NULL. */
 int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
-                      long long* label_i64, unsigned char* label_u8, unsigned long long* count, float* conf_mask, pfst_stream_t stream);
+                      long long* label_i64, unsigned char* label_u8, unsigned long long* count, float* conf_mask, float* max_prob,
+                      pfst_stream_t stream);
 
 /* ---- evaluation: intersect_and_union (rsiseg/core/evaluation/metrics.py:26-86).  hist[3*C] (+)= per-class
  * #intersect, #pred, #label over pixels whose label != ignore_index (caller zeroes hist once per evaluation) */

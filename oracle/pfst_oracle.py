@@ -112,6 +112,17 @@ def param_keys(sd):
 # ---------------------------------------------------------------------------
 # network forward (functional)
 # ---------------------------------------------------------------------------
+CAPTURE = None      # tests set this to a dict: every named activation is stored with retain_grad(), so that after backward()
+                    # each layer's upstream gradient is available (tests/test_layer_backward_gpu.py)
+
+
+def _cap(name, t):
+    if CAPTURE is not None and t.requires_grad:
+        t.retain_grad()
+        CAPTURE[name] = t
+    return t
+
+
 def _bn(sd, key, x, relu=True, train=True):
     y = F.batch_norm(x, sd[key + '.running_mean'], sd[key + '.running_var'], sd[key + '.weight'],
                      sd[key + '.bias'], training=train, momentum=BN_MOM, eps=BN_EPS)
@@ -121,7 +132,7 @@ def _bn(sd, key, x, relu=True, train=True):
 
 
 def _cbr(sd, ck, bk, x, stride=1, pad=0, dil=1, groups=1, relu=True, train=True):
-    return _bn(sd, bk, F.conv2d(x, sd[ck + '.weight'], None, stride, pad, dil, groups), relu, train)
+    return _cap(ck, _bn(sd, bk, F.conv2d(x, sd[ck + '.weight'], None, stride, pad, dil, groups), relu, train))
 
 
 def backbone_forward(sd, x, train=True, pre=''):
@@ -130,7 +141,7 @@ def backbone_forward(sd, x, train=True, pre=''):
     x = _cbr(sd, b + 'stem.0', b + 'stem.1', x, 2, 1, train=train)
     x = _cbr(sd, b + 'stem.3', b + 'stem.4', x, 1, 1, train=train)
     x = _cbr(sd, b + 'stem.6', b + 'stem.7', x, 1, 1, train=train)
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _cap(b + 'maxpool', F.max_pool2d(x, 3, 2, 1))
     outs = []
     for li, (nb, stride, dil) in enumerate(zip(STAGE_BLOCKS, STAGE_STRIDES, STAGE_DILATIONS)):
         for bi in range(nb):
@@ -143,7 +154,7 @@ def backbone_forward(sd, x, train=True, pre=''):
             o = _cbr(sd, p + '.conv3', p + '.bn3', o, relu=False, train=train)
             if bi == 0:
                 idt = _cbr(sd, p + '.downsample.0', p + '.downsample.1', x, s, relu=False, train=train)
-            x = F.relu(o + idt)
+            x = _cap(p + '.out', F.relu(o + idt))
         outs.append(x)
     return tuple(outs)
 
@@ -158,20 +169,20 @@ def decode_head_forward(sd, feats, train=True, drop_mask=None, pre=''):
     """DepthwiseSeparableASPPHead.forward (sep_aspp_head.py:79-111) -> (logits, features)."""
     h = pre + 'decode_head'
     c1, c4 = feats[0], feats[3]
-    pool = _cbr(sd, h + '.image_pool.1.conv', h + '.image_pool.1.bn', c4.mean((2, 3), keepdim=True), train=train)
-    outs = [F.interpolate(pool, size=c4.shape[2:], mode='bilinear', align_corners=False),
+    pool = _cbr(sd, h + '.image_pool.1.conv', h + '.image_pool.1.bn', _cap(h + '.gap', c4.mean((2, 3), keepdim=True)), train=train)
+    outs = [_cap(h + '.image_pool.up', F.interpolate(pool, size=c4.shape[2:], mode='bilinear', align_corners=False)),
             _cbr(sd, h + '.aspp_modules.0.conv', h + '.aspp_modules.0.bn', c4, train=train)]
     for i, d in zip((1, 2, 3), ASPP_DILATIONS[1:]):
         outs.append(_dwsep(sd, f'{h}.aspp_modules.{i}', c4, d, train))
     features = _cbr(sd, h + '.bottleneck.conv', h + '.bottleneck.bn', torch.cat(outs, 1), 1, 1, train=train)
     c1o = _cbr(sd, h + '.c1_bottleneck.conv', h + '.c1_bottleneck.bn', c1, train=train)
-    up = F.interpolate(features, size=c1o.shape[2:], mode='bilinear', align_corners=False)
+    up = _cap(h + '.up', F.interpolate(features, size=c1o.shape[2:], mode='bilinear', align_corners=False))
     o = torch.cat([up, c1o], 1)
     o = _dwsep(sd, h + '.sep_bottleneck.0', o, 1, train)
     o = _dwsep(sd, h + '.sep_bottleneck.1', o, 1, train)
     if drop_mask is not None:
         o = o * drop_mask
-    logits = F.conv2d(o, sd[h + '.conv_seg.weight'], sd[h + '.conv_seg.bias'])
+    logits = _cap(h + '.conv_seg', F.conv2d(o, sd[h + '.conv_seg.weight'], sd[h + '.conv_seg.bias']))
     return logits, features
 
 
@@ -181,7 +192,7 @@ def aux_head_forward(sd, feats, train=True, drop_mask=None, pre=''):
     o = _cbr(sd, a + '.convs.0.conv', a + '.convs.0.bn', feats[2], 1, 1, train=train)
     if drop_mask is not None:
         o = o * drop_mask
-    return F.conv2d(o, sd[a + '.conv_seg.weight'], sd[a + '.conv_seg.bias'])
+    return _cap(a + '.conv_seg', F.conv2d(o, sd[a + '.conv_seg.weight'], sd[a + '.conv_seg.bias']))
 
 
 # ---------------------------------------------------------------------------

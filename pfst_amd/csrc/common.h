@@ -65,16 +65,24 @@ __device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 do
   return r;
 }
 
-// torch's area_pixel_compute_source_index for bilinear, align_corners=False
-// (ATen/native/UpSample.h): src = max(0, scale*(dst+0.5)-0.5)
+// torch's area_pixel_compute_source_index for bilinear, align_corners=False (ATen/native/UpSample.h):
+// src = max(0, scale*(dst+0.5)-0.5).  The arithmetic is PINNED (explicit fma / rn intrinsics, immune to -ffp-contract) to
+// what torch's kernels evaluate, determined bit-for-bit against F.interpolate (tests/test_hip_ops.py): the source index is one
+// fma, the four-tap blend is t = fma(lx0, v00, lx1*v01); out = fma(ly0, t0, ly1*t1).  The pseudo-label index map depends
+// on these roundings wherever two classes tie to within an ulp.
 __device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
-  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  float s = __fmaf_rn(scale, __fadd_rn((float)dst, 0.5f), -0.5f);
   s = s < 0.f ? 0.f : s;
   i0 = (int)s;
   if (i0 > in_size - 1) i0 = in_size - 1;
   i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-  l1 = s - (float)i0;
-  l0 = 1.f - l1;
+  l1 = __fsub_rn(s, (float)i0);
+  l0 = __fsub_rn(1.f, l1);
+}
+__device__ __forceinline__ float bilin_blend(float v00, float v01, float v10, float v11, float lx0, float lx1, float ly0, float ly1) {
+  const float t0 = __fmaf_rn(lx0, v00, __fmul_rn(lx1, v01));
+  const float t1 = __fmaf_rn(lx0, v10, __fmul_rn(lx1, v11));
+  return __fmaf_rn(ly0, t0, __fmul_rn(ly1, t1));
 }
 
 // internal (not part of the C ABI): K-quad weight-gradient fast path, conv_wgrad_q.hip

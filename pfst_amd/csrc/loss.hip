@@ -21,8 +21,7 @@ __device__ __forceinline__ Bilin make_bilin(int oy, int ox, float sh, float sw, 
   return b;
 }
 __device__ __forceinline__ float interp(const float* __restrict__ p, int w, const Bilin& b) {
-  return b.ly0 * (b.lx0 * p[b.y0 * w + b.x0] + b.lx1 * p[b.y0 * w + b.x1]) +
-         b.ly1 * (b.lx0 * p[b.y1 * w + b.x0] + b.lx1 * p[b.y1 * w + b.x1]);
+  return bilin_blend(p[b.y0 * w + b.x0], p[b.y0 * w + b.x1], p[b.y1 * w + b.x0], p[b.y1 * w + b.x1], b.lx0, b.lx1, b.ly0, b.ly1);
 }
 
 // grid: (blocks over H*W, N).  One thread per full-resolution pixel.
@@ -112,11 +111,14 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
-// grid: (blocks over H*W, N)
+// grid: (blocks over H*W, N).  The reference's rule (pfgst.py:259-261): p = softmax(z) = exp(z - max) / sum (torch's softmax
+// arithmetic: sequential fp32 sum over the classes, IEEE division), then torch.max over p -- the FIRST class whose ROUNDED
+// probability equals the maximum wins.  That differs from the arg-max of z whenever two distinct logits give probabilities
+// that round to the same float (flat early-training logits), so the comparison is made on p, not on z.
 __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restrict__ logits, int C, int h, int w, int H, int W,
                                                            float sh, float sw, float thr, long long* __restrict__ l64,
                                                            unsigned char* __restrict__ l8, unsigned long long* __restrict__ count,
-                                                           float* __restrict__ conf) {
+                                                           float* __restrict__ conf, float* __restrict__ prob) {
   __shared__ double sm[16];
   const int n = blockIdx.y;
   const float* lp = logits + (i64)n * C * h * w;
@@ -126,16 +128,18 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
     const int oy = p / W, ox = p - oy * W;
     const Bilin b = make_bilin(oy, ox, sh, sw, h, w);
     float mx = -INFINITY;
-    int arg = 0;
-    for (int c = 0; c < C; ++c) {
-      const float z = interp(lp + (i64)c * hw, w, b);
-      if (z > mx) { mx = z; arg = c; }   // strict '>' keeps the FIRST maximum like torch.max
-    }
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, interp(lp + (i64)c * hw, w, b));
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
-    const float pmax = 1.f / se;         // softmax value of the arg-max class
+    float pmax = -1.f;
+    int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float pc = __fdiv_rn(expf(interp(lp + (i64)c * hw, w, b) - mx), se);
+      if (pc > pmax) { pmax = pc; arg = c; }   // strict '>' keeps the FIRST maximal probability like torch.max
+    }
     if (pmax >= thr) cnt += 1.0;
     if (conf) conf[(i64)n * H * W + p] = pmax >= thr ? 1.f : 0.f;     // thre_type='part' (pfgst.py:267-268)
+    if (prob) prob[(i64)n * H * W + p] = pmax;
     if (l64) l64[(i64)n * H * W + p] = arg;
     if (l8) l8[(i64)n * H * W + p] = (unsigned char)arg;
   }
@@ -248,12 +252,12 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
 
 extern "C" int pfst_pseudo_label(const float* logits, int N, int C, int h, int w, int H, int W, float threshold,
                                  long long* label_i64, unsigned char* label_u8, unsigned long long* count, float* conf_mask,
-                                 pfst_stream_t stream) {
+                                 float* max_prob, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && (label_i64 || label_u8) && count && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(count, 0, sizeof(unsigned long long), s) != hipSuccess) return PFST_ERR_LAUNCH;
   hipLaunchKernelGGL(pseudo_label_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, logits, C, h, w, H, W,
-                     (float)h / (float)H, (float)w / (float)W, threshold, label_i64, label_u8, count, conf_mask);
+                     (float)h / (float)H, (float)w / (float)W, threshold, label_i64, label_u8, count, conf_mask, max_prob);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -122,7 +122,7 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ x, i64 x_bs, fl
     float ly0, ly1, lx0, lx1;
     bilin_src(oy, sh, Hi, y0, y1, ly0, ly1);
     bilin_src(ox, sw, Wi, x0, x1, lx0, lx1);
-    const float v = ly0 * (lx0 * xp[y0 * Wi + x0] + lx1 * xp[y0 * Wi + x1]) + ly1 * (lx0 * xp[y1 * Wi + x0] + lx1 * xp[y1 * Wi + x1]);
+    const float v = bilin_blend(xp[y0 * Wi + x0], xp[y0 * Wi + x1], xp[y1 * Wi + x0], xp[y1 * Wi + x1], lx0, lx1, ly0, ly1);
     yp[o] = v;
   }
 }

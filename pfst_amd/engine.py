@@ -52,17 +52,32 @@ class Var:
 
 
 class Tape:
-    """Closures recorded in forward order, executed in reverse; None tape = no-grad (teacher) mode."""
+    """Closures recorded in forward order, executed in reverse; None tape = no-grad (teacher) mode.
 
-    def __init__(self):
+    Every closure may carry a `tag` (op name + the Vars it reads / writes); `observer(tag, phase)` is called with phase
+    'pre' / 'post' around each tagged closure during backward().  The product never sets an observer; the per-link backward
+    parity test uses it to feed every closure of the network AS WIRED the oracle's upstream gradient."""
+
+    def __init__(self, observer=None):
         self.fns = []
+        self.observer = observer
 
-    def record(self, fn):
-        self.fns.append(fn)
+    def record(self, fn, tag=None):
+        self.fns.append((fn, tag))
+
+    def pop(self):
+        return self.fns.pop()
 
     def backward(self):
+        obs = self.observer
         while self.fns:
-            self.fns.pop()()
+            fn, tag = self.fns.pop()
+            if obs is not None and tag is not None:
+                obs(tag, 'pre')
+                fn()
+                obs(tag, 'post')
+            else:
+                fn()
 
 
 class ParamArena:

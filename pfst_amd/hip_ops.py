@@ -512,8 +512,8 @@ def ce_finalize(acc, numel, loss_weight):
     return out
 
 
-def pseudo_label(logits, size, threshold, want_i64=True, want_conf=False):
-    """-> (label int64 [N,H,W] | None, label uint8 [N,H,W], count uint64-as-int64 [1][, conf float [N,H,W]])"""
+def pseudo_label(logits, size, threshold, want_i64=True, want_conf=False, want_prob=False):
+    """-> (label int64 [N,H,W] | None, label uint8 [N,H,W], count uint64-as-int64 [1][, conf float [N,H,W]][, max prob float [N,H,W]])"""
     _dense(logits)
     n, c, h, w = logits.shape
     H, W = size
@@ -521,8 +521,15 @@ def pseudo_label(logits, size, threshold, want_i64=True, want_conf=False):
     l8 = torch.empty(n, H, W, dtype=U8, device=logits.device)
     cnt = torch.empty(1, dtype=I64, device=logits.device)
     conf = torch.empty(n, H, W, device=logits.device) if want_conf else None
-    call('pfst_pseudo_label', logits.data_ptr(), n, c, h, w, H, W, float(threshold), _p(l64), l8.data_ptr(), cnt.data_ptr(), _p(conf), _stream())
-    return (l64, l8, cnt, conf) if want_conf else (l64, l8, cnt)
+    prob = torch.empty(n, H, W, device=logits.device) if want_prob else None
+    call('pfst_pseudo_label', logits.data_ptr(), n, c, h, w, H, W, float(threshold), _p(l64), l8.data_ptr(), cnt.data_ptr(), _p(conf),
+         _p(prob), _stream())
+    res = (l64, l8, cnt)
+    if want_conf:
+        res += (conf,)
+    if want_prob:
+        res += (prob,)
+    return res
 
 
 def label_presence(label_u8):

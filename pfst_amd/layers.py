@@ -191,7 +191,7 @@ def conv_forward(x, conv, tape, out=None):
             dy = yv.grad
             conv_backward(x, conv, dy, saved_v)
             yv.free_grad()
-        tape.record(bwd)
+        tape.record(bwd, dict(op='conv', conv=conv, x=x, out=yv))
     return yv
 
 
@@ -329,5 +329,5 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         conv_backward(x, conv, dpre, saved_v)
         if yv.parent is None:
             yv.free_grad()
-    tape.record(bwd)
+    tape.record(bwd, dict(op='conv_bn_act', conv=conv, bn=bn, x=x, residual=residual, relu=relu, out=yv))
     return yv

@@ -105,7 +105,7 @@ class ResNetV1c(nn.Module):
             def bwd_pool():
                 xin._grad = ops.maxpool_bwd(pooled.grad, idx, xin.data.shape[-2:])
                 pooled.free_grad()
-            tape.record(bwd_pool)
+            tape.record(bwd_pool, dict(op='maxpool', name='backbone.maxpool', x=xin, out=pooled))
         outs = []
         for i, name in enumerate(self.res_layers):
             for blk in getattr(self, name):
@@ -180,7 +180,8 @@ class CrossEntropyLoss(nn.Module):
             def bwd():
                 buf, accf = logits.grad_target()
                 ops.ce_upsample_bwd(ld, label_u8, lse, scale, weight, cw, ignore_index, out=buf, accumulate=accf)
-            tape.record(bwd)
+            tape.record(bwd, dict(op='ce', x=logits, out=None, label=label_u8, weight=weight, class_weight=self.class_weight,
+                                  loss_weight=grad_scale * self.loss_weight, ignore_index=ignore_index))
         return out
 
 
@@ -220,7 +221,7 @@ class BaseDecodeHead(nn.Module):
                 def bwd():
                     src._grad = ops.channel_scale(dropped.grad, mask)
                     dropped.free_grad()
-                tape.record(bwd)
+                tape.record(bwd, dict(op='channel_scale', x=src, out=dropped, mask=mask))
         return conv_forward(feat, self.conv_seg, tape)
 
     def losses(self, seg_logit, seg_label_u8, seg_weight, tape, grad_scale=1.0):
@@ -277,7 +278,8 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
                 ops.broadcast_hw(pooled.grad, buf, 1.0 / hw, True)
                 pooled.free_grad()
             # order on the tape: gap-backward must run AFTER the image_pool conv's backward, pool-broadcast before it
-            self._reorder_pool(tape, bwd_gap, bwd_pool)
+            self._reorder_pool(tape, (bwd_gap, dict(op='gap', name='decode_head.gap', x=x, out=pooled)),
+                               (bwd_pool, dict(op='broadcast', name='decode_head.image_pool.up', x=pa, out=cat.slice(0, ch))))
         self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
         for i in range(1, len(self.dilations)):
             self.aspp_modules[i](x, tape, out=cat.slice((i + 1) * ch, (i + 2) * ch))
@@ -290,7 +292,7 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
             def bwd_up():
                 buf, acc = feats.grad_target()
                 ops.resize_bilinear_bwd(cat2.grad[:, 0:ch], (h, w), out=buf, accumulate=acc)
-            tape.record(bwd_up)
+            tape.record(bwd_up, dict(op='resize', name='decode_head.up', x=feats, out=cat2.slice(0, ch)))
         self.c1_bottleneck(c1, tape, out=cat2.slice(ch, ch + self.c1_channels))
         o = self.sep_bottleneck[0](cat2, tape)
         o = self.sep_bottleneck[1](o, tape)
@@ -301,10 +303,10 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
     def _reorder_pool(tape, bwd_gap, bwd_pool):
         # forward recorded: [..., image_pool ConvModule closure]; we need tape order
         # [bwd_gap, conv closure, bwd_pool] so that reverse execution is pool -> conv -> gap.
-        conv_closure = tape.fns.pop()
-        tape.record(bwd_gap)
-        tape.record(conv_closure)
-        tape.record(bwd_pool)
+        conv_closure = tape.pop()
+        tape.record(*bwd_gap)
+        tape.record(*conv_closure)
+        tape.record(*bwd_pool)
 
 
 @HEADS.register_module()

@@ -419,6 +419,67 @@ def test_pseudo_label_bit_exact(ops):
     assert abs(int(cnt.item()) - int((prob >= 0.9).sum())) <= 2   # 1-ulp threshold ties only
 
 
+def _near_tie_logits(C, h, seed, mags):
+    """logits whose two best classes are 0, 1 or 2 ulp apart, in both index orders, at the given magnitudes; a quarter of the
+    pixels have ALL classes equal.  (flat early-training teacher logits produce exactly these situations)"""
+    gen = g(seed)
+    n = 2
+    base = torch.randn(n, C, h, h, generator=gen) * 0.5
+    t = torch.tensor(mags)[torch.randint(0, len(mags), (n, 1, h, h), generator=gen)]
+    a = torch.randint(0, C, (n, 1, h, h), generator=gen)
+    b = (a + torch.randint(1, C, (n, 1, h, h), generator=gen)) % C            # b < a and b > a both occur
+    k = torch.randint(0, 4, (n, 1, h, h), generator=gen)
+    z = (t - 3.0 - base.abs()).clone()
+    z.scatter_(1, a, t)
+    zb = t.clone()
+    down = t
+    for kk in (1, 2):
+        down = torch.nextafter(down, torch.full_like(down, -float('inf')))
+        zb = torch.where(k == kk, down, zb)
+    z.scatter_(1, b, zb)
+    return torch.where(k == 3, t.expand_as(z), z).contiguous(), k
+
+
+@pytest.mark.parametrize('C', [2, 6, 33])
+@pytest.mark.parametrize('up', [1, 4])
+def test_pseudo_label_tie_rule_is_softmax_then_max(ops, C, up):
+    """pfgst.py:259-261: `torch.max(torch.softmax(logits, 1), 1)` -- the FIRST class whose rounded PROBABILITY is maximal, which
+    is not the arg-max of the logits when distinct logits give equal probabilities.  Adversarial near-tie logits (top two 0 / 1 / 2
+    ulp apart in both index orders, all-equal pixels), without and with the fused bilinear up-sampling.
+    Bit-exact against torch's own softmax->max evaluated with the device's exp (the arithmetic the kernel pins: sequential fp32
+    sum, IEEE division; probabilities agree to 0 ulp).  Against torch-CPU the map may differ ONLY where torch's CPU and GPU builds
+    differ from each other (the CPU softmax uses Sleef's 2-ulp vector exp; measured: <= 8 of 8192 adversarial pixels)."""
+    h = 32
+    for mags in ([0.01, 0.1, 0.5], [1.0, 3.0, 7.5], [-0.02, -1.0, -6.0], [0.003, 20.0, -40.0]):
+        z, k = _near_tie_logits(C, h, 11 + C, mags)
+        H = h * up
+        zu = z if up == 1 else F.interpolate(z, size=(H, H), mode='bilinear', align_corners=False)
+        if up > 1:
+            mine = ops.resize_bilinear(z.to(DEV), (H, H)).cpu()
+            assert torch.equal(mine, zu), 'bilinear up-sampling must reproduce F.interpolate bit for bit (power-of-two scale)'
+        p_cpu, l_cpu = torch.max(torch.softmax(zu, 1), 1)
+        p_dev, l_dev = torch.max(torch.softmax(zu.to(DEV), 1), 1)
+        l64, l8, cnt, prob = ops.pseudo_label(z.to(DEV), (H, H), 0.5, want_prob=True)
+        assert torch.equal(l64.cpu(), l_dev.cpu()), f'C={C} mags={mags}: label map differs from torch.max(torch.softmax) on {int((l64.cpu() != l_dev.cpu()).sum())} pixels'
+        assert torch.equal(prob.cpu(), p_dev.cpu()), 'max probability must equal torch softmax bit for bit'
+        assert int(cnt.item()) == int((p_dev >= 0.5).sum())
+        diff_cpu = l64.cpu() != l_cpu
+        assert bool((diff_cpu <= (l_dev.cpu() != l_cpu)).all()) and int(diff_cpu.sum()) <= 16
+        if up == 1:
+            assert bool((l64.cpu()[k[:, 0] == 3] == 0).all()), 'all-equal logits: the first class wins'
+            # the rule matters: the arg-max of the logits is a different map on these inputs
+            if mags[0] in (0.01, -0.02):
+                assert int((z.argmax(1) != l_cpu).sum()) > 100
+
+
+@pytest.mark.parametrize('hi,ho', [(32, 64), (32, 128), (16, 128), (33, 100), (24, 96)])
+def test_resize_bilinear_bit_exact(ops, hi, ho):
+    """the up-sampling arithmetic is pinned to torch's (source index = one fma; blend = fma(lx0, v00, lx1*v01), fma(ly0, t0, ly1*t1))"""
+    x = torch.randn(2, 5, hi, hi, generator=g(hi)) * 3
+    ref = F.interpolate(x, size=(ho, ho), mode='bilinear', align_corners=False)
+    assert torch.equal(ops.resize_bilinear(x.to(DEV), (ho, ho)).cpu(), ref)
+
+
 def test_class_mix_exact(ops):
     n, S = 3, 32
     gt = torch.randint(0, 6, (n, 1, S, S), generator=g(1))

@@ -35,6 +35,14 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+def assert_elementwise(a, ref, what, rtol=TOL, atol_rel=1e-4):
+    """element-wise mixed bound |a - ref| <= atol_rel * max|ref| + rtol * |ref| (beside the norm-wise `rel`)"""
+    a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+    bound = atol_rel * float(ref.abs().max()) + rtol * ref.abs()
+    worst = float(((a - ref).abs() / bound).max())
+    assert worst <= 1.0, f'{what}: worst element at {worst:.2f}x the bound'
+
+
 @pytest.fixture(params=['f32', 'bf16x6'])
 def conv_math(request):
     """run the end-to-end parity under both convolution arithmetics (fp32 MFMA default; fp32-faithful bf16 split)"""
@@ -96,6 +104,10 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
         assert rel(dbg['src_logits'], ex['src_logits']) < TOL
         assert rel(dbg['mix_logits'], ex['mix_logits']) < TOL
         assert rel(dbg['ema_dec'], ex['ema_dec']) < TOL
+        assert_elementwise(dbg['src_logits'], ex['src_logits'], 'source logits')
+        assert_elementwise(dbg['mix_logits'], ex['mix_logits'], 'mixed-pass logits')
+        assert_elementwise(dbg['ema_logits'], ex['ema_logits_low'], 'teacher logits')
+        assert_elementwise(dbg['ema_dec'], ex['ema_dec'], 'teacher decoded features')
         assert rel(dbg['mixed_w'], ex['mixed_w']) < 1e-5
         for k in olog:
             assert abs(lv[k] - olog[k]) <= TOL * max(abs(olog[k]), 1e-2), (it, k, lv[k], olog[k])
