@@ -47,12 +47,18 @@ WORKLOADS = {
     'pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8': dict(num_classes=6, in_channels=3, size=1024, per_gpu_batch=8, downscale=0.5),
     'pfst_vaih_irrg2pots_irrg_deeplabv3plus_r50-d8': dict(num_classes=6, in_channels=3, size=1024, per_gpu_batch=8, downscale=0.5),
     'pfst_inria_da_deeplabv3plus_r50-d8': dict(num_classes=2, in_channels=3, size=1024, per_gpu_batch=8, downscale=0.5),
-    'pfst_season_net_sp2fa_deeplabv3plus_r50-d8': dict(num_classes=33, in_channels=10, size=512, per_gpu_batch=8, downscale=1),
+    'pfst_season_net_sp2fa_deeplabv3plus_r50-d8': dict(num_classes=33, in_channels=10, size=512, per_gpu_batch=8, downscale=1,
+                                                       strong_aug_denorm_type='none'),
 }
 
 
 def workload_cfg(name, **overrides):
     w = dict(WORKLOADS[name])
     cfg = uda_cfg(w['num_classes'], w['in_channels'], downscale=w['downscale'])
+    if 'strong_aug_denorm_type' in w:                   # configs/pfst/pfst_season_net_sp2fa_*.py:53
+        cfg['strong_aug_denorm_type'] = w['strong_aug_denorm_type']
+    in_channels = overrides.pop('in_channels', None)    # e.g. the SHIPPED 3-band SeasonNet variant of BASELINE config #5
+    if in_channels is not None:
+        cfg['model']['backbone']['in_channels'] = w['in_channels'] = in_channels
     cfg.update(overrides)
     return copy.deepcopy(cfg), w

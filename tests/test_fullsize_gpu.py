@@ -218,3 +218,108 @@ def test_whole_train_step_at_baseline_size():
         assert abs(outs[0][k] - outs[1][k]) <= 1e-4 * max(1.0, abs(outs[0][k])), k     # reproducible given the RNG state
     rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
     assert rel < 5e-2, rel    # fp32 atomics reorder + random-init conditioning; identical inputs, no logic differences
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs #4 (INRIA, C=2 @1024^2) and #5 (SeasonNet, C=33, 10 bands, downscale=1 @512^2) at their per-GPU size b=8
+# (VERDICT r1 'What's weak' #4): one whole train step each + the kernel identities that depend on C / Cin.
+# ---------------------------------------------------------------------------------------------------------------------------
+OTHER_WORKLOADS = [('pfst_inria_da_deeplabv3plus_r50-d8', None), ('pfst_season_net_sp2fa_deeplabv3plus_r50-d8', None),
+                   ('pfst_season_net_sp2fa_deeplabv3plus_r50-d8', 3)]      # the last one: the 3-band config as shipped
+
+
+@pytest.mark.parametrize('name,bands', OTHER_WORKLOADS)
+def test_whole_train_step_inria_and_seasonnet_at_per_gpu_size(name, bands):
+    import pfst_amd  # noqa: F401
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import OPTIMIZER, workload_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import fill_state_dict, synth_batch
+    over = dict(pseudo_threshold=0.6 if 'inria' in name else 0.05)
+    if bands is not None:
+        over['in_channels'] = bands
+    cfg, w = workload_cfg(name, **over)
+    logs = []
+    for rep in range(2):
+        model = UDA.build(cfg)
+        sd = model.state_dict()
+        fill_state_dict(sd, 0)
+        w0 = sd['model.backbone.stem.0.weight'].clone()
+        assert w0.shape[1] == w['in_channels']
+        model.cuda()
+        opt = build_optimizer(model, OPTIMIZER)
+        batch = synth_batch(w['per_gpu_batch'], w['size'], w['num_classes'], cin=w['in_channels'], seed=1234, device='cuda')
+        random.seed(0); np.random.seed(0); torch.manual_seed(0)
+        out = model.train_step(batch, opt)
+        lv = out['log_vars']
+        assert len(lv) == 14 and all(np.isfinite(v) for v in lv.values()), lv
+        assert out['num_samples'] == w['per_gpu_batch'] == 8
+        a, t = model.student_arena, model._teacher_arena
+        assert bool(torch.isfinite(a.grad).all()) and float(a.grad.abs().sum()) > 0
+        # EMA == the student's weights of step 0 (pfgst.py:105-113); the student has moved by one AdamW step since
+        assert torch.equal(t.view(t.data, 'backbone.stem.0.weight').cpu(), w0)
+        assert not torch.equal(a.view(a.data, 'backbone.stem.0.weight').cpu(), w0)
+        assert 0.0 < lv['decode.loss_ce'] < 2.0 * np.log(w['num_classes']) + 1.0
+        assert lv['loss_sim_pos'] != 0.0 and lv['loss_sim_neg'] != 0.0      # the PFGSTLoss target region is not empty
+        logs.append(lv)
+        del model, opt, batch
+        torch.cuda.empty_cache()
+    for k in logs[0]:
+        assert abs(logs[0][k] - logs[1][k]) <= 1e-4 * max(1.0, abs(logs[0][k])), k     # reproducible given the RNG state
+
+
+@pytest.mark.parametrize('C,h,S', [(2, 256, 1024), (33, 128, 512)])
+def test_ce_and_pseudo_label_properties_other_class_counts(ops, C, h, S):
+    g = torch.Generator(device='cuda').manual_seed(50 + C)
+    logits = torch.randn(B, C, h, h, device='cuda', generator=g) * 2
+    label = torch.randint(0, C, (B, S, S), device='cuda', generator=g, dtype=torch.int64)
+    label[:, :8, :8] = 255
+    l8 = ops.to_u8(label)
+    w = torch.rand(B, S, S, device='cuda', generator=g)
+    lse, acc = ops.ce_upsample_fwd(logits, l8, w)
+    dl = ops.ce_upsample_bwd(logits, l8, lse, 1.0 / (B * S * S), w)
+    assert float(dl.double().sum(1).abs().max()) < 1e-6 * float(dl.abs().max()) + 1e-12   # softmax - onehot sums to 0 over C classes
+    assert 0 < float(acc[0] / (B * S * S)) < 10 and int(acc[2]) == B * S * S - B * 64
+    l64, l8p, cnt, prob = ops.pseudo_label(logits, (S, S), 0.0, want_prob=True)
+    assert int(cnt) == B * S * S and int(l64.max()) < C and torch.equal(l64, l8p.long())
+    up = torch.nn.functional.interpolate(logits[:1].cpu(), size=(S, S), mode='bilinear', align_corners=False)
+    p_ref, l_ref = up.softmax(1).max(1)
+    assert torch.equal(l64[0].cpu(), l_ref[0]), 'pseudo-label map bit-exact vs torch (CPU) on one full-size image'
+    # the probability itself: same definition, torch-CPU evaluates exp with Sleef's 2-ulp vector routine -> a few ulp
+    ulp = (prob[0].cpu().view(torch.int32).long() - p_ref[0].view(torch.int32).long()).abs().max()
+    assert int(ulp) <= 64, int(ulp)
+
+
+def test_ten_band_stem_adjoint_at_512(ops):
+    """config #5's generic-K stem kernel (Cin = 10, stride 2) at its real size: <conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)>"""
+    g = torch.Generator(device='cuda').manual_seed(9)
+    ci, co, hw = 10, 32, 512
+    x = torch.randn(B, ci, hw, hw, device='cuda', generator=g)
+    w = torch.randn(co, ci, 3, 3, device='cuda', generator=g) * 0.1
+    wf, wd = ops.pack_weight(w)
+    y = ops.conv_fprop(x, wf, co, 3, 2, 1, 1)
+    assert tuple(y.shape) == (B, co, 256, 256)
+    dy = torch.randn(y.shape, device='cuda', generator=g)
+    dx = ops.conv_dgrad(dy, wd, ci, (hw, hw), 3, 2, 1, 1)
+    dw = torch.zeros_like(w)
+    ops.conv_wgrad_(dw, x, dy, 3, 2, 1, 1)
+    lhs = dot(y, dy)
+    close(lhs, dot(x, dx), 2e-4)
+    close(lhs, dot(w, dw), 2e-4)
+    ref = torch.nn.functional.conv2d(x[:1].cpu().double(), w.cpu().double(), None, 2, 1)
+    assert float((y[:1].cpu().double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+def test_pfgst_loss_nearest_upsample_path_at_seasonnet_size(ops):
+    """downscale=1 (config #5): the 1/8 features are replicated 2x2 onto the 1/4 logit grid (128^2 at S=512, b=8).  The HIP
+    path computes the similarity at the source resolution with dilation d/2 and replicates the 9-channel map; here against the
+    literal formulation (nearest up-sampling of the FEATURES, then the dilation-d similarity) built from the same kernels."""
+    g = torch.Generator(device='cuda').manual_seed(12)
+    feat = torch.randn(B, 512, 64, 64, device='cuda', generator=g)
+    sim_lo, _ = ops.sim_map(feat, 1)
+    sim_a = ops.upsample_nearest(sim_lo, 2)
+    sim_b, _ = ops.sim_map(ops.upsample_nearest(feat, 2), 2)
+    assert float((sim_a - sim_b).abs().max()) < 2e-6
+    gs = torch.randn(sim_a.shape, device='cuda', generator=g)
+    # adjoint of the replication: <up(s), g> = <s, up^T(g)>
+    close(dot(sim_a, gs), dot(sim_lo, ops.upsample_nearest_bwd(gs, 2)), 1e-5)
