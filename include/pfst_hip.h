@@ -32,6 +32,17 @@ int pfst_axpy_f32(float* y, const float* x, float alpha, long long n, pfst_strea
 int pfst_i64_to_u8(const long long* src, unsigned char* dst, long long n, pfst_stream_t stream);
 int pfst_u8_to_i64(const unsigned char* src, long long* dst, long long n, pfst_stream_t stream);
 
+/* fused BatchNorm-backward sums of a data-gradient launch, see pfst_conv_igemm */
+typedef struct pfst_bnb_fuse {
+  const float* x;            /* pre-BN tensor [N][M][P] of the layer that owns the gradient being written */
+  long long x_bs;            /* its batch stride (elements) */
+  const float* y;            /* that layer's output: ReLU gate = y > 0 (residual layers); NULL: gate recomputed from x as bn_apply did */
+  long long y_bs;
+  const float* coef;         /* [M][4] = (mean, invstd, sc, sh) of that layer as pfst_bn_finalize_partials / pfst_bn_stats wrote them */
+  float* partials;           /* out: [M][T][2] = (sum dz, sum dz * x) per channel and slot */
+  int relu;
+} pfst_bnb_fuse_t;
+
 /* ---- dense convolution as implicit GEMM on fp32 MFMA (F.conv2d, groups=1) ---------------
  * resnet.py:169-209 (Bottleneck 1x1/3x3), resnet.py:593-624 (stem), aspp_head.py:32-42,85-92,
  * fcn_head.py:40-49, decode_head.py:242-247 (conv_seg), mmcv pointwise convs. */
@@ -43,7 +54,13 @@ int pfst_conv_pack_weight(const float* w, float* wk_fprop, float* wk_dgrad, int 
  * ksize in {1,3}; accumulate != 0 adds into `out`. */
 int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
                     int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                    int mode, int accumulate, float* stats, pfst_stream_t stream);
+                    int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb, pfst_stream_t stream);
+/* Fused BatchNorm-BACKWARD sums (bnb != NULL, data-gradient launches): when `out` is the COMPLETE gradient dL/dy of a
+ * conv -> BN(train) -> [+residual] -> ReLU layer's output (this launch is the last writer of that buffer; with accumulate != 0 the
+ * sums are taken over old + new), the epilogue also writes per-channel partials of  S1 = sum dz,  S2' = sum dz * x  (dz = dy * ReLU gate)
+ * to bnb->partials[M][N * pfst_conv_stats_slots(M, Ho, Wo)][2]; pfst_bn_backward then skips its reduction pass (torch's
+ * native_batch_norm_backward makes the same two sums).  Needs C % 16 == 0, M a multiple of the row tile (128 for M > 64, else 64 / 32),
+ * no bias, stats == NULL; returns PFST_ERR_ARG otherwise (the caller then simply does not fuse). */
 /* Fused BatchNorm statistics: if `stats` != NULL the epilogue also writes per-channel partial (sum, sum of squares)
  * pairs to stats[M][N * pfst_conv_stats_slots(M, Ho, Wo)][2] (fp32, no atomics); reduce them with
  * pfst_bn_finalize_partials.  Saves the separate full-tensor read of pfst_bn_stats. */
@@ -108,10 +125,14 @@ int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long l
 /* batch mean / 1/sqrt(biased var + eps) per channel; updates running stats (unbiased var) when
  * running_mean != NULL.  ws: >= 2*C doubles of scratch. */
 int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
-                  float* running_mean, float* running_var, float momentum, float eps, double* ws, pfst_stream_t stream);
+                  float* running_mean, float* running_var, float momentum, float eps, double* ws,
+                  const float* gamma, const float* beta, float* coef, pfst_stream_t stream);
+/* coef != NULL (needs gamma, beta): also writes coef[C][4] = (mean, invstd, sc = invstd*gamma, sh = beta - mean*sc), the per-channel
+ * record the fused BatchNorm-backward sums of a data-gradient launch read (pfst_bnb_fuse_t) */
 /* the same from the conv epilogue's partials[C][T][2] (count = N*H*W elements per channel) */
 int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
-                              float* running_mean, float* running_var, float momentum, float eps, pfst_stream_t stream);
+                              float* running_mean, float* running_var, float momentum, float eps,
+                              const float* gamma, const float* beta, float* coef, pfst_stream_t stream);
 /* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).  relu_mask != NULL (needs relu, HW % 256 == 0, 16-byte aligned planes):
  * also writes the ReLU gate as a bitmask of N*C*HW/64 words for pfst_bn_backward -- the backward of a residual layer then reads
  * 1 bit per element instead of the fp32 output y in both of its passes. */
@@ -126,7 +147,9 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                      float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                      float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                     double* ws, pfst_stream_t stream);
+                     double* ws, const float* bwd_partials, int bwd_slots, pfst_stream_t stream);
+/* bwd_partials != NULL: (sum dz, sum dz*x) were already produced by the launch that wrote dy (pfst_bnb_fuse_t, [C][bwd_slots][2]); the
+ * reduction pass over dy and x is skipped and only the partials are summed (fp64). */
 
 /* ---- pooling / resize ---------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:638); idx holds the winning tap 0..8 */

@@ -41,9 +41,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
 }
 
+// coef[c] = (mean, invstd, sc, sh): what the fused BatchNorm-backward sums of a data-gradient launch read (pfst_bnb_fuse_t)
+__device__ __forceinline__ void write_coef(float4* __restrict__ coef, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                           int c, float mean, float invstd) {
+  if (!coef) return;
+  float sc, sh;
+  bn_affine(mean, invstd, gamma[c], beta[c], sc, sh);
+  coef[c] = make_float4(mean, invstd, sc, sh);
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double count, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar,
-                                   float momentum, float eps) {
+                                   float momentum, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float4* __restrict__ coef) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double m = ws[2 * c] / count;
@@ -51,6 +61,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double 
   if (var < 0.0) var = 0.0;
   mean[c] = (float)m;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  write_coef(coef, gamma, beta, c, mean[c], invstd[c]);
   if (rmean) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
@@ -62,7 +73,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double 
 __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ part, int T, double count,
                                                                     float* __restrict__ mean, float* __restrict__ invstd,
                                                                     float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                    float momentum, float eps) {
+                                                                    float momentum, float eps, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float4* __restrict__ coef) {
   __shared__ double sm[16];
   const int c = blockIdx.x;
   const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    write_coef(coef, gamma, beta, c, mean[c], invstd[c]);
     if (rmean) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
@@ -95,8 +108,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int C, int HW, int relu, unsigned long long* __restrict__ mask) {
   const int c = blockIdx.y, n = blockIdx.z;
-  const float sc = invstd[c] * gamma[c];
-  const float sh = beta[c] - mean[c] * sc;
+  float sc, sh;
+  bn_affine(mean[c], invstd[c], gamma[c], beta[c], sc, sh);
   const float* xp = x + (i64)n * x_bs + (i64)c * HW;
   const float* rp = res ? res + (i64)n * res_bs + (i64)c * HW : nullptr;
   float* yp = y + (i64)n * y_bs + (i64)c * HW;
@@ -105,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const int n4 = HW >> 2;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
       float4 v = reinterpret_cast<const float4*>(xp)[i];
-      v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+      v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh);
       if (rp) {
         const float4 r = reinterpret_cast<const float4*>(rp)[i];
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
   } else {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) {
-      float v = fmaf(xp[i], sc, sh);
+      float v = __fmaf_rn(xp[i], sc, sh);
       if (rp) v += rp[i];
       if (relu) v = fmaxf(v, 0.f);
       yp[i] = v;
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __device__ __forceinline__ bool relu_on(const unsigned long long* __restrict__ mp, const float* __restrict__ yp, int i, float xv,
                                         float sc, float sh) {
   if (mp) return (mp[(i >> 8) * 4 + (i & 3)] >> ((i >> 2) & 63)) & 1ull;
-  return (yp ? yp[i] : fmaf(xv, sc, sh)) > 0.f;
+  return (yp ? yp[i] : __fmaf_rn(xv, sc, sh)) > 0.f;
 }
 
 // ReLU gates of the 4 elements of float4 number i4 of a plane (same sources as relu_on)
@@ -150,7 +163,7 @@ __device__ __forceinline__ void relu_on4(const unsigned long long* __restrict__ 
     const float4 yv = reinterpret_cast<const float4*>(yp)[i4];
     on[0] = yv.x > 0.f; on[1] = yv.y > 0.f; on[2] = yv.z > 0.f; on[3] = yv.w > 0.f;
   } else {
-    on[0] = fmaf(xv.x, sc, sh) > 0.f; on[1] = fmaf(xv.y, sc, sh) > 0.f; on[2] = fmaf(xv.z, sc, sh) > 0.f; on[3] = fmaf(xv.w, sc, sh) > 0.f;
+    on[0] = __fmaf_rn(xv.x, sc, sh) > 0.f; on[1] = __fmaf_rn(xv.y, sc, sh) > 0.f; on[2] = __fmaf_rn(xv.z, sc, sh) > 0.f; on[3] = __fmaf_rn(xv.w, sc, sh) > 0.f;
   }
 }
 
@@ -167,7 +180,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int c = blockIdx.y, n = blockIdx.z;
   const float mu = mean[c], is = invstd[c];
   // ReLU mask: from the saved output y, or (no residual) recomputed bit-identically to bn_apply from x -- saves the y read
-  const float sc = is * gamma[c], sh = (beta ? beta[c] : 0.f) - mu * sc;
+  float sc, sh;
+  bn_affine(mu, is, gamma[c], beta ? beta[c] : 0.f, sc, sh);
   const i64 base = (i64)c * HW;
   const float* gp = dy + (i64)n * dy_bs + base;
   const float* yp = y ? y + (i64)n * y_bs + base : nullptr;
@@ -210,6 +224,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// the two sums from the data-gradient epilogue's partials part[c][T][2] (pfst_bnb_fuse_t) -> ws[2c], ws[2c+1]     grid: C blocks
+// part = (sum dz, sum dz * x):  sum dz * xhat = invstd * (sum dz*x - mean * sum dz), in fp64
+__global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __restrict__ part, int T, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, double* __restrict__ ws) {
+  __shared__ double sm[16];
+  const int c = blockIdx.x;
+  const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
+  double s = 0.0, sx = 0.0;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    const float2 v = p[i];
+    s += (double)v.x;
+    sx += (double)v.y;
+  }
+  s = block_sum_d(s, sm);
+  sx = block_sum_d(sx, sm);
+  if (threadIdx.x == 0) {
+    ws[2 * c] = s;
+    ws[2 * c + 1] = (double)invstd[c] * (sx - (double)mean[c] * s);
+  }
+}
+
 // backward pass 2     grid: (blocks over HW, C, N)
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
@@ -226,7 +261,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
   const double m1 = ws[2 * c] * inv_count, m2 = ws[2 * c + 1] * inv_count;
   const double gs = (double)gamma[c] * (double)is;
-  const float sc = is * gamma[c], sh = (beta ? beta[c] : 0.f) - mu * sc;
+  float sc, sh;
+  bn_affine(mu, is, gamma[c], beta ? beta[c] : 0.f, sc, sh);
   if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
     if (dgamma) dgamma[c] += (float)ws[2 * c + 1];
     if (dbeta) dbeta[c] += (float)ws[2 * c];
@@ -292,7 +328,9 @@ inline void split_for(int HW, int C, int N, int& splits, int& chunk) {
 }  // namespace
 
 extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
-                             float* running_mean, float* running_var, float momentum, float eps, double* ws, pfst_stream_t stream) {
+                             float* running_mean, float* running_var, float momentum, float eps, double* ws,
+                             const float* gamma, const float* beta, float* coef, pfst_stream_t stream) {
+  PFST_CHECK_ARG(!coef || (gamma && beta));
   PFST_CHECK_ARG(x && mean && invstd && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   hipStream_t s = (hipStream_t)stream;
@@ -301,17 +339,19 @@ extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int H
   split_for(HW, C, N, splits, chunk);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C, N), dim3(256), 0, s, x, x_bs, HW, chunk, ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, C, (double)N * HW, mean, invstd, running_mean,
-                     running_var, momentum, eps);
+                     running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
-                                         float* running_mean, float* running_var, float momentum, float eps, pfst_stream_t stream) {
+                                         float* running_mean, float* running_var, float momentum, float eps,
+                                         const float* gamma, const float* beta, float* coef, pfst_stream_t stream) {
   PFST_CHECK_ARG(partials && mean && invstd && T > 0 && C > 0 && count > 0);
+  PFST_CHECK_ARG(!coef || (gamma && beta));
   PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
-                     running_mean, running_var, momentum, eps);
+                     running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -335,12 +375,15 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                                 float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                                double* ws, pfst_stream_t stream) {
+                                double* ws, const float* bwd_partials, int bwd_slots, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0));
   PFST_CHECK_ARG(!relu || relu_mask || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
+  PFST_CHECK_ARG(!bwd_partials || bwd_slots > 0);
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+  const bool fused = bwd_partials != nullptr;      // the sums came out of the launch that produced dy: no reduction pass
+  if (fused) hipLaunchKernelGGL(bn_bwd_partials_kernel, dim3(C), dim3(256), 0, s, bwd_partials, bwd_slots, mean, invstd, ws);
+  else if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
   const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs | dx_bs | (y ? y_bs : 0) | (dres ? dres_bs : 0)) & 3) == 0 &&
@@ -349,13 +392,15 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   if (gx < 1) gx = 1;
   const double inv_count = 1.0 / ((double)N * HW);
   if (vec) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                       beta, HW, chunk, relu, relu_mask, ws);
+    if (!fused)
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
+                         beta, HW, chunk, relu, relu_mask, ws);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws);
   } else {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                       beta, HW, chunk, relu, relu_mask, ws);
+    if (!fused)
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
+                         beta, HW, chunk, relu, relu_mask, ws);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws);
   }

@@ -79,6 +79,12 @@ __device__ __forceinline__ void bilin_src(int dst, float scale, int in_size, int
   l1 = __fsub_rn(s, (float)i0);
   l0 = __fsub_rn(1.f, l1);
 }
+// scale / shift of the normalisation, ONE definition for bn_apply, bn_backward and the fused data-gradient epilogue: the ReLU gate
+// recomputed in backward must be bit-identical to the forward decision, so the roundings are pinned
+__device__ __forceinline__ void bn_affine(float mean, float invstd, float gamma, float beta, float& sc, float& sh) {
+  sc = __fmul_rn(invstd, gamma);
+  sh = __fmaf_rn(-mean, sc, beta);
+}
 __device__ __forceinline__ float bilin_blend(float v00, float v01, float v10, float v11, float lx0, float lx1, float ly0, float ly1) {
   const float t0 = __fmaf_rn(lx0, v00, __fmul_rn(lx1, v01));
   const float t1 = __fmaf_rn(lx0, v10, __fmul_rn(lx1, v11));
@@ -90,6 +96,8 @@ bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs,
 int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int Cout,
                         int Ho, int Wo, int ksize, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s);
 // internal: K-quad implicit-GEMM convolution (Cin % 16 == 0), conv_igemm_q.hip
+struct pfst_bnb_fuse;
+typedef struct pfst_bnb_fuse PfstBnbArgs;   // include/pfst_hip.h: fused BatchNorm-backward sums of a data-gradient launch (null = off)
 int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
                         int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
-                        hipStream_t s);
+                        hipStream_t s, const PfstBnbArgs* bnb = nullptr);

@@ -3,8 +3,18 @@
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (output channel).
 #pragma once
 #include "common.h"
+#include "../../include/pfst_hip.h"
 
 typedef float pfst_f32x16 __attribute__((ext_vector_type(16)));
+
+// Fused BatchNorm-BACKWARD statistics (data-gradient launches).  When the tensor this launch writes is the COMPLETE gradient dL/dy
+// of a conv -> BN(train) -> [+res] -> ReLU layer's output y (the launch is the last writer into that gradient buffer), the epilogue
+// also emits per-block partials of the two reductions BatchNorm backward needs,
+//     S1[c] = sum dz,   S2[c] = sum dz * xhat,     dz = dy * [ReLU gate],  xhat = (x - mean[c]) * invstd[c],
+// from the final (accumulated) values it holds in registers, so the separate two-tensor reduction pass of pfst_bn_backward is
+// dropped (its 2N of HBM reads move into an MFMA-bound kernel whose HBM is idle).  x = the layer's pre-BN tensor; the gate comes
+// from y (> 0) for residual layers, else it is recomputed from x exactly as bn_apply computed it (bn_affine below).
+typedef pfst_bnb_fuse_t PfstBnbArgs;      // include/pfst_hip.h (plain C struct of the ABI); value-initialised = off
 
 // Transposing butterfly over the 32 lanes of each half-wave: every lane enters with NV values (one per accumulator row) and
 // leaves with ONE fully reduced value, lane l holding value index l & (NV-1).  Each step exchanges half of the remaining
@@ -42,15 +52,16 @@ __device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31
   return a[0];
 }
 
-template <int TM, int TN, int WAVES_N, int BN>
-__device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
+// BNB: 0 = off; fused BatchNorm-backward sums with the ReLU gate 1 = recomputed from x, 2 = read from y, 3 = none (layer without ReLU)
+template <int TM, int TN, int WAVES_N, int BN, int BNB = 0>
+__device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
-                                              int wm0, int wn0, int bx, int n, int wid, int lane) {
+                                              int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs()) {
   const int l31 = lane & 31, lh = lane >> 5;
   // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
   // the 32 lanes of each half-wave (transposing butterfly) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
   // reduces the slots in fp64.  Saves the separate full-tensor read of bn_stats.
-  if (stats) {
+  if (BNB == 0 && stats) {           // (the fused-backward variants are launched without forward statistics)
     const int gx = (P + BN - 1) / BN;
     const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
     constexpr int NV = TM * 16;
@@ -86,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
   // Fast path (all rows of this wave's sub-tile inside M, no bias): BUFFER stores -- one voffset per lane and column block
   // (pixel + the half-wave's 4-row shift; ragged pixel tiles use an out-of-range offset that the hardware drops), the row as
   // a SCALAR soffset: no vector arithmetic per element at all.
-  if (!bias && m0 + wm0 + TM * 32 <= M) {
+  if (BNB != 0 || (!bias && m0 + wm0 + TM * 32 <= M)) {     // BNB launches: whole row tiles and no bias (checked on the host)
     constexpr unsigned OOB = 0x80000000u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, M * P * 4, 0x00020000);
     unsigned voff[TN];
@@ -99,7 +110,22 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
     // otherwise every store below (and every accumulate load, each with its own vmcnt(0) wait) is wrapped in a waterfall
     // loop over the 'divergent' soffset -- measured 120-300 k cycles per workgroup.
     const int row0 = m0 + wm0;
-    if (!accumulate) {
+    if (BNB && accumulate) {
+      // the fused BatchNorm-backward sums below need the FINAL gradient: fold the old values into the accumulators first (the
+      // 16 loads of a 32x32 block issued back to back), then take the plain store path
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += old[r];
+        }
+    }
+    if (BNB || !accumulate) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -111,25 +137,76 @@ __device__ __forceinline__ void conv_epilogue(const pfst_f32x16 (&acc)[TM][TN], 
                                                   4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
           }
         }
-      return;
-    }
-    // accumulate: the 16 loads of a 32x32 block are issued back to back, then added and stored (one latency per block, not 64)
+    } else {
+      // accumulate: the 16 loads of a 32x32 block are issued back to back, then added and stored (one latency per block, not 64)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float old[16];
+        for (int j = 0; j < TN; ++j) {
+          float old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+          for (int r = 0; r < 16; ++r)
+            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-        {
-          const float v = acc[i][j][r] + old[r];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
-                                                4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
+          for (int r = 0; r < 16; ++r)
+          {
+            const float v = acc[i][j][r] + old[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
+                                                  4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
+          }
         }
+    }
+    if (BNB) {
+      // S1 = sum dz and the RAW second sum S2' = sum dz * x of the layer that owns this gradient (pfst_bnb_fuse_t); pfst_bn_backward turns
+      // them into sum dz * xhat = invstd * (S2' - mean * S1) in fp64.  Loads mirror the stores: the pixel (+ half-wave row shift) on the
+      // voffset, the row on the scalar soffset; the ReLU gate is recomputed from x with the layer's (sc, sh) -- coef[row] holds
+      // (mean, invstd, sc, sh) as bn_affine produced them in the forward pass -- or read from y for residual layers.
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bnb.x) + (i64)n * bnb.x_bs, 0, M * P * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bnb.y ? bnb.y + (i64)n * bnb.y_bs : bnb.x), 0,
+                                                                          M * P * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bnb.coef), 0, M * 16, 0x00020000);
+      constexpr bool gate_x = BNB == 1, gate_y = BNB == 2;
+      const unsigned cvoff = 64u * (unsigned)lh + 8u;           // row + 4 lh, fields (sc, sh)
+      const int gxp = (P + BN - 1) / BN;
+      const int slot = (n * gxp + bx) * WAVES_N + (wid % WAVES_N);
+      // one 32-row block of the wave tile at a time (16 values per lane and sum): keeps the live set at acc + 32 registers
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float sv[16], sq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          float sc = 0.f, sh = 0.f;
+          if (gate_x) {
+            const float2 c2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(cr, cvoff, 16 * row, 0));
+            sc = c2.x; sh = c2.y;
+          }
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float xv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[j], 4 * P * row, 0));
+            float dz = voff[j] != OOB ? acc[i][j][r] : 0.f;
+            if (gate_y) {
+              const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, voff[j], 4 * P * row, 0));
+              dz = yv > 0.f ? dz : 0.f;
+            } else if (gate_x) {
+              dz = __fmaf_rn(xv, sc, sh) > 0.f ? dz : 0.f;
+            }
+            a += dz;
+            b = fmaf(dz, xv, b);
+          }
+          sv[r] = a;
+          sq[r] = b;
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 rows of loads in flight (register budget)
+        }
+        const float ts = half_wave_transpose_sum<16>(sv, l31);
+        const float tq = half_wave_transpose_sum<16>(sq, l31);
+        // lane l31 (both 16-lane rows hold the same sums) owns accumulator row r = l31 & 15 of block i
+        const int r = l31 & 15;
+        const int m = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 < 16) reinterpret_cast<float2*>(bnb.partials)[(i64)m * stats_T + slot] = make_float2(ts, tq);
       }
+    }
     return;
   }
 #pragma unroll

@@ -37,11 +37,12 @@ __device__ __forceinline__ bool src_coord_q(int o, int t, int a, int b, int c0, 
   return (odd == 0) & (s >= 0) & (s < lim);
 }
 
-template <int BM>
+// BNB: the data-gradient launch that completes dL/dy of a BatchNorm layer also emits that layer's backward sums (conv_epilogue.h)
+template <int BM, int BNB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void conv_igemm_q_kernel(
     const float* __restrict__ in_all, i64 in_bs, const float4* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ out_all, i64 out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, PfstBnbArgs bnb) {
   constexpr int BN = QBN, BK = QBK, NQ = QNQ;
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 #ifdef PFST_CLOCK_STAMPS
   const unsigned long long t_clk2 = __builtin_amdgcn_s_memtime();
 #endif
-  conv_epilogue<TM, TN, WAVES_N, BN>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
-                                     t_bx, t_n, wid, lane);
+  conv_epilogue<TM, TN, WAVES_N, BN, BNB>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
+                                          t_bx, t_n, wid, lane, bnb);
 #ifdef PFST_CLOCK_STAMPS
   if (tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);                  // the stores have left the wave
@@ -222,10 +223,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 template <int BM>
 int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
              int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
-             hipStream_t s) {
+             const PfstBnbArgs* bnb, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), groups, N);
-  hipLaunchKernelGGL((conv_igemm_q_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
-                     out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+  if (bnb && bnb->x) {
+    // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, one GEMM group
+    PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
+#define PFST_LAUNCH_BNB(MODE_)                                                                                                        \
+    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, MODE_>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out, \
+                       out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
+    if (!bnb->relu) PFST_LAUNCH_BNB(3);
+    else if (bnb->y) PFST_LAUNCH_BNB(2);
+    else PFST_LAUNCH_BNB(1);
+#undef PFST_LAUNCH_BNB
+  } else {
+    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, 0>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
+                       out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs());
+  }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -234,8 +247,8 @@ int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, flo
 
 int pfst_igemm_q_launch(const float* in, i64 in_bs, const float* wq, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
                         int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
-                        hipStream_t s) {
-  if (M > 64) return launch_q<128>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
-  if (M > 32) return launch_q<64>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
-  return launch_q<32>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, s);
+                        hipStream_t s, const PfstBnbArgs* bnb) {
+  if (M > 64) return launch_q<128>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, bnb, s);
+  if (M > 32) return launch_q<64>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, bnb, s);
+  return launch_q<32>(in, in_bs, wq, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, groups, bnb, s);
 }

@@ -432,8 +432,9 @@ extern "C" int pfst_conv_stats_slots(int M, int Ho, int Wo) {
 
 extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk, const float* bias, float* out, long long out_bs,
                                int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                               int mode, int accumulate, float* stats, pfst_stream_t stream) {
+                               int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG(!bnb || ((C % BK_MIN) == 0 && bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
   // 32-bit byte offsets inside one image / one weight tensor (buffer descriptors): fail loudly beyond 2 GiB
@@ -450,7 +451,7 @@ extern "C" int pfst_conv_igemm(const float* in, long long in_bs, const float* wk
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   const bool generic = (C % BK_MIN) != 0;
   if (!generic)      // Cin % 16 == 0: K-quad kernel (conv_igemm_q.hip), weights packed [K/4][M][4]
-    return pfst_igemm_q_launch(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
+    return pfst_igemm_q_launch(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s, bnb);
   if (M > 64) return launch_igemm_generic<128>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
   if (M > 32) return launch_igemm_generic<64>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);
   return launch_igemm_generic<32>(in, in_bs, wk, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, s);

@@ -11,14 +11,28 @@ from . import hip_ops as ops
 
 
 class Var:
-    """An activation (dense NCHW tensor, or a channel slice of a parent Var) with a gradient slot."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1')
+    """An activation (dense NCHW tensor, or a channel slice of a parent Var) with a gradient slot.
+
+    `bn`: set on the output of a conv -> BN layer (layers.BnBackwardCtx).  The data-gradient launch that COMPLETES this Var's
+    gradient can then emit the layer's BatchNorm-backward sums from its epilogue.  Which launch completes it is static: the tape
+    runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
+    The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
+    `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
         self._grad = None
         self.requires_grad = requires_grad
         self.parent, self.c0, self.c1 = parent, c0, c1
+        self.bn = None
+        self._claimed = self._sealed = False
+
+    def claim_first_use(self):
+        """forward: called by every consumer that may fuse; True for the first caller only (= the last gradient writer)"""
+        first = not self._claimed
+        self._claimed = True
+        return first and self.parent is None
 
     @property
     def grad(self):
@@ -27,8 +41,13 @@ class Var:
             return None if pg is None else pg[:, self.c0:self.c1]
         return self._grad
 
-    def grad_target(self):
-        """-> (buffer, accumulate): where a backward kernel must write this Var's gradient."""
+    def grad_target(self, final=False):
+        """-> (buffer, accumulate): where a backward kernel must write this Var's gradient.  final: the caller completes the
+        gradient (and fuses the owner's BatchNorm-backward sums): later writers are an error."""
+        if self._sealed:
+            raise RuntimeError('gradient written after the launch that fused its BatchNorm-backward sums (a consumer did not '
+                               'claim_first_use() in forward order)')
+        self._sealed = bool(final)
         if self.parent is not None:
             buf, acc = self.parent.grad_target_full()
             return buf[:, self.c0:self.c1], acc

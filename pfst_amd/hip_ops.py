@@ -4,6 +4,7 @@ Every function checks device / dtype / layout on the host (a wrong shape must ne
 passes raw device pointers + the current HIP stream, and returns torch tensors it allocated.
 There is NO fallback: a missing libpfst_hip.so or a CPU tensor raises.
 Tensors may be channel slices of a bigger NCHW tensor (batch stride != C*H*W)."""
+import ctypes
 import os
 
 import torch
@@ -110,12 +111,23 @@ def conv_stats_slots(n, cout, ho, wo):
     return n * lib().pfst_conv_stats_slots(cout, ho, wo)
 
 
-def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None, beta=None):
+    """gamma / beta given: also returns coef [C,4] = (mean, invstd, sc, sh), the record the fused BatchNorm-backward sums read"""
     mean = torch.empty(c, device=stats.device)
     invstd = torch.empty(c, device=stats.device)
+    coef = torch.empty(c, 4, device=stats.device) if gamma is not None else None
     call('pfst_bn_finalize_partials', stats.data_ptr(), slots, c, float(count), mean.data_ptr(), invstd.data_ptr(),
-         _p(running_mean), _p(running_var), momentum, eps, _stream())
-    return mean, invstd
+         _p(running_mean), _p(running_var), momentum, eps, _p(gamma), _p(beta), _p(coef), _stream())
+    return (mean, invstd, coef) if gamma is not None else (mean, invstd)
+
+
+class _BnbFuseStruct(ctypes.Structure):           # pfst_bnb_fuse_t (include/pfst_hip.h)
+    _fields_ = [('x', ctypes.c_void_p), ('x_bs', ctypes.c_longlong), ('y', ctypes.c_void_p), ('y_bs', ctypes.c_longlong),
+                ('coef', ctypes.c_void_p), ('partials', ctypes.c_void_p), ('relu', ctypes.c_int)]
+
+
+def bnb_tile_rows(m):
+    return 128 if m > 64 else (64 if m > 32 else 32)
 
 
 def conv_fprop(x, wk, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
@@ -129,11 +141,13 @@ def conv_fprop(x, wk, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, 
     slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
     st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm', x.data_ptr(), _bs(x), _dense(wk).data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, _stream())
     return (out, st, slots) if want_stats else out
 
 
-def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False, bnb=None):
+    """bnb = (pre, y | None, coef, relu): `out` is the COMPLETE gradient of a conv -> BN layer's output and this launch also emits
+    that layer's BatchNorm-backward sums (pfst_bnb_fuse_t); returns (out, partials, slots) then."""
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
     assert wk_d.numel() == ksize * ksize * co * cin
@@ -141,9 +155,18 @@ def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, ac
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)
     assert tuple(out.shape) == (n, cin, hi, wi)
+    fuse, part, slots = 0, None, 0
+    if bnb is not None:
+        pre, y, coef, relu = bnb
+        assert tuple(pre.shape) == (n, cin, hi, wi) and (y is None or tuple(y.shape) == tuple(pre.shape))
+        assert co % 16 == 0 and cin % bnb_tile_rows(cin) == 0 and tuple(coef.shape) == (cin, 4)
+        slots = conv_stats_slots(n, cin, hi, wi)
+        part = torch.empty(2 * cin * slots, dtype=F32, device=dy.device)     # owned by the consumer layer's context until its bn_backward ran
+        st = _BnbFuseStruct(pre.data_ptr(), _bs(pre), _p(y), 0 if y is None else _bs(y), _dense(coef).data_ptr(), part.data_ptr(), int(relu))
+        fuse = ctypes.addressof(st)
     call('pfst_conv_igemm', dy.data_ptr(), _bs(dy), _dense(wk_d).data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
-    return out
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, _stream())
+    return (out, part, slots) if bnb is not None else out
 
 
 def pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None):
@@ -355,13 +378,14 @@ def _ws(dev, nbytes=2 * 8 * 4096):
     return t
 
 
-def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None, beta=None):
     n, c, h, w = x.shape
     mean = torch.empty(c, device=x.device)
     invstd = torch.empty(c, device=x.device)
+    coef = torch.empty(c, 4, device=x.device) if gamma is not None else None
     call('pfst_bn_stats', x.data_ptr(), _bs(x), n, c, h * w, mean.data_ptr(), invstd.data_ptr(), _p(running_mean),
-         _p(running_var), float(momentum), float(eps), _ws(x.device, 16 * c).data_ptr(), _stream())
-    return mean, invstd
+         _p(running_var), float(momentum), float(eps), _ws(x.device, 16 * c).data_ptr(), _p(gamma), _p(beta), _p(coef), _stream())
+    return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
 def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False):
@@ -382,8 +406,9 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, w
 
 
 def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None,
-                mask=None):
-    """mask: the bitmask bn_apply(..., want_mask=True) returned; replaces y as the source of the ReLU gate"""
+                mask=None, partials=None, slots=0):
+    """mask: the bitmask bn_apply(..., want_mask=True) returned; replaces y as the source of the ReLU gate.
+    partials / slots: the (sum dz, sum dz*x) partials the launch that wrote dy emitted (conv_dgrad(bnb=...)): no reduction pass"""
     n, c, h, w = x.shape
     assert dy.shape == x.shape
     assert mask is None or (mask.dtype == torch.int64 and mask.numel() == n * c * h * w // 64 and (h * w) % 256 == 0)
@@ -392,7 +417,7 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
     call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _p(beta), dx.data_ptr(), _bs(dx),
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
-         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _stream())
+         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _stream())
     return dx
 
 

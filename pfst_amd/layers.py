@@ -31,6 +31,18 @@ WINOGRAD = os.environ.get('PFST_WINOGRAD', '1') == '1'
 _WINO_DEFAULT_CC = 128 * 128 if ops.WINO_TILE == 4 else 256 * 256
 WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', _WINO_DEFAULT_CC))
 WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', _WINO_DEFAULT_CC))
+# BatchNorm backward: the two per-channel sums come out of the epilogue of the data-gradient launch that completes dL/dy
+# (csrc/conv_epilogue.h, pfst_bnb_fuse_t) wherever that launch is a K-quad implicit GEMM; elsewhere the two-pass kernels run.
+FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
+
+
+class BnBackwardCtx:
+    """what the launch completing a conv -> BN layer's output gradient needs to emit that layer's BatchNorm-backward sums"""
+    __slots__ = ('pre', 'y', 'coef', 'relu', 'partials', 'slots')
+
+    def __init__(self, pre, y, coef, relu):
+        self.pre, self.y, self.coef, self.relu = pre, y, coef, relu
+        self.partials, self.slots = None, 0
 
 
 class bn_eval:
@@ -93,12 +105,22 @@ class Conv2dP(nn.Module):
         return ops.conv_fprop(xd, self.wf, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                               want_stats=want_stats)
 
-    def dgrad(self, dy, in_hw, out, accumulate):
+    def can_fuse_bn_backward(self):
+        """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
+        return (FUSE_BN_BWD and not self.depthwise and not self.wino and not self.split_d and self.cout % 16 == 0
+                and self.cin % ops.bnb_tile_rows(self.cin) == 0)
+
+    def dgrad(self, dy, in_hw, out, accumulate, bn=None):
+        """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient"""
         if self.wino:
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate)
         if self.split_d:
             return ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                                         out=out, accumulate=accumulate)
+        if bn is not None:
+            _, bn.partials, bn.slots = ops.conv_dgrad(dy, self.wd, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
+                                                      out=out, accumulate=accumulate, bnb=(bn.pre, bn.y, bn.coef, bn.relu))
+            return out
         return ops.conv_dgrad(dy, self.wd, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                               out=out, accumulate=accumulate)
 
@@ -187,9 +209,11 @@ def conv_forward(x, conv, tape, out=None):
     saved_v = None if conv.depthwise else conv.saved_v
     yv = Var(y, tape is not None)
     if tape is not None:
+        final = x.claim_first_use()
+
         def bwd():
             dy = yv.grad
-            conv_backward(x, conv, dy, saved_v)
+            conv_backward(x, conv, dy, saved_v, final)
             yv.free_grad()
         tape.record(bwd, dict(op='conv', conv=conv, x=x, out=yv))
     return yv
@@ -243,8 +267,17 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side_stream)
 
 
-def conv_backward(x, conv, dy, saved_v=None):
-    """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward"""
+def _dgrad_into(x, conv, dy, final):
+    """data gradient of `conv` into x's gradient buffer; when this launch completes the gradient of a conv -> BN layer's output
+    (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
+    fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward()
+    buf, acc = x.grad_target(final=fuse)
+    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None)
+
+
+def conv_backward(x, conv, dy, saved_v=None, final=False):
+    """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward;
+    final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use)"""
     xd = x.data
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
@@ -256,8 +289,7 @@ def conv_backward(x, conv, dy, saved_v=None):
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
-            buf, acc = x.grad_target()
-            conv.dgrad(dy, xd.shape[-2:], buf, acc)
+            _dgrad_into(x, conv, dy, final)
         return
     if conv.depthwise:
         ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
@@ -274,8 +306,7 @@ def conv_backward(x, conv, dy, saved_v=None):
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
-            buf, acc = x.grad_target()
-            conv.dgrad(dy, xd.shape[-2:], buf, acc)
+            _dgrad_into(x, conv, dy, final)
 
 
 def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
@@ -297,11 +328,15 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         assert tape is None, 'eval-mode BN is inference only'
         mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)
     else:
+        want_coef = tape is not None and FUSE_BN_BWD
+        gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
         if fused_stats:
             n, c, h, w = pre.shape
-            mean, invstd = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+            res = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
         else:
-            mean, invstd = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS)
+            res = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
+        mean, invstd = res[:2]
+        coef = res[2] if want_coef else None
         bn._pending_batches += 1
     out_var = None
     if isinstance(out, Var):                       # slice of a concat Var
@@ -316,6 +351,13 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     if tape is None:
         return out_var if out_var is not None else Var(y, False)
     yv = out_var if out_var is not None else Var(y, True)
+    final = x.claim_first_use()
+    if residual is not None:
+        residual.claim_first_use()
+    if coef is not None and out_var is None:
+        # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
+        # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
+        yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)
 
     def bwd():
         dy = yv.grad
@@ -324,9 +366,10 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
             dres, dacc = residual.grad_target()
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
+        part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate)
-        conv_backward(x, conv, dpre, saved_v)
+                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots)
+        conv_backward(x, conv, dpre, saved_v, final)
         if yv.parent is None:
             yv.free_grad()
     tape.record(bwd, dict(op='conv_bn_act', conv=conv, bn=bn, x=x, residual=residual, relu=relu, out=yv))

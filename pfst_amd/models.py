@@ -260,6 +260,12 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         n, _, h, w = x.data.shape
         ch, nb = self.channels, len(self.dilations) + 1
         cat = Var(torch.empty(n, nb * ch, h, w, device=x.data.device), tape is not None)
+        # The ASPP branches first, the image-pool branch after them (they write disjoint slices, so the forward result does not
+        # depend on the order): in backward the pool branch's broadcast then lands in dL/dx BEFORE the 1x1 branch's data gradient,
+        # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
+        self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
+        for i in range(1, len(self.dilations)):
+            self.aspp_modules[i](x, tape, out=cat.slice((i + 1) * ch, (i + 2) * ch))
         # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)
         pooled = Var(ops.global_avgpool(x.data), tape is not None)
         pa = self.image_pool[1](pooled, tape)
@@ -280,9 +286,6 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
             # order on the tape: gap-backward must run AFTER the image_pool conv's backward, pool-broadcast before it
             self._reorder_pool(tape, (bwd_gap, dict(op='gap', name='decode_head.gap', x=x, out=pooled)),
                                (bwd_pool, dict(op='broadcast', name='decode_head.image_pool.up', x=pa, out=cat.slice(0, ch))))
-        self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
-        for i in range(1, len(self.dilations)):
-            self.aspp_modules[i](x, tape, out=cat.slice((i + 1) * ch, (i + 2) * ch))
         feats = self.bottleneck(cat, tape)
         # decoder: upsample x2 to c1 size, concat with the 48-channel c1 projection
         H, W = c1.data.shape[-2:]

@@ -21,4 +21,4 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.pfst_fill_f32(None, 10, 0.0, None) == -1
     assert b'spatial.hip' in L.pfst_last_error()
-    assert L.pfst_conv_igemm(None, 0, None, None, None, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, None) == -1
+    assert L.pfst_conv_igemm(None, 0, None, None, None, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, None, None, None) == -1

@@ -21,7 +21,7 @@ for C, M, with_stats in [(2048, 512, 0), (512, 2048, 0), (512, 2048, 1), (256, 1
     st = torch.empty(2 * M * B * L.pfst_conv_stats_slots(M, H, H), device='cuda') if with_stats else None
     def run():
         L.pfst_conv_igemm(vp(x.data_ptr()), ctypes.c_longlong(C * H * H), vp(wf.data_ptr()), None, vp(y.data_ptr()), ctypes.c_longlong(M * H * H),
-                          B, C, H, H, M, H, H, 1, 1, 1, 0, 0, 0, vp(st.data_ptr()) if with_stats else None, None)
+                          B, C, H, H, M, H, H, 1, 1, 1, 0, 0, 0, vp(st.data_ptr()) if with_stats else None, None, None)
     t0 = time.time()
     while time.time() - t0 < 1.0:           # sustained load on random data before reading the stamps
         for _ in range(20): run()
