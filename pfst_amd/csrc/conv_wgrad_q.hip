@@ -27,7 +27,8 @@ constexpr int QBJ = 128;
 template <int BM, int T, int WBK>
 __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil, int pad, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs) {
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil, int pad, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs,
+    int gx, int gy, int gz, int xcd_order) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -47,10 +48,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
   const int P = Ho * Wo, HiWi = Hi * Wi, J = Cin * T;
-  const int j0 = blockIdx.x * QBJ, m0 = blockIdx.y * BM;
-  // blockIdx.z = ((group * N) + image) * chunks + chunk; groups > 1: batched products that share shapes (the 16 transform
+  // Workgroup -> (j tile, m tile, K slice).  The gx*gy tiles of ONE K slice z (an image's pixel chunk) read the same dy rows
+  // (shared along j) and x rows (shared along m): (M + J) * chunk_len * 4 bytes in all, against gx*gy times that if every tile
+  // fetched its own.  Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md), each with its own L2, so the
+  // linear id is decoded such that all tiles of a slice land on ONE XCD (id % 8) and run there back to back: slice z = 8 s + xcd.
+  // (The plain 3-D grid put the tiles of a slice on all 8 XCDs: every L2 fetched every operand row.)  The last gz % 8 slices
+  // keep the plain order.
+  int bx, by, bz;
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (xcd_order && lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * QBJ, m0 = by * BM;
+  // bz = ((group * N) + image) * chunks + chunk; groups > 1: batched products that share shapes (the 16 transform
   // indices of the Winograd weight gradient), each with its own x / dy / dw
-  const int ng = blockIdx.z / chunks, chunk = blockIdx.z - ng * chunks;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
   const int grp = ng / N, n = ng - grp * N;
   const int pbeg = chunk * chunk_len;
   const int pend = min(P, pbeg + chunk_len);
@@ -230,14 +253,16 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff >= 0.93) break;
   }
   if (chunks_env > 0) chunks = chunks_env;
-  while ((i64)N * groups * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
-  dim3 grid(cdiv(J, QBJ), cdiv(M, BM), N * groups * chunks);
+  static const int xcd_env = getenv("PFST_WGRAD_XCD") ? atoi(getenv("PFST_WGRAD_XCD")) : 1;
+  const int gx = cdiv(J, QBJ), gy = cdiv(M, BM), gz = N * groups * chunks;
+  PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
+  dim3 grid(gx * gy * gz);
   // occupancy cap (pfst_conv_wgrad_set_lds_pad): unused dynamic LDS, so that fewer workgroups fit per CU and a concurrently running
   // HBM-bound kernel of another stream finds registers and wave slots
   hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
-                     dil, pad, chunks, chunk_len, N, x_gs, dy_gs, dw_gs);
+                     dil, pad, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, gx, gy, gz, xcd_env);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

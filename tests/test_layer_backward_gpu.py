@@ -78,7 +78,7 @@ def test_every_backward_link_as_wired(wino):
         arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
         model.repack_weights(need_dgrad=True)
         names = {id(m): n for n, m in model.named_modules()}
-        rows, state = [], {}
+        rows, state, n_fused = [], {}, [0]
 
         def out_name(tag):
             if tag['op'] in ('conv_bn_act', 'conv'):
@@ -165,6 +165,13 @@ def test_every_backward_link_as_wired(wino):
                     assert g is not None and tuple(g.shape) == tuple(dy.shape), (name, None if g is None else g.shape, dy.shape)
                     state['own_dy_err'] = mixed_err(g, dy)[1]      # how far the HIP chain's own accumulated gradient had drifted
                     g.copy_(dy.cuda())                              # in place: slices of concat gradients stay wired
+                    if tag['out'].bn is not None:
+                        # the launch that completed this gradient emitted the layer's BatchNorm-backward sums from ITS values; the
+                        # forced gradient invalidates them, so this link is checked on the two-pass kernels.  The fused sums are
+                        # checked at kernel level (tests/test_bn_backward_fused_gpu.py) and as wired by comparing whole steps with
+                        # the fusion on / off (tests/test_train_step_gpu.py::test_fused_bn_backward_does_not_change_the_step).
+                        n_fused[0] += tag['out'].bn.partials is not None
+                        tag['out'].bn.partials = None
                 state.update(dy=dy, before={k: _grad_of(v) for k, v in inputs_of(tag)},
                              pbefore={k: p.grad.clone() for k, p in params_of(tag)})
                 return
@@ -194,6 +201,8 @@ def test_every_backward_link_as_wired(wino):
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
     for op, name, k, worst, nrm, fe, de, _ in sorted(rows, key=lambda r: -r[3])[:25]:
         print(f'   {worst:8.3f} {nrm:9.2e}  fwd {fe:8.1e}  chain-dy {de:8.1e}  {name}:{k} [{op}]')
+    print(f'   {n_fused[0]} BatchNorm layers had received fused backward sums from the launch completing their gradient')
+    assert n_fused[0] >= 40
     checked_ops = {r[0] for r in rows}
     assert {'conv_bn_act', 'conv', 'maxpool', 'resize', 'gap', 'broadcast', 'ce'} <= checked_ops, checked_ops
     n_bn = sum(1 for m in model.modules() if isinstance(m, layers.BatchNorm2dP))

@@ -378,3 +378,32 @@ def test_stream_overlap_options_do_not_change_the_step():
         assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
     assert rel(g1, g0) < 1e-4, rel(g1, g0)
     assert rel(t1, t0) < 1e-5
+
+
+def test_fused_bn_backward_does_not_change_the_step():
+    """layers.FUSE_BN_BWD: the BatchNorm-backward sums come out of the epilogue of the data-gradient launch that completes dL/dy
+    (csrc/conv_epilogue.h) instead of a reduction pass -- same mathematics, so one whole train step (both student graphs, as
+    wired: accumulate epilogues, residual gates, the final-writer logic of engine.Var) must give the same gradients and the same
+    second-step losses with the fusion on and off."""
+    from pfst_amd import layers
+    from pfst_amd.synthetic import synth_batch
+    batch = to_dev(synth_batch(2, 128, 6, seed=77), 'cuda')
+    runs = []
+    prev = layers.FUSE_BN_BWD
+    for fuse in (False, True):
+        layers.FUSE_BN_BWD = fuse
+        try:
+            model, opt, _, _ = _build(0.30)
+            random.seed(100); np.random.seed(100)
+            log0 = model.train_step(batch, opt)['log_vars']
+            grad0 = model.student_arena.grad.clone().cpu()
+            random.seed(101); np.random.seed(101)
+            log1 = model.train_step(batch, opt)['log_vars']
+        finally:
+            layers.FUSE_BN_BWD = prev
+        runs.append((log0, grad0, log1))
+    (a0, g0, a1), (b0, g1, b1) = runs
+    for k in a0:
+        assert abs(a0[k] - b0[k]) <= 1e-6 * max(abs(a0[k]), 1e-2), (k, a0[k], b0[k])       # forward is untouched
+        assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
+    assert rel(g1, g0) < 2e-4, rel(g1, g0)     # fp32 partial sums in a different order, amplified by the BN chain (atomics noise alone: 1e-4)
