@@ -52,11 +52,35 @@ __device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31
   return a[0];
 }
 
+// The same reduction through LDS (16 values per lane = the rows of one 32x32 accumulator block): fp32 MFMA and VALU share the
+// vector pipe, so the butterfly's ~3 VALU instructions per exchange come out of the co-resident waves' matrix throughput; LDS
+// traffic does not.  Each lane writes its 16 values as 4 ds_write_b128 (lane stride 20 floats: the 16 lanes of a b128 group hit 16
+// distinct bank quads), then lane (l31, lh) adds value (l31 & 15) of the 16 even (l31 < 16) or odd (l31 >= 16) lanes of its
+// half-wave (16 conflict-free ds_read_b32: value index and lane parity spread over disjoint banks) and the two halves are
+// combined with one lane ^ 16 exchange.  Same contract as half_wave_transpose_sum<16>.  `ws`: this wave's 64 * 20 floats; the
+// caller has put a workgroup barrier between the main loop's last LDS reads and the first call.
+constexpr int PFST_ROWSUM_LDS_FLOATS = 64 * 20;
+__device__ __forceinline__ float half_wave_rowsum_lds(const float (&v)[16], float* __restrict__ ws, int lane) {
+  float4* wr = reinterpret_cast<float4*>(ws + lane * 20);
+  wr[0] = make_float4(v[0], v[1], v[2], v[3]);
+  wr[1] = make_float4(v[4], v[5], v[6], v[7]);
+  wr[2] = make_float4(v[8], v[9], v[10], v[11]);
+  wr[3] = make_float4(v[12], v[13], v[14], v[15]);
+  const int l31 = lane & 31;
+  const float* rd = ws + ((lane & 32) + (l31 >> 4)) * 20 + (l31 & 15);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += rd[i * 40];
+  return s + lane_xchg<0>(s);
+}
+
 // BNB: 0 = off; fused BatchNorm-backward sums with the ReLU gate 1 = recomputed from x, 2 = read from y, 3 = none (layer without ReLU)
-template <int TM, int TN, int WAVES_N, int BN, int BNB = 0>
+// LDSRED: the per-row sums are reduced through the LDS scratch `lds` (half_wave_rowsum_lds) instead of the DPP butterfly
+template <int TM, int TN, int WAVES_N, int BN, int BNB = 0, bool LDSRED = false>
 __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
-                                              int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs()) {
+                                              int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs(),
+                                              float* __restrict__ lds = nullptr) {
   const int l31 = lane & 31, lh = lane >> 5;
   // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
   // the 32 lanes of each half-wave (transposing butterfly) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
@@ -64,6 +88,32 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
   if (BNB == 0 && stats) {           // (the fused-backward variants are launched without forward statistics)
     const int gx = (P + BN - 1) / BN;
     const int slot = (n * gx + bx) * WAVES_N + (wid % WAVES_N);
+    if constexpr (LDSRED) {
+      // reduction through LDS, one 32-row block at a time (see half_wave_rowsum_lds)
+      float* ws = lds + wid * PFST_ROWSUM_LDS_FLOATS;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float sv[16], sq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float a = 0.f, b = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int pp = p0 + wn0 + j * 32 + l31;
+            const float v = pp < P ? acc[i][j][r] : 0.f;
+            a += v;
+            b = fmaf(v, v, b);
+          }
+          sv[r] = a;
+          sq[r] = b;
+        }
+        const float ts = half_wave_rowsum_lds(sv, ws, lane);
+        const float tq = half_wave_rowsum_lds(sq, ws, lane);
+        const int r = l31 & 15;
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 < 16 && m < M) reinterpret_cast<float2*>(stats)[(i64)m * stats_T + slot] = make_float2(ts, tq);
+      }
+    } else {
     constexpr int NV = TM * 16;
     float sv[NV], sq[NV];
 #pragma unroll
@@ -90,6 +140,7 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
     if (l31 < NV && m < M) {
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
       *dst = make_float2(ts, tq);
+    }
     }
   }
   // Store.  fp32 MFMA and VALU share the vector pipe, so per-element address arithmetic and bounds checks in a 64-store
@@ -197,10 +248,15 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
           }
           sv[r] = a;
           sq[r] = b;
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // keep at most 4 rows of loads in flight (register budget)
+#ifndef PFST_BNB_ROWS_IN_FLIGHT
+#define PFST_BNB_ROWS_IN_FLIGHT 4
+#endif
+          if (PFST_BNB_ROWS_IN_FLIGHT < 16 && (r % PFST_BNB_ROWS_IN_FLIGHT) == PFST_BNB_ROWS_IN_FLIGHT - 1)
+            __builtin_amdgcn_sched_barrier(0);     // bound the rows of loads in flight (register budget)
         }
-        const float ts = half_wave_transpose_sum<16>(sv, l31);
-        const float tq = half_wave_transpose_sum<16>(sq, l31);
+        float* ws = lds + wid * PFST_ROWSUM_LDS_FLOATS;
+        const float ts = LDSRED ? half_wave_rowsum_lds(sv, ws, lane) : half_wave_transpose_sum<16>(sv, l31);
+        const float tq = LDSRED ? half_wave_rowsum_lds(sq, ws, lane) : half_wave_transpose_sum<16>(sq, l31);
         // lane l31 (both 16-lane rows hold the same sums) owns accumulator row r = l31 & 15 of block i
         const int r = l31 & 15;
         const int m = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;

@@ -53,8 +53,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
   constexpr int A_N = (A_CH + 255) / 256;
   constexpr unsigned OOB = 0x80000000u;
 
-  __shared__ float4 As[2][NQ * BM];
-  __shared__ float4 Bs[2][NQ * BN];
+  // one LDS block: the A / B double buffers of the main loop, reused by the epilogue's row reductions (4 waves x 5 KB)
+  constexpr int LDS_F4 = 2 * NQ * BM + 2 * NQ * BN;
+  static_assert(LDS_F4 * 4 >= 4 * PFST_ROWSUM_LDS_FLOATS, "epilogue scratch must fit into the main loop's LDS");
+  __shared__ float4 smem[LDS_F4];
+  float4 (*As)[NQ * BM] = reinterpret_cast<float4 (*)[NQ * BM]>(smem);
+  float4 (*Bs)[NQ * BN] = reinterpret_cast<float4 (*)[NQ * BN]>(smem + 2 * NQ * BM);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
 #ifdef PFST_CLOCK_STAMPS
@@ -204,8 +208,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
 #ifdef PFST_CLOCK_STAMPS
   const unsigned long long t_clk2 = __builtin_amdgcn_s_memtime();
 #endif
-  conv_epilogue<TM, TN, WAVES_N, BN, BNB>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
-                                          t_bx, t_n, wid, lane, bnb);
+  float* red = nullptr;
+  if (BNB != 0 || stats) {                          // wave-uniform: the epilogue reduces its per-row sums through LDS
+    __syncthreads();                                // every wave is done reading the last K-slice
+    red = reinterpret_cast<float*>(smem);
+  }
+  conv_epilogue<TM, TN, WAVES_N, BN, BNB, true>(acc, out_all + (i64)t_n * out_bs, bias, stats, stats_T, accumulate, M, P, t_m0, t_p0, wm0, wn0,
+                                          t_bx, t_n, wid, lane, bnb, red);
 #ifdef PFST_CLOCK_STAMPS
   if (tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);                  // the stores have left the wave

@@ -6,6 +6,7 @@
 // (:151-152), top_k=None (:229-231), downscale None / 1.
 // Neighbour index k = ty*3+tx, offset ((ty-1)*d, (tx-1)*d) -- the order nn.Unfold produces.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/pfst_hip.h"
 
 namespace {
@@ -128,6 +129,185 @@ __global__ __launch_bounds__(256) void sim_map_bwd_kernel(const float* __restric
       dp[o] = accumulate ? dp[o] + v : v;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Fast path of the cosine similarity (the shipped configuration): a wave owns a strip of 64 float4 = 256 consecutive pixels
+// (whole rows: W/4 in {16, 32, 64}) and a slice of the channels.  Per channel a lane issues THREE aligned 16-byte loads (rows
+// y-d, y, y+d); the +-d column shifts of the nine taps come from the neighbouring lanes' registers (two or four wave shuffles
+// per row), the centre row stays in registers, the zero padding of nn.Unfold is a mask at the row ends / missing rows.  The 36
+// dot products and the squared norms of the three rows accumulate per lane; the four waves of a block (channel quarters) are
+// combined through LDS, and the neighbours' norms of the cosine denominator are the SAME sums shifted by the tap -- no
+// per-tap norm accumulation (the first kernel spent 9 of its 18 fma per channel on them).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void shift_pair(const float4& v, bool has_prev, bool has_next, float4& left, float4& right) {
+  // left = elements (x0 - D .. x0 - D + 3), right = (x0 + D .. x0 + D + 3) of the row whose aligned float4 at x0 this lane holds
+  static_assert(D == 1 || D == 2, "feature-grid dilation 1 or 2");
+  if (D == 2) {
+    const float pz = __shfl_up(v.z, 1, 64), pw = __shfl_up(v.w, 1, 64), nx = __shfl_down(v.x, 1, 64), ny = __shfl_down(v.y, 1, 64);
+    left = make_float4(has_prev ? pz : 0.f, has_prev ? pw : 0.f, v.x, v.y);
+    right = make_float4(v.z, v.w, has_next ? nx : 0.f, has_next ? ny : 0.f);
+  } else {
+    const float pw = __shfl_up(v.w, 1, 64), nx = __shfl_down(v.x, 1, 64);
+    left = make_float4(has_prev ? pw : 0.f, v.x, v.y, v.z);
+    right = make_float4(v.y, v.z, v.w, has_next ? nx : 0.f);
+  }
+}
+__device__ __forceinline__ void fma4(float4& acc, const float4& a, const float4& b) {
+  acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y); acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
+}
+__device__ __forceinline__ float4 ld4_or_zero(const float* __restrict__ p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+constexpr int SIMQ_VALS = 48;       // per lane: 9 taps x 4 pixels of dot products + 3 rows x 4 pixels of squared norms
+
+// grid: (H*W / 256, N), 256 threads
+template <int D>
+__global__ __launch_bounds__(256) void sim_map_cos_q_kernel(const float* __restrict__ feat, int C, int H, int W, float* __restrict__ sim,
+                                                            float* __restrict__ norm) {
+  extern __shared__ float red[];                      // [4 waves][SIMQ_VALS][64 lanes]
+  const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int HW = H * W, wq = W >> 2;
+  const int pix4 = blockIdx.x * 64 + lane;
+  const int y = pix4 / wq, xq = pix4 - y * wq;
+  const bool has_prev = xq > 0, has_next = xq < wq - 1;
+  const bool up = y - D >= 0, dn = y + D < H;
+  const int cpw = C >> 2;                             // channels of this wave (host: C % 4 == 0)
+  const float* fp = feat + ((i64)n * C + (i64)wid * cpw) * HW + (i64)y * W + 4 * xq;
+  float4 dot[9], nn[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dot[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 3; ++t) nn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 2
+  for (int c = 0; c < cpw; ++c, fp += HW) {
+    float4 r[3];
+    r[0] = ld4_or_zero(fp - D * W, up);
+    r[1] = *reinterpret_cast<const float4*>(fp);
+    r[2] = ld4_or_zero(fp + D * W, dn);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float4 l, rr;
+      shift_pair<D>(r[t], has_prev, has_next, l, rr);
+      fma4(dot[3 * t + 0], r[1], l);
+      fma4(dot[3 * t + 1], r[1], r[t]);
+      fma4(dot[3 * t + 2], r[1], rr);
+      fma4(nn[t], r[t], r[t]);
+    }
+  }
+  // combine the four channel quarters
+  float* mine = red + (wid * SIMQ_VALS) * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    mine[(4 * k + 0) * 64] = dot[k].x; mine[(4 * k + 1) * 64] = dot[k].y; mine[(4 * k + 2) * 64] = dot[k].z; mine[(4 * k + 3) * 64] = dot[k].w;
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    mine[(36 + 4 * t + 0) * 64] = nn[t].x; mine[(36 + 4 * t + 1) * 64] = nn[t].y; mine[(36 + 4 * t + 2) * 64] = nn[t].z; mine[(36 + 4 * t + 3) * 64] = nn[t].w;
+  }
+  __syncthreads();
+  if (wid != 0) return;
+  auto total = [&](int v) {
+    return (red[(0 * SIMQ_VALS + v) * 64 + lane] + red[(1 * SIMQ_VALS + v) * 64 + lane]) +
+           (red[(2 * SIMQ_VALS + v) * 64 + lane] + red[(3 * SIMQ_VALS + v) * 64 + lane]);
+  };
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dot[k] = make_float4(total(4 * k), total(4 * k + 1), total(4 * k + 2), total(4 * k + 3));
+#pragma unroll
+  for (int t = 0; t < 3; ++t) nn[t] = make_float4(total(36 + 4 * t), total(37 + 4 * t), total(38 + 4 * t), total(39 + 4 * t));
+  auto clampn = [](const float4& q) {
+    return make_float4(fmaxf(sqrtf(q.x), COS_EPS), fmaxf(sqrtf(q.y), COS_EPS), fmaxf(sqrtf(q.z), COS_EPS), fmaxf(sqrtf(q.w), COS_EPS));
+  };
+  const float4 na = clampn(nn[1]);
+  const i64 o = (i64)n * 9 * HW + 4 * (i64)pix4;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    float4 l, rr;
+    shift_pair<D>(nn[t], has_prev, has_next, l, rr);         // squared norms of the tap pixels (0 in the padding -> COS_EPS)
+    const float4 nb[3] = {clampn(l), clampn(nn[t]), clampn(rr)};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const float4 d = dot[3 * t + u];
+      const float4 q = make_float4(d.x / (na.x * nb[u].x), d.y / (na.y * nb[u].y), d.z / (na.z * nb[u].z), d.w / (na.w * nb[u].w));
+      *reinterpret_cast<float4*>(sim + o + (i64)(3 * t + u) * HW) = q;
+    }
+  }
+  *reinterpret_cast<float4*>(norm + (i64)n * HW + 4 * (i64)pix4) = make_float4(sqrtf(nn[1].x), sqrtf(nn[1].y), sqrtf(nn[1].z), sqrtf(nn[1].w));
+}
+
+// adjoint, same data movement: dF(r) = B(r) F(r) + sum_k A_k(r) F(r + D_k) with the per-pixel coefficients of sim_map_bwd_kernel,
+// computed once per wave (from the 9-channel maps), then three aligned 16-byte loads + one 16-byte store per channel.
+// grid: (H*W / 256, channel chunks, N), 256 threads; wave w of chunk j handles channels [(4 j + w) cpw, +cpw)
+template <int D>
+__global__ __launch_bounds__(256) void sim_map_bwd_cos_q_kernel(const float* __restrict__ feat, const float* __restrict__ sim,
+                                                                const float* __restrict__ norm, const float* __restrict__ gsim, int C, int H,
+                                                                int W, int cpw, float* __restrict__ dfeat, int accumulate) {
+  const int n = blockIdx.z, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int HW = H * W, wq = W >> 2;
+  const int pix4 = blockIdx.x * 64 + lane;
+  const int y = pix4 / wq, xq = pix4 - y * wq;
+  const bool has_prev = xq > 0, has_next = xq < wq - 1;
+  const bool up = y - D >= 0, dn = y + D < H;
+  const float* sp = sim + (i64)n * 9 * HW;
+  const float* gp = gsim + (i64)n * 9 * HW;
+  const float* np_ = norm + (i64)n * HW;
+  float A[9][4], B[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int x = 4 * xq + e, p = y * W + x;
+    const float nr = fmaxf(np_[p], COS_EPS);
+    float b = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int sy = y + (k / 3 - 1) * D, sx = x + (k % 3 - 1) * D;
+      const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W && k != 4;
+      A[k][e] = 0.f;
+      if (ok) {
+        const int q = sy * W + sx;
+        const float g1 = gp[(i64)k * HW + p], g2 = gp[(i64)(8 - k) * HW + q];
+        A[k][e] = (g1 + g2) / (nr * fmaxf(np_[q], COS_EPS));
+        b -= g1 * sp[(i64)k * HW + p] + g2 * sp[(i64)(8 - k) * HW + q];
+      }
+    }
+    B[e] = b / (nr * nr);
+  }
+  const int c0 = (blockIdx.y * 4 + wid) * cpw;
+  const i64 base = ((i64)n * C + c0) * HW + (i64)y * W + 4 * xq;
+  const float* fp = feat + base;
+  float* dp = dfeat + base;
+#pragma unroll 2
+  for (int c = 0; c < cpw && c0 + c < C; ++c, fp += HW, dp += HW) {
+    float4 r[3];
+    r[0] = ld4_or_zero(fp - D * W, up);
+    r[1] = *reinterpret_cast<const float4*>(fp);
+    r[2] = ld4_or_zero(fp + D * W, dn);
+    float4 v = make_float4(B[0] * r[1].x, B[1] * r[1].y, B[2] * r[1].z, B[3] * r[1].w);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      float4 l, rr;
+      shift_pair<D>(r[t], has_prev, has_next, l, rr);
+      const float4 nb[3] = {l, r[t], rr};
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = 3 * t + u;
+        v.x = fmaf(A[k][0], nb[u].x, v.x); v.y = fmaf(A[k][1], nb[u].y, v.y); v.z = fmaf(A[k][2], nb[u].z, v.z); v.w = fmaf(A[k][3], nb[u].w, v.w);
+      }
+    }
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(dp);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dp) = v;
+  }
+}
+
+// the fast path applies to whole-row strips of 256 pixels and feature-grid dilation 1 or 2 (every shipped configuration)
+inline bool simq_ok(const void* a, const void* b, int C, int H, int W, int dil) {
+  const int wq = W / 4;
+  return (dil == 1 || dil == 2) && W % 4 == 0 && (wq == 16 || wq == 32 || wq == 64) && ((i64)H * W) % 256 == 0 && C % 4 == 0 &&
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !getenv("PFST_SIM_MAP_SLOW");
 }
 
 // ---- source statistics.  grid: (blocks over H*W, N)
@@ -435,7 +615,12 @@ extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int d
   PFST_CHECK_ARG(feat && sim && norm && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
   PFST_CHECK_ARG(sim_type == 0 || (sim_type == 1 && sigma > 0.f));
   const dim3 grid(px_blocks((i64)H * W), N);
-  if (sim_type == 1)
+  if (sim_type == 0 && simq_ok(feat, sim, C, H, W, dil) && (reinterpret_cast<uintptr_t>(norm) & 15) == 0) {
+    const dim3 gq((unsigned)(((i64)H * W) / 256), N);
+    const size_t lds = 4 * SIMQ_VALS * 64 * sizeof(float);
+    if (dil == 1) hipLaunchKernelGGL(sim_map_cos_q_kernel<1>, gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+    else hipLaunchKernelGGL(sim_map_cos_q_kernel<2>, gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+  } else if (sim_type == 1)
     hipLaunchKernelGGL(sim_map_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, 1.f / (sigma * sigma), sim, norm);
   else
     hipLaunchKernelGGL(sim_map_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, 0.f, sim, norm);
@@ -448,7 +633,12 @@ extern "C" int pfst_sim_map_bwd(const float* feat, const float* sim, const float
   PFST_CHECK_ARG(feat && sim && norm && gsim && dfeat && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
   PFST_CHECK_ARG(sim_type == 0 || (sim_type == 1 && sigma > 0.f));
   const dim3 grid(px_blocks((i64)H * W), N);
-  if (sim_type == 1)
+  if (sim_type == 0 && simq_ok(feat, dfeat, C, H, W, dil)) {
+    const int cpw = 32;                                   // channels per wave: the coefficient set-up is amortised over them
+    const dim3 gq((unsigned)(((i64)H * W) / 256), cdiv(C, 4 * cpw), N);
+    if (dil == 1) hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<1>, gq, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, cpw, dfeat, accumulate);
+    else hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<2>, gq, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, cpw, dfeat, accumulate);
+  } else if (sim_type == 1)
     hipLaunchKernelGGL(sim_map_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, dil,
                        1.f / (sigma * sigma), dfeat, accumulate);
   else

@@ -34,6 +34,10 @@ WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', _WINO_DEFAULT_C
 # BatchNorm backward: the two per-channel sums come out of the epilogue of the data-gradient launch that completes dL/dy
 # (csrc/conv_epilogue.h, pfst_bnb_fuse_t) wherever that launch is a K-quad implicit GEMM; elsewhere the two-pass kernels run.
 FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
+# ... but only where that launch is MFMA-bound: with a short contraction (K = Cout * taps of the consuming conv) the data gradient is
+# itself HBM-bound (layer1: 2 * 64 flop per 8 bytes written + accumulated), and reading the pre-BN tensor there costs what the
+# reduction pass would have cost (measured: fusing everywhere moves 11 ms/step out of pfst_bn_backward and 10 ms into the GEMMs)
+FUSE_BN_BWD_MIN_K = int(os.environ.get('PFST_FUSE_BN_BWD_MIN_K', '512'))
 
 
 class BnBackwardCtx:
@@ -108,7 +112,7 @@ class Conv2dP(nn.Module):
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and not self.split_d and self.cout % 16 == 0
-                and self.cin % ops.bnb_tile_rows(self.cin) == 0)
+                and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= FUSE_BN_BWD_MIN_K)
 
     def dgrad(self, dy, in_hw, out, accumulate, bn=None):
         """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient"""

@@ -538,6 +538,27 @@ def test_pfgst_loss_pieces_against_golden(ops, golden_dir):
     assert_close(dl, torch.from_numpy(s['pl_grad_logits']), 1e-3, 'd logits_trg')
 
 
+@pytest.mark.parametrize('n,C,H,W,d', [(2, 24, 16, 64, 2), (1, 36, 8, 128, 1), (2, 8, 4, 256, 2), (1, 512, 8, 128, 2), (2, 20, 6, 64, 1),
+                                       (2, 12, 10, 20, 2)])       # the last shape takes the generic kernel
+def test_sim_map_fast_path_against_torch(ops, n, C, H, W, d):
+    """cosine similarity to the 9 dilated neighbours (pfgst_loss.py:193-208) and its adjoint: the strip kernels (16-byte loads, taps from
+    the neighbouring lanes, channel quarters combined through LDS) against F.unfold + F.cosine_similarity + autograd."""
+    x = torch.randn(n, C, H, W, generator=g(C + W)).requires_grad_()
+    u = F.unfold(x, 3, dilation=d, padding=d).view(n, C, 9, H, W)
+    ref = F.cosine_similarity(u, x.unsqueeze(2), dim=1)
+    gs = torch.randn(n, 9, H, W, generator=g(7))
+    (ref * gs).sum().backward()
+    xd = x.detach().to(DEV)
+    sim, norm = ops.sim_map(xd, d)
+    assert float((sim.cpu() - ref.detach()).abs().max()) < 2e-6
+    assert_close(norm, x.detach().norm(dim=1), 1e-6, 'feature norm')
+    dx = ops.sim_map_bwd(xd, sim, norm, gs.to(DEV), d)
+    assert_close(dx, x.grad, 1e-5, 'sim_map adjoint')
+    base = torch.randn(n, C, H, W, generator=g(9)).to(DEV)
+    acc = ops.sim_map_bwd(xd, sim, norm, gs.to(DEV), d, out=base.clone(), accumulate=True)
+    assert_close(acc - base, x.grad, 1e-5, 'sim_map adjoint, accumulate')
+
+
 def test_ema_adamw_flat(ops):
     n = 10007
     p = torch.randn(n, generator=g(1)).requires_grad_()
