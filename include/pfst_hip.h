@@ -221,7 +221,9 @@ int pfst_sim_map(const float* feat, int N, int C, int H, int W, int dil, int sim
                  pfst_stream_t stream);
 /* d feat (+)= adjoint of pfst_sim_map for upstream gradient gsim[n][9][H][W] */
 int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
-                     int sim_type, float sigma, float* dfeat, int accumulate, pfst_stream_t stream);
+                     int sim_type, float sigma, float* dfeat, int accumulate, float* coef_ws, pfst_stream_t stream);
+/* coef_ws: 10*N*H*W floats of scratch (per-pixel stencil coefficients) for the strip kernel of the cosine path; NULL selects the
+ * generic kernel */
 /* source statistics: sets (neighbour label == / != centre label, centre != 255) of src sims.
  * gt is full resolution [N][Hg][Wg] uint8, nearest-sampled to HxW.
  * loss_type 0 (mean_std): stats[0..5] = n_pos, sum_pos, sumsq_pos, n_neg, sum_neg, sumsq_neg

@@ -140,6 +140,14 @@ __global__ __launch_bounds__(256) void sim_map_bwd_kernel(const float* __restric
 // combined through LDS, and the neighbours' norms of the cosine denominator are the SAME sums shifted by the tap -- no
 // per-tap norm accumulation (the first kernel spent 9 of its 18 fma per channel on them).
 // ---------------------------------------------------------------------------------------------------------------------------
+// Strip owned by workgroup bx of gx: a strip reads the rows y-d..y+d, i.e. the centre rows of its neighbour strips, so neighbouring
+// strips must share an L2.  Workgroups are dealt round-robin over the 8 XCDs (bx % 8, as gx % 8 == 0 keeps the rows of the grid
+// aligned), hence XCD x gets the CONTIGUOUS strips x*gx/8 .. (x+1)*gx/8 - 1: only the rows at the 16 chunk borders are fetched twice
+// (with the identity mapping every row crossed the fabric three times: the first strip kernel ran at 6.5 TB/s of fabric reads).
+__device__ __forceinline__ int strip_of(int bx, int gx) {
+  return (gx & 7) == 0 ? (bx & 7) * (gx >> 3) + (bx >> 3) : bx;
+}
+
 template <int D>
 __device__ __forceinline__ void shift_pair(const float4& v, bool has_prev, bool has_next, float4& left, float4& right) {
   // left = elements (x0 - D .. x0 - D + 3), right = (x0 + D .. x0 + D + 3) of the row whose aligned float4 at x0 this lane holds
@@ -163,25 +171,25 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* __restrict__ p, bool 
 
 constexpr int SIMQ_VALS = 48;       // per lane: 9 taps x 4 pixels of dot products + 3 rows x 4 pixels of squared norms
 
-// grid: (H*W / 256, N), 256 threads
-template <int D>
-__global__ __launch_bounds__(256) void sim_map_cos_q_kernel(const float* __restrict__ feat, int C, int H, int W, float* __restrict__ sim,
+// grid: (H*W / 256, N), 64 * NW threads (NW = 4 or 8 channel slices per strip)
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void sim_map_cos_q_kernel(const float* __restrict__ feat, int C, int H, int W, float* __restrict__ sim,
                                                             float* __restrict__ norm) {
   extern __shared__ float red[];                      // [4 waves][SIMQ_VALS][64 lanes]
   const int n = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int HW = H * W, wq = W >> 2;
-  const int pix4 = blockIdx.x * 64 + lane;
+  const int pix4 = strip_of(blockIdx.x, gridDim.x) * 64 + lane;
   const int y = pix4 / wq, xq = pix4 - y * wq;
   const bool has_prev = xq > 0, has_next = xq < wq - 1;
   const bool up = y - D >= 0, dn = y + D < H;
-  const int cpw = C >> 2;                             // channels of this wave (host: C % 4 == 0)
+  const int cpw = C / NW;                             // channels of this wave (host: C % NW == 0)
   const float* fp = feat + ((i64)n * C + (i64)wid * cpw) * HW + (i64)y * W + 4 * xq;
   float4 dot[9], nn[3];
 #pragma unroll
   for (int k = 0; k < 9; ++k) dot[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int t = 0; t < 3; ++t) nn[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
+#pragma unroll 4
   for (int c = 0; c < cpw; ++c, fp += HW) {
     float4 r[3];
     r[0] = ld4_or_zero(fp - D * W, up);
@@ -197,16 +205,35 @@ __global__ __launch_bounds__(256) void sim_map_cos_q_kernel(const float* __restr
       fma4(nn[t], r[t], r[t]);
     }
   }
-  // combine the four channel quarters
-  float* mine = red + (wid * SIMQ_VALS) * 64 + lane;
+  // combine the channel slices: (NW = 8: waves 4..7 hand their sums to waves 0..3 first, so the LDS block stays 4 slices)
+  auto put = [&](int slot) {
+    float* mine = red + (slot * SIMQ_VALS) * 64 + lane;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    mine[(4 * k + 0) * 64] = dot[k].x; mine[(4 * k + 1) * 64] = dot[k].y; mine[(4 * k + 2) * 64] = dot[k].z; mine[(4 * k + 3) * 64] = dot[k].w;
-  }
+    for (int k = 0; k < 9; ++k) {
+      mine[(4 * k + 0) * 64] = dot[k].x; mine[(4 * k + 1) * 64] = dot[k].y; mine[(4 * k + 2) * 64] = dot[k].z; mine[(4 * k + 3) * 64] = dot[k].w;
+    }
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    mine[(36 + 4 * t + 0) * 64] = nn[t].x; mine[(36 + 4 * t + 1) * 64] = nn[t].y; mine[(36 + 4 * t + 2) * 64] = nn[t].z; mine[(36 + 4 * t + 3) * 64] = nn[t].w;
+    for (int t = 0; t < 3; ++t) {
+      mine[(36 + 4 * t + 0) * 64] = nn[t].x; mine[(36 + 4 * t + 1) * 64] = nn[t].y; mine[(36 + 4 * t + 2) * 64] = nn[t].z; mine[(36 + 4 * t + 3) * 64] = nn[t].w;
+    }
+  };
+  if (NW == 8) {
+    if (wid >= 4) put(wid - 4);
+    __syncthreads();
+    if (wid < 4) {
+      const float* o = red + (wid * SIMQ_VALS) * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        dot[k].x += o[(4 * k + 0) * 64]; dot[k].y += o[(4 * k + 1) * 64]; dot[k].z += o[(4 * k + 2) * 64]; dot[k].w += o[(4 * k + 3) * 64];
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        nn[t].x += o[(36 + 4 * t + 0) * 64]; nn[t].y += o[(36 + 4 * t + 1) * 64]; nn[t].z += o[(36 + 4 * t + 2) * 64]; nn[t].w += o[(36 + 4 * t + 3) * 64];
+      }
+    }
+    __syncthreads();
   }
+  if (wid < 4) put(wid);
   __syncthreads();
   if (wid != 0) return;
   auto total = [&](int v) {
@@ -237,63 +264,72 @@ __global__ __launch_bounds__(256) void sim_map_cos_q_kernel(const float* __restr
   *reinterpret_cast<float4*>(norm + (i64)n * HW + 4 * (i64)pix4) = make_float4(sqrtf(nn[1].x), sqrtf(nn[1].y), sqrtf(nn[1].z), sqrtf(nn[1].w));
 }
 
-// adjoint, same data movement: dF(r) = B(r) F(r) + sum_k A_k(r) F(r + D_k) with the per-pixel coefficients of sim_map_bwd_kernel,
-// computed once per wave (from the 9-channel maps), then three aligned 16-byte loads + one 16-byte store per channel.
-// grid: (H*W / 256, channel chunks, N), 256 threads; wave w of chunk j handles channels [(4 j + w) cpw, +cpw)
-template <int D>
-__global__ __launch_bounds__(256) void sim_map_bwd_cos_q_kernel(const float* __restrict__ feat, const float* __restrict__ sim,
-                                                                const float* __restrict__ norm, const float* __restrict__ gsim, int C, int H,
-                                                                int W, int cpw, float* __restrict__ dfeat, int accumulate) {
-  const int n = blockIdx.z, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int HW = H * W, wq = W >> 2;
-  const int pix4 = blockIdx.x * 64 + lane;
-  const int y = pix4 / wq, xq = pix4 - y * wq;
-  const bool has_prev = xq > 0, has_next = xq < wq - 1;
-  const bool up = y - D >= 0, dn = y + D < H;
+// adjoint, same data movement: dF(r) = B(r) F(r) + sum_k A_k(r) F(r + D_k).  The per-pixel coefficients (sim_map_bwd_kernel's
+// prologue) are computed once by sim_bwd_coef_kernel into coef[n][10][HW] = (A_0..A_8 with A_4 = 0, B); the stencil kernel then
+// reads them as ten aligned float4 and streams the channels: three 16-byte loads + one 16-byte store each.
+// grid: (blocks over H*W, N)
+__global__ __launch_bounds__(256) void sim_bwd_coef_kernel(const float* __restrict__ sim, const float* __restrict__ norm,
+                                                           const float* __restrict__ gsim, int H, int W, int dil, float* __restrict__ coef) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
   const float* sp = sim + (i64)n * 9 * HW;
   const float* gp = gsim + (i64)n * 9 * HW;
   const float* np_ = norm + (i64)n * HW;
-  float A[9][4], B[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int x = 4 * xq + e, p = y * W + x;
+  float* cp = coef + (i64)n * 10 * HW;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
     const float nr = fmaxf(np_[p], COS_EPS);
     float b = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const int sy = y + (k / 3 - 1) * D, sx = x + (k % 3 - 1) * D;
+      const int sy = y + (k / 3 - 1) * dil, sx = x + (k % 3 - 1) * dil;
       const bool ok = sy >= 0 && sy < H && sx >= 0 && sx < W && k != 4;
-      A[k][e] = 0.f;
+      float a = 0.f;
       if (ok) {
         const int q = sy * W + sx;
         const float g1 = gp[(i64)k * HW + p], g2 = gp[(i64)(8 - k) * HW + q];
-        A[k][e] = (g1 + g2) / (nr * fmaxf(np_[q], COS_EPS));
+        a = (g1 + g2) / (nr * fmaxf(np_[q], COS_EPS));
         b -= g1 * sp[(i64)k * HW + p] + g2 * sp[(i64)(8 - k) * HW + q];
       }
+      cp[(i64)k * HW + p] = a;
     }
-    B[e] = b / (nr * nr);
+    cp[(i64)9 * HW + p] = b / (nr * nr);
   }
+}
+
+// grid: (H*W / 256, channel chunks, N), 256 threads; wave w of chunk j handles channels [(4 j + w) cpw, +cpw)
+template <int D>
+__global__ __launch_bounds__(256) void sim_map_bwd_cos_q_kernel(const float* __restrict__ feat, const float* __restrict__ coef, int C, int H,
+                                                                int W, int cpw, float* __restrict__ dfeat, int accumulate) {
+  const int n = blockIdx.z, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int HW = H * W, wq = W >> 2;
+  const int pix4 = strip_of(blockIdx.x, gridDim.x) * 64 + lane;
+  const int y = pix4 / wq, xq = pix4 - y * wq;
+  const bool has_prev = xq > 0, has_next = xq < wq - 1;
+  const bool up = y - D >= 0, dn = y + D < H;
+  const float* cp = coef + (i64)n * 10 * HW + 4 * (i64)pix4;
+  float4 A[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) A[k] = *reinterpret_cast<const float4*>(cp + (i64)k * HW);
+  const float4 B = *reinterpret_cast<const float4*>(cp + (i64)9 * HW);
   const int c0 = (blockIdx.y * 4 + wid) * cpw;
   const i64 base = ((i64)n * C + c0) * HW + (i64)y * W + 4 * xq;
   const float* fp = feat + base;
   float* dp = dfeat + base;
-#pragma unroll 2
+#pragma unroll 4
   for (int c = 0; c < cpw && c0 + c < C; ++c, fp += HW, dp += HW) {
     float4 r[3];
     r[0] = ld4_or_zero(fp - D * W, up);
     r[1] = *reinterpret_cast<const float4*>(fp);
     r[2] = ld4_or_zero(fp + D * W, dn);
-    float4 v = make_float4(B[0] * r[1].x, B[1] * r[1].y, B[2] * r[1].z, B[3] * r[1].w);
+    float4 v = make_float4(B.x * r[1].x, B.y * r[1].y, B.z * r[1].z, B.w * r[1].w);
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
       float4 l, rr;
       shift_pair<D>(r[t], has_prev, has_next, l, rr);
-      const float4 nb[3] = {l, r[t], rr};
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int k = 3 * t + u;
-        v.x = fmaf(A[k][0], nb[u].x, v.x); v.y = fmaf(A[k][1], nb[u].y, v.y); v.z = fmaf(A[k][2], nb[u].z, v.z); v.w = fmaf(A[k][3], nb[u].w, v.w);
-      }
+      fma4(v, A[3 * t + 0], l);
+      fma4(v, A[3 * t + 1], r[t]);
+      fma4(v, A[3 * t + 2], rr);
     }
     if (accumulate) {
       const float4 o = *reinterpret_cast<const float4*>(dp);
@@ -618,8 +654,13 @@ extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int d
   if (sim_type == 0 && simq_ok(feat, sim, C, H, W, dil) && (reinterpret_cast<uintptr_t>(norm) & 15) == 0) {
     const dim3 gq((unsigned)(((i64)H * W) / 256), N);
     const size_t lds = 4 * SIMQ_VALS * 64 * sizeof(float);
-    if (dil == 1) hipLaunchKernelGGL(sim_map_cos_q_kernel<1>, gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
-    else hipLaunchKernelGGL(sim_map_cos_q_kernel<2>, gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+    if (C % 8 == 0 && C >= 64) {                   // 8 channel slices per strip: 16 waves per CU at the BASELINE shape
+      if (dil == 1) hipLaunchKernelGGL((sim_map_cos_q_kernel<1, 8>), gq, dim3(512), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+      else hipLaunchKernelGGL((sim_map_cos_q_kernel<2, 8>), gq, dim3(512), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+    } else {
+      if (dil == 1) hipLaunchKernelGGL((sim_map_cos_q_kernel<1, 4>), gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+      else hipLaunchKernelGGL((sim_map_cos_q_kernel<2, 4>), gq, dim3(256), lds, (hipStream_t)stream, feat, C, H, W, sim, norm);
+    }
   } else if (sim_type == 1)
     hipLaunchKernelGGL(sim_map_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, dil, 1.f / (sigma * sigma), sim, norm);
   else
@@ -629,15 +670,17 @@ extern "C" int pfst_sim_map(const float* feat, int N, int C, int H, int W, int d
 }
 
 extern "C" int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, const float* gsim, int N, int C, int H, int W, int dil,
-                                int sim_type, float sigma, float* dfeat, int accumulate, pfst_stream_t stream) {
+                                int sim_type, float sigma, float* dfeat, int accumulate, float* coef_ws, pfst_stream_t stream) {
   PFST_CHECK_ARG(feat && sim && norm && gsim && dfeat && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
   PFST_CHECK_ARG(sim_type == 0 || (sim_type == 1 && sigma > 0.f));
   const dim3 grid(px_blocks((i64)H * W), N);
-  if (sim_type == 0 && simq_ok(feat, dfeat, C, H, W, dil)) {
-    const int cpw = 32;                                   // channels per wave: the coefficient set-up is amortised over them
+  if (sim_type == 0 && coef_ws && simq_ok(feat, dfeat, C, H, W, dil) && (reinterpret_cast<uintptr_t>(coef_ws) & 15) == 0) {
+    PFST_CHECK_ARG(coef_ws != nullptr);
+    hipLaunchKernelGGL(sim_bwd_coef_kernel, grid, dim3(256), 0, (hipStream_t)stream, sim, norm, gsim, H, W, dil, coef_ws);
+    const int cpw = 16;                                   // channels per wave
     const dim3 gq((unsigned)(((i64)H * W) / 256), cdiv(C, 4 * cpw), N);
-    if (dil == 1) hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<1>, gq, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, cpw, dfeat, accumulate);
-    else hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<2>, gq, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, cpw, dfeat, accumulate);
+    if (dil == 1) hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<1>, gq, dim3(256), 0, (hipStream_t)stream, feat, coef_ws, C, H, W, cpw, dfeat, accumulate);
+    else hipLaunchKernelGGL(sim_map_bwd_cos_q_kernel<2>, gq, dim3(256), 0, (hipStream_t)stream, feat, coef_ws, C, H, W, cpw, dfeat, accumulate);
   } else if (sim_type == 1)
     hipLaunchKernelGGL(sim_map_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, feat, sim, norm, gsim, C, H, W, dil,
                        1.f / (sigma * sigma), dfeat, accumulate);

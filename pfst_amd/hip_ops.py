@@ -606,8 +606,9 @@ def sim_map_bwd(feat, sim, norm, gsim, dil, out=None, accumulate=False, sim_type
     if out is None:
         assert not accumulate
         out = torch.empty_like(feat)
+    coef = torch.empty(n * 10 * h * w, dtype=F32, device=feat.device) if sim_type == 'cosine' else None
     call('pfst_sim_map_bwd', _dense(feat).data_ptr(), _dense(sim).data_ptr(), _dense(norm).data_ptr(), _dense(gsim).data_ptr(),
-         n, c, h, w, dil, SIM_TYPES[sim_type], float(sigma), _dense(out).data_ptr(), int(accumulate), _stream())
+         n, c, h, w, dil, SIM_TYPES[sim_type], float(sigma), _dense(out).data_ptr(), int(accumulate), _p(coef), _stream())
     return out
 
 
