@@ -81,8 +81,10 @@ class KernelTimer:
         if name == 'pfst_bn_backward':                    # minimum: read dy, x (+ y for the residual form), write dx (+ dres)
             nel = 4.0 * a[17] * a[18] * a[19]
             return name, 0.0, nel * (3 + (1 if a[2] else 0) + (1 if a[12] else 0))
-        if name == 'pfst_adamw_step':
-            return name, 0.0, 0.0
+        if name == 'pfst_sim_map':                        # read the feature map once, write the 9-channel map
+            return name, 0.0, 4.0 * a[1] * a[3] * a[4] * (a[2] + 10)
+        if name == 'pfst_sim_map_bwd':                    # read features + 9-channel maps, write the feature gradient
+            return name, 0.0, 4.0 * a[4] * a[6] * a[7] * (2 * a[5] + 19)
         return name, 0.0, 0.0
 
     def call(self, name, *args):
@@ -115,12 +117,13 @@ class KernelTimer:
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_hbm_traffic_per_launch.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB units,
+    (profiles/rNN_pmc_hbm_traffic_per_launch.json, newest round: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if no record matches."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic_per_launch.json')
-    if not os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_per_launch.json')))
+    if not paths:
         return None
-    rec = json.load(open(path))
+    rec = json.load(open(paths[-1]))        # the newest round's record
     def norm(k):               # 'conv_igemm_kernel<128, false, 16, 128>' -> 'conv_igemm_kernel<128,false>' (first two template args)
         k = k.replace(' ', '')
         if '<' not in k:
@@ -299,6 +302,16 @@ def main():
                                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom[0]),
                                'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
                                'algorithmic_flops_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
+            # the second-largest MFMA kernel (weight gradients) in the same form, so its over-fetch ratio (PMC traffic vs algorithmic
+            # bytes: x + dy read once, dw written) is visible in the record too
+            wk = 'conv_wgrad_q_kernel<128,1>'
+            if wk in agg:
+                wc, wms, wfl, wnb = agg[wk]
+                res['roofline_wgrad'] = {'kernel': wk, 'bound': 'mfma', 'achieved': wfl / (wms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                                         'unit': 'TFLOP/s', 'frac': wfl / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                         'traffic': pmc_traffic(wk), 'launches': wc, 'avg_launch_ms': wms / wc,
+                                         'measured_in': 'second pass (all launches bracketed)',
+                                         'algorithmic_flops_per_launch': wfl / wc, 'algorithmic_bytes_per_launch': wnb / wc}
             all_fl = sum(v[2] for v in mfma.values())
             all_ms = sum(v[1] for v in mfma.values())
             res['mfma_all_convs'] = {'tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
