@@ -1,14 +1,24 @@
-"""Batch sources for the train step.  The reference's CPU data pipeline (rsiseg/datasets) is out
-of scope for the kernels; what the hot path needs is the batch CONTRACT of UDADataset after collation
-(rsiseg/datasets/uda_dataset.py:116-135): img / img_metas / gt_semantic_seg / target_img / target_img_metas /
-target_img_strong_aug.  Two sources: seeded synthetic tensors (benchmarks, tests) and a minimal ISPRS tile reader."""
+"""Batch sources of the train step and the evaluation.
+
+What the hot path consumes is the CONTRACT of the reference's UDADataset after collation (rsiseg/datasets/
+uda_dataset.py:116-135): img / img_metas / gt_semantic_seg / target_img / target_img_metas / target_img_strong_aug.
+Sources:
+  * synthetic_loader   -- seeded synthetic device batches (benchmarks, tests);
+  * TileFolder         -- a folder dataset of converted tiles (rsiseg/datasets/custom.py:85-175, isprs.py) read with PIL and pushed
+                          through the config's own pipeline list (pfst_amd/pipeline.py);
+  * UDADataset         -- the source/target pairing + rare-class sampling of the reference, same NumPy RNG stream;
+  * epoch_indices / uda_batches -- the distributed sampler (samplers/distributed_sampler.py:11-70) and the collation."""
+import json
 import os
-import random
 
 import numpy as np
 import torch
 
-from .synthetic import NORM_CFG, synth_batch
+from .pipeline import Pipeline, reduce_zero_label
+from .synthetic import synth_batch
+
+ISPRS_CLASSES = ('impervious_surface', 'building', 'low_vegetation', 'tree', 'car', 'clutter')      # rsiseg/datasets/isprs.py
+ISPRS_PALETTE = [[255, 255, 255], [0, 0, 255], [0, 255, 255], [0, 255, 0], [255, 255, 0], [255, 0, 0]]
 
 
 def synthetic_loader(batch_size, size, num_classes, in_channels=3, seed=1234, device='cuda', distinct=4):
@@ -20,159 +30,177 @@ def synthetic_loader(batch_size, size, num_classes, in_channels=3, seed=1234, de
         i += 1
 
 
-class ISPRSTiles:
-    """1024x1024 PNG tiles produced by tools/convert_datasets/potsdam.py / vaihingen.py (img_dir/*.png, ann_dir/*.png)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# folder dataset
+# ----------------------------------------------------------------------------------------------------------------------
+def _read_image_bgr(path):
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'), np.uint8)[..., ::-1]      # BGR like mmcv.imread
 
-    def __init__(self, img_dir, ann_dir=None, crop_size=(512, 512), ratio_range=(0.5, 2.0), cat_max_ratio=0.75,
-                 img_scale=(1024, 1024), mean=NORM_CFG['mean'], std=NORM_CFG['std'], train=True):
-        from PIL import Image  # noqa: F401
-        self.img_dir, self.ann_dir = img_dir, ann_dir
-        self.files = sorted(f for f in os.listdir(img_dir) if f.lower().endswith(('.png', '.jpg', '.tif')))
-        self.crop_size, self.ratio_range, self.cat_max_ratio, self.img_scale = crop_size, ratio_range, cat_max_ratio, img_scale
-        self.mean, self.std = np.array(mean, np.float32), np.array(std, np.float32)
-        self.train = train
+
+def _read_label(path):
+    from PIL import Image
+    return np.asarray(Image.open(path), np.uint8)                                # imdecode_backend='pillow' (loading.py:118)
+
+
+class TileFolder:
+    """`img_dir/*.png` (+ `ann_dir/*.png`) under `data_root`, items produced by the config's pipeline.
+
+    cfg: the reference's dataset dict (type / data_root / img_dir / ann_dir / pipeline / gt_seg_map_loader_cfg ...);
+    test_mode: no annotations in the items (apis/train.py:153 builds the validation set this way); the ground truth for the
+    metric comes from `gt_seg_map(idx)`, loaded as `gt_seg_map_loader_cfg` says (custom.py:236-252)."""
+
+    def __init__(self, cfg, test_mode=False):
+        cfg = dict(cfg)
+        root = cfg.get('data_root') or ''
+        self.img_dir = os.path.join(root, cfg['img_dir'])
+        self.ann_dir = os.path.join(root, cfg['ann_dir']) if cfg.get('ann_dir') else None
+        self.img_suffix, self.seg_suffix = cfg.get('img_suffix', '.png'), cfg.get('seg_map_suffix', '.png')
+        self.ignore_index = cfg.get('ignore_index', 255)
+        self.CLASSES = tuple(cfg.get('classes') or ISPRS_CLASSES)
+        self.PALETTE = cfg.get('palette') or ISPRS_PALETTE
+        self.test_mode = test_mode
+        self.pipeline = Pipeline(cfg['pipeline'])
+        self.gt_loader_cfg = dict(cfg.get('gt_seg_map_loader_cfg') or {})
+        names = sorted(f for f in os.listdir(self.img_dir) if f.endswith(self.img_suffix))
+        self.img_infos = [dict(filename=f, ann=dict(seg_map=f[:-len(self.img_suffix)] + self.seg_suffix)) for f in names]
 
     def __len__(self):
-        return len(self.files)
+        return len(self.img_infos)
 
-    def _load(self, idx):
-        from PIL import Image
-        name = self.files[idx]
-        img = Image.open(os.path.join(self.img_dir, name)).convert('RGB')
-        ann = Image.open(os.path.join(self.ann_dir, os.path.splitext(name)[0] + '.png')) if self.ann_dir else None
-        return img, ann
+    def gt_seg_map(self, idx):
+        seg = _read_label(os.path.join(self.ann_dir, self.img_infos[idx]['ann']['seg_map']))
+        return reduce_zero_label(seg) if self.gt_loader_cfg.get('reduce_zero_label') else seg
 
-    def get(self, idx, strong=False):
-        """Resize(ratio 0.5-2) -> RandomCrop(cat_max_ratio) -> RandomRotate90 -> flips -> Normalize
-        (configs/_base_/datasets/pots_irrg2vaih_irrg.py:11-45); `strong` adds a brightness/contrast perturbation."""
-        from PIL import Image
-        img, ann = self._load(idx)
-        if self.train:
-            r = random.uniform(*self.ratio_range)
-            size = (int(self.img_scale[0] * r + 0.5), int(self.img_scale[1] * r + 0.5))
-            img = img.resize(size, Image.BILINEAR)
-            ann = ann.resize(size, Image.NEAREST) if ann is not None else None
-        im = np.asarray(img, np.float32)
-        lab = np.asarray(ann, np.uint8) if ann is not None else np.full(im.shape[:2], 255, np.uint8)
-        if self.train:
-            ch, cw = self.crop_size
-            ph, pw = max(ch - im.shape[0], 0), max(cw - im.shape[1], 0)
-            if ph or pw:
-                im = np.pad(im, ((0, ph), (0, pw), (0, 0)))
-                lab = np.pad(lab, ((0, ph), (0, pw)), constant_values=255)
+    def __getitem__(self, idx):
+        info = self.img_infos[idx]
+        img = _read_image_bgr(os.path.join(self.img_dir, info['filename']))
+        seg = None
+        if not self.test_mode and self.ann_dir is not None:
+            seg = _read_label(os.path.join(self.ann_dir, info['ann']['seg_map']))
+        out = self.pipeline(img, seg)
+        item = {k: torch.from_numpy(v) for k, v in out.items() if isinstance(v, np.ndarray)}
+        item['img_metas'] = dict(filename=info['filename'], ori_shape=img.shape, img_shape=tuple(out['img'].shape[1:]) + (3,),
+                                 img_norm_cfg=out['img_norm_cfg'])
+        return item
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# source / target pairing (+ rare-class sampling)
+# ----------------------------------------------------------------------------------------------------------------------
+class RareClassSampling:
+    """uda_dataset.py:17-40,57-90,92-114: classes ordered by total pixel count, p = softmax((1 - freq) / T) evaluated with
+    torch in float32 (the probabilities feed np.random.choice, so the arithmetic is the reference's), the files holding
+    more than `min_pixels` of each class, and the draw: class -> file -> up to 10 re-crops -> a uniform target."""
+
+    def __init__(self, source, options, stats_root, path2name):
+        self.temperature = options['class_temp']
+        self.min_crop_ratio, self.min_pixels = options['min_crop_ratio'], options['min_pixels']
+        totals = {}
+        with open(os.path.join(stats_root, 'sample_class_stats.json')) as f:
+            for per_file in json.load(f):
+                for key, n in per_file.items():
+                    if key != 'file':
+                        totals[int(key)] = totals.get(int(key), 0) + n
+        order = sorted(totals.items(), key=lambda kv: kv[1])               # stable: ties keep first-seen order like dict sorting
+        self.classes = [c for c, _ in order]
+        freq = torch.tensor([n for _, n in order])
+        freq = freq / torch.sum(freq)
+        self.probs = torch.softmax((1 - freq) / self.temperature, dim=-1).numpy()
+        with open(os.path.join(stats_root, 'samples_with_class.json')) as f:
+            listing = {int(k): v for k, v in json.load(f).items()}
+        self.files = {}
+        for c in self.classes:
+            self.files[c] = [path.split('/')[-1] for path, pixels in listing[c] if pixels > self.min_pixels]
+            assert len(self.files[c]) > 0
+        self.index_of = {}
+        for i, info in enumerate(source.img_infos):
+            name = info['ann']['seg_map']
+            self.index_of[name.split('/')[-1] if path2name else name] = i
+
+    def draw(self, source, target):
+        c = np.random.choice(self.classes, p=self.probs)
+        i = self.index_of[np.random.choice(self.files[c])]
+        item = source[i]
+        if self.min_crop_ratio > 0:
             for _ in range(10):
-                y = random.randint(0, im.shape[0] - ch)
-                x = random.randint(0, im.shape[1] - cw)
-                crop = lab[y:y + ch, x:x + cw]
-                vals, cnt = np.unique(crop[crop != 255], return_counts=True)
-                if len(cnt) > 1 and cnt.max() / cnt.sum() < self.cat_max_ratio:
+                if torch.sum(item['gt_semantic_seg'].data == c) > self.min_pixels * self.min_crop_ratio:
                     break
-            im, lab = im[y:y + ch, x:x + cw], lab[y:y + ch, x:x + cw]
-            k = random.randint(0, 3)
-            im, lab = np.rot90(im, k), np.rot90(lab, k)
-            if random.random() < 0.5:
-                im, lab = im[:, ::-1], lab[:, ::-1]
-            if random.random() < 0.5:
-                im, lab = im[::-1], lab[::-1]
-        aug = None
-        if strong:
-            aug = np.clip(im * random.uniform(0.6, 1.4) + random.uniform(-32, 32), 0, 255)
-            aug = (aug - self.mean) / self.std
-        im = (im - self.mean) / self.std
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
-        return t(im), torch.from_numpy(np.ascontiguousarray(lab))[None], (t(aug) if aug is not None else None)
-
-
-def get_rcs_class_probs(data_root, temperature):
-    """Rare-class-sampling distribution (rsiseg/datasets/uda_dataset.py:17-40): classes sorted by total pixel count,
-    p = softmax((1 - freq) / T) in float32 as torch computes it."""
-    import json
-    with open(os.path.join(data_root, 'sample_class_stats.json')) as f:
-        sample_class_stats = json.load(f)
-    overall = {}
-    for s in sample_class_stats:
-        s.pop('file')
-        for c, n in s.items():
-            overall[int(c)] = overall.get(int(c), 0) + n
-    overall = dict(sorted(overall.items(), key=lambda item: item[1]))
-    freq = torch.tensor(list(overall.values()))
-    freq = freq / torch.sum(freq)
-    freq = torch.softmax((1 - freq) / temperature, dim=-1)
-    return list(overall.keys()), freq.numpy()
+                item = source[i]                          # another random crop of the same tile
+        other = target[np.random.choice(range(len(target)))]
+        return {**item, 'target_img_metas': other['img_metas'], 'target_img': other['img']}
 
 
 class UDADataset:
-    """Source/target pairing of the reference (uda_dataset.py:43-135): sample idx = (source[idx // len(target)],
-    target[idx % len(target)]); with `rare_class_sampling` a class is drawn from get_rcs_class_probs, then a source file
-    containing it, re-cropped up to 10 times until it holds enough pixels of that class, then a uniform target -- the
-    same NumPy RNG calls in the same order, so a seeded run picks the same samples as the reference."""
+    """sample idx = (source[idx // len(target)], target[idx % len(target)]) (uda_dataset.py:116-135); with
+    `rare_class_sampling` every item is a RareClassSampling.draw instead."""
 
     def __init__(self, source, target, cfg):
-        import json
-        self.source, self.target = source, target
-        self.ignore_index = target.ignore_index
-        self.CLASSES, self.PALETTE = target.CLASSES, target.PALETTE
-        self.path2name = cfg.get('path2name', False)
         assert target.ignore_index == source.ignore_index and target.CLASSES == source.CLASSES and target.PALETTE == source.PALETTE
-        rcs = cfg.get('rare_class_sampling')
-        self.rcs_enabled = rcs is not None
+        self.source, self.target = source, target
+        self.ignore_index, self.CLASSES, self.PALETTE = target.ignore_index, target.CLASSES, target.PALETTE
+        self.path2name = cfg.get('path2name', False)
+        options = cfg.get('rare_class_sampling')
+        self.rcs_enabled = options is not None
         if self.rcs_enabled:
-            self.rcs_class_temp, self.rcs_min_crop_ratio, self.rcs_min_pixels = rcs['class_temp'], rcs['min_crop_ratio'], rcs['min_pixels']
             root = cfg['source'].get('rcs_root', cfg['source']['data_root'])
-            self.rcs_classes, self.rcs_classprob = get_rcs_class_probs(root, self.rcs_class_temp)
-            with open(os.path.join(root, 'samples_with_class.json')) as f:
-                swc = {int(k): v for k, v in json.load(f).items() if int(k) in self.rcs_classes}
-            self.samples_with_class = {}
-            for c in self.rcs_classes:
-                self.samples_with_class[c] = [file.split('/')[-1] for file, pixels in swc[c] if pixels > self.rcs_min_pixels]
-                assert len(self.samples_with_class[c]) > 0
-            self.file_to_idx = {}
-            for i, info in enumerate(self.source.img_infos):
-                file = info['ann']['seg_map']
-                self.file_to_idx[file.split('/')[-1] if self.path2name else file] = i
-
-    def get_rare_class_sample(self):
-        c = np.random.choice(self.rcs_classes, p=self.rcs_classprob)
-        f1 = np.random.choice(self.samples_with_class[c])
-        i1 = self.file_to_idx[f1]
-        s1 = self.source[i1]
-        if self.rcs_min_crop_ratio > 0:
-            for _ in range(10):
-                if torch.sum(s1['gt_semantic_seg'].data == c) > self.rcs_min_pixels * self.rcs_min_crop_ratio:
-                    break
-                s1 = self.source[i1]                  # a new random crop of the same source image
-        s2 = self.target[np.random.choice(range(len(self.target)))]
-        return {**s1, 'target_img_metas': s2['img_metas'], 'target_img': s2['img']}
-
-    def __getitem__(self, idx):
-        if self.rcs_enabled:
-            return self.get_rare_class_sample()
-        s1 = self.source[idx // len(self.target)]
-        s2 = self.target[idx % len(self.target)]
-        out = {**s1, 'target_img_metas': s2['img_metas'], 'target_img': s2['img']}
-        if 'img_strong_aug' in s2:
-            out['target_img_strong_aug'] = s2['img_strong_aug']
-        if 'ori_img' in s2:
-            out['target_img_ori'] = s2['ori_img']
-        return out
+            self.rcs = RareClassSampling(source, options, root, self.path2name)
+            self.rcs_classes, self.rcs_classprob = self.rcs.classes, self.rcs.probs
 
     def __len__(self):
         return len(self.source) * len(self.target)
 
+    def __getitem__(self, idx):
+        if self.rcs_enabled:
+            return self.rcs.draw(self.source, self.target)
+        a, b = self.source[idx // len(self.target)], self.target[idx % len(self.target)]
+        item = {**a, 'target_img_metas': b['img_metas'], 'target_img': b['img']}
+        for key, name in (('img_strong_aug', 'target_img_strong_aug'), ('ori_img', 'target_img_ori')):
+            if key in b:
+                item[name] = b[key]
+        return item
 
-def uda_loader(source, target, batch_size, device='cuda', seed=0, rank=0, world=1):
-    """UDADataset pairing (uda_dataset.py:116-135: idx // len(target), idx % len(target)) -> collated device batches."""
-    rng = random.Random(seed + rank)
-    meta = dict(img_norm_cfg=dict(mean=list(NORM_CFG['mean']), std=list(NORM_CFG['std'])))
-    n = len(source) * len(target)
+
+def build_uda_dataset(train_cfg):
+    """cfg.data.train of the PFST configs: dict(type='UDADataset', source=..., target=..., rare_class_sampling=...)"""
+    return UDADataset(TileFolder(train_cfg['source']), TileFolder(train_cfg['target']), train_cfg)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sampler + collation
+# ----------------------------------------------------------------------------------------------------------------------
+def epoch_indices(n, world=1, rank=0, epoch=0, seed=0, shuffle=True):
+    """samplers/distributed_sampler.py:42-70 on top of torch's DistributedSampler: one seeded permutation per epoch shared by
+    all ranks, padded by wrapping to a multiple of the world size, rank r takes every world-th index from r."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(epoch + seed)
+        order = torch.randperm(n, generator=g).tolist()
+    else:
+        order = list(range(n))
+    per_rank = -(-n // world)
+    total = per_rank * world
+    order += order[:total - len(order)]
+    return order[rank:total:world]
+
+
+def collate(items, device):
+    """mmcv collate of DataContainers for the PFST keys: stacked tensors, lists of metas"""
+    batch = {}
+    for key in ('img', 'gt_semantic_seg', 'target_img', 'target_img_strong_aug'):
+        if key in items[0]:
+            batch[key] = torch.stack([it[key] for it in items]).to(device, non_blocking=True)
+    batch['img_metas'] = [it['img_metas'] for it in items]
+    batch['target_img_metas'] = [it['target_img_metas'] for it in items]
+    return batch
+
+
+def uda_batches(dataset, batch_size, device='cuda', seed=0, rank=0, world=1, start_epoch=0):
+    """infinite iterator of collated device batches, epoch after epoch (drop_last=True like rsiseg/datasets/builder.py:107);
+    single-process loading -- `workers_per_gpu` worker processes are a deployment concern outside the hot path"""
+    epoch = start_epoch
     while True:
-        imgs, gts, timgs, taugs = [], [], [], []
-        for _ in range(batch_size):
-            idx = rng.randrange(n)
-            s_img, s_gt, _ = source.get(idx // len(target))
-            t_img, _, t_aug = target.get(idx % len(target), strong=True)
-            imgs.append(s_img), gts.append(s_gt), timgs.append(t_img), taugs.append(t_aug)
-        metas = [dict(meta) for _ in range(batch_size)]
-        yield dict(img=torch.stack(imgs).to(device), img_metas=metas, gt_semantic_seg=torch.stack(gts).to(device),
-                   target_img=torch.stack(timgs).to(device), target_img_metas=metas,
-                   target_img_strong_aug=torch.stack(taugs).to(device))
+        idx = epoch_indices(len(dataset), world, rank, epoch, seed)
+        for b in range(len(idx) // batch_size):
+            yield collate([dataset[i] for i in idx[b * batch_size:(b + 1) * batch_size]], device)
+        epoch += 1

@@ -48,3 +48,24 @@ def check_same_keys(names, group=None):
         t = t.cuda()
     dist.all_reduce(t, group=group)
     assert int(t.item()) == len(names) * dist.get_world_size(group), 'loss log variables are different across GPUs!'
+
+
+def broadcast_module_state_(module, src=0, group=None):
+    """What wrapping the model in MMDistributedDataParallel does at construction (rsiseg/apis/train.py:104-112): every rank starts
+    from rank `src`'s parameters and buffers.  Without it `--diff_seed` (or any rank-dependent initialisation) would average the
+    gradients of DIFFERENT replicas.  Tensors are moved through the backend's device (CUDA for nccl == RCCL, CPU for gloo)."""
+    if not is_distributed():
+        return
+    on_gpu = dist.get_backend(group) == 'nccl'
+    for _, t in sorted(module.state_dict().items()):
+        if not torch.is_tensor(t):
+            continue
+        buf = t.detach()
+        if on_gpu and not buf.is_cuda:
+            buf = buf.cuda()
+        elif not on_gpu and buf.is_cuda:
+            buf = buf.cpu()
+        buf = buf.contiguous()
+        dist.broadcast(buf, src=src, group=group)
+        if buf.data_ptr() != t.data_ptr():
+            t.detach().copy_(buf)

@@ -61,3 +61,52 @@ def evaluate(model, batches, num_classes, ignore_index=255):
     for c in range(num_classes):
         res[f'IoU.{c}'] = 100 * float(m['IoU'][c])
     return res
+
+
+def revise_checkpoint_keys(state_dict, revise_keys=((r'^module\.', ''), ('model.', ''))):
+    """mmcv.runner.load_checkpoint(revise_keys=...) as tools/test.py:237-242 calls it: every (pattern, replacement) is applied with
+    re.sub to every key -- a PFGST checkpoint's `model.<student key>` becomes `<student key>`; the teacher's `ema_model.*`
+    keys turn into names the segmentor does not have and are ignored (strict=False)."""
+    import re
+    from collections import OrderedDict
+    out = OrderedDict()
+    for k, v in state_dict.items():
+        for pattern, repl in revise_keys:
+            k = re.sub(pattern, repl, k)
+        out[k] = v
+    return out
+
+
+def build_eval_fn(val_cfg, num_classes, device, metric='mIoU', max_images=None):
+    """The validation pass the reference's EvalHook / DistEvalHook run every `evaluation.interval` iterations
+    (rsiseg/apis/train.py:152-168, core/evaluation/eval_hooks.py:12-58, apis/test.py single_gpu_test with pre_eval): whole-tile
+    inference of the student with samples_per_gpu = 1, per-class area statistics summed over the images (ranks take every
+    world-th image and the statistics are all-reduced), then the metric table.  -> fn(model) -> {'aAcc', 'mIoU', 'mAcc', 'IoU.<c>'}"""
+    import torch.distributed as dist
+    from .data import TileFolder
+    dataset = TileFolder(val_cfg, test_mode=True)
+    metrics = (metric,) if isinstance(metric, str) else tuple(metric)
+
+    @torch.no_grad()
+    def run(model):
+        seg = model.get_model() if hasattr(model, 'get_model') else model
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
+        acc = AreaAccumulator(num_classes, dataset.ignore_index, device)
+        n = len(dataset) if max_images is None else min(len(dataset), max_images)
+        for i in range(rank, n, world):
+            item = dataset[i]
+            pred8, _ = seg.inference(item['img'][None].to(device), [item['img_metas']], rescale=True)
+            gt = torch.from_numpy(dataset.gt_seg_map(i)).to(device)
+            acc.update(pred8.reshape(gt.shape), gt)
+        if world > 1:
+            dist.all_reduce(acc.hist)
+        m = total_area_to_metrics(*acc.areas(), metrics=metrics)
+        res = OrderedDict(aAcc=100 * float(m['aAcc']))
+        for name, table in m.items():
+            if name != 'aAcc':
+                res['m' + name] = 100 * float(np.nanmean(table))
+        for c in range(num_classes):
+            res[f'IoU.{dataset.CLASSES[c] if c < len(dataset.CLASSES) else c}'] = 100 * float(m['IoU'][c]) if 'IoU' in m else float('nan')
+        return res
+    return run

@@ -89,7 +89,28 @@ class ResNetV1c(nn.Module):
             self.res_layers.append(name)
 
     def init_weights(self):
-        pass   # convs are kaiming-initialised at construction; pretrained weights come via load_state_dict
+        """resnet.py:430-452 with pretrained=None: Kaiming (fan_out, relu) convolutions -- done at construction --, BatchNorm weight 1 /
+        bias 0, and with zero_init_residual the LAST norm of every Bottleneck starts at 0 (each block starts as the identity).
+        A `pretrained` checkpoint path is loaded instead (mmcv 'Pretrained' init: backbone keys, strict=False); model-zoo URLs such as
+        open-mmlab://resnet50_v1c cannot be resolved here (no network) and fail loudly."""
+        if self.pretrained is not None:
+            import os
+            if not (isinstance(self.pretrained, str) and os.path.exists(self.pretrained)):
+                raise FileNotFoundError(f'pretrained={self.pretrained!r} is not a local checkpoint file (no network here): pass a file, '
+                                        'use --load-from, or set pretrained=None for random initialisation')
+            ckpt = torch.load(self.pretrained, map_location='cpu', weights_only=False)
+            sd = ckpt.get('state_dict', ckpt)
+            sd = {(k[len('backbone.'):] if k.startswith('backbone.') else k): v for k, v in sd.items()}
+            self.load_state_dict(sd, strict=False)
+            return
+        for m in self.modules():
+            if isinstance(m, BatchNorm2dP):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
 
     def forward(self, x, tape=None):
         s = self.stem

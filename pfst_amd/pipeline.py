@@ -1,0 +1,264 @@
+"""CPU data pipeline of the PFST configs, restated in NumPy and driven by the reference's own
+`data.train.source.pipeline` / `target.pipeline` / `test_pipeline` lists (configs/_base_/datasets/*.py), so the shipped
+dataset configs drive it unchanged.
+
+Reference (all under rsiseg/datasets/pipelines): loading.py:100-163 (LoadAnnotations, reduce_zero_label),
+transforms.py:11-260 (Resize: ratio sampled with np.random.random_sample, keep-ratio rescale), :262-329 (RandomFlip),
+:331-402 (Pad), :404-451 (Normalize), :644-736 (RandomCrop + cat_max_ratio retries), :942-1059 (PhotoMetricDistortion),
+:1061-1160 (StrongAugmentation = the same distortion written to `img_strong_aug`), rsi_aug.py:29-108 (RandomRotate90),
+formating.py:189-217 (DefaultFormatBundle), test_time_aug.py (MultiScaleFlipAug with one scale, no flip).
+
+The random decisions use the global NumPy RNG with the reference's calls in the reference's order (np.random.random_sample for
+the scale ratio, np.random.randint for crop offsets, np.random.rand / np.random.choice for rotation and flips,
+np.random.randint / uniform for the photometric steps), so a seeded worker draws the same augmentation parameters.
+PIXEL parity is unpinned: the reference resizes / converts colour with OpenCV (cv2.resize INTER_LINEAR fixed-point
+arithmetic, cv2.cvtColor 8-bit HSV), which is not installed here and has no vectors in the reference's tests; this module
+implements the same geometry (half-pixel centres, keep-ratio rounding of mmcv.rescale_size) and the documented 8-bit HSV
+formulas in float arithmetic.
+
+Images travel as HxWx3 uint8 in BGR order like mmcv.imread, `Normalize(to_rgb=True)` swaps them; labels as HxW uint8."""
+import numpy as np
+
+IGNORE = 255
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# pixel operations
+# ----------------------------------------------------------------------------------------------------------------------
+def reduce_zero_label(seg):
+    """loading.py:151-155: 0 -> 255 (ignore), k -> k-1"""
+    seg = seg.copy()
+    seg[seg == 0] = 255
+    seg = seg - 1
+    seg[seg == 254] = 255
+    return seg
+
+
+def rescale_size(old_hw, scale):
+    """mmcv.rescale_size with a (long, short) edge tuple: the largest size that fits, rounded half up"""
+    h, w = old_hw
+    long_e, short_e = max(scale), min(scale)
+    f = min(long_e / max(h, w), short_e / min(h, w))
+    return int(h * float(f) + 0.5), int(w * float(f) + 0.5)
+
+
+def _src_index(n_out, n_in):
+    """half-pixel-centre source coordinates of cv2.resize(INTER_LINEAR): x_src = (x + .5) * in/out - .5, clamped"""
+    s = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    i0 = np.floor(s).astype(np.int64)
+    f = s - i0
+    lo = np.clip(i0, 0, n_in - 1)
+    hi = np.clip(i0 + 1, 0, n_in - 1)
+    f = np.where(i0 < 0, 0.0, f)
+    return lo, hi, f.astype(np.float32)
+
+
+def resize_bilinear_u8(img, out_hw):
+    h, w = img.shape[:2]
+    H, W = out_hw
+    if (H, W) == (h, w):
+        return img
+    y0, y1, fy = _src_index(H, h)
+    x0, x1, fx = _src_index(W, w)
+    a = img.astype(np.float32)
+    top = a[y0][:, x0] * (1 - fx)[None, :, None] + a[y0][:, x1] * fx[None, :, None]
+    bot = a[y1][:, x0] * (1 - fx)[None, :, None] + a[y1][:, x1] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def resize_nearest(seg, out_hw):
+    """cv2.resize(INTER_NEAREST): src = floor(dst * in/out)"""
+    h, w = seg.shape[:2]
+    H, W = out_hw
+    if (H, W) == (h, w):
+        return seg
+    yi = np.minimum((np.arange(H) * (h / H)).astype(np.int64), h - 1)
+    xi = np.minimum((np.arange(W) * (w / W)).astype(np.int64), w - 1)
+    return seg[yi][:, xi]
+
+
+def bgr2hsv_u8(img):
+    """cv2.cvtColor(BGR2HSV) for 8-bit images: H in [0, 180), S, V in [0, 255]"""
+    b, g, r = [img[..., i].astype(np.float32) for i in range(3)]
+    v = np.maximum(np.maximum(b, g), r)
+    mn = np.minimum(np.minimum(b, g), r)
+    d = v - mn
+    s = np.where(v > 0, d / np.maximum(v, 1e-12) * 255.0, 0.0)
+    dd = np.maximum(d, 1e-12)
+    h = np.where(v == r, (g - b) / dd, np.where(v == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd)) * 60.0
+    h = np.where(d == 0, 0.0, h)
+    h = np.where(h < 0, h + 360.0, h) / 2.0
+    out = np.stack([np.rint(h) % 180, np.rint(s), v], -1)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def hsv2bgr_u8(hsv):
+    h = hsv[..., 0].astype(np.float32) * 2.0
+    s = hsv[..., 1].astype(np.float32) / 255.0
+    v = hsv[..., 2].astype(np.float32)
+    c = v * s
+    hp = h / 60.0
+    x = c * (1 - np.abs(hp % 2 - 1))
+    z = np.zeros_like(c)
+    sector = np.floor(hp).astype(np.int64) % 6
+    r = np.choose(sector, [c, x, z, z, x, c])
+    g = np.choose(sector, [x, c, c, x, z, z])
+    b = np.choose(sector, [z, z, x, c, c, x])
+    m = v - c
+    out = np.stack([b + m, g + m, r + m], -1)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
+def _convert(img, alpha=1.0, beta=0.0):
+    """transforms.py:975-979: float multiply-add, clip, truncate to uint8"""
+    return np.clip(img.astype(np.float32) * alpha + beta, 0, 255).astype(np.uint8)
+
+
+def photometric_distortion(img, brightness_delta=32, contrast_range=(0.5, 1.5), saturation_range=(0.5, 1.5), hue_delta=18):
+    """transforms.py:981-1048 (and StrongAugmentation :1077-1144): every step with probability 1/2, contrast before or after
+    the HSV steps; the RNG calls are numpy.random's randint / uniform in the reference's order"""
+    rnd = np.random
+    if rnd.randint(2):
+        img = _convert(img, beta=rnd.uniform(-brightness_delta, brightness_delta))
+    mode = rnd.randint(2)
+    if mode == 1 and rnd.randint(2):
+        img = _convert(img, alpha=rnd.uniform(*contrast_range))
+    if rnd.randint(2):
+        hsv = bgr2hsv_u8(img)
+        hsv[..., 1] = _convert(hsv[..., 1], alpha=rnd.uniform(*saturation_range))
+        img = hsv2bgr_u8(hsv)
+    if rnd.randint(2):
+        hsv = bgr2hsv_u8(img)
+        hsv[..., 0] = (hsv[..., 0].astype(int) + rnd.randint(-hue_delta, hue_delta)) % 180
+        img = hsv2bgr_u8(hsv)
+    if mode == 0 and rnd.randint(2):
+        img = _convert(img, alpha=rnd.uniform(*contrast_range))
+    return img
+
+
+def normalize(img, mean, std, to_rgb=True):
+    """mmcv.imnormalize: (BGR -> RGB,) subtract mean, divide by std, float32"""
+    a = img.astype(np.float32)
+    if to_rgb:
+        a = a[..., ::-1]
+    return (a - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+
+
+def pad_to(a, hw, value):
+    """mmcv.impad(shape=...): bottom / right padding"""
+    ph, pw = max(hw[0] - a.shape[0], 0), max(hw[1] - a.shape[1], 0)
+    if not (ph or pw):
+        return a
+    widths = ((0, ph), (0, pw)) + ((0, 0),) * (a.ndim - 2)
+    return np.pad(a, widths, constant_values=value)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the pipeline: a list of (name, kwargs) steps compiled from the reference's config list
+# ----------------------------------------------------------------------------------------------------------------------
+_KNOWN = {'LoadImageFromFile', 'LoadAnnotations', 'LoadAnnotationsPseudoLabelsV2', 'Resize', 'RandomCrop', 'RandomRotate90',
+          'RandomFlip', 'StrongAugmentation', 'PhotoMetricDistortion', 'Normalize', 'Pad', 'DefaultFormatBundle', 'Collect',
+          'ImageToTensor', 'MultiScaleFlipAug'}
+
+
+class Pipeline:
+    """steps: the reference's list of dict(type=..., **kw).  __call__(img_bgr_u8, seg_u8 | None) -> dict with float32 CHW arrays
+    `img` (+ `img_strong_aug`), uint8 `gt_semantic_seg` [1,H,W] and `img_norm_cfg`."""
+
+    def __init__(self, steps):
+        flat = []
+        for s in steps:
+            s = dict(s)
+            t = s.pop('type')
+            if t not in _KNOWN:
+                raise NotImplementedError(f'pipeline step {t} is outside the PFST dataset configs')
+            if t == 'MultiScaleFlipAug':           # one scale, no flip (the shipped test pipelines): inline its transforms
+                if s.get('flip') or s.get('img_ratios') is not None:
+                    raise NotImplementedError('multi-scale / flip test-time augmentation is outside the PFST configs')
+                scale = s['img_scale']
+                for q in s['transforms']:
+                    q = dict(q)
+                    qt = q.pop('type')
+                    if qt == 'Resize':
+                        q.setdefault('img_scale', scale)
+                    flat.append((qt, q))
+                continue
+            flat.append((t, s))
+        self.steps = flat
+        self.reduce_zero_label = any(k.get('reduce_zero_label') for t, k in flat if t.startswith('LoadAnnotations'))
+
+    def __call__(self, img, seg=None):
+        out = {'img': img}
+        if seg is not None and self.reduce_zero_label:
+            seg = reduce_zero_label(seg)
+        norm_cfg = None
+        for t, k in self.steps:
+            if t == 'Resize':
+                scale = k.get('img_scale')
+                scale = tuple(scale[0]) if isinstance(scale, (list, tuple)) and isinstance(scale[0], (list, tuple)) else tuple(scale)
+                if k.get('ratio_range') is not None:
+                    lo, hi = k['ratio_range']
+                    ratio = np.random.random_sample() * (hi - lo) + lo
+                    scale = (int(scale[0] * ratio), int(scale[1] * ratio))
+                if k.get('keep_ratio', True):
+                    hw = rescale_size(out['img'].shape[:2], scale)
+                else:
+                    hw = (scale[1], scale[0])
+                out['img'] = resize_bilinear_u8(out['img'], hw)
+                if seg is not None:
+                    seg = resize_nearest(seg, hw)
+            elif t == 'RandomCrop':
+                ch, cw = k['crop_size']
+                ratio, ign = k.get('cat_max_ratio', 1.0), k.get('ignore_index', IGNORE)
+
+                def bbox():
+                    mh, mw = max(out['img'].shape[0] - ch, 0), max(out['img'].shape[1] - cw, 0)
+                    oh, ow = np.random.randint(0, mh + 1), np.random.randint(0, mw + 1)
+                    return oh, oh + ch, ow, ow + cw
+                y1, y2, x1, x2 = bbox()
+                if ratio < 1.0 and seg is not None:
+                    for _ in range(10):
+                        labels, cnt = np.unique(seg[y1:y2, x1:x2], return_counts=True)
+                        cnt = cnt[labels != ign]
+                        if len(cnt) > 1 and np.max(cnt) / np.sum(cnt) < ratio:
+                            break
+                        y1, y2, x1, x2 = bbox()
+                out['img'] = out['img'][y1:y2, x1:x2]
+                if seg is not None:
+                    seg = seg[y1:y2, x1:x2]
+            elif t == 'RandomRotate90':
+                if np.random.rand() < k.get('prob', 1.0):
+                    rot = int(np.random.choice([0, 1, 2, 3]))
+                    out['img'] = np.rot90(out['img'], k=rot, axes=(0, 1)).copy()
+                    if seg is not None:
+                        seg = np.rot90(seg, k=rot, axes=(0, 1)).copy()
+            elif t == 'RandomFlip':
+                p = k.get('prob', k.get('flip_ratio'))
+                if np.random.rand() < p:
+                    ax = 1 if k.get('direction', 'horizontal') == 'horizontal' else 0
+                    out['img'] = np.flip(out['img'], ax)
+                    if seg is not None:
+                        seg = np.flip(seg, ax).copy()
+            elif t == 'StrongAugmentation':
+                out['img_strong_aug'] = photometric_distortion(np.ascontiguousarray(out['img']), **k)
+            elif t == 'PhotoMetricDistortion':
+                out['img'] = photometric_distortion(np.ascontiguousarray(out['img']), **k)
+            elif t == 'Normalize':
+                norm_cfg = dict(mean=list(k['mean']), std=list(k['std']), to_rgb=k.get('to_rgb', True))
+                for key in ('img', 'img_strong_aug'):
+                    if key in out:
+                        out[key] = normalize(out[key], k['mean'], k['std'], k.get('to_rgb', True))
+            elif t == 'Pad':
+                if k.get('size') is None:
+                    raise NotImplementedError('Pad(size_divisor) is outside the PFST configs')
+                for key in ('img', 'img_strong_aug'):
+                    if key in out:
+                        out[key] = pad_to(out[key], k['size'], k.get('pad_val', 0))
+                if seg is not None:
+                    seg = pad_to(seg, out['img'].shape[:2], k.get('seg_pad_val', IGNORE))
+        res = {key: np.ascontiguousarray(out[key].transpose(2, 0, 1), dtype=np.float32) for key in ('img', 'img_strong_aug') if key in out}
+        if seg is not None:
+            res['gt_semantic_seg'] = np.ascontiguousarray(seg, dtype=np.uint8)[None]
+        res['img_norm_cfg'] = norm_cfg
+        return res

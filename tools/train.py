@@ -4,9 +4,9 @@
   python tools/train.py configs/pfst/pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8.py --work-dir work_dirs/x
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
 
-The reference's dataset pipeline is out of scope: `--synthetic` trains on seeded synthetic tiles (benchmarks);
-otherwise `cfg.data.train.source/target` `img_dir`/`ann_dir` folders of converted ISPRS tiles are read by the
-minimal reader in pfst_amd/data.py."""
+`--synthetic` trains on seeded synthetic tiles (benchmarks); otherwise `cfg.data.train` (UDADataset: source / target folders of
+converted tiles, each with the config's own pipeline list) is read by pfst_amd/data.py + pfst_amd/pipeline.py, and
+`cfg.data.val` is evaluated every `evaluation.interval` iterations unless --no-validate (rsiseg/apis/train.py:152-168)."""
 import argparse
 import os
 import sys
@@ -34,6 +34,8 @@ def parse_args(argv=None):
     p.add_argument('--local_rank', '--local-rank', type=int, default=0)
     p.add_argument('--auto-resume', action='store_true')
     p.add_argument('--synthetic', action='store_true', help='seeded synthetic batches instead of cfg.data')
+    p.add_argument('--random-init', action='store_true',
+                   help='train from random initialisation when cfg.model.pretrained cannot be loaded (model-zoo URL, no network)')
     p.add_argument('--max-iters', type=int, default=None)
     p.add_argument('--batch-size', type=int, default=None)
     p.add_argument('--crop-size', type=int, default=None)
@@ -72,7 +74,9 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     import pfst_amd  # noqa: F401
-    from pfst_amd.data import ISPRSTiles, synthetic_loader, uda_loader
+    from pfst_amd import dist as pdist
+    from pfst_amd.data import build_uda_dataset, synthetic_loader, uda_batches
+    from pfst_amd.evaluation import build_eval_fn
     from pfst_amd.optim import build_optimizer
     from pfst_amd.registry import build_train_model
     from pfst_amd.runner import IterBasedRunner, find_latest_checkpoint, init_random_seed, set_random_seed
@@ -92,33 +96,45 @@ def main(argv=None):
     seed = seed + rank if args.diff_seed else seed
     set_random_seed(seed, args.deterministic)
 
-    if cfg.model.get('pretrained'):
-        print(f'note: pretrained={cfg.model.pretrained!r} is not downloadable here; use --load-from for a checkpoint')
+    load_from = args.load_from or cfg.get('load_from')
+    resume = args.resume_from or cfg.get('resume_from')
+    if resume is None and args.auto_resume:
+        resume = find_latest_checkpoint(work_dir)
+    pretrained = cfg.model.get('pretrained')
+    if pretrained and not os.path.exists(str(pretrained)):
+        # e.g. 'open-mmlab://resnet50_v1c': a model-zoo URL cannot be fetched here.  Never silently replace it by random weights.
+        if not (load_from or resume or args.random_init or args.synthetic):
+            raise SystemExit(f'cfg.model.pretrained={pretrained!r} cannot be loaded offline: give --load-from / --resume-from a '
+                             'checkpoint, point `pretrained` to a local file, or pass --random-init explicitly')
         cfg.model['pretrained'] = None
     model = build_train_model(cfg)
     model.init_weights()
     model.to(dev)
     optimizer = build_optimizer(model, cfg.optimizer)
-    runner = IterBasedRunner(model, optimizer, cfg, work_dir)
-    if args.load_from or cfg.get('load_from'):
-        runner.load_checkpoint(args.load_from or cfg.load_from)
-    resume = args.resume_from or cfg.get('resume_from')
-    if resume is None and args.auto_resume:
-        resume = find_latest_checkpoint(work_dir)
+    nc = cfg.model.decode_head.num_classes
+    eval_fn = None
+    data_cfg = cfg.get('data') or {}
+    if not args.no_validate and not args.synthetic and 'val' in data_cfg:
+        ev = cfg.get('evaluation') or {}
+        eval_fn = build_eval_fn(data_cfg['val'], nc, dev, metric=ev.get('metric', 'mIoU'))
+    runner = IterBasedRunner(model, optimizer, cfg, work_dir, eval_fn=eval_fn)
+    if load_from:
+        runner.load_checkpoint(load_from)
     if resume:
         runner.resume(resume)
+    # every rank continues from rank 0's parameters and buffers (what MMDistributedDataParallel's constructor does in the reference);
+    # only then may the per-rank random streams diverge (--diff_seed)
+    pdist.broadcast_module_state_(model)
 
-    nc = cfg.model.decode_head.num_classes
-    bs = args.batch_size or (cfg.get('data') or {}).get('samples_per_gpu', 2)
+    bs = args.batch_size or data_cfg.get('samples_per_gpu', 2)
     cin = cfg.model.backbone.get('in_channels', 3)
-    if args.synthetic or 'train' not in (cfg.get('data') or {}):
+    if args.synthetic or 'train' not in data_cfg:
         loader = synthetic_loader(bs, args.crop_size or 1024, nc, cin, seed=1234 + rank, device=dev)
     else:
-        tr = cfg.data.train
-        crop = (args.crop_size,) * 2 if args.crop_size else (512, 512)
-        src = ISPRSTiles(os.path.join(tr.source.data_root, tr.source.img_dir), os.path.join(tr.source.data_root, tr.source.ann_dir), crop)
-        trg = ISPRSTiles(os.path.join(tr.target.data_root, tr.target.img_dir), None, crop)
-        loader = uda_loader(src, trg, bs, dev, seed, rank, world)
+        # img_scale / ratio_range / crop_size / reduce_zero_label / flips / photometric steps all come from the config's pipelines
+        dataset = build_uda_dataset(data_cfg['train'])
+        model.CLASSES = dataset.CLASSES
+        loader = uda_batches(dataset, bs, dev, seed=cfg.get('seed') or 0, rank=rank, world=world)
     runner.run(iter(loader))
     runner.save_checkpoint()
     if distributed:
