@@ -172,7 +172,8 @@ int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C
 
 /* ---- fused bilinear-upsample + softmax cross-entropy + accuracy (decode_head.py:249-283,
  * cross_entropy_loss.py:45-65, accuracy.py:6-61).  logits are [N][C][h][w]; labels/weights [N][H][W].
- * acc[0] += sum_i w_i*cw[y_i]*nll_i (0 at ignore), acc[1] += #correct, acc[2] += #non-ignored.
+ * acc[0] += sum_i w_i*cw[y_i]*nll_i (0 at ignore), acc[1] += #correct, acc[2] += #non-ignored, acc[3] += #labels that are neither
+ * in [0, C) nor ignore_index (F.cross_entropy raises on those; pfst_ce_finalize reports the count so the caller can).  acc: 4 doubles.
  * lse[N][H][W] (log-sum-exp of the upsampled logits) is saved for the backward. */
 int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
                          const float* class_weight, int H, int W, int ignore_index, float* lse, double* acc, pfst_stream_t stream);
@@ -258,7 +259,7 @@ int pfst_adamw_step(float* p, const float* g, float* m, float* v, long long n, f
                     float eps, float weight_decay, int step, float grad_scale, pfst_stream_t stream);
 
 /* ---- loss bookkeeping (base.py:177-222) ------------------------------------------------------- */
-/* out[0] = loss_weight*acc[0]/numel ; out[1] = 100*(acc[1]+eps)/(acc[2]+eps) */
+/* out[0] = loss_weight*acc[0]/numel ; out[1] = 100*(acc[1]+eps)/(acc[2]+eps) ; out[2] = acc[3] (count of invalid labels) */
 int pfst_ce_finalize(const double* acc, double numel, float loss_weight, float* out, pfst_stream_t stream);
 
 #ifdef __cplusplus

@@ -389,7 +389,7 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None):
+                 blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None, ignore_top=0, ignore_bottom=0):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -406,6 +406,7 @@ class OraclePFGST:
         # features (pfgst.py:229-231,255-257; pfgst_loss.py:50-51)
         self.feat_level = feat_level
         self.thre_type = thre_type
+        self.ignore_top, self.ignore_bottom = ignore_top, ignore_bottom      # pseudo_weight_ignore_top / _bottom (pfgst.py:273-276)
         self.local_iter = 0
 
     def train_step(self, batch, masks=None, drop_masks=None, return_extras=False, pseudo_override=None):
@@ -430,6 +431,10 @@ class OraclePFGST:
             pl, n_conf = pseudo_override
             if self.thre_type == 'all':
                 pw = (n_conf / pl.numel()) * torch.ones(pl.shape, dtype=ema_logits.dtype)
+        if self.ignore_top > 0:
+            pw[:, :self.ignore_top, :] = 0
+        if self.ignore_bottom > 0:
+            pw[:, -self.ignore_bottom:, :] = 0
         if masks is None:
             masks = class_masks(gt)
         mixed_img, mixed_lbl, mixed_w = class_mix(masks, img, trg_aug, gt, pl, pw)

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   const int n = blockIdx.y;
   const float* lp = logits + (i64)n * C * h * w;
   const int hw = h * w;
-  double loss = 0.0, correct = 0.0, valid = 0.0;
+  double loss = 0.0, correct = 0.0, valid = 0.0, bad = 0.0;
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < H * W; p += gridDim.x * blockDim.x) {
     const int oy = p / W, ox = p - oy * W;
     const Bilin b = make_bilin(oy, ox, sh, sw, h, w);
@@ -55,8 +55,12 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
       loss += (double)(wgt * (l - zl));
       valid += 1.0;
       if (arg == lab) correct += 1.0;
+    } else if (lab != ignore) {
+      bad += 1.0;       // a label in [C, 255] other than ignore_index: F.cross_entropy raises on it, so must the caller (acc[3])
     }
   }
+  bad = block_sum_d(bad, sm);
+  if (threadIdx.x == 0 && bad > 0.0) atomicAdd(&acc[3], bad);
   loss = block_sum_d(loss, sm);
   correct = block_sum_d(correct, sm);
   valid = block_sum_d(valid, sm);
@@ -220,6 +224,7 @@ __global__ void ce_finalize_kernel(const double* __restrict__ acc, double numel,
   const double eps = 1.1920928955078125e-07;  // torch.finfo(float32).eps
   out[0] = (float)((double)loss_weight * (acc[0] / numel));
   out[1] = (float)((acc[1] + eps) * (100.0 / (acc[2] + eps)));
+  out[2] = (float)acc[3];
 }
 
 inline int px_blocks(i64 n) {

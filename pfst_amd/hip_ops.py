@@ -506,7 +506,7 @@ def channel_scale(x, mask):
 
 # ---------------------------------------------------------------- losses
 def ce_upsample_fwd(logits, label_u8, pix_weight=None, class_weight=None, ignore_index=255):
-    """-> (lse [N,H,W], acc float64[3] = (weighted nll sum, #correct, #valid))"""
+    """-> (lse [N,H,W], acc float64[4] = (weighted nll sum, #correct, #valid, #labels outside [0,C) that are not ignore_index))"""
     _dense(logits), _dense(label_u8, U8)
     n, c, h, w = logits.shape
     H, W = label_u8.shape[-2:]
@@ -514,7 +514,7 @@ def ce_upsample_fwd(logits, label_u8, pix_weight=None, class_weight=None, ignore
     if pix_weight is not None:
         assert _dense(pix_weight).numel() == n * H * W
     lse = torch.empty(n, H, W, device=logits.device)
-    acc = torch.zeros(3, dtype=F64, device=logits.device)
+    acc = torch.zeros(4, dtype=F64, device=logits.device)
     call('pfst_ce_upsample_fwd', logits.data_ptr(), n, c, h, w, label_u8.data_ptr(), _p(pix_weight), _p(class_weight), H, W,
          ignore_index, lse.data_ptr(), acc.data_ptr(), _stream())
     return lse, acc
@@ -532,7 +532,8 @@ def ce_upsample_bwd(logits, label_u8, lse, scale, pix_weight=None, class_weight=
 
 
 def ce_finalize(acc, numel, loss_weight):
-    out = torch.empty(2, device=acc.device)
+    """-> float32[3] = (loss, acc_seg %, #invalid labels)"""
+    out = torch.empty(3, device=acc.device)
     call('pfst_ce_finalize', acc.data_ptr(), float(numel), float(loss_weight), out.data_ptr(), _stream())
     return out
 

@@ -247,7 +247,9 @@ class BaseDecodeHead(nn.Module):
 
     def losses(self, seg_logit, seg_label_u8, seg_weight, tape, grad_scale=1.0):
         out = self.loss_decode.fused(seg_logit, seg_label_u8, seg_weight, tape, self.ignore_index, grad_scale)
-        return {self.loss_decode.loss_name: out[0:1], 'acc_seg': out[1:2]}
+        # '_bad_labels': labels outside [0, C) other than ignore_index (F.cross_entropy raises on them); travels with the packed
+        # scalars of the step and is checked on the host after the step's single read (uda.PFGST.forward_train), never logged
+        return {self.loss_decode.loss_name: out[0:1], 'acc_seg': out[1:2], '_bad_labels': out[2:3]}
 
     def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg, seg_weight=None, tape=None, grad_scale=1.0):
         seg_logits, feats = self.forward(inputs, return_features=True, tape=tape, training=True)

@@ -100,7 +100,10 @@ class PFGSTLoss(nn.Module):
         else:                                           # pfgst_loss.py:116-131
             out = OrderedDict(loss_src_pos=l4[0:1], loss_src_neg=l4[1:2])
         out.update(loss_sim_pos=l2[0:1], loss_sim_neg=l2[1:2])
-        out['vis|density_sim_feat'] = (ema_sim, all9)
+        if tensors.get('want_vis'):
+            # pfgst_loss.py:134-137: (img_trg, 1 - mean_k sim_ema, the all-nine-neighbours-unmixed mask) -- visualisation only, built
+            # with torch ops because it is off the hot path (PFGST.return_vis_states)
+            out['vis|density_sim_feat'] = (tensors.get('img_trg'), 1 - ema_sim.mean(dim=1, keepdim=True), all9.bool())
         return out
 
 
@@ -159,8 +162,8 @@ class PFGST(UDADecorator):
         self.strong_aug_denorm_type = cfg.get('strong_aug_denorm_type', 'mean_std')
         self.apply_no_mix = cfg.get('apply_no_mix', False)
         assert self.mix == 'class'
-        bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type not in ('all', 'part'), ps_top=self.psweight_ignore_top > 0,
-                   ps_bottom=self.psweight_ignore_bottom > 0,
+        bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type not in ('all', 'part'),
+                   ps_rows=self.psweight_ignore_top < 0 or self.psweight_ignore_bottom < 0,
                    apply_no_mix=self.apply_no_mix, print_grad=self.print_grad_magnitude)
         bad = [k for k, v in bad.items() if v]
         if bad:
@@ -177,6 +180,8 @@ class PFGST(UDADecorator):
             if not isinstance(aux_losses, (list, tuple)):
                 aux_losses = [aux_losses]
             self.aux_losses = nn.ModuleList([build_loss(dict(l)) for l in aux_losses])
+        # the reference returns three `vis|*` tuples of live tensors from every step (pfgst.py:335,346-352) for its plotting hooks;
+        # they cost argmax / interpolate passes over full-resolution tensors, so they are built only when asked for
         self.return_vis_states = False
         self.debug = None                    # tests set this to a dict to capture intermediates
         self._student_arena = self._teacher_arena = None
@@ -325,6 +330,16 @@ class PFGST(UDADecorator):
         res = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None, want_conf=part)
         pl64, pl8, conf_count = res[:3]
         trg_weight = res[3] if part else None        # per-pixel 0/1 weights instead of the scalar fraction q
+        if self.psweight_ignore_top > 0 or self.psweight_ignore_bottom > 0:
+            # pfgst.py:273-276: no trust in the pseudo labels of the top / bottom rows.  The scalar q becomes a per-pixel map
+            # (q exactly as the reference forms it: python-float count / size stored to float32) with those rows zeroed.
+            if trg_weight is None:
+                q = (conf_count.double() / float(pl8.numel())).float()
+                trg_weight = q.expand(pl8.shape).contiguous()
+            if self.psweight_ignore_top > 0:
+                trg_weight[:, :self.psweight_ignore_top, :] = 0
+            if self.psweight_ignore_bottom > 0:
+                trg_weight[:, -self.psweight_ignore_bottom:, :] = 0
         if self.injected_pseudo is not None:
             if dbg is not None:
                 dbg['own_pseudo_label'], dbg['own_conf_count'] = pl64, conf_count
@@ -353,15 +368,15 @@ class PFGST(UDADecorator):
         # ---- auxiliary pseudo-feature losses
         vis_states = {}
         if self.apply_aux:
-            tensors = dict(gt_src=gt8, x_src=src_dec, x_ema=ema_dec, logits_trg=mixed_logits, mix_masks=mix_masks)
+            tensors = dict(gt_src=gt8, x_src=src_dec, x_ema=ema_dec, logits_trg=mixed_logits, mix_masks=mix_masks,
+                           img_trg=mixed_img, want_vis=self.return_vis_states)
             for loss_module in self.aux_losses:
                 aux = loss_module(tensors, tape=tape)
                 vis = {k: v for k, v in aux.items() if k.startswith('vis|')}
                 for k in vis:
                     aux.pop(k)
                 scalars.update(aux)
-                if dbg is not None:
-                    dbg['aux_vis'] = vis
+                vis_states.update(vis)
 
         # ---- one backward over both student graphs + aux (pfgst.py:344)
         tape.backward()
@@ -384,9 +399,19 @@ class PFGST(UDADecorator):
             packed = pdist.reduce_log_vector(packed)
         vals = packed.cpu().tolist()                                      # the step's single blocking read
         log_vars = OrderedDict(zip(names, vals))
+        for k in [k for k in log_vars if k.rsplit('.', 1)[-1].startswith('_')]:
+            v = log_vars.pop(k)                 # not a log value: the CE kernels' count of labels outside [0, C) / ignore_index
+            if k.endswith('_bad_labels') and v > 0:
+                raise ValueError(f'{int(v)} label values outside [0, {self.num_classes}) other than ignore_index reached the cross-entropy '
+                                 f'({k}); F.cross_entropy raises on them in the reference -- check reduce_zero_label / the label maps')
         log_vars['loss'] = sum(v for k, v in log_vars.items() if 'loss' in k)
 
         if self.return_vis_states:
-            vis_states['vis|seg_mask_mix'] = (mixed_img, mixed_lbl64)
+            # pfgst.py:346-352, the reference's tuple layouts
+            arg = lambda lg: lg.max(dim=1)[1].unsqueeze(1)
+            mix_lbl = mixed_lbl64 if mixed_lbl64 is not None else ops.to_i64(mixed_lbl8)
+            vis_mix = torch.where(mixed_w.unsqueeze(1) > 0.0, mix_lbl, torch.full_like(mix_lbl, 255))
+            vis_states['vis|seg_mask_src'] = (img, gt_semantic_seg, arg(src_logits.data))
+            vis_states['vis|seg_mask_mix'] = (mixed_img, vis_mix, arg(mixed_logits.data).float())
         self.local_iter += 1
         return log_vars, vis_states

@@ -407,3 +407,59 @@ def test_fused_bn_backward_does_not_change_the_step():
         assert abs(a0[k] - b0[k]) <= 1e-6 * max(abs(a0[k]), 1e-2), (k, a0[k], b0[k])       # forward is untouched
         assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
     assert rel(g1, g0) < 2e-4, rel(g1, g0)     # fp32 partial sums in a different order, amplified by the BN chain (atomics noise alone: 1e-4)
+
+
+def test_vis_states_follow_the_reference_layout():
+    """pfgst.py:335,346-352 + pfgst_loss.py:134-137: `states` holds three tuples of live tensors.  Off by default (they cost
+    full-resolution passes nothing on the path needs); with `return_vis_states` the reference's layout and values."""
+    from pfst_amd.synthetic import synth_batch
+    gold = np.load(os.path.join(G, 'train_step.npz'))
+    model, opt, student, teacher = _build(0.30)
+    batch = to_dev(synth_batch(2, 128, 6, seed=1234), 'cuda')
+    random.seed(0); np.random.seed(0)
+    assert model.train_step(batch, opt)['states'] == {}
+    model, opt, student, teacher = _build(0.30)
+    model.return_vis_states = True
+    random.seed(0); np.random.seed(0)
+    st = model.train_step(batch, opt)['states']
+    assert set(st) == {'vis|density_sim_feat', 'vis|seg_mask_src', 'vis|seg_mask_mix'}
+    shapes = {k: [tuple(t.shape) for t in v] for k, v in st.items()}
+    assert shapes['vis|density_sim_feat'] == [(2, 3, 128, 128), (2, 1, 16, 16), (2, 1, 16, 16)]          # SURVEY App. B
+    assert shapes['vis|seg_mask_src'] == [(2, 3, 128, 128), (2, 1, 128, 128), (2, 1, 32, 32)]
+    assert shapes['vis|seg_mask_mix'] == [(2, 3, 128, 128), (2, 1, 128, 128), (2, 1, 32, 32)]
+    assert st['vis|density_sim_feat'][2].dtype == torch.bool and st['vis|seg_mask_mix'][2].dtype == torch.float32
+    assert (st['vis|seg_mask_mix'][1].cpu().numpy() != gold['it0_mixed_lbl']).mean() < 2e-3
+    assert (st['vis|seg_mask_mix'][2].cpu().numpy().astype(np.int64) != gold['it0_mix_pred']).mean() < 5e-3
+
+
+def test_pseudo_weight_ignore_rows_and_invalid_labels():
+    """pseudo_weight_ignore_top / _bottom (pfgst.py:273-276) against the oracle; a label outside [0, C) that is not ignore_index
+    raises after the step's single read, as F.cross_entropy does in the reference."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = uda_cfg(threshold=0.30)
+    cfg['pseudo_weight_ignore_top'], cfg['pseudo_weight_ignore_bottom'] = 16, 8
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 9)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 6, seed=55)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.30, teacher_sd=teacher, ignore_top=16, ignore_bottom=8)
+    random.seed(4); np.random.seed(4)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(4); np.random.seed(4)
+    model.debug = {}
+    model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    assert torch.equal(model.debug['mixed_w'].cpu(), ex['mixed_w'])
+    assert float(ex['mixed_w'][:, :16][ex['masks'][:, 0, :16] == 0].abs().max()) == 0.0          # the rows really are zeroed
+    for k, v in olog.items():
+        assert abs(out['log_vars'][k] - v) <= TOL * max(abs(v), 1e-2), (k, out['log_vars'][k], v)
+    bad = to_dev(synth_batch(2, 128, 6, seed=56), 'cuda')
+    bad['gt_semantic_seg'][0, 0, 40:44, 40:44] = 7
+    with pytest.raises(ValueError, match='outside'):
+        model.train_step(bad, opt)
