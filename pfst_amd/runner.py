@@ -144,4 +144,7 @@ class IterBasedRunner:
                 res = self.eval_fn(self.model)
                 if is_main():
                     self.log(f'Iter(val) [{self.iter}]\t' + ', '.join(f'{k}: {v:.2f}' for k, v in res.items() if not k.startswith('IoU.')))
+                    if self.work_dir:
+                        with open(os.path.join(self.work_dir, 'log.json'), 'a') as f:
+                            f.write(json.dumps(dict(mode='val', iter=self.iter, **res)) + '\n')
         return self.iter

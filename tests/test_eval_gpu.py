@@ -83,3 +83,58 @@ def test_runner_checkpoint_resume(tmp_path):
     assert runner2.iter == 4 and model2.local_iter == 4
     st = list(opt2._flat.values())[0]
     assert st['step'] == 4            # Adam moments and step count survived the resume
+
+
+def test_train_cli_on_tile_folders_with_validation_and_test_cli(tmp_path):
+    """tools/train.py on folder datasets through the config's own pipelines, the validation pass every `evaluation.interval`
+    iterations (apis/train.py:152-168; dead in round 1), then tools/test.py on the PFGST checkpoint with the reference's key
+    revision (tools/test.py:237-242)."""
+    import json
+    import os
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import test as test_cli
+    import train as train_cli
+    from test_data_pipeline_cpu import NORM, SOURCE, TARGET, TEST, _tile
+    for dom, n in (('pots', 4), ('vaih', 3)):
+        os.makedirs(tmp_path / dom / 'img_dir/train'), os.makedirs(tmp_path / dom / 'ann_dir/train')
+        for i in range(n):
+            img, seg = _tile(7 * n + i, 256)
+            Image.fromarray(img).save(tmp_path / dom / 'img_dir/train' / f't{i}.png')
+            Image.fromarray(seg).save(tmp_path / dom / 'ann_dir/train' / f't{i}.png')
+    small = lambda pl: [dict(s, crop_size=(128, 128)) if s['type'] == 'RandomCrop' else dict(s, size=(128, 128)) if s['type'] == 'Pad' else
+                        dict(s, img_scale=(192, 192)) if s['type'] == 'Resize' else s for s in pl]
+    test_pl = [TEST[0], dict(TEST[1], img_scale=(128, 128))]
+    loader = dict(reduce_zero_label=True)
+    ds = lambda dom, pl: dict(type='ISPRSDataset', data_root=str(tmp_path / dom), img_dir='img_dir/train', ann_dir='ann_dir/train',
+                              gt_seg_map_loader_cfg=loader, pipeline=pl)
+    from pfst_amd.presets import LR_CONFIG, OPTIMIZER
+    cfg = uda_cfg(threshold=0.3)
+    model_cfg = cfg.pop('model')
+    cfg.pop('max_iters')
+    text = ('model = %r\nuda = %r\noptimizer = %r\nlr_config = %r\nrunner = dict(type="IterBasedRunner", max_iters=2)\n'
+            'checkpoint_config = dict(by_epoch=False, interval=2)\nevaluation = dict(interval=2, metric="mIoU")\nlog_config = dict(interval=1)\n'
+            'seed = 0\ndata = %r\n') % (model_cfg, cfg, dict(OPTIMIZER), dict(LR_CONFIG),
+                                       dict(samples_per_gpu=2, workers_per_gpu=0,
+                                            train=dict(type='UDADataset', source=ds('pots', small(SOURCE)), target=ds('vaih', small(TARGET)),
+                                                       rare_class_sampling=None),
+                                            val=ds('vaih', test_pl), test=ds('vaih', test_pl)))
+    cfg_path = tmp_path / 'toy_pfst.py'
+    cfg_path.write_text(text)
+    work = tmp_path / 'work'
+    train_cli.main([str(cfg_path), '--work-dir', str(work), '--seed', '0'])
+    lines = [json.loads(l) for l in open(work / 'log.json')]
+    assert [l['iter'] for l in lines if l['mode'] == 'train'] == [1, 2]
+    val = [l for l in lines if l['mode'] == 'val']
+    assert len(val) == 1 and val[0]['iter'] == 2 and 0.0 <= val[0]['mIoU'] <= 100.0 and 'aAcc' in val[0]
+    ck = work / 'iter_2.pth'
+    assert ck.exists()
+    res = test_cli.main([str(cfg_path), str(ck), '--eval', 'mIoU', '--revise-checkpoint-key', '--split', 'val'])
+    assert abs(res['mIoU'] - val[0]['mIoU']) < 1e-6               # the same student weights, the same tiles
+    with pytest.raises(SystemExit):
+        test_cli.main([str(cfg_path), str(ck), '--split', 'val'])    # without the key revision the student's keys are missing
+    # --no-validate: no validation lines
+    work2 = tmp_path / 'work2'
+    train_cli.main([str(cfg_path), '--work-dir', str(work2), '--seed', '0', '--no-validate'])
+    assert not [l for l in map(json.loads, open(work2 / 'log.json')) if l['mode'] == 'val']

@@ -607,7 +607,7 @@ def test_pfgst_loss_option_variants_against_golden(ops, golden_dir, name):
     xe = Var(torch.from_numpy(z['x_ema']).to(DEV), False)
     tape = Tape()
     out = loss(dict(logits_trg=lt, x_ema=xe, x_src=xs, gt_src=ops.to_u8(torch.from_numpy(z['gt_src']).to(DEV)),
-                    mix_masks=ops.to_u8(torch.from_numpy(z['mix_masks']).to(DEV))), tape)
+                    mix_masks=ops.to_u8(torch.from_numpy(z['mix_masks']).to(DEV)), want_vis=True), tape)
     names = [k for k in out if not k.startswith('vis|')]
     assert names == list(z[name + '|names'])
     got = np.array([float(out[k].sum()) for k in names])
@@ -615,5 +615,5 @@ def test_pfgst_loss_option_variants_against_golden(ops, golden_dir, name):
     tape.backward()
     assert_close(lt.grad, torch.from_numpy(z[name + '|grad_logits']), 1e-3, 'd logits_trg')
     assert_close(xs.grad, torch.from_numpy(z[name + '|grad_xsrc']), 1e-3, 'd x_src')
-    dens = 1 - out['vis|density_sim_feat'][0].mean(1, keepdim=True)
+    dens = out['vis|density_sim_feat'][1]          # the reference's tuple: (img_trg, 1 - mean_k sim_ema, unmixed-neighbourhood mask)
     assert_close(dens, torch.from_numpy(z[name + '|density']), 1e-4, 'density')
