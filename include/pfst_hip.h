@@ -231,12 +231,19 @@ int pfst_sim_map_bwd(const float* feat, const float* sim, const float* norm, con
  * loss_type 1 / 2 (margin / margin2, pfgst_loss.py:116-131): stats[1] = sum relu(margin_pos - s)^e over positive pairs,
  *   stats[4] = sum relu(s - margin_neg)^e over negative pairs, e = loss_type */
 int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
-                       float margin_pos, float margin_neg, double* stats, pfst_stream_t stream);
+                       float margin_pos, float margin_neg, double* stats, const void* select, pfst_stream_t stream);
 /* loss_type 0: losses[0..3] = -w*mean_pos, w*mean_neg, w*std_pos, w*std_neg; 1 / 2: losses[0..1] = w_pos*mean hinge_pos,
  * w_neg*mean hinge_neg (losses[2..3] = 0); gsim = d(sum of the losses)/d sim */
 int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
                       float margin_pos, float margin_neg, const double* stats,
-                      float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream);
+                      float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, const void* select, pfst_stream_t stream);
+/* src_perc (pfgst_loss.py:98-102: only the int(n * src_perc) smallest positive / largest negative similarities enter the source
+ * losses): pfst_src_sim_select finds, with an exact radix select and no sort, the threshold value of each set and the share of its
+ * ties that lies inside the sorted prefix; pass the filled `select` buffer (pfst_src_sim_select_bytes() bytes, 8-byte aligned) to
+ * pfst_src_sim_stats / pfst_src_sim_grad, or NULL for all pairs. */
+int pfst_src_sim_select_bytes(void);
+int pfst_src_sim_select(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double src_perc,
+                        void* select, pfst_stream_t stream);
 /* prob[n][c][y][x] = softmax_c(logits[n][c][y*ds][x*ds]) (nearest down-scaling by ds) */
 int pfst_softmax_down(const float* logits, int N, int C, int h, int w, int ds, float* prob, int H, int W, pfst_stream_t stream);
 /* valid[n][y][x] = (gt != 255) && all 9 dilated neighbours un-mixed; count[0] = #valid */
@@ -245,7 +252,8 @@ int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char* mix_mask, 
 /* top-k target losses (top_k = 0: all nine pairs, the reference's top_k=None); acc[0] += sum loc_pos, acc[1] += sum loc_neg
  * over valid pixels; gP[n][9][y][x] = d(w_pos*mean loc_pos + w_neg*mean loc_neg)/d cross_prob (0 when count <= 1) */
 int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
-                       int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream);
+                       int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, float* g_sim, pfst_stream_t stream);
+/* g_sim != NULL: also d(losses)/d ema_sim [N][9][H][W] -- needed only when the similarity has trainable inputs (proj_net) */
 /* d logits[n][c][y*ds][x*ds] += softmax-backward( sum_k gP[k] * prob_c(neighbour k) ); unfold_grad != 0 (detach_unfold=False)
  * adds the gradient through the unfolded factor: coefficient gP[k][r] + gP[8-k][r+D_k] */
 int pfst_cross_prob_bwd(const float* prob, const float* gP, int N, int C, int H, int W, int dil, int ds, int unfold_grad,

@@ -299,10 +299,13 @@ def class_mix(masks, img, trg_img, gt, pseudo_lbl, pseudo_w):
 # PFGSTLoss
 # ---------------------------------------------------------------------------
 def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2, top_k=3, downscale=0.5,
-               sim_type='cosine', sigma=30.0, src_loss_type='mean_std', margin=(0.5, 0.5), detach_unfold=True):
+               sim_type='cosine', sigma=30.0, src_loss_type='mean_std', margin=(0.5, 0.5), detach_unfold=True,
+               src_perc=None, proj=None):
     """PFGSTLoss.forward with cross_prob_type='trg', feat_level=None (pfgst_loss.py:44-234); options:
     sim_type 'cosine' | 'gaussian' (:199-208), src_loss_type 'mean_std' | 'margin' | 'margin2' (:107-131),
-    detach_unfold (:151-152), top_k None = all k*k pairs (:229-231), downscale None (:54-57).  Returns (losses, extras)."""
+    detach_unfold (:151-152), top_k None = all k*k pairs (:229-231), downscale None (:54-57), src_perc = keep the hardest fraction of
+    the source pairs (:98-102: the smallest positive / largest negative similarities), proj = (weight, bias) of the 1x1 proj_net
+    applied to BOTH feature maps (:34-36,73-75).  Returns (losses, extras)."""
     unfold = lambda t: F.unfold(t, k, dilation=dil, padding=(k // 2) * dil)
     kk = k * k
     if downscale is not None:
@@ -329,11 +332,16 @@ def pfgst_loss(logits_trg, x_ema, x_src, gt_src, mix_masks, weights, k=3, dil=2,
         assert sim_type == 'cosine'
         return F.cosine_similarity(u, x.unsqueeze(2), dim=1)   # (B, kk, H, W)
 
+    if proj is not None:
+        x_src, x_ema = F.conv2d(x_src, proj[0], proj[1]), F.conv2d(x_ema, proj[0], proj[1])
     ema_sim, src_sim = sim_of(x_ema), sim_of(x_src)
     nb = unfold(gt_).view(B, kk, H, W).long()
     ctr = gt_.long().expand(B, kk, H, W)
     vs = valid_src.expand(B, kk, H, W)
     pos, neg = src_sim[(nb == ctr) & vs], src_sim[(nb != ctr) & vs]
+    if src_perc is not None:
+        pos = pos.sort()[0][:int(pos.shape[0] * src_perc)]
+        neg = neg.sort(descending=True)[0][:int(neg.shape[0] * src_perc)]
 
     mask = valid_src & all9
     if top_k is not None:

@@ -356,11 +356,113 @@ __device__ __forceinline__ int src_pair_class(const unsigned char* __restrict__ 
   return nb == ctr ? 1 : 2;
 }
 
+// ---- src_perc (pfgst_loss.py:98-102): only the hardest fraction of the source pairs enters the source losses -- the smallest
+// positive and the largest negative similarities: `sorted[:int(n * src_perc)]`.  A sorted prefix is {s < t} plus some of the ties
+// {s == t}, t the K-th smallest value, so no sort is needed: an exact radix select (4 passes of 8 bits over order-preserving
+// integer keys) finds t and the number of ties inside the prefix; ties share that number equally (they are equal values, so the
+// losses are the reference's; only the split of the gradient among EXACTLY equal similarities is even instead of by sort position).
+// Negative pairs use the complemented key (descending order).
+struct SrcSel {                       // one per set (0: positive pairs, 1: negative pairs)
+  unsigned int prefix;                // key bits fixed so far; after the last pass: key of the K-th element
+  unsigned int shift;                 // bit position of the digit the next histogram pass resolves (24, 16, 8, 0)
+  unsigned long long rank;            // 1-based rank of the wanted element among the keys matching `prefix`
+  unsigned long long K;               // int(n * src_perc)
+  float w_tie;                        // weight of the elements whose key == prefix (ties inside the prefix / all ties)
+  int done;
+};
+__device__ __forceinline__ unsigned int order_key(float v, bool descending) {
+  const unsigned int u = __float_as_uint(v);
+  const unsigned int k = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return descending ? ~k : k;
+}
+__device__ __forceinline__ float sel_weight(const SrcSel* __restrict__ sel, int set, float v) {
+  if (!sel) return 1.f;
+  const unsigned int k = order_key(v, set == 1);
+  return k < sel[set].prefix ? 1.f : (k == sel[set].prefix ? sel[set].w_tie : 0.f);
+}
+
+// grid: (blocks over H*W, N): histogram of the current digit of the keys matching the prefix
+__global__ __launch_bounds__(256) void src_sel_hist_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
+                                                           int Hg, int Wg, int dil, const SrcSel* __restrict__ sel, unsigned int* __restrict__ hist) {
+  __shared__ unsigned int sh[2 * 256];
+  sh[threadIdx.x] = 0; sh[256 + threadIdx.x] = 0;
+  __syncthreads();
+  const int n = blockIdx.y, HW = H * W;
+  const unsigned char* g = gt + (i64)n * Hg * Wg;
+  const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
+  const unsigned int shift0 = sel[0].shift, shift1 = sel[1].shift;
+  // keys match when their bits ABOVE the current digit equal the prefix (first pass: shift = 24, nothing fixed yet)
+  const unsigned int hi0 = shift0 >= 24 ? 0u : (0xFFFFFFFFu << (shift0 + 8)), hi1 = shift1 >= 24 ? 0u : (0xFFFFFFFFu << (shift1 + 8));
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    const int ctr = g[(i64)nearest_src(y, sgy, Hg) * Wg + nearest_src(x, sgx, Wg)];
+    if (ctr == 255) continue;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
+      const float v = sim[((i64)n * 9 + k) * HW + p];
+      if (cls == 1) {
+        const unsigned int key = order_key(v, false);
+        if (((key ^ sel[0].prefix) & hi0) == 0) atomicAdd(&sh[(key >> shift0) & 255u], 1u);
+      } else {
+        const unsigned int key = order_key(v, true);
+        if (((key ^ sel[1].prefix) & hi1) == 0) atomicAdd(&sh[256 + ((key >> shift1) & 255u)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+  if (sh[256 + threadIdx.x]) atomicAdd(&hist[256 + threadIdx.x], sh[256 + threadIdx.x]);
+}
+
+// one block, 2 threads used: resolve the digit, advance the state, clear the histogram
+// first: 2 = initialise the state (before the first histogram), 1 = first digit (also fixes K from the set size), 0 = later digits
+__global__ void src_sel_scan_kernel(SrcSel* __restrict__ sel, unsigned int* __restrict__ hist, double perc, int first) {
+  const int set = threadIdx.x;
+  if (first == 2) {
+    if (set < 2) {
+      sel[set].prefix = 0; sel[set].shift = 24; sel[set].rank = 0; sel[set].K = 0; sel[set].w_tie = 0.f; sel[set].done = 0;
+    }
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+    return;
+  }
+  if (set < 2) {
+    SrcSel& st = sel[set];
+    unsigned int* h = hist + 256 * set;
+    if (first) {
+      unsigned long long n = 0;
+      for (int d = 0; d < 256; ++d) n += h[d];
+      st.K = (unsigned long long)((double)n * perc);         // int(n * src_perc): truncation of the double product
+      st.rank = st.K;
+      st.prefix = 0;
+      st.done = st.K == 0;
+      st.w_tie = 0.f;                                          // K == 0: nothing selected (no key is below prefix 0)
+    }
+    if (!st.done) {
+      unsigned long long cum = 0;
+      int d = 0;
+      for (; d < 256; ++d) {
+        if (cum + h[d] >= st.rank) break;
+        cum += h[d];
+      }
+      st.prefix |= (unsigned int)d << st.shift;
+      st.rank -= cum;
+      if (st.shift == 0) {
+        st.w_tie = (float)((double)st.rank / (double)h[d]);   // `rank` of the h[d] ties lie inside the sorted prefix
+        st.done = 1;
+      }
+    }
+    st.shift = st.shift >= 8 ? st.shift - 8 : 0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+}
+
 // loss_type 0: count / sum / sum of squares (mean & unbiased std, :107-115); 1 / 2: count / sum of relu(m0 - s)^e for positive
 // pairs and relu(s - m1)^e for negative pairs, e = loss_type (:116-131).
 __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
                                                         int Hg, int Wg, int dil, int loss_type, float m0, float m1,
-                                                        double* __restrict__ stats) {
+                                                        double* __restrict__ stats, const SrcSel* __restrict__ sel) {
   __shared__ double sm[16];
   const int n = blockIdx.y, HW = H * W;
   const unsigned char* g = gt + (i64)n * Hg * Wg;
@@ -373,13 +475,15 @@ __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
-      const double s = (double)sim[((i64)n * 9 + k) * HW + p];
+      const float sv = sim[((i64)n * 9 + k) * HW + p];
+      const double s = (double)sv;
+      const double wt = (double)sel_weight(sel, cls == 1 ? 0 : 1, sv);       // src_perc: 1 inside the kept prefix, 0 outside
       const int o = cls == 1 ? 0 : 3;
       if (loss_type == 0) {
-        a[o] += 1.0; a[o + 1] += s; a[o + 2] += s * s;
+        a[o] += wt; a[o + 1] += wt * s; a[o + 2] += wt * s * s;
       } else {
         const double h = cls == 1 ? fmax((double)m0 - s, 0.0) : fmax(s - (double)m1, 0.0);
-        a[o] += 1.0; a[o + 1] += loss_type == 1 ? h : h * h;
+        a[o] += wt; a[o + 1] += wt * (loss_type == 1 ? h : h * h);
       }
     }
   }
@@ -404,7 +508,7 @@ __global__ __launch_bounds__(256) void src_grad_kernel(const float* __restrict__
                                                        int Hg, int Wg, int dil, int loss_type, float m0, float m1,
                                                        const double* __restrict__ stats, float w_pos,
                                                        float w_neg, float w_pos_std, float w_neg_std, float* __restrict__ gsim,
-                                                       float* __restrict__ losses) {
+                                                       float* __restrict__ losses, const SrcSel* __restrict__ sel) {
   const int n = blockIdx.y, HW = H * W;
   const unsigned char* g = gt + (i64)n * Hg * Wg;
   const float sgy = (float)Hg / (float)H, sgx = (float)Wg / (float)W;
@@ -428,7 +532,7 @@ __global__ __launch_bounds__(256) void src_grad_kernel(const float* __restrict__
           const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
           const double s = (double)sim[o];
           const double h = cls == 1 ? (double)m0 - s : s - (double)m1;
-          if (h > 0.0) gr = (float)((cls == 1 ? -cp : cn) * (loss_type == 1 ? 1.0 : 2.0 * h));
+          if (h > 0.0) gr = (float)((cls == 1 ? -cp : cn) * (loss_type == 1 ? 1.0 : 2.0 * h)) * sel_weight(sel, cls == 1 ? 0 : 1, sim[o]);
         }
         gsim[o] = gr;
       }
@@ -457,7 +561,7 @@ __global__ __launch_bounds__(256) void src_grad_kernel(const float* __restrict__
       if (ctr != 255) {
         const int cls = src_pair_class(g, Hg, Wg, sgy, sgx, H, W, y, x, k, dil, ctr);
         const double s = (double)sim[o];
-        gr = cls == 1 ? (float)(pa + pb * (s - mp.mean)) : (float)(na + nb * (s - mn.mean));
+        gr = (cls == 1 ? (float)(pa + pb * (s - mp.mean)) : (float)(na + nb * (s - mn.mean))) * sel_weight(sel, cls == 1 ? 0 : 1, sim[o]);
       }
       gsim[o] = gr;
     }
@@ -514,7 +618,7 @@ __global__ __launch_bounds__(256) void trg_valid_kernel(const unsigned char* __r
 __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict__ ema_sim, const float* __restrict__ prob,
                                                         const unsigned char* __restrict__ valid, const unsigned long long* __restrict__ count,
                                                         int C, int H, int W, int dil, int top_k, float w_pos, float w_neg,
-                                                        float* __restrict__ gP, double* __restrict__ acc) {
+                                                        float* __restrict__ gP, double* __restrict__ acc, float* __restrict__ gS) {
   __shared__ double sm[16];
   const int n = blockIdx.y, HW = H * W;
   const double cnt = (double)count[0];
@@ -527,7 +631,10 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
     const i64 base = (i64)n * 9 * HW + p;
     if (!valid[(i64)n * HW + p]) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) gP[base + (i64)k * HW] = 0.f;
+      for (int k = 0; k < 9; ++k) {
+        gP[base + (i64)k * HW] = 0.f;
+        if (gS) gS[base + (i64)k * HW] = 0.f;
+      }
       continue;
     }
     const int y = p / W, x = p - y * W;
@@ -549,6 +656,7 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
         spos += (double)(-s[k] * P[k]);
         sneg += (double)(-(1.f - s[k]) * (1.f - P[k]));
         gP[base + (i64)k * HW] = -s[k] * cpos + (1.f - s[k]) * cneg;
+        if (gS) gS[base + (i64)k * HW] = -P[k] * cpos + (1.f - P[k]) * cneg;     // d/d sim: the teacher side (proj_net's weights)
       }
       continue;
     }
@@ -564,24 +672,29 @@ __global__ __launch_bounds__(256) void topk_loss_kernel(const float* __restrict_
         }
       }
     }
-    float g[9];
+    float g[9], gs[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) g[k] = 0.f;
+    for (int k = 0; k < 9; ++k) { g[k] = 0.f; gs[k] = 0.f; }
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      float gj = 0.f;
+      float gj = 0.f, gsj = 0.f;
       if (j <= top_k) {            // top-(k+1) largest: loc_pos = -sim * P
         spos += (double)(-s[j] * P[j]);
         gj = -s[j] * cpos;
+        gsj = -P[j] * cpos;
       } else if (j >= 9 - top_k) { // top-k smallest: loc_neg = -(1-sim) * (1-P)
         sneg += (double)(-(1.f - s[j]) * (1.f - P[j]));
         gj = (1.f - s[j]) * cneg;
+        gsj = (1.f - P[j]) * cneg;
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) if (id[j] == k) g[k] = gj;
+      for (int k = 0; k < 9; ++k) if (id[j] == k) { g[k] = gj; gs[k] = gsj; }
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) gP[base + (i64)k * HW] = g[k];
+    for (int k = 0; k < 9; ++k) {
+      gP[base + (i64)k * HW] = g[k];
+      if (gS) gS[base + (i64)k * HW] = gs[k];
+    }
   }
   spos = block_sum_d(spos, sm);
   sneg = block_sum_d(sneg, sm);
@@ -692,24 +805,44 @@ extern "C" int pfst_sim_map_bwd(const float* feat, const float* sim, const float
 }
 
 extern "C" int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
-                                  float margin_pos, float margin_neg, double* stats, pfst_stream_t stream) {
+                                  float margin_pos, float margin_neg, double* stats, const void* select, pfst_stream_t stream) {
   PFST_CHECK_ARG(sim && gt && stats && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
   PFST_CHECK_ARG(loss_type >= 0 && loss_type <= 2);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, 6 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
   hipLaunchKernelGGL(src_stats_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, loss_type, margin_pos,
-                     margin_neg, stats);
+                     margin_neg, stats, reinterpret_cast<const SrcSel*>(select));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
 
 extern "C" int pfst_src_sim_grad(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, int loss_type,
                                  float margin_pos, float margin_neg, const double* stats,
-                                 float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses, pfst_stream_t stream) {
+                                 float w_pos, float w_neg, float w_pos_std, float w_neg_std, float* gsim, float* losses,
+                                 const void* select, pfst_stream_t stream) {
   PFST_CHECK_ARG(sim && gt && stats && gsim && losses && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
   PFST_CHECK_ARG(loss_type >= 0 && loss_type <= 2);
   hipLaunchKernelGGL(src_grad_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, sim, gt, H, W, Hg, Wg, dil,
-                     loss_type, margin_pos, margin_neg, stats, w_pos, w_neg, w_pos_std, w_neg_std, gsim, losses);
+                     loss_type, margin_pos, margin_neg, stats, w_pos, w_neg, w_pos_std, w_neg_std, gsim, losses,
+                     reinterpret_cast<const SrcSel*>(select));
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_src_sim_select_bytes(void) { return (int)(2 * sizeof(SrcSel) + 512 * sizeof(unsigned int)); }
+
+extern "C" int pfst_src_sim_select(const float* sim, const unsigned char* gt, int N, int H, int W, int Hg, int Wg, int dil, double src_perc,
+                                   void* select, pfst_stream_t stream) {
+  PFST_CHECK_ARG(sim && gt && select && N > 0 && N <= 65535 && H > 0 && W > 0 && Hg > 0 && Wg > 0 && dil >= 1);
+  PFST_CHECK_ARG(src_perc >= 0.0 && src_perc <= 1.0 && (reinterpret_cast<uintptr_t>(select) & 7) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  SrcSel* st = reinterpret_cast<SrcSel*>(select);
+  unsigned int* hist = reinterpret_cast<unsigned int*>(st + 2);
+  for (int pass = 0; pass < 4; ++pass) {
+    if (pass == 0) hipLaunchKernelGGL(src_sel_scan_kernel, dim3(1), dim3(256), 0, s, st, hist, src_perc, 2);   // initialise shift = 24
+    hipLaunchKernelGGL(src_sel_hist_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, st, hist);
+    hipLaunchKernelGGL(src_sel_scan_kernel, dim3(1), dim3(256), 0, s, st, hist, src_perc, pass == 0 ? 1 : 0);
+  }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -733,13 +866,14 @@ extern "C" int pfst_trg_valid_mask(const unsigned char* gt, const unsigned char*
 }
 
 extern "C" int pfst_sim_topk_loss(const float* ema_sim, const float* prob, const unsigned char* valid, const unsigned long long* count,
-                                  int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc, pfst_stream_t stream) {
+                                  int N, int C, int H, int W, int dil, int top_k, float w_pos, float w_neg, float* gP, double* acc,
+                                  float* g_sim, pfst_stream_t stream) {
   PFST_CHECK_ARG(ema_sim && prob && valid && count && gP && acc && N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0 && dil >= 1);
   PFST_CHECK_ARG(top_k >= 0 && 2 * top_k + 1 <= 9);    // 0 = all nine pairs (top_k=None)
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(acc, 0, 2 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
   hipLaunchKernelGGL(topk_loss_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, ema_sim, prob, valid, count, C, H, W, dil, top_k,
-                     w_pos, w_neg, gP, acc);
+                     w_pos, w_neg, gP, acc, g_sim);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -613,18 +613,25 @@ def sim_map_bwd(feat, sim, norm, gsim, dil, out=None, accumulate=False, sim_type
     return out
 
 
-def src_sim_losses(sim, gt_u8, dil, w_pos, w_neg, w_pos_std=0.0, w_neg_std=0.0, loss_type='mean_std', margin=(0.5, 0.5)):
-    """-> (losses float32[4] (mean_std) or [2] used of 4 (margin / margin2), gsim [N,9,H,W])"""
+def src_sim_losses(sim, gt_u8, dil, w_pos, w_neg, w_pos_std=0.0, w_neg_std=0.0, loss_type='mean_std', margin=(0.5, 0.5), src_perc=None):
+    """-> (losses float32[4] (mean_std) or [2] used of 4 (margin / margin2), gsim [N,9,H,W]).
+    src_perc: only the int(n * src_perc) smallest positive / largest negative similarities count (pfgst_loss.py:98-102)"""
     n, _, h, w = sim.shape
     hg, wg = gt_u8.shape[-2:]
     lt = SRC_LOSS_TYPES[loss_type]
+    sel = None
+    if src_perc is not None:
+        sel = torch.empty(lib().pfst_src_sim_select_bytes() // 8 + 1, dtype=I64, device=sim.device)       # 8-byte aligned scratch
+        call('pfst_src_sim_select', _dense(sim).data_ptr(), _dense(gt_u8, U8).data_ptr(), n, h, w, hg, wg, dil, float(src_perc),
+             sel.data_ptr(), _stream())
     stats = torch.empty(6, dtype=F64, device=sim.device)
     call('pfst_src_sim_stats', _dense(sim).data_ptr(), _dense(gt_u8, U8).data_ptr(), n, h, w, hg, wg, dil, lt, float(margin[0]),
-         float(margin[1]), stats.data_ptr(), _stream())
+         float(margin[1]), stats.data_ptr(), _p(sel), _stream())
     gsim = torch.empty_like(sim)
     losses = torch.empty(4, device=sim.device)
     call('pfst_src_sim_grad', sim.data_ptr(), gt_u8.data_ptr(), n, h, w, hg, wg, dil, lt, float(margin[0]), float(margin[1]),
-         stats.data_ptr(), float(w_pos), float(w_neg), float(w_pos_std), float(w_neg_std), gsim.data_ptr(), losses.data_ptr(), _stream())
+         stats.data_ptr(), float(w_pos), float(w_neg), float(w_pos_std), float(w_neg_std), gsim.data_ptr(), losses.data_ptr(), _p(sel),
+         _stream())
     return losses, gsim
 
 
@@ -648,17 +655,18 @@ def trg_valid_mask(gt_u8, mix_mask_u8, hw, dil):
     return valid, all9, cnt
 
 
-def sim_topk_loss(ema_sim, prob, valid, count, dil, top_k, w_pos, w_neg):
-    """top_k None / 0 = all nine pairs.  -> (losses float32[2], gP [N,9,H,W])"""
+def sim_topk_loss(ema_sim, prob, valid, count, dil, top_k, w_pos, w_neg, want_sim_grad=False):
+    """top_k None / 0 = all nine pairs.  -> (losses float32[2], gP [N,9,H,W][, d losses / d ema_sim [N,9,H,W]])"""
     top_k = int(top_k or 0)
     n, c, h, w = prob.shape
     gP = torch.empty(n, 9, h, w, device=prob.device)
+    gS = torch.empty(n, 9, h, w, device=prob.device) if want_sim_grad else None
     acc = torch.empty(2, dtype=F64, device=prob.device)
     call('pfst_sim_topk_loss', _dense(ema_sim).data_ptr(), _dense(prob).data_ptr(), _dense(valid, U8).data_ptr(), count.data_ptr(),
-         n, c, h, w, dil, top_k, float(w_pos), float(w_neg), gP.data_ptr(), acc.data_ptr(), _stream())
+         n, c, h, w, dil, top_k, float(w_pos), float(w_neg), gP.data_ptr(), acc.data_ptr(), _p(gS), _stream())
     out = torch.empty(2, device=prob.device)
     call('pfst_sim_loss_finalize', acc.data_ptr(), count.data_ptr(), top_k, float(w_pos), float(w_neg), out.data_ptr(), _stream())
-    return out, gP
+    return (out, gP, gS) if want_sim_grad else (out, gP)
 
 
 def cross_prob_bwd_(dlogits, prob, gP, dil, ds, unfold_grad=False):

@@ -34,10 +34,12 @@ class PFGSTLoss(nn.Module):
         # Implemented: the shipped options plus the variants reachable from the same configs: sim_type
         # 'cosine' | 'gaussian' (sigma), src_loss_type 'mean_std' | 'margin' | 'margin2' (margin), detach_unfold True | False,
         # top_k 1..4 | None, downscale 0.5 | 1 | None, feat_level None | 0..3 (a backbone feature map instead of the decoded
-        # features, with PFGST(use_decoded_feats=False)).  Everything else fails loudly.
+        # features, with PFGST(use_decoded_feats=False)), src_perc (the hardest fraction of the source pairs), proj_net_cfg (a
+        # trainable 1x1 projection of both feature maps).  Everything else (cross_prob_type='ema', kernel_size != 3) fails loudly.
         bad = dict(kernel_size=kernel_size != 3, sim_type=sim_type not in ('cosine', 'gaussian'),
                    feat_level=feat_level is not None and feat_level not in (0, 1, 2, 3),
-                   src_perc=src_perc is not None, proj_net=proj_net_cfg is not None,
+                   src_perc=src_perc is not None and not 0.0 <= src_perc <= 1.0,
+                   proj_net=proj_net_cfg is not None and not {'in_channels', 'out_channels'} <= set(proj_net_cfg),
                    src_loss_type=src_loss_type not in ('mean_std', 'margin', 'margin2'), cross_prob_type=cross_prob_type != 'trg',
                    downscale=downscale not in (None, 0.5, 1, 1.0), top_k=top_k is not None and not (1 <= top_k <= 4),
                    weights=not isinstance(weights, dict), sigma=not sigma > 0)
@@ -50,6 +52,14 @@ class PFGSTLoss(nn.Module):
         self.unfold_grad = not detach_unfold
         self.ds = 1 if downscale is None else int(round(1.0 / downscale))
         self.feat_level = feat_level
+        self.src_perc = src_perc
+        self.proj_net = None
+        if proj_net_cfg is not None:                         # pfgst_loss.py:34-36: nn.Conv2d(in, out, kernel_size=1), default init
+            ref_init = nn.Conv2d(proj_net_cfg['in_channels'], proj_net_cfg['out_channels'], kernel_size=1)
+            self.proj_net = layers.Conv2dP(proj_net_cfg['in_channels'], proj_net_cfg['out_channels'], 1, bias=True)
+            with torch.no_grad():
+                self.proj_net.weight.copy_(ref_init.weight)
+                self.proj_net.bias.copy_(ref_init.bias)
 
     def forward(self, tensors, tape=None):
         """tensors: logits_trg (Var, student logits of the mixed pass), x_ema (Var), x_src (Var),
@@ -74,22 +84,45 @@ class PFGSTLoss(nn.Module):
         if d % u != 0:
             raise NotImplementedError(f'PFGSTLoss: dilation {d} not divisible by the feature up-sampling factor {u}')
         fd = d // u
-        ema_sim, _ = ops.sim_map(x_ema.data, fd, self.sim_type, self.sigma)
+        proj, raw_src, raw_ema = self.proj_net, x_src, x_ema
+        if proj is not None:
+            # pfgst_loss.py:73-75: the same trainable 1x1 convolution on both maps (it commutes with the nearest resize above)
+            for p in proj.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p.data)
+            proj.repack(need_dgrad=True)
+            from .engine import Var
+            x_src = Var(proj.fprop(raw_src.data, bias=proj.bias.data), True)
+            x_ema = Var(proj.fprop(raw_ema.data, bias=proj.bias.data), False)
+        ema_sim, ema_norm = ops.sim_map(x_ema.data, fd, self.sim_type, self.sigma)
         src_sim_f, src_norm = ops.sim_map(x_src.data, fd, self.sim_type, self.sigma)
         src_sim = src_sim_f
+        ema_sim_lowres = ema_sim
         if u > 1:
             ema_sim, src_sim = ops.upsample_nearest(ema_sim, u), ops.upsample_nearest(src_sim_f, u)
         l4, gsim = ops.src_sim_losses(src_sim, gt8, d, w['src_pos'], w['src_neg'], w.get('src_pos_std', 0.0), w.get('src_neg_std', 0.0),
-                                      self.src_loss_type, self.margin)
+                                      self.src_loss_type, self.margin, src_perc=self.src_perc)
         prob = ops.softmax_down(lt.data, self.ds)
         valid, all9, cnt = ops.trg_valid_mask(gt8, mm8, (H, W), d)
-        l2, gP = ops.sim_topk_loss(ema_sim, prob, valid, cnt, d, self.top_k, w['sim_pos'], w['sim_neg'])
+        res = ops.sim_topk_loss(ema_sim, prob, valid, cnt, d, self.top_k, w['sim_pos'], w['sim_neg'],
+                                want_sim_grad=proj is not None and tape is not None)
+        l2, gP = res[0], res[1]
+        gS = res[2] if len(res) > 2 else None
+        ema_sim_f = ema_sim_lowres if u > 1 else ema_sim
         if tape is not None:
             def bwd():
                 buf, acc = x_src.grad_target()
                 g_f = gsim if u == 1 else ops.upsample_nearest_bwd(gsim, u)
                 ops.sim_map_bwd(x_src.data, src_sim_f, src_norm, g_f, fd, out=buf, accumulate=acc, sim_type=self.sim_type,
                                 sigma=self.sigma)
+                if proj is not None:
+                    # the projection's weights collect gradient from BOTH branches: the teacher-side similarity is a function of
+                    # them too (the reference's x_ema carries no graph, proj_net(x_ema) does)
+                    gs_f = gS if u == 1 else ops.upsample_nearest_bwd(gS, u)
+                    g_ema = ops.sim_map_bwd(x_ema.data, ema_sim_f, ema_norm, gs_f, fd, sim_type=self.sim_type, sigma=self.sigma)
+                    ops.conv_wgrad_(proj.weight.grad, raw_ema.data, g_ema, 1)
+                    ops.bias_grad_(proj.bias.grad, g_ema)
+                    layers.conv_backward(raw_src, proj, x_src.grad)
                 buf, acc = lt.grad_target()
                 if not acc:
                     ops.fill_(buf, 0.0)
@@ -396,6 +429,10 @@ class PFGST(UDADecorator):
             if self.local_iter == 0:
                 pdist.check_same_keys(names)
             pdist.allreduce_mean_(arena.grad)          # student gradients only; the teacher stays rank-local
+            for loss_module in (self.aux_losses if self.apply_aux else []):
+                for p in loss_module.parameters():     # trainable parameters of an auxiliary loss (PFGSTLoss.proj_net)
+                    if p.grad is not None:
+                        pdist.allreduce_mean_(p.grad.view(-1))
             packed = pdist.reduce_log_vector(packed)
         vals = packed.cpu().tolist()                                      # the step's single blocking read
         log_vars = OrderedDict(zip(names, vals))

@@ -382,6 +382,53 @@ def gen_pfgst_options(ref):
     np.savez_compressed(os.path.join(OUT, 'pfgst_options.npz'), **out)
 
 
+PFGST_OPTION_VARIANTS2 = {
+    # round 2: the two remaining PFGSTLoss options of SURVEY.md §8 f4 (pfgst_loss.py:34-36,73-75 proj_net; :98-102 src_perc)
+    'src_perc': dict(src_perc=0.6),
+    'src_perc_margin': dict(src_perc=0.35, src_loss_type='margin', margin=[0.5, 0.1]),
+    'proj_net': dict(proj_net_cfg=dict(in_channels=32, out_channels=16)),
+    'proj_net_src_perc_all': dict(proj_net_cfg=dict(in_channels=32, out_channels=24), src_perc=0.8, top_k=None),
+}
+
+
+def gen_pfgst_options2(ref):
+    """PFGSTLoss with proj_net (a trainable 1x1 convolution applied to BOTH feature maps; its gradient also flows through the
+    teacher-side similarity) and src_perc (sort-and-truncate of the source similarities).  Same seeded inputs as gen_pfgst_options;
+    the projection's randomly initialised weights are stored with the fixture."""
+    g = torch.Generator().manual_seed(21)
+    B, C, S = 2, 6, 128
+    lt0 = torch.randn(B, C, S // 4, S // 4, generator=g) * 2
+    xe = torch.randn(B, 32, S // 8, S // 8, generator=g)
+    xs0 = torch.randn(B, 32, S // 8, S // 8, generator=g)
+    gts = torch.randint(0, C, (B, 1, 4, 4), generator=g).repeat_interleave(S // 4, 2).repeat_interleave(S // 4, 3)
+    gts[:, :, :8, :8] = 255
+    mm = (torch.rand(B, 1, 2, 2, generator=g) > 0.6).long().repeat_interleave(S // 2, 2).repeat_interleave(S // 2, 3)
+    out = dict(logits_trg=lt0.numpy(), x_ema=xe.numpy(), x_src=xs0.numpy(), gt_src=gts.numpy(), mix_masks=mm.numpy(),
+               variants=np.array(list(PFGST_OPTION_VARIANTS2)))
+    for i, (name, over) in enumerate(PFGST_OPTION_VARIANTS2.items()):
+        cfg = dict(uda_cfg()['aux_losses'][0])
+        cfg.update(over)
+        torch.manual_seed(100 + i)                         # nn.Conv2d's default initialisation of proj_net
+        PL = ref.builder.build_loss(cfg)
+        lt, xs = lt0.clone().requires_grad_(), xs0.clone().requires_grad_()
+        res = PL(dict(logits_trg=lt, logits_ema=None, gt_src=gts, x_ema=xe, x_src=xs, img_trg=None, mix_masks=mm))
+        names = [k for k in res if not k.startswith('vis|')]
+        tot = sum(res[n].sum() for n in names)
+        tot.backward()
+        out[name + '|names'] = np.array(names)
+        out[name + '|losses'] = np.array([float(res[n].sum()) for n in names], dtype=np.float64)
+        out[name + '|grad_logits'] = lt.grad.numpy().copy()
+        out[name + '|grad_xsrc'] = xs.grad.numpy().copy()
+        out[name + '|density'] = res['vis|density_sim_feat'][1].numpy().copy()
+        if PL.proj_net is not None:
+            out[name + '|proj_weight'] = PL.proj_net.weight.detach().numpy().copy()
+            out[name + '|proj_bias'] = PL.proj_net.bias.detach().numpy().copy()
+            out[name + '|grad_proj_weight'] = PL.proj_net.weight.grad.numpy().copy()
+            out[name + '|grad_proj_bias'] = PL.proj_net.bias.grad.numpy().copy()
+        print(name, dict(zip(names, out[name + '|losses'])))
+    np.savez_compressed(os.path.join(OUT, 'pfgst_options2.npz'), **out)
+
+
 def gen_uda_dataset(ref):
     """UDADataset (rsiseg/datasets/uda_dataset.py:17-135): index pairing and rare-class sampling on toy datasets; records the
     RCS class probabilities and the (source index, class-pixel count, target index) sequence drawn under a NumPy seed."""
@@ -547,7 +594,9 @@ def gen_train_step(ref):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'dataset', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'seg', 'step']
+    if 'options2' in which:
+        gen_pfgst_options2(ref)
     if 'small' in which:
         gen_small_ops(ref)
     if 'options' in which:

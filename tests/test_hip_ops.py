@@ -617,3 +617,72 @@ def test_pfgst_loss_option_variants_against_golden(ops, golden_dir, name):
     assert_close(xs.grad, torch.from_numpy(z[name + '|grad_xsrc']), 1e-3, 'd x_src')
     dens = out['vis|density_sim_feat'][1]          # the reference's tuple: (img_trg, 1 - mean_k sim_ema, unmixed-neighbourhood mask)
     assert_close(dens, torch.from_numpy(z[name + '|density']), 1e-4, 'density')
+
+
+PFGST_VARIANTS2 = {         # tests/golden/make_golden.py:PFGST_OPTION_VARIANTS2 (src_perc, proj_net -- SURVEY.md §8 f4)
+    'src_perc': dict(src_perc=0.6),
+    'src_perc_margin': dict(src_perc=0.35, src_loss_type='margin', margin=(0.5, 0.1)),
+    'proj_net': dict(proj_net_cfg=dict(in_channels=32, out_channels=16)),
+    'proj_net_src_perc_all': dict(proj_net_cfg=dict(in_channels=32, out_channels=24), src_perc=0.8, top_k=None),
+}
+
+
+@pytest.mark.parametrize('name', list(PFGST_VARIANTS2))
+def test_pfgst_loss_src_perc_and_proj_net_against_golden(ops, golden_dir, name):
+    """src_perc (radix-select threshold instead of the reference's sort, pfgst_loss.py:98-102) and proj_net (trainable 1x1
+    projection of both feature maps, :34-36,73-75; its weights also receive the gradient of the teacher-side similarity):
+    loss values, both input gradients and the projection's gradients against vectors from the executed reference."""
+    import os
+    import pfst_amd  # noqa: F401
+    from pfst_amd.engine import Tape, Var
+    from pfst_amd.uda import PFGSTLoss
+    z = np.load(os.path.join(golden_dir, 'pfgst_options2.npz'))
+    cfg = dict(kernel_size=3, dilation=2, top_k=3, weights={k: 0.1 for k in ('src_pos', 'src_neg', 'sim_pos', 'sim_neg', 'src_pos_std', 'src_neg_std')},
+               sim_type='cosine', feat_level=None, detach_unfold=True, downscale=0.5)
+    cfg.update(PFGST_VARIANTS2[name])
+    loss = PFGSTLoss(**cfg).to(DEV)
+    if loss.proj_net is not None:
+        with torch.no_grad():
+            loss.proj_net.weight.copy_(torch.from_numpy(z[name + '|proj_weight']))
+            loss.proj_net.bias.copy_(torch.from_numpy(z[name + '|proj_bias']))
+    lt = Var(torch.from_numpy(z['logits_trg']).to(DEV), True)
+    xs = Var(torch.from_numpy(z['x_src']).to(DEV), True)
+    xe = Var(torch.from_numpy(z['x_ema']).to(DEV), False)
+    tape = Tape()
+    out = loss(dict(logits_trg=lt, x_ema=xe, x_src=xs, gt_src=ops.to_u8(torch.from_numpy(z['gt_src']).to(DEV)),
+                    mix_masks=ops.to_u8(torch.from_numpy(z['mix_masks']).to(DEV)), want_vis=True), tape)
+    names = [k for k in out if not k.startswith('vis|')]
+    assert names == list(z[name + '|names'])
+    got = np.array([float(out[k].sum()) for k in names])
+    assert np.allclose(got, z[name + '|losses'], rtol=1e-4, atol=1e-7), (got, z[name + '|losses'])
+    tape.backward()
+    assert_close(lt.grad, torch.from_numpy(z[name + '|grad_logits']), 1e-3, 'd logits_trg')
+    assert_close(xs.grad, torch.from_numpy(z[name + '|grad_xsrc']), 1e-3, 'd x_src')
+    assert_close(out['vis|density_sim_feat'][1], torch.from_numpy(z[name + '|density']), 1e-4, 'density')
+    if loss.proj_net is not None:
+        assert_close(loss.proj_net.weight.grad, torch.from_numpy(z[name + '|grad_proj_weight']), 1e-3, 'd proj_net.weight')
+        assert_close(loss.proj_net.bias.grad, torch.from_numpy(z[name + '|grad_proj_bias']), 1e-3, 'd proj_net.bias')
+
+
+def test_src_perc_selection_counts(ops):
+    """the radix select keeps exactly int(n * perc) pairs per set (ties weighted fractionally): the weighted counts equal the
+    reference's prefix lengths, for several fractions incl. the degenerate ones"""
+    gen = g(3)
+    n, H = 2, 16
+    sim = (torch.rand(n, 9, H, H, generator=gen) * 2 - 1).round(decimals=2)          # many exact ties
+    gt = torch.randint(0, 4, (n, 1, 4, 4), generator=gen).repeat_interleave(H // 4 * 8, 2).repeat_interleave(H // 4 * 8, 3)
+    gt[:, :, :8, :8] = 255
+    gt8 = ops.to_u8(gt.to(DEV))
+    _, g_all = ops.src_sim_losses(sim.to(DEV), gt8, 2, 0.1, 0.1, 0.1, 0.1)
+    for perc in (1.0, 0.5, 0.123, 0.0):
+        from pfst_amd._lib import lib
+        sel = torch.empty(lib().pfst_src_sim_select_bytes() // 8 + 1, dtype=torch.int64, device=DEV)
+        hg = gt.shape[-1]
+        ops.call('pfst_src_sim_select', sim.to(DEV).data_ptr(), gt8.data_ptr(), n, H, H, hg, hg, 2, float(perc), sel.data_ptr(), 0)
+        stats = torch.zeros(6, dtype=torch.float64, device=DEV)
+        ops.call('pfst_src_sim_stats', sim.to(DEV).data_ptr(), gt8.data_ptr(), n, H, H, hg, hg, 2, 0, 0.5, 0.5, stats.data_ptr(), sel.data_ptr(), 0)
+        full = torch.zeros(6, dtype=torch.float64, device=DEV)
+        ops.call('pfst_src_sim_stats', sim.to(DEV).data_ptr(), gt8.data_ptr(), n, H, H, hg, hg, 2, 0, 0.5, 0.5, full.data_ptr(), 0, 0)
+        torch.cuda.synchronize()
+        for o in (0, 3):
+            assert abs(float(stats[o]) - int(float(full[o]) * perc)) < 1e-3, (perc, o, float(stats[o]), float(full[o]))
