@@ -397,13 +397,16 @@ class OraclePFGST:
 
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
-                 blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None, ignore_top=0, ignore_bottom=0):
+                 blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None, ignore_top=0, ignore_bottom=0,
+                 proj=None):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
         for k in self.pkeys:
             self.student[k].requires_grad_(True)
-        self.opt = torch.optim.AdamW([self.student[k] for k in self.pkeys], lr=lr, betas=betas,
+        # PFGSTLoss.proj_net: (weight, bias) of the trainable 1x1 projection; optimised with the student (it is a sub-module of PFGST)
+        self.proj = None if proj is None else tuple(t.clone().requires_grad_(True) for t in proj)
+        self.opt = torch.optim.AdamW([self.student[k] for k in self.pkeys] + list(self.proj or ()), lr=lr, betas=betas,
                                      weight_decay=weight_decay)
         self.alpha, self.tau, self.trg_w = alpha, pseudo_threshold, trg_loss_weight
         self.aux_w = aux_weights or DEFAULT_LOSS_W
@@ -451,7 +454,8 @@ class OraclePFGST:
         mix_loss, lv = parse_losses(OrderedDict(('mix.' + k, v) for k, v in mlosses.items()))
         lv.pop('loss'); log.update(lv)
         x_ema, x_src = (ema_dec, src_dec) if self.feat_level is None else (ema_feats[self.feat_level], feats[self.feat_level])
-        aux, extras = pfgst_loss(mix_logits, x_ema, x_src, gt, masks, self.aux_w, downscale=self.downscale, **self.loss_opts)
+        aux, extras = pfgst_loss(mix_logits, x_ema, x_src, gt, masks, self.aux_w, downscale=self.downscale, proj=self.proj,
+                                 **self.loss_opts)
         aux_loss, lv = parse_losses(aux)
         lv.pop('loss'); log.update(lv)
         total = clean_loss + self.trg_w * mix_loss + aux_loss
@@ -462,6 +466,7 @@ class OraclePFGST:
             extras.update(pseudo_label=pl, n_conf=n_conf, masks=masks, mixed_img=mixed_img, mixed_lbl=mixed_lbl,
                           mixed_w=mixed_w, src_logits=src_logits.detach(), mix_logits=mix_logits.detach(),
                           ema_logits=ema_logits, ema_logits_low=ema_low, ema_dec=ema_dec, src_dec=src_dec.detach(),
-                          grads=OrderedDict((k, self.student[k].grad.clone()) for k in self.pkeys))
+                          grads=OrderedDict((k, self.student[k].grad.clone()) for k in self.pkeys),
+                          proj_grads=None if self.proj is None else tuple(t.grad.clone() for t in self.proj))
             return log, extras
         return log

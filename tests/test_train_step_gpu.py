@@ -274,7 +274,7 @@ def test_step_with_pfgst_loss_option_variants():
     from pfst_amd.presets import uda_cfg as preset_cfg
     from pfst_amd.registry import UDA
     from pfst_amd.synthetic import synth_batch
-    opts = dict(sim_type='gaussian', sigma=20.0, top_k=None, detach_unfold=False, src_loss_type='margin2', margin=(0.7, 0.2))
+    opts = dict(sim_type='gaussian', sigma=20.0, top_k=None, detach_unfold=False, src_loss_type='margin2', margin=(0.7, 0.2), src_perc=0.7)
     cfg = preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.3)
     cfg['aux_losses'][0].update(opts)
     model = UDA.build(cfg)
@@ -466,3 +466,39 @@ def test_pseudo_weight_ignore_rows_and_invalid_labels():
     bad['gt_semantic_seg'][0, 0, 40:44, 40:44] = 7
     with pytest.raises(ValueError, match='outside'):
         model.train_step(bad, opt)
+
+
+def test_step_with_trainable_projection():
+    """PFGSTLoss(proj_net_cfg=...) inside a whole train step (pfgst_loss.py:34-36,73-75): the projection is a parameter of the UDA
+    module (state_dict key aux_losses.0.proj_net.*), receives gradient from the source AND the teacher branch, and is stepped by
+    AdamW with the student.  Losses and the projection's gradient against the oracle."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.3)
+    cfg['aux_losses'][0]['proj_net_cfg'] = dict(in_channels=512, out_channels=64)
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 9)
+    model.load_state_dict(both, strict=False)
+    assert 'aux_losses.0.proj_net.weight' in model.state_dict() and 'aux_losses.0.proj_net.bias' in model.state_dict()
+    model.cuda()
+    pw, pb = model.aux_losses[0].proj_net.weight.detach().cpu().clone(), model.aux_losses[0].proj_net.bias.detach().cpu().clone()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 6, seed=77)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.3, teacher_sd=teacher, proj=(pw, pb))
+    random.seed(3); np.random.seed(3)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(3); np.random.seed(3)
+    model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    for k, v in olog.items():
+        tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    proj = model.aux_losses[0].proj_net
+    assert rel(proj.weight.grad, ex['proj_grads'][0]) < 2e-2, rel(proj.weight.grad, ex['proj_grads'][0])     # one BN layer above the features
+    assert rel(proj.bias.grad, ex['proj_grads'][1]) < 2e-2
+    assert not torch.equal(proj.weight.detach().cpu(), pw)                     # AdamW stepped it
+    assert rel(proj.weight, oracle.proj[0]) < 1e-3
