@@ -103,7 +103,8 @@ int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cou
 int pfst_wino_stats_slots(int H, int W, int dil, int m);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
-                    pfst_stream_t stream);
+                    int split, pfst_stream_t stream);
+/* split != 0: the transform-domain products with the fp32-faithful bf16x6 split on the bf16 matrix cores */
 /* the same GEMMs on the fp32-faithful bf16x6 path: plain [X][Cout][Cin] filter sets (normal / flipped) -> X split-packed sets of
  * 6*Cout*Cin bytes each -> pfst_wino_gemm_split */
 int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);

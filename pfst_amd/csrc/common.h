@@ -95,6 +95,10 @@ __device__ __forceinline__ float bilin_blend(float v00, float v01, float v10, fl
 bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, int dil);
 int pfst_wgrad_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int Cout,
                         int Ho, int Wo, int ksize, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s);
+// internal: bf16x6-split K-quad weight gradient of 1x1 / grouped transform-domain products, conv_split.hip
+bool pfst_wgrad_split_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride);
+int pfst_wgrad_split_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Cout, int P, int groups,
+                              i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s);
 // internal: K-quad implicit-GEMM convolution (Cin % 16 == 0), conv_igemm_q.hip
 struct pfst_bnb_fuse;
 typedef struct pfst_bnb_fuse PfstBnbArgs;   // include/pfst_hip.h: fused BatchNorm-backward sums of a data-gradient launch (null = off)

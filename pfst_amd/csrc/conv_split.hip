@@ -11,6 +11,7 @@
 // pfst_conv_pack_weight_split into the exact LDS image [k16-group][piece][k-half][row][8 x bf16]; activations are split
 // in registers on their way from HBM to LDS (fp32 NCHW stays the storage format everywhere).
 #include "conv_epilogue.h"
+#include <math.h>
 #include "../../include/pfst_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -348,6 +349,170 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of 1x1 convolutions (and the transform-domain products of the Winograd weight gradient) with the 6-term
+// split, "K-quad" data movement: both operands are pixel(K)-contiguous, so a thread stages 8 consecutive pixels of one row
+// with TWO buffer_load_dwordx4 (no per-element address arithmetic, no per-element range checks: whole quads are in or out),
+// splits them once in registers and writes the three 16-byte pieces of the [piece][k-half][row][8 x bf16] LDS image.
+// On the bf16 matrix pipe VALU work co-issues with the MFMAs (unlike the fp32-input MFMA), so the 16 splits per thread and
+// K-step (~90 VALU) hide behind the 24 MFMAs of the step.  Tiling, split-K chunking and the XCD-contiguous slice order are
+// those of conv_wgrad_q_kernel (conv_wgrad_q.hip).  The first split kernel (conv_wgrad_split_kernel below: 16 scalar loads
+// with index arithmetic per thread and step) ran at 70-90 TFLOP/s-equivalent, slower than the fp32-MFMA kernel.
+// ---------------------------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(256) void conv_wgrad_split_q_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz, int xcd_order) {
+  constexpr int BJ = 128;
+  constexpr int WM = BM >= 64 ? 64 : 32;
+  constexpr int WAVES_M = BM / WM;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WN = BJ / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr unsigned OOB = 0x80000000u;
+
+  __shared__ uint4 As[2][2 * NP * BM];
+  __shared__ uint4 Bs[2][2 * NP * BJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  int bx, by, bz;                                   // tile and K slice: all tiles of a slice on one XCD (see conv_wgrad_q_kernel)
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (xcd_order && lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * BJ, m0 = by * BM;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
+
+  // staging role: thread -> (row, k-half): 8 consecutive pixels of one row per operand
+  const int srow = tid >> 1, half = tid & 1;
+  const bool a_thread = srow < BM;
+  const unsigned a_voff = (a_thread && m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
+  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
+
+  float4 areg[2], breg[2];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, int so) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0));
+  };
+  auto load_tile = [&](int pk0) {
+    const int p = pk0 + 8 * half;                 // P % 4 == 0 and chunk_len % 16 == 0: a quad is entirely in or out
+    const bool v0 = p < pend, v1 = p + 4 < pend;
+    const int soff = pk0 * 4;
+    areg[0] = ld4(a_rsrc, v0 ? a_voff : OOB, soff);
+    areg[1] = ld4(a_rsrc, v1 ? a_voff : OOB, soff + 16);
+    breg[0] = ld4(b_rsrc, v0 ? b_voff : OOB, soff);
+    breg[1] = ld4(b_rsrc, v1 ? b_voff : OOB, soff + 16);
+  };
+  auto store_tile = [&](int buf) {
+    uint4 q0, q1, q2;
+    if (a_thread) {
+      const float va[8] = {areg[0].x, areg[0].y, areg[0].z, areg[0].w, areg[1].x, areg[1].y, areg[1].z, areg[1].w};
+      split8(va, q0, q1, q2);
+      As[buf][(0 * 2 + half) * BM + srow] = q0;
+      As[buf][(1 * 2 + half) * BM + srow] = q1;
+      As[buf][(2 * 2 + half) * BM + srow] = q2;
+    }
+    const float vb[8] = {breg[0].x, breg[0].y, breg[0].z, breg[0].w, breg[1].x, breg[1].y, breg[1].z, breg[1].w};
+    split8(vb, q0, q1, q2);
+    Bs[buf][(0 * 2 + half) * BJ + srow] = q0;
+    Bs[buf][(1 * 2 + half) * BJ + srow] = q1;
+    Bs[buf][(2 * 2 + half) * BJ + srow] = q2;
+  };
+
+  const int KT = (pend - pbeg + 15) / 16;
+  load_tile(pbeg);
+  store_tile(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) load_tile(pbeg + (kt + 1) * 16);
+    bf16x8 af[TM][NP], bf[TN][NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i][pl] = __builtin_bit_cast(bf16x8, As[cur][(pl * 2 + lh) * BM + wm0 + i * 32 + l31]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[cur][(pl * 2 + lh) * BJ + wn0 + j * 32 + l31]);
+    }
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int BM>
+int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
+                         i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
+  const int tiles = cdiv(J, 128) * cdiv(M, BM) * groups;
+  // split-K chunking: whole rounds of resident workgroups (49 KB of LDS: 3 per CU)
+  const double slots = 256.0 * 3;
+  int chunks = 1;
+  double best = -1.0;
+  for (int c = 1; c <= 64 && (c == 1 || P / c >= 512); ++c) {
+    const double rounds = (double)tiles * N * c / slots;
+    const double eff = rounds < 2.0 ? 0.45 * rounds : rounds / ceil(rounds);
+    if (eff > best + 0.02) { best = eff; chunks = c; }
+    if (eff >= 0.93) break;
+  }
+  int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
+  chunks = cdiv(P, chunk_len);
+  const int gx = cdiv(J, 128), gy = cdiv(M, BM), gz = N * groups * chunks;
+  PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
+  hipLaunchKernelGGL((conv_wgrad_split_q_kernel<BM>), dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
+                     N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
 template <int BM, int T>
 int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                        int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
@@ -422,6 +587,8 @@ extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float
   PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
   PFST_CHECK_ARG(x_bs >= (i64)Cin * Hi * Wi && dy_bs >= (i64)Cout * Ho * Wo);
   hipStream_t s = (hipStream_t)stream;
+  if (pfst_wgrad_split_q_eligible(x, x_bs, dy, dy_bs, Hi, Wi, Ho, Wo, ksize, stride))
+    return pfst_wgrad_split_q_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, Ho * Wo, 1, 0, 0, 0, s);
 #define PFST_WGS(BM_)                                                                                                  \
   return ksize == 3 ? launch_wgrad_split<BM_, 9>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s) \
                     : launch_wgrad_split<BM_, 1>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, Cout, Ho, Wo, stride, dil, pad, s)
@@ -429,6 +596,21 @@ extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float
   if (Cout > 32) { PFST_WGS(64); }
   PFST_WGS(32);
 #undef PFST_WGS
+}
+
+// internal: K-quad split weight gradient of 1x1 / grouped transform-domain products (used by pfst_conv_wgrad_split and pfst_wino_wgrad)
+bool pfst_wgrad_split_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride) {
+  if (ksize != 1 || stride != 1 || Hi != Ho || Wi != Wo) return false;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) return false;
+  if ((x_bs | dy_bs) & 3) return false;
+  return ((i64)Ho * Wo) % 4 == 0;
+}
+int pfst_wgrad_split_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Cout, int P, int groups,
+                              i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
+  PFST_CHECK_ARG((i64)Cin * P * 4 < (1ll << 31) && (i64)Cout * P * 4 < (1ll << 31));
+  if (Cout > 64) return launch_wgrad_split_q<128>(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, P, groups, x_gs, dy_gs, dw_gs, s);
+  if (Cout > 32) return launch_wgrad_split_q<64>(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, P, groups, x_gs, dy_gs, dw_gs, s);
+  return launch_wgrad_split_q<32>(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, P, groups, x_gs, dy_gs, dw_gs, s);
 }
 
 // ---- Winograd on the bf16x6 GEMM (conv_winograd.hip supplies the transforms): the (m+2)^2 transform-domain products as ONE

@@ -323,8 +323,9 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     return res if len(res) > 1 else res[0]
 
 
-def wino_wgrad_(dw, x, dy, dil, v=None, m=None):
-    """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass (same m)"""
+def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False):
+    """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass (same m);
+    split: the transform-domain products with the fp32-faithful bf16x6 split instead of the fp32-input MFMA"""
     n, ci, h, w = x.shape
     co = dy.shape[1]
     m, nx = _wino_m(m)
@@ -337,7 +338,7 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None):
         call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _stream())
     assert v.numel() >= nx * n * ci * t
     call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _stream())
-    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m, _stream())
+    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m, int(split), _stream())
     return dw
 
 

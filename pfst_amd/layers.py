@@ -20,7 +20,10 @@ _BN_EVAL = False
 #   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32), the default and what every reported number uses;
 #   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores (csrc/conv_split.hip), opt-in.
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
-WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '0') == '1'
+# bf16x6 mode: the 1x1 and Winograd-domain weight gradients run on the K-quad split kernel (1.5x the fp32-MFMA one); the rare direct
+# 3x3 / strided ones stay on fp32 MFMA unless PFST_WGRAD_SPLIT_ALL=1 (the generic split kernel is slower than fp32 MFMA)
+WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
+WGRAD_SPLIT_ALL = os.environ.get('PFST_WGRAD_SPLIT_ALL', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
 # Winograd F(m x m,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 4x (m = 4, default) or 2.25x
 # (PFST_WINO_TILE=2) fewer MACs.
@@ -271,6 +274,18 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side_stream)
 
 
+def _wgrad(conv, xd, dy, saved_v):
+    """weight gradient of a dense convolution into conv.weight.grad (fp32 atomics): Winograd-domain, 1x1 / 3x3 K-quad or generic
+    kernel; in bf16x6 mode the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 matrix cores"""
+    split = CONV_MATH == 'bf16x6' and WGRAD_SPLIT
+    if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
+        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v, split=split)
+    elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
+        ops.conv_wgrad_split_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+    else:
+        ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+
+
 def _dgrad_into(x, conv, dy, final):
     """data gradient of `conv` into x's gradient buffer; when this launch completes the gradient of a conv -> BN layer's output
     (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
@@ -285,10 +300,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False):
     xd = x.data
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
-            if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-                ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v)
-            else:
-                ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+            _wgrad(conv, xd, dy, saved_v)
         _on_side_stream(wg, dy, xd, saved_v)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
@@ -301,12 +313,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False):
             buf, acc = x.grad_target()
             ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
-        if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-            ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v)
-        else:
-            # the split wgrad kernel is correct but (first version) slower than the fp32-MFMA one: opt-in only
-            wgrad = ops.conv_wgrad_split_ if (CONV_MATH == 'bf16x6' and WGRAD_SPLIT) else ops.conv_wgrad_
-            wgrad(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
+        _wgrad(conv, xd, dy, saved_v)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
