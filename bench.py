@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 WORKLOAD = 'pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA, spec (a tuned loop on random data sustains 1250-1500: DVFS)
 DOMINANT_KERNEL = 'conv_igemm_q_kernel<128>'     # expected dominant kernel (checked against the full per-kernel pass)
 
 
@@ -54,6 +55,19 @@ class KernelTimer:
             quad = stride == 1 and ((ks == 1 and (ho * wo) % 4 == 0) or (ks == 3 and wo % 16 == 0 and dil <= 8))   # pfst_wgrad_q_eligible
             kern = f'conv_wgrad_q_kernel<{bm},{ks * ks}>' if quad else f'conv_wgrad_kernel<{bm},{ks * ks}>'
             return kern, 2.0 * n * co * ci * ks * ks * ho * wo, nbytes
+        if name == 'pfst_conv_igemm_split':
+            n, c, hi, wi, m, ho, wo, ks, mode = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[17]
+            bm = 128 if m > 64 else (64 if m > 32 else 32)
+            px = ho * wo if mode == 0 else hi * wi
+            return f'conv_igemm_split_kernel<{bm}>', 2.0 * n * m * c * ks * ks * px, 4.0 * (n * c * hi * wi + n * m * ho * wo) + 6.0 * c * ks * ks * m
+        if name == 'pfst_wino_gemm_split':
+            n, k, m, t, nx = a[3], a[4], a[5], a[6], (a[7] + 2) ** 2
+            bm = 128 if m > 64 else (64 if m > 32 else 32)
+            return f'conv_igemm_split_kernel<{bm}>', 2.0 * nx * n * m * k * t, 4.0 * nx * (n * k * t + n * m * t) + 6.0 * nx * k * m
+        if name == 'pfst_conv_wgrad_split':
+            n, ci, co, ho, wo, ks = a[5], a[6], a[9], a[10], a[11], a[12]
+            bm = 128 if co > 64 else (64 if co > 32 else 32)
+            return f'conv_wgrad_split_q_kernel<{bm}>', 2.0 * n * co * ci * ks * ks * ho * wo, 4.0 * (n * ci * a[7] * a[8] + n * co * ho * wo + 2 * co * ci * ks * ks)
         # Winograd path: the X = (m+2)^2 transform-domain GEMMs are one launch of the same K-quad kernel (gridDim.y = X); the
         # flops booked are the GEMM's own (what the kernel executes), not the direct-convolution count it replaces
         if name == 'pfst_wino_gemm':
@@ -63,7 +77,8 @@ class KernelTimer:
         if name == 'pfst_wino_wgrad':
             n, ci, co, t, nx = a[4], a[5], a[6], a[7], (a[8] + 2) ** 2
             bm = 128 if co > 64 else (64 if co > 32 else 32)
-            return f'conv_wgrad_q_kernel<{bm},1>', 2.0 * nx * n * co * ci * t, 4.0 * nx * (n * ci * t + n * co * t + 2 * co * ci)
+            kern = f'conv_wgrad_split_q_kernel<{bm}>' if a[9] else f'conv_wgrad_q_kernel<{bm},1>'
+            return kern, 2.0 * nx * n * co * ci * t, 4.0 * nx * (n * ci * t + n * co * t + 2 * co * ci)
         if name in ('pfst_wino_input', 'pfst_wino_dy'):          # read the image once, write X transform planes of T = HW/m^2 tiles
             return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * (1.0 + (a[8] + 2) ** 2 / a[8] ** 2)
         if name == 'pfst_wino_output':
@@ -365,8 +380,40 @@ def main():
                 model2.train_step(batch, opt2)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
-            res['alt_math'] = {'mode': 'bf16x6 split MFMA for fprop+dgrad GEMMs incl. the Winograd ones (fp32-faithful, opt-in via PFST_CONV_MATH=bf16x6)',
-                               'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
+            alt = {'mode': 'bf16x6 split MFMA (fp32-faithful 6-term bf16 split) for the fprop / dgrad GEMMs incl. the Winograd ones and the 1x1 / '
+                           'Winograd-domain weight gradients; opt-in via PFST_CONV_MATH=bf16x6', 'value': b * args.steps / dt,
+                   'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
+            if not args.no_kernel_timing:
+                # its own roofline leg, against the bf16 dense peak: the split kernel executes 6 bf16 MFMA flops per algorithmic flop
+                timer.records, timer.only, timer.enabled = [], None, True
+                hip_ops.call = timer.call
+                for i in range(args.steps):
+                    model2.train_step(batch, opt2)
+                torch.cuda.synchronize()
+                timer.enabled = False
+                hip_ops.call = timer.inner
+                agg2 = timer.summary()
+                sk = {k: v for k, v in agg2.items() if 'split' in k and v[2] > 0}
+                if sk:
+                    k0, (cnt, ms, fl, nb) = max(sk.items(), key=lambda kv: kv[1][1])
+                    tf = 6.0 * fl / (ms * 1e-3) / 1e12
+                    alt['roofline'] = {'kernel': k0, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA)',
+                                       'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12, 'launches': cnt,
+                                       'avg_launch_ms': ms / cnt, 'ms_per_step': ms / args.steps}
+                    alt['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:8]}
+            # both opt-in features together: bf16x6 arithmetic + stream-level overlap
+            layers.set_overlap(True, True)
+            for i in range(max(1, args.warmup)):
+                model2.train_step(batch, opt2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                model2.train_step(batch, opt2)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            layers.set_overlap(False, False)
+            alt['with_stream_overlap'] = {'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
+            res['alt_math'] = alt
             layers.CONV_MATH = 'f32'
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(w['num_classes'], usable_cpus())

@@ -184,14 +184,17 @@ def test_class_mix_identities_full_size(ops):
     assert torch.equal(mi, 0.0 * img + trg) and torch.equal(ml[:, 0], pl) and bool((mw == float(q)).all())
 
 
-def test_whole_train_step_at_baseline_size():
+@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
+def test_whole_train_step_at_baseline_size(math):
     import pfst_amd  # noqa: F401
+    from pfst_amd import layers
     from pfst_amd.optim import build_optimizer
     from pfst_amd.presets import OPTIMIZER, workload_cfg
     from pfst_amd.registry import UDA
     from pfst_amd.synthetic import fill_state_dict, synth_batch
     cfg, w = workload_cfg('pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8', pseudo_threshold=0.2)
     outs, grads = [], []
+    prev_math, layers.CONV_MATH = layers.CONV_MATH, math
     for rep in range(2):
         model = UDA.build(cfg)
         fill_state_dict(model.state_dict(), 0)
@@ -214,10 +217,20 @@ def test_whole_train_step_at_baseline_size():
             assert model.local_iter == 2
         del model, opt
         torch.cuda.empty_cache()
+    layers.CONV_MATH = prev_math
     for k in outs[0]:
         assert abs(outs[0][k] - outs[1][k]) <= 1e-4 * max(1.0, abs(outs[0][k])), k     # reproducible given the RNG state
     rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
     assert rel < 5e-2, rel    # fp32 atomics reorder + random-init conditioning; identical inputs, no logic differences
+    if math == 'f32':
+        test_whole_train_step_at_baseline_size.f32 = (outs[0], grads[0].cpu())
+    elif hasattr(test_whole_train_step_at_baseline_size, 'f32'):
+        # the two arithmetics of the dense convolutions agree on the whole full-size step: the forward losses to 1e-4, the
+        # gradient to the same few percent that two fp32 runs differ by (atomics order amplified by ~70 train-mode BN layers)
+        o32, g32 = test_whole_train_step_at_baseline_size.f32
+        for k in o32:
+            assert abs(outs[0][k] - o32[k]) <= 1e-3 * max(1.0, abs(o32[k])), (k, outs[0][k], o32[k])
+        assert float((grads[0].cpu() - g32).norm() / g32.norm()) < 1e-1
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
