@@ -71,7 +71,7 @@ int pfst_conv_stats_slots(int M, int Ho, int Wo);
 int pfst_conv_pack_weight_split(const float* w, void* wk6_fprop, void* wk6_dgrad, int Cout, int Cin, int T, pfst_stream_t stream);
 int pfst_conv_igemm_split(const float* in, long long in_bs, const void* wk6, const float* bias, float* out, long long out_bs,
                           int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                          int mode, int accumulate, float* stats, pfst_stream_t stream);
+                          int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb, pfst_stream_t stream);
 int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,
                           int N, int Cin, int Hi, int Wi, int Cout, int Ho, int Wo, int ksize, int stride, int dil, int pad,
                           pfst_stream_t stream);

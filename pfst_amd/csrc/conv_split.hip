@@ -48,11 +48,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& p0, uint4& p1
   p2 = make_uint4(h2[0] | (unsigned)h2[1] << 16, h2[2] | (unsigned)h2[3] << 16, h2[4] | (unsigned)h2[5] << 16, h2[6] | (unsigned)h2[7] << 16);
 }
 
-template <int BM>
+// BNB != 0: the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h); on the bf16
+// matrix pipe the epilogue's VALU work co-issues with the other waves' MFMAs
+template <int BM, int BNB = 0>
 __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, PfstBnbArgs bnb) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -183,7 +185,14 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     __syncthreads();
   }
 
-  conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+  if (BNB != 0) {
+    // (the main loop ended with a workgroup barrier: Bs is free) the per-row sums are reduced through 20 KB of the B double buffer
+    static_assert(sizeof(Bs) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into the B double buffer");
+    conv_epilogue<TM, TN, WAVES_N, BN, BNB, true>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
+                                                  reinterpret_cast<float*>(&Bs[0][0]));
+  } else {
+    conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+  }
 }
 
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.
@@ -532,10 +541,21 @@ int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, flo
 template <int BM>
 int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias, float* out, i64 out_bs, int N, int C, int Hi,
                  int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
-                 hipStream_t s) {
+                 hipStream_t s, const PfstBnbArgs* bnb = nullptr) {
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), groups, N);
-  hipLaunchKernelGGL((conv_igemm_split_kernel<BM>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
-                     Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+  if (bnb && bnb->x) {
+    PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
+#define PFST_LAUNCH_SPLIT_BNB(MODE_)                                                                                              \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, MODE_>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, \
+                       Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
+    if (!bnb->relu) PFST_LAUNCH_SPLIT_BNB(3);
+    else if (bnb->y) PFST_LAUNCH_SPLIT_BNB(2);
+    else PFST_LAUNCH_SPLIT_BNB(1);
+#undef PFST_LAUNCH_SPLIT_BNB
+  } else {
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, 0>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
+                       Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs());
+  }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -555,8 +575,9 @@ extern "C" int pfst_conv_pack_weight_split(const float* w, void* wk6_fprop, void
 
 extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const void* wk6, const float* bias, float* out, long long out_bs,
                                      int N, int C, int Hi, int Wi, int M, int Ho, int Wo, int ksize, int stride, int dil, int pad,
-                                     int mode, int accumulate, float* stats, pfst_stream_t stream) {
+                                     int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk6 && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
   if (C % 16 != 0) {
@@ -573,9 +594,9 @@ extern "C" int pfst_conv_igemm_split(const float* in, long long in_bs, const voi
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   hipStream_t s = (hipStream_t)stream;
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
-  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
-  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
-  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s);
+  if (M > 64) return launch_split<128>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s, bnb);
+  if (M > 32) return launch_split<64>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s, bnb);
+  return launch_split<32>(in, in_bs, wk6, bias, out, out_bs, N, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, 1, s, bnb);
 }
 
 extern "C" int pfst_conv_wgrad_split(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw,

@@ -155,14 +155,9 @@ def conv_dgrad(dy, wk_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, ac
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)
     assert tuple(out.shape) == (n, cin, hi, wi)
-    fuse, part, slots = 0, None, 0
+    fuse, part, slots, st = 0, None, 0, None
     if bnb is not None:
-        pre, y, coef, relu = bnb
-        assert tuple(pre.shape) == (n, cin, hi, wi) and (y is None or tuple(y.shape) == tuple(pre.shape))
-        assert co % 16 == 0 and cin % bnb_tile_rows(cin) == 0 and tuple(coef.shape) == (cin, 4)
-        slots = conv_stats_slots(n, cin, hi, wi)
-        part = torch.empty(2 * cin * slots, dtype=F32, device=dy.device)     # owned by the consumer layer's context until its bn_backward ran
-        st = _BnbFuseStruct(pre.data_ptr(), _bs(pre), _p(y), 0 if y is None else _bs(y), _dense(coef).data_ptr(), part.data_ptr(), int(relu))
+        st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
         fuse = ctypes.addressof(st)
     call('pfst_conv_igemm', dy.data_ptr(), _bs(dy), _dense(wk_d).data_ptr(), 0, out.data_ptr(), _bs(out),
          n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, _stream())
@@ -189,20 +184,36 @@ def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out
     slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
     st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm_split', x.data_ptr(), _bs(x), wk6.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, _stream())
     return (out, st, slots) if want_stats else out
 
 
-def conv_dgrad_split(dy, wk6_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+def _bnb_struct(bnb, n, cin, hi, wi, co, dev):
+    """-> (ctypes struct kept alive by the caller, partials tensor, slots) for a fused BatchNorm-backward data-gradient launch"""
+    pre, y, coef, relu = bnb
+    assert tuple(pre.shape) == (n, cin, hi, wi) and (y is None or tuple(y.shape) == tuple(pre.shape))
+    assert co % 16 == 0 and cin % bnb_tile_rows(cin) == 0 and tuple(coef.shape) == (cin, 4)
+    slots = conv_stats_slots(n, cin, hi, wi)
+    part = torch.empty(2 * cin * slots, dtype=F32, device=dev)     # owned by the consumer layer's context until its bn_backward ran
+    st = _BnbFuseStruct(pre.data_ptr(), _bs(pre), _p(y), 0 if y is None else _bs(y), _dense(coef).data_ptr(), part.data_ptr(), int(relu))
+    return st, part, slots
+
+
+def conv_dgrad_split(dy, wk6_d, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False, bnb=None):
+    """bnb: as conv_dgrad (returns (out, partials, slots) then)"""
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
     assert wk6_d.numel() == 6 * ksize * ksize * co * cin
     if out is None:
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)
+    fuse, part, slots, st = 0, None, 0, None
+    if bnb is not None:
+        st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
+        fuse = ctypes.addressof(st)
     call('pfst_conv_igemm_split', dy.data_ptr(), _bs(dy), wk6_d.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
-    return out
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, _stream())
+    return (out, part, slots) if bnb is not None else out
 
 
 def conv_wgrad_(dw, x, dy, ksize, stride=1, dil=1, pad=0):

@@ -41,6 +41,9 @@ FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
 # itself HBM-bound (layer1: 2 * 64 flop per 8 bytes written + accumulated), and reading the pre-BN tensor there costs what the
 # reduction pass would have cost (measured: fusing everywhere moves 11 ms/step out of pfst_bn_backward and 10 ms into the GEMMs)
 FUSE_BN_BWD_MIN_K = int(os.environ.get('PFST_FUSE_BN_BWD_MIN_K', '512'))
+# the bf16x6 data-gradient kernel carries the same epilogue; measured (b=8, 4-step runs): 439.2 ms with every launch fused, 437.7 ms with none --
+# the cost is not VALU-vs-MFMA contention but the longer workgroup lifetime, in either arithmetic
+FUSE_BN_BWD_MIN_K_SPLIT = int(os.environ.get('PFST_FUSE_BN_BWD_MIN_K_SPLIT', '512'))
 
 
 class BnBackwardCtx:
@@ -114,14 +117,20 @@ class Conv2dP(nn.Module):
 
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
-        return (FUSE_BN_BWD and not self.depthwise and not self.wino and not self.split_d and self.cout % 16 == 0
-                and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= FUSE_BN_BWD_MIN_K)
+        min_k = FUSE_BN_BWD_MIN_K_SPLIT if self.split_d else FUSE_BN_BWD_MIN_K
+        return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
+                and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
     def dgrad(self, dy, in_hw, out, accumulate, bn=None):
         """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient"""
         if self.wino:
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate)
         if self.split_d:
+            if bn is not None:
+                _, bn.partials, bn.slots = ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation,
+                                                                self.padding, out=out, accumulate=accumulate,
+                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu))
+                return out
             return ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                                         out=out, accumulate=accumulate)
         if bn is not None:

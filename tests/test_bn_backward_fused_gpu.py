@@ -31,8 +31,9 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('n,c,co,h,w,k,dil,mode,acc', CASES)
-def test_fused_bn_backward_sums_match_two_pass_and_autograd(ops, n, c, co, h, w, k, dil, mode, acc):
+def test_fused_bn_backward_sums_match_two_pass_and_autograd(ops, n, c, co, h, w, k, dil, mode, acc, math):
     g = torch.Generator().manual_seed(c + co + h)
     pad = dil if k == 3 else 0
     pre = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.8)              # pre-BN tensor of the owner layer (non-zero mean)
@@ -62,12 +63,17 @@ def test_fused_bn_backward_sums_match_two_pass_and_autograd(ops, n, c, co, h, w,
     gd, bd = gamma.to(DEV), beta.to(DEV)
     y = ops.bn_apply(xd, mean, invstd, gd, bd, relu, None if res is None else res.to(DEV))
     assert rel(y, y64) < 1e-5
-    _, wd = ops.pack_weight(wc.to(DEV))
+    if math == 'f32':
+        _, wd = ops.pack_weight(wc.to(DEV))
+        dgrad = ops.conv_dgrad
+    else:                                   # the fp32-faithful bf16x6 data-gradient kernel carries the same fused epilogue
+        _, wd = ops.pack_weight_split(wc.to(DEV))
+        dgrad = ops.conv_dgrad_split
     outs = {}
     for fused in (False, True):
         buf = old.to(DEV).clone() if acc else torch.empty(n, c, h, w, device=DEV)
         bnb = (xd, y if mode == 'gate_y' else None, coef, relu) if fused else None
-        r = ops.conv_dgrad(dyc.to(DEV), wd, c, (h, w), k, 1, dil, pad, out=buf, accumulate=acc, bnb=bnb)
+        r = dgrad(dyc.to(DEV), wd, c, (h, w), k, 1, dil, pad, out=buf, accumulate=acc, bnb=bnb)
         part, slots = (r[1], r[2]) if fused else (None, 0)
         dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
         dx = ops.bn_backward(buf, y if mode == 'gate_y' else None, xd, mean, invstd, gd, dg, db, relu, beta=bd, partials=part, slots=slots)
