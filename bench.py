@@ -139,16 +139,22 @@ def pmc_traffic(kernel):
     if not paths:
         return None
     rec = json.load(open(paths[-1]))        # the newest round's record
-    def norm(k):               # 'conv_igemm_kernel<128, false, 16, 128>' -> 'conv_igemm_kernel<128,false>' (first two template args)
+    def split(k):              # 'conv_igemm_q_kernel<128, 0>' -> ('conv_igemm_q_kernel', ['128', '0'])
         k = k.replace(' ', '')
         if '<' not in k:
-            return k
+            return k, []
         base, args = k.split('<', 1)
-        return base + '<' + ','.join(args.rstrip('>').split(',')[:2]) + '>'
-    for k, v in rec.items():
-        if isinstance(v, dict) and norm(k) == norm(kernel):
-            return (v['fetch_MB_corrected'] + v['write_MB']) * 1e6
-    return None
+        return base, args.rstrip('>').split(',')
+    base, want = split(kernel)
+    tot, calls = 0.0, 0
+    for k, v in rec.items():          # all instantiations whose leading template arguments match (e.g. the fused-epilogue variants
+        if not isinstance(v, dict):   # <128, 0..3> of conv_igemm_q_kernel<128>), weighted by their launch counts
+            continue
+        b, a = split(k)
+        if b == base and a[:len(want)] == want:
+            tot += (v['fetch_MB_corrected'] + v['write_MB']) * 1e6 * v['calls']
+            calls += v['calls']
+    return tot / calls if calls else None
 
 
 def _cpu_model():
