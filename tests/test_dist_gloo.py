@@ -38,3 +38,45 @@ def test_gradient_and_log_exchange_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True, True), (1, True, True)]
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch.nn as nn
+    from pfst_amd import dist as pdist
+    from pfst_amd.data import epoch_indices
+    torch.manual_seed(100 + rank)                   # --diff_seed: every rank initialises differently ...
+    m = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 4, 1))
+    m[1].running_mean.add_(rank + 1.0)
+    before = torch.cat([t.flatten().float() for t in m.state_dict().values()])
+    pdist.broadcast_module_state_(m)                # ... and continues from rank 0's parameters AND buffers
+    after = torch.cat([t.flatten().float() for t in m.state_dict().values()])
+    gathered = [torch.empty_like(after) for _ in range(world)]
+    dist.all_gather(gathered, after)
+    same = all(torch.equal(g, gathered[0]) for g in gathered)
+    changed = not torch.equal(before, after)
+    # the sampler shards one shared permutation: the ranks' index sets are disjoint and cover the data set
+    idx = torch.tensor(epoch_indices(10, world, rank, epoch=2, seed=3))
+    allidx = [torch.empty_like(idx) for _ in range(world)]
+    dist.all_gather(allidx, idx)
+    cover = sorted(torch.cat(allidx).tolist()) == list(range(10))
+    q.put((rank, bool(same), bool(changed), bool(cover)))
+    dist.destroy_process_group()
+
+
+def test_rank0_state_broadcast_and_sampler_sharding_world2():
+    """tools/train.py: after building (and loading) the model every rank takes rank 0's state before the per-rank random streams may
+    diverge -- what MMDistributedDataParallel's constructor does in the reference (rsiseg/apis/train.py:104-112); ADVICE r1."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, False, True), (1, True, True, True)]        # rank 1 changed, rank 0 did not; all equal afterwards
