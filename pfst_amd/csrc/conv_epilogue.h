@@ -248,11 +248,7 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
           }
           sv[r] = a;
           sq[r] = b;
-#ifndef PFST_BNB_ROWS_IN_FLIGHT
-#define PFST_BNB_ROWS_IN_FLIGHT 4
-#endif
-          if (PFST_BNB_ROWS_IN_FLIGHT < 16 && (r % PFST_BNB_ROWS_IN_FLIGHT) == PFST_BNB_ROWS_IN_FLIGHT - 1)
-            __builtin_amdgcn_sched_barrier(0);     // bound the rows of loads in flight (register budget)
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // 4 rows of loads in flight (register budget; 8 / 16 measured: same time)
         }
         float* ws = lds + wid * PFST_ROWSUM_LDS_FLOATS;
         const float ts = LDSRED ? half_wave_rowsum_lds(sv, ws, lane) : half_wave_transpose_sum<16>(sv, l31);

@@ -142,20 +142,21 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
       set_tap();
     }
   };
+  uint4 bq0, bq1, bq2;                               // the split pieces of this thread's 8 activations of the NEXT K-step
+  auto split_tile = [&]() { split8(breg, bq0, bq1, bq2); };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_N; ++i) {
       const int c = tid + 256 * i;
       if (c < A_CHUNKS) As[buf][c] = areg[i];
     }
-    uint4 q0, q1, q2;
-    split8(breg, q0, q1, q2);
-    Bs[buf][(0 * 2 + kh) * BN + pix] = q0;
-    Bs[buf][(1 * 2 + kh) * BN + pix] = q1;
-    Bs[buf][(2 * 2 + kh) * BN + pix] = q2;
+    Bs[buf][(0 * 2 + kh) * BN + pix] = bq0;
+    Bs[buf][(1 * 2 + kh) * BN + pix] = bq1;
+    Bs[buf][(2 * 2 + kh) * BN + pix] = bq2;
   };
 
   load_tile(0);
+  split_tile();
   store_tile(0);
   __syncthreads();
 
@@ -171,7 +172,10 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
 #pragma unroll
       for (int j = 0; j < TN; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[cur][(pl * 2 + lh) * BN + wn0 + j * 32 + l31]);
     }
-    // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0)
+    // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0).  (Placing the in-register split of the next K-step's
+    // activations between the two halves of the MFMA stream instead of after it was measured: no difference, the split is not on
+    // the critical path.  Counters, profiles/r02 notes in DESIGN.md: the matrix pipe is 58 % busy at ~2.0 GHz; 3 workgroups per CU
+    // of 154 registers / 49 KB LDS, one barrier per 768 MFMA-cycles, and 5.33 rounds of tiles rounded up to 6.)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -181,7 +185,10 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-    if (kt + 1 < KT) store_tile(cur ^ 1);
+    if (kt + 1 < KT) {
+      split_tile();
+      store_tile(cur ^ 1);
+    }
     __syncthreads();
   }
 
