@@ -216,11 +216,33 @@ class PFGST(UDADecorator):
         # the reference returns three `vis|*` tuples of live tensors from every step (pfgst.py:335,346-352) for its plotting hooks;
         # they cost argmax / interpolate passes over full-resolution tensors, so they are built only when asked for
         self.return_vis_states = False
-        self.debug = None                    # tests set this to a dict to capture intermediates
+        self._test = None                    # parity-test hooks (see the properties below); no config can set them
         self._student_arena = self._teacher_arena = None
-        self.injected_mix_classes = None     # parity tests may inject the class choice
-        self.injected_pseudo = None          # ... and (uint8 label map, confident-pixel count) to decouple the
-                                             # student-gradient check from 1-ulp arg-max ties in the teacher logits
+
+    # ------------------------------------------------------------------ test hooks (never set by configs / the trainer)
+    class _TestHooks:
+        """debug: dict that captures intermediates; injected_mix_classes: the class choice; injected_pseudo: (uint8 label map,
+        confident-pixel count) -- decouples the student-gradient check from 1-ulp arg-max ties in the teacher logits"""
+        __slots__ = ('debug', 'injected_mix_classes', 'injected_pseudo')
+
+        def __init__(self):
+            self.debug = self.injected_mix_classes = self.injected_pseudo = None
+
+    def _hook(self, name, value=None, set_=False):
+        if set_:
+            if self._test is None:
+                if value is None:
+                    return None
+                self._test = PFGST._TestHooks()
+            setattr(self._test, name, value)
+            if all(getattr(self._test, k) is None for k in PFGST._TestHooks.__slots__):
+                self._test = None
+            return None
+        return None if self._test is None else getattr(self._test, name)
+
+    debug = property(lambda self: self._hook('debug'), lambda self, v: self._hook('debug', v, True))
+    injected_mix_classes = property(lambda self: self._hook('injected_mix_classes'), lambda self, v: self._hook('injected_mix_classes', v, True))
+    injected_pseudo = property(lambda self: self._hook('injected_pseudo'), lambda self, v: self._hook('injected_pseudo', v, True))
 
     # ------------------------------------------------------------------ state
     def get_extra_state(self):
@@ -263,8 +285,8 @@ class PFGST(UDADecorator):
     # ------------------------------------------------------------------ class mix (dacs_transforms.py:110-126)
     def _choose_mix_classes(self, presence, batch_size):
         """`torch.unique` over the whole batch + one NumPy `choice` per image (global RNG stream as the reference)."""
-        if self.injected_mix_classes is not None:
-            return self.injected_mix_classes
+        if self._test is not None and self._test.injected_mix_classes is not None:
+            return self._test.injected_mix_classes
         classes = np.nonzero(presence)[0]
         n = classes.shape[0]
         k = int((n + n % 2) / 2)
@@ -294,7 +316,8 @@ class PFGST(UDADecorator):
         model, ema = self.get_model(), self.get_ema_model()
         batch_size = img.shape[0]
         S_hw = img.shape[-2:]
-        dbg = self.debug
+        hooks = self._test                   # None in production: the parity tests' capture / injection points hang off ONE object
+        dbg = hooks.debug if hooks is not None else None
 
         # the optimizer's zero_grad() may have detached .grad views (set_to_none): re-attach + zero the arena
         arena = self._student_arena
@@ -363,6 +386,11 @@ class PFGST(UDADecorator):
         res = ops.pseudo_label(ema_logits.data, S_hw, self.pseudo_threshold, want_i64=dbg is not None, want_conf=part)
         pl64, pl8, conf_count = res[:3]
         trg_weight = res[3] if part else None        # per-pixel 0/1 weights instead of the scalar fraction q
+        if hooks is not None and hooks.injected_pseudo is not None:
+            if dbg is not None:
+                dbg['own_pseudo_label'], dbg['own_conf_count'] = pl64, conf_count
+            pl8, conf_count = hooks.injected_pseudo
+            pl64 = ops.to_i64(pl8) if dbg is not None else None
         if self.psweight_ignore_top > 0 or self.psweight_ignore_bottom > 0:
             # pfgst.py:273-276: no trust in the pseudo labels of the top / bottom rows.  The scalar q becomes a per-pixel map
             # (q exactly as the reference forms it: python-float count / size stored to float32) with those rows zeroed.
@@ -373,11 +401,6 @@ class PFGST(UDADecorator):
                 trg_weight[:, :self.psweight_ignore_top, :] = 0
             if self.psweight_ignore_bottom > 0:
                 trg_weight[:, -self.psweight_ignore_bottom:, :] = 0
-        if self.injected_pseudo is not None:
-            if dbg is not None:
-                dbg['own_pseudo_label'], dbg['own_conf_count'] = pl64, conf_count
-            pl8, conf_count = self.injected_pseudo
-            pl64 = ops.to_i64(pl8) if dbg is not None else None
 
         # ---- class mix
         presence_evt.synchronize()
