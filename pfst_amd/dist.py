@@ -8,7 +8,11 @@ Backend-agnostic on purpose (nccl == RCCL on the GPUs, gloo in the CPU tests).""
 import torch
 import torch.distributed as dist
 
+import os
+
 SLICE_ELEMS = 16 * 1024 * 1024      # 64 MB per collective
+# bucketed all-reduce overlapped with the backward sweep (GradReducer); PFST_DDP_OVERLAP=0: one reduction after the sweep
+OVERLAP_ALLREDUCE = os.environ.get('PFST_DDP_OVERLAP', '1') == '1'
 
 
 def is_distributed():
@@ -69,3 +73,51 @@ def broadcast_module_state_(module, src=0, group=None):
         dist.broadcast(buf, src=src, group=group)
         if buf.data_ptr() != t.data_ptr():
             t.detach().copy_(buf)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce overlapped with the backward sweep (what MMDistributedDataParallel's reducer does in the
+    reference: rsiseg/apis/train.py:104-112, fired from total_loss.backward(), pfgst.py:344).
+
+    The student gradient lives in ONE flat arena whose layout follows the module order (backbone stem .. layer4, decode head,
+    auxiliary head), and the single backward sweep runs the mixed-pass graph first and the source-pass graph last, each from the
+    heads down to the stem.  So during the SOURCE pass's backward the arena becomes final from its END towards its start: marker
+    closures recorded in that pass's forward (`ready(offset)`: everything at or above `offset` is final) launch the all-reduce of
+    the finished tail asynchronously -- RCCL runs it on its own stream behind everything queued so far -- while the sweep
+    continues; `finish()` reduces what is left and makes the current stream wait for all of it.  Mean over ranks (AVG on RCCL, SUM
+    and a scale on gloo)."""
+
+    def __init__(self, flat, group=None, min_bucket=1 << 20):
+        assert flat.dim() == 1 and flat.is_contiguous()
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group)
+        self.avg = dist.get_backend(group) == 'nccl'
+        self.hi = flat.numel()               # everything at or above `hi` is already on its way
+        self.min_bucket = min_bucket
+        self.pending = []
+
+    def _launch(self, lo, hi):
+        if hi <= lo:
+            return
+        from . import layers
+        layers.join_side_stream()            # weight gradients queued on a side stream (opt-in overlap) must have landed
+        chunk = self.flat[lo:hi]
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        self.pending.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk))
+
+    def ready(self, offset):
+        """gradients at arena offsets >= offset are final"""
+        offset = max(0, min(int(offset), self.hi))
+        if self.hi - offset >= self.min_bucket:
+            self._launch(offset, self.hi)
+            self.hi = offset
+
+    def finish(self):
+        self._launch(0, self.hi)
+        self.hi = 0
+        for work, chunk in self.pending:
+            work.wait()
+            if not self.avg:
+                chunk.mul_(1.0 / self.world)
+        self.pending = []
+        return self.flat

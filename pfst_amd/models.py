@@ -112,7 +112,9 @@ class ResNetV1c(nn.Module):
                 if isinstance(m, Bottleneck):
                     nn.init.zeros_(m.bn3.weight)
 
-    def forward(self, x, tape=None):
+    def forward(self, x, tape=None, grad_ready=None):
+        """grad_ready (data-parallel runs, last pass of the backward sweep only): callable(stage) recorded as marker closures --
+        when marker `layer{i}` runs in backward, the gradients of layer{i} and of everything after it are final"""
         s = self.stem
         x = conv_bn_act(x, s[0], s[1], tape)
         x = conv_bn_act(x, s[3], s[4], tape)
@@ -129,6 +131,8 @@ class ResNetV1c(nn.Module):
             tape.record(bwd_pool, dict(op='maxpool', name='backbone.maxpool', x=xin, out=pooled))
         outs = []
         for i, name in enumerate(self.res_layers):
+            if grad_ready is not None and tape is not None:
+                tape.record(lambda name=name: grad_ready(name))
             for blk in getattr(self, name):
                 x = blk(x, tape)
             if i in self.out_indices:
@@ -380,9 +384,9 @@ class EncoderDecoder(nn.Module):
         for m in self.convs():
             m.repack(need_dgrad)
 
-    def extract_feat(self, img, tape=None):
+    def extract_feat(self, img, tape=None, grad_ready=None):
         x = img if isinstance(img, Var) else Var(img, False)
-        return self.backbone(x, tape)
+        return self.backbone(x, tape, grad_ready) if grad_ready is not None else self.backbone(x, tape)
 
     def encode_decode(self, img, img_metas=None):
         """teacher-style forward: no tape, dropout off, BN still in train mode; returns the LOW-resolution
@@ -426,9 +430,13 @@ class EncoderDecoder(nn.Module):
         return self.forward_test(img, img_metas, **kwargs)
 
     def forward_train(self, img, img_metas, gt_semantic_seg, seg_weight=None, return_feats=False,
-                      return_decoded_feats=False, return_logits=False, return_states=False, tape=None, grad_scale=1.0):
-        """gt_semantic_seg: uint8 [N,1,H,W]; returns the losses dict (device tensors) like the reference."""
-        x = self.extract_feat(img, tape)
+                      return_decoded_feats=False, return_logits=False, return_states=False, tape=None, grad_scale=1.0,
+                      grad_ready=None):
+        """gt_semantic_seg: uint8 [N,1,H,W]; returns the losses dict (device tensors) like the reference.
+        grad_ready: see ResNetV1c.forward; the marker `heads` covers both heads"""
+        x = self.extract_feat(img, tape, grad_ready)
+        if grad_ready is not None and tape is not None:
+            tape.record(lambda: grad_ready('heads'))
         losses, states = dict(), dict()
         loss_decode, state = self.decode_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg, seg_weight,
                                                             tape=tape, grad_scale=grad_scale)

@@ -365,9 +365,19 @@ class PFGST(UDADecorator):
                 ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
             ema_dec = ema_states['decoded_features'] if self.use_decoded_feats else ema_states['feats']
 
-        # ---- student on source
+        # ---- student on source.  Data-parallel runs: this pass is recorded first, so its closures run LAST in the single backward
+        # sweep -- its marker closures tell the reducer which tail of the gradient arena is final (dist.GradReducer)
+        reducer = grad_ready = None
+        if pdist.is_distributed() and pdist.OVERLAP_ALLREDUCE:
+            reducer = pdist.GradReducer(arena.grad)
+            cuts = {'heads': arena.offsets[next(n for n in arena.names if not n.startswith('backbone.'))]}
+            for n in arena.names:
+                stage = n.split('.')[1] if n.startswith('backbone.layer') else None
+                if stage and stage not in cuts:
+                    cuts[stage] = arena.offsets[n]
+            grad_ready = lambda stage: reducer.ready(cuts[stage])
         clean = model.forward_train(img.contiguous(), img_metas, gt8, None, return_feats=True, return_logits=True,
-                                    return_decoded_feats=self.use_decoded_feats, tape=tape)
+                                    return_decoded_feats=self.use_decoded_feats, tape=tape, grad_ready=grad_ready)
         src_dec = clean.pop('features')                       # pfgst.py:229-231: the backbone feature tuple, or ...
         if self.use_decoded_feats:
             src_dec = clean.pop('decoded_features')           # ... the decode head's 512-channel map (all shipped configs)
@@ -451,7 +461,10 @@ class PFGST(UDADecorator):
         if pdist.is_distributed():
             if self.local_iter == 0:
                 pdist.check_same_keys(names)
-            pdist.allreduce_mean_(arena.grad)          # student gradients only; the teacher stays rank-local
+            if reducer is not None:
+                reducer.finish()                       # the tail buckets have been in flight since the source pass's backward
+            else:
+                pdist.allreduce_mean_(arena.grad)      # student gradients only; the teacher stays rank-local
             for loss_module in (self.aux_losses if self.apply_aux else []):
                 for p in loss_module.parameters():     # trainable parameters of an auxiliary loss (PFGSTLoss.proj_net)
                     if p.grad is not None:

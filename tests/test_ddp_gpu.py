@@ -41,9 +41,14 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step(tmp_path):
-    port = 29600 + (os.getpid() % 1000)
+@pytest.mark.parametrize('overlap', ['1', '0'])
+def test_two_rank_data_parallel_step(tmp_path, overlap):
+    """overlap=1: the bucketed reducer launched from marker closures of the source pass's backward (dist.GradReducer);
+    overlap=0: one reduction after the sweep.  Same result."""
+    os.environ['PFST_DDP_OVERLAP'] = overlap         # read at import in the spawned ranks
+    port = 29600 + (os.getpid() % 1000) + (7 if overlap == '1' else 0)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    os.environ.pop('PFST_DDP_OVERLAP', None)
     r0 = torch.load(tmp_path / 'r0.pt', weights_only=False)
     r1 = torch.load(tmp_path / 'r1.pt', weights_only=False)
     assert torch.equal(r0['grad'], r1['grad']), 'all ranks must hold the same reduced gradient'
@@ -67,7 +72,20 @@ def _nccl_worker(rank, world, port, outdir):
     t = torch.tensor([3.5], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
-    ok = bool(torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))) and float(t) == 3.5
+    # the bucketed reducer's async AVG all-reduces on slices of one flat buffer, behind work queued on the current stream
+    from pfst_amd import dist as pdist
+    flat = torch.zeros(3_000_000, device='cuda')
+    flat += torch.arange(3_000_000, dtype=torch.float32, device='cuda') % 97         # producer kernel still in the queue
+    red = pdist.GradReducer(flat)
+    red.ready(2_000_000)
+    flat[:2_000_000] *= 2.0                                                           # the sweep keeps writing the rest
+    red.ready(1_000_000)
+    red.finish()
+    torch.cuda.synchronize()
+    expect = torch.arange(3_000_000, dtype=torch.float32) % 97
+    expect[:2_000_000] *= 2.0
+    ok_red = bool(torch.equal(flat.cpu(), expect))
+    ok = bool(torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float32))) and float(t) == 3.5 and ok_red
     open(os.path.join(outdir, 'nccl_ok'), 'w').write(str(ok))
     dist.destroy_process_group()
 

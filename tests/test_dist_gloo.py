@@ -22,6 +22,18 @@ def _worker(rank, world, port, q):
     red = pdist.reduce_log_vector(packed)
     ok2 = torch.allclose(red, torch.tensor([1.5, 15.0, 0.5]))
     pdist.check_same_keys(['a', 'b', 'c'])
+    # the overlapped, bucketed reducer: tails of the arena are launched as they become final, the rest at finish()
+    arena = base * (rank + 1)
+    red = pdist.GradReducer(arena, min_bucket=1000)
+    red.ready(90_000)            # [90000, n) goes out
+    red.ready(89_500)            # smaller than a bucket: deferred
+    arena[:60_000] += 1.0        # "the backward sweep" keeps writing the part that is not final yet
+    red.ready(60_000)            # [60000, 90000)
+    assert len(red.pending) == 2 and red.hi == 60_000
+    red.finish()
+    expect = base * 1.5
+    expect[:60_000] += 1.0
+    ok1 = ok1 and torch.allclose(arena, expect, rtol=1e-6, atol=1e-6) and not red.pending
     q.put((rank, bool(ok1), bool(ok2)))
     dist.destroy_process_group()
 
