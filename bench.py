@@ -110,7 +110,9 @@ class KernelTimer:
             return self.inner(name, *args)
         if self.per_layer and flops > 0:
             idx = {'pfst_conv_igemm': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad': (5, 6, 7, 9, 12, 14),
-                   'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7)}[name]
+                   'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7),
+                   'pfst_conv_igemm_split': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad_split': (5, 6, 7, 9, 12, 14),
+                   'pfst_wino_gemm_split': (3, 4, 5, 6)}[name]
             key = key + (' wino ' if 'wino' in name else ' ') + ' '.join(str(args[i]) for i in idx)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

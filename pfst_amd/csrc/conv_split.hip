@@ -12,6 +12,9 @@
 // in registers on their way from HBM to LDS (fp32 NCHW stays the storage format everywhere).
 #include "conv_epilogue.h"
 #include <math.h>
+#include <type_traits>
+#include <utility>
+#include <stdlib.h>
 #include "../../include/pfst_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,7 +53,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& p0, uint4& p1
 
 // BNB != 0: the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h); on the bf16
 // matrix pipe the epilogue's VALU work co-issues with the other waves' MFMAs
-template <int BM, int BNB = 0>
+// DIAG != 0: timing-ablation builds for tools/split_ablation.py (results are WRONG by construction; never launched by the product path):
+// 1 no split + LDS store, 2 no global loads, 3 no MFMAs, 4 no LDS fragment reads, 5 no in-loop barrier,
+// 6 s_memtime stamps around the four phases of a K-step, summed per wave into the `stats` buffer as 6 (of 8) x u32 (not an output value)
+template <int BM, int BNB = 0, int DIAG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -161,16 +167,40 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   __syncthreads();
 
   const int l31 = lane & 31, lh = lane >> 5;
+  unsigned long long tprev = 0;
+  unsigned ph[6] = {0, 0, 0, 0, 0, 0};
+  if (DIAG == 6) tprev = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < KT; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
+    if (DIAG != 2) {
+      if (kt + 1 < KT) load_tile(kt + 1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(breg[i]));
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) asm volatile("" : "+v"(areg[i].x), "+v"(areg[i].y), "+v"(areg[i].z), "+v"(areg[i].w));
+    }
+    if (DIAG == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[4] += (unsigned)(t - tprev);          // global loads issued
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     bf16x8 af[TM][NP], bf[TN][NP];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
+      if (DIAG != 4) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i][pl] = __builtin_bit_cast(bf16x8, As[cur][(pl * 2 + lh) * BM + wm0 + i * 32 + l31]);
+        for (int i = 0; i < TM; ++i) af[i][pl] = __builtin_bit_cast(bf16x8, As[cur][(pl * 2 + lh) * BM + wm0 + i * 32 + l31]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[cur][(pl * 2 + lh) * BN + wn0 + j * 32 + l31]);
+        for (int j = 0; j < TN; ++j) bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[cur][(pl * 2 + lh) * BN + wn0 + j * 32 + l31]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { bf16x8 t = __builtin_bit_cast(bf16x8, areg[0]); asm volatile("" : "+v"(t)); af[i][pl] = t; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bf16x8 t = __builtin_bit_cast(bf16x8, areg[0]); asm volatile("" : "+v"(t)); bf[j][pl] = t; }
+      }
     }
     // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0).  (Placing the in-register split of the next K-step's
     // activations between the two halves of the MFMA stream instead of after it was measured: no difference, the split is not on
@@ -178,18 +208,76 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
     // of 154 registers / 49 KB LDS, one barrier per 768 MFMA-cycles, and 5.33 rounds of tiles rounded up to 6.)
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-    if (kt + 1 < KT) {
-      split_tile();
-      store_tile(cur ^ 1);
+    if (DIAG == 6) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[0] += (unsigned)(t - tprev);
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (DIAG != 3) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i][pl]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j][pl]));
+      }
+    }
+    if (DIAG == 6) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[1] += (unsigned)(t - tprev);
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (DIAG != 1) {
+      if (DIAG == 6) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        ph[5] += (unsigned)(t - tprev);          // global loads landed
+        tprev = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (kt + 1 < KT) {
+        split_tile();
+        store_tile(cur ^ 1);
+      }
+      if (DIAG == 6) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        ph[2] += (unsigned)(t - tprev);
+        tprev = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(breg[i]));
+#pragma unroll
+      for (int i = 0; i < A_N; ++i) asm volatile("" ::"v"(areg[i].x), "v"(areg[i].y), "v"(areg[i].z), "v"(areg[i].w));
+    }
+    if (DIAG != 5) __syncthreads();
+    if (DIAG == 6) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      ph[3] += (unsigned)(t - tprev);
+      tprev = t;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (DIAG == 6) {
+    if (lane == 0 && stats) {
+      unsigned* dbg = reinterpret_cast<unsigned*>(stats) + ((((i64)n * gridDim.x + blockIdx.x) * 4 + wid) * 8);
+      dbg[0] = ph[0]; dbg[1] = ph[1]; dbg[2] = ph[2]; dbg[3] = ph[3]; dbg[4] = ph[4]; dbg[5] = ph[5];
+    }
+    stats = nullptr;
   }
 
   if (BNB != 0) {
@@ -200,6 +288,232 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   } else {
     conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same 128 x 128 tile with a software-pipelined K-step.  In-kernel stamps on the kernel above (tools/split_ablation.py, DIAG 6,
+// three waves per SIMD) per wave and K-step: 581 cycles to ISSUE the 11 global loads, 228 until the fragments landed, 1080 for the 24
+// MFMAs (768 alone), 10 waiting for the global loads, 1363 for the 44-instruction split + 6 LDS stores, 232 at the barrier.  Beside
+// ANOTHER wave's back-to-back MFMAs a wave gets roughly one vector instruction per MFMA slot issued; inside its OWN MFMA stream a wave
+// hides up to five (MI355X guide, 'single-issue instructions hidden per MFMA gap').  So every wave here carries its own loads,
+// fragment reads, split arithmetic and LDS stores in the gaps of its own 24 MFMAs (sched_group_barrier), and the K loop is cut into
+// branch-free blocks: the tap switch happens between them, not inside.
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {       // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), always unrolled
+  static_for_seq(std::make_integer_sequence<int, N>(), static_cast<F&&>(f));
+}
+
+// The in-register split as 44 single VALU instructions pinned in place (volatile asm): plain arithmetic is sunk to the LDS stores by the
+// compiler and packed into v_pk_add_f32, which is slow beside MFMAs.  K = 0..43 on the eight values v[0..8): two pairs in lockstep
+// (independent neighbours), 11 ops per pair -- stage 0/1 {cvt_pk, << 16, & 0xffff0000, sub, sub}, stage 2 {cvt_pk}.
+struct SplitState {
+  unsigned hp[NP][4];            // packed bf16 pairs of the three pieces
+  unsigned tl[4], th[4];         // a piece widened back to fp32 (low / high element)
+  float ra[4], rb[4];            // running remainders of the pairs
+};
+template <int K>
+__device__ __forceinline__ void split_op(const float (&v)[8], SplitState& s) {
+  constexpr int half = K / 22, r = K % 22, q = 2 * half + (r & 1), o = r >> 1;    // o = 0..10
+  constexpr int st = o / 5, op = o % 5;
+  if constexpr (op == 0) {
+    if constexpr (st == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(s.hp[0][q]) : "v"(v[2 * q]), "v"(v[2 * q + 1]));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(s.hp[st][q]) : "v"(s.ra[q]), "v"(s.rb[q]));
+  } else if constexpr (op == 1) {
+    asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(s.tl[q]) : "v"(s.hp[st][q]));
+  } else if constexpr (op == 2) {
+    asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(s.th[q]) : "v"(s.hp[st][q]));
+  } else if constexpr (op == 3) {
+    if constexpr (st == 0) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.ra[q]) : "v"(v[2 * q]), "v"(s.tl[q]));
+    else asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.ra[q]) : "v"(s.ra[q]), "v"(s.tl[q]));
+  } else {
+    if constexpr (st == 0) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.rb[q]) : "v"(v[2 * q + 1]), "v"(s.th[q]));
+    else asm volatile("v_sub_f32 %0, %1, %2" : "=v"(s.rb[q]) : "v"(s.rb[q]), "v"(s.th[q]));
+  }
+}
+__device__ __forceinline__ uint4 split_piece(const SplitState& s, int pl) { return make_uint4(s.hp[pl][0], s.hp[pl][1], s.hp[pl][2], s.hp[pl][3]); }
+template <int BNB>
+__device__ __forceinline__ void conv_igemm_split_pipe_body(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, const PfstBnbArgs& bnb) {
+  constexpr int BM = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
+  constexpr int A_N = 2 * NP * BM / 256;                 // 3 chunks of 16 bytes per thread: [piece][half][row]
+  __shared__ uint4 As[2][2 * NP * BM];
+  __shared__ uint4 Bs[2][2 * NP * BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  const int P = Ho * Wo, HiWi = Hi * Wi;
+  int bx, by;
+  {
+    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int lin = blockIdx.x;
+    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD (see above)
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    } else {
+      by = lin / gx;
+      bx = lin - by * gx;
+    }
+  }
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
+  const int spt = C / 16;                                // K-steps per filter tap
+  const int KT = spt * ks * ks;
+  in += (i64)n * in_bs;
+  out += (i64)n * out_bs;
+
+  const int pix = tid & (BN - 1), kh = tid >> 7;
+  const int p = p0 + pix;
+  const bool pvalid = p < P;
+  const int oy = pvalid ? p / Wo : 0;
+  const int ox = pvalid ? p - oy * Wo : 0;
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk6) + (i64)blockIdx.y * KT * 2 * NP * M, 0,
+                                                                         KT * 2 * NP * M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
+  // one vector offset per operand; chunk i of the weight image / channel i of the activations is a SCALAR offset on top (an
+  // out-of-range base stays out of range: the scalar parts are far below 2 GiB)
+  unsigned a_voff, b_voff;
+  {
+    const int seg = tid / BM, row = tid - seg * BM;        // chunk c = tid + 256 i -> segment seg + 2 i, same row
+    a_voff = (m0 + row < M) ? 16u * ((unsigned)seg * (unsigned)M + (unsigned)(m0 + row)) : OOB;
+  }
+  const int a_chunk = 2 * M * 16, b_chan = HiWi * 4;
+  auto set_tap = [&](int ty, int tx) {
+    int sy, sx;
+    const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+    b_voff = ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
+  };
+
+  uint4 areg[A_N];
+  float breg[8];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int a_step = 2 * NP * M * 16;                    // bytes of one K-step of the weight image
+  int a_soff = 0;                                        // of the tile the NEXT load fetches
+  auto load_tile = [&](int b_soff) {
+#pragma unroll
+    for (int i = 0; i < A_N; ++i)
+      areg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + i * a_chunk, 0));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff, b_soff + i * b_chan, 0));
+    a_soff += a_step;
+  };
+  auto split_store = [&](int buf) {
+    uint4 bq0, bq1, bq2;
+    split8(breg, bq0, bq1, bq2);
+#pragma unroll
+    for (int i = 0; i < A_N; ++i) As[buf][tid + 256 * i] = areg[i];
+    Bs[buf][(0 * 2 + kh) * BN + pix] = bq0;
+    Bs[buf][(1 * 2 + kh) * BN + pix] = bq1;
+    Bs[buf][(2 * 2 + kh) * BN + pix] = bq2;
+  };
+
+  set_tap(0, 0);
+  load_tile(0);
+  split_store(0);
+  __syncthreads();
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  int cur = 0;
+  // one K-step: consumes the tile in LDS buffer `cur`; LOAD: also fetches, splits and stores the next tile into the other buffer.
+  // The issue order is fixed slot by slot (a full scheduling barrier after each): 4 fragment reads, then 24 slots of one MFMA + fillers --
+  //   slots 0-7   one fragment read (in the order the terms need them) + one activation load
+  //   slots 8-10  one weight-image load
+  //   slots 11-21 four instructions of the 44-instruction split of the eight activations (split_op)
+  //   slots 22-23 the three weight-image and the three activation LDS stores (the matrix pipe is still busy with the last MFMAs)
+  auto step = [&](auto load_tag, int b_soff) {
+    constexpr bool LOAD = decltype(load_tag)::value;
+    bf16x8 af[TM][NP], bf[TN][NP];
+    auto read_frag = [&](int r) {       // r = 0..11: (a2, b0) | (a1, b1) | (a0, b2), rows i / columns j inside
+      const int q = r >> 2, e = r & 3;
+      if (e < 2) af[e][2 - q] = __builtin_bit_cast(bf16x8, As[cur][((2 - q) * 2 + lh) * BM + wm0 + e * 32 + l31]);
+      else bf[e - 2][q] = __builtin_bit_cast(bf16x8, Bs[cur][(q * 2 + lh) * BN + wn0 + (e - 2) * 32 + l31]);
+    };
+    static_for<4>([&](auto rc) { read_frag(decltype(rc)::value); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    SplitState sp;
+    static_for<24>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (m < 8) read_frag(4 + m);
+      if constexpr (LOAD) {
+        if constexpr (m < 8) breg[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff, b_soff + m * b_chan, 0));
+        else if constexpr (m < 11)
+          areg[m - 8] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (m - 8) * a_chunk, 0));
+        else if constexpr (m < 22) {
+          static_for<4>([&](auto kc) { split_op<(m - 11) * 4 + decltype(kc)::value>(breg, sp); });
+        } else if constexpr (m == 22) {
+          As[cur ^ 1][tid] = areg[0];
+          As[cur ^ 1][tid + 256] = areg[1];
+        } else {
+          As[cur ^ 1][tid + 512] = areg[2];
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) Bs[cur ^ 1][(pl * 2 + kh) * BN + pix] = split_piece(sp, pl);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (LOAD) a_soff += a_step;
+    __syncthreads();
+    cur ^= 1;
+  };
+  const int chan_step = 16 * HiWi * 4;
+  for (int ty = 0; ty < ks; ++ty)
+    for (int tx = 0; tx < ks; ++tx) {
+      for (int sidx = 1; sidx < spt; ++sidx) step(std::true_type(), sidx * chan_step);
+      // the last K-step of this tap fetches the first tile of the next one
+      int nty = ty, ntx = tx + 1;
+      if (ntx == ks) { ntx = 0; nty += 1; }
+      if (nty < ks) {
+        set_tap(nty, ntx);
+        step(std::true_type(), 0);
+      } else {
+        step(std::false_type(), 0);
+      }
+    }
+
+  if (BNB != 0) {
+    static_assert(sizeof(Bs) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into the B double buffer");
+    conv_epilogue<TM, TN, WAVES_N, BN, BNB, true>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
+                                                  reinterpret_cast<float*>(&Bs[0][0]));
+  } else {
+    conv_epilogue<TM, TN, WAVES_N, BN>(acc, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+  }
+}
+
+// the plain variant is held to 168 registers (three workgroups per CU, what its 48 KB of LDS allow); the fused-BatchNorm-backward
+// epilogues need more and run two per CU
+__global__ __launch_bounds__(256, 3) void conv_igemm_split_pipe_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+  conv_igemm_split_pipe_body<0>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                                PfstBnbArgs());
+}
+template <int BNB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_pipe_bnb_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, PfstBnbArgs bnb) {
+  conv_igemm_split_pipe_body<BNB>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                                  bnb);
 }
 
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.
@@ -505,6 +819,149 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_q_kernel(
   }
 }
 
+// The K-quad split weight gradient with the wave's own staging work inside its MFMA stream (see conv_igemm_split_pipe_body for the
+// measurement behind it).  Both operands are split in registers here (88 VALU per K-step), so the loads run TWO tiles ahead into
+// alternating register sets: step k consumes LDS buffer k & 1, splits tile k+1 (loaded during step k-1) in the gaps of its 24 MFMAs
+// and stores it to the other buffer, and issues the loads of tile k+2.  Tiles past the end of the K slice load zeros (out-of-range
+// buffer offsets) and are never consumed, so the step is branch-free.  BM = 128 only.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_split_q_pipe_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz, int xcd_order) {
+  constexpr int BM = 128, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ uint4 As[2][2 * NP * BM];
+  __shared__ uint4 Bs[2][2 * NP * BJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  int bx, by, bz;                                   // tile and K slice: all tiles of a slice on one XCD (see conv_wgrad_q_kernel)
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (xcd_order && lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * BJ, m0 = by * BM;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
+
+  const int srow = tid >> 1, half = tid & 1;        // staging role: 8 consecutive pixels of one row per operand
+  const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
+  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
+
+  float la[2][8], lb[2][8];                         // two register sets of loaded tiles
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // load q = 0..3 of the tile starting at pixel pk0: (A, B) x (first, second quad); P % 4 == 0 and chunk_len % 16 == 0: a quad is
+  // entirely in or out
+  auto load_quad = [&](auto qc, auto setc, int pk0) {
+    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value;
+    const int p = pk0 + 8 * half + 4 * (q & 1);
+    const bool v = p < pend;
+    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(q < 2 ? a_rsrc : b_rsrc, v ? (q < 2 ? a_voff : b_voff) : OOB,
+                                                                                      pk0 * 4 + 16 * (q & 1), 0));
+    float (&dst)[8] = q < 2 ? la[SET] : lb[SET];
+    dst[4 * (q & 1) + 0] = t.x; dst[4 * (q & 1) + 1] = t.y; dst[4 * (q & 1) + 2] = t.z; dst[4 * (q & 1) + 3] = t.w;
+  };
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // prologue: tile 0 through the plain split into buffer 0, tile 1 into register set 1
+  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
+  {
+    uint4 q0, q1, q2;
+    split8(la[0], q0, q1, q2);
+    As[0][(0 * 2 + half) * BM + srow] = q0; As[0][(1 * 2 + half) * BM + srow] = q1; As[0][(2 * 2 + half) * BM + srow] = q2;
+    split8(lb[0], q0, q1, q2);
+    Bs[0][(0 * 2 + half) * BJ + srow] = q0; Bs[0][(1 * 2 + half) * BJ + srow] = q1; Bs[0][(2 * 2 + half) * BJ + srow] = q2;
+  }
+  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 16); });
+  __syncthreads();
+
+  // one K-step on LDS buffer CUR = k & 1.  Issue order, a full scheduling barrier after each slot: 4 fragment reads, then 24 slots of
+  // one MFMA + fillers -- slots 0-7 one fragment read, 0-3 one global load of tile k+2, 0-21 four split instructions of tile k+1
+  // (dy first), 11 / 22 the three LDS stores of the dy / x pieces.
+  auto step = [&](auto curc, int kt) {
+    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+    bf16x8 af[TM][NP], bf[TN][NP];
+    auto read_frag = [&](int r) {       // r = 0..11: (a2, b0) | (a1, b1) | (a0, b2), rows i / columns j inside
+      const int q = r >> 2, e = r & 3;
+      if (e < 2) af[e][2 - q] = __builtin_bit_cast(bf16x8, As[CUR][((2 - q) * 2 + lh) * BM + wm0 + e * 32 + l31]);
+      else bf[e - 2][q] = __builtin_bit_cast(bf16x8, Bs[CUR][(q * 2 + lh) * BJ + wn0 + (e - 2) * 32 + l31]);
+    };
+    static_for<4>([&](auto rc) { read_frag(decltype(rc)::value); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    SplitState sa, sb;
+    const int pk2 = pbeg + (kt + 2) * 16;
+    static_for<24>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (m < 8) read_frag(4 + m);
+      if constexpr (m < 22) {
+        static_for<4>([&](auto kc) {
+          constexpr int k = m * 4 + decltype(kc)::value;
+          if constexpr (k < 44) split_op<k>(la[NXT], sa);
+          else split_op<k - 44>(lb[NXT], sb);
+        });
+      }
+      // (the loads of tile k+2 overwrite set CUR: its values were split during the previous step)
+      if constexpr (m < 4) load_quad(mc, curc, pk2);
+      if constexpr (m == 11) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) As[NXT][(pl * 2 + half) * BM + srow] = split_piece(sa, pl);
+      }
+      if constexpr (m == 22) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) Bs[NXT][(pl * 2 + half) * BJ + srow] = split_piece(sb, pl);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  const int KT = (pend - pbeg + 15) / 16;
+  for (int kt = 0; kt < KT; kt += 2) {
+    step(std::integral_constant<int, 0>(), kt);
+    if (kt + 1 < KT) step(std::integral_constant<int, 1>(), kt + 1);
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
 template <int BM>
 int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                          i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
@@ -523,8 +980,13 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, BM), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  hipLaunchKernelGGL((conv_wgrad_split_q_kernel<BM>), dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
-                     N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
+  static const int pipe = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;            // 0: the un-pipelined main loop
+  if (BM == 128 && pipe)
+    hipLaunchKernelGGL(conv_wgrad_split_q_pipe_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
+                       N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
+  else
+    hipLaunchKernelGGL((conv_wgrad_split_q_kernel<BM>), dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
+                       N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -550,18 +1012,44 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
                  int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
                  hipStream_t s, const PfstBnbArgs* bnb = nullptr) {
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), groups, N);
+  static const int lds_pad = getenv("PFST_SPLIT_LDS_PAD") ? atoi(getenv("PFST_SPLIT_LDS_PAD")) : 0;   // diagnostic: occupancy cap
+  static const int pipe_env = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;        // 0: the un-pipelined main loop
+  // measured per layer (bf16x6 train step): the pipelined loop wins from K = 512 up, loses 1-5 % on the short 1x1 / Winograd-domain GEMMs
+  const bool pipe = pipe_env == 2 || (pipe_env == 1 && (i64)C * ks * ks >= 512);
   if (bnb && bnb->x) {
     PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_SPLIT_BNB(MODE_)                                                                                              \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, MODE_>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, \
-                       Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
+    if (BM == 128 && pipe)                                                                                                         \
+      hipLaunchKernelGGL((conv_igemm_split_pipe_bnb_kernel<MODE_>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, \
+                         Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb);                                            \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((conv_igemm_split_kernel<BM, MODE_>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C,  \
+                         Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
     if (!bnb->relu) PFST_LAUNCH_SPLIT_BNB(3);
     else if (bnb->y) PFST_LAUNCH_SPLIT_BNB(2);
     else PFST_LAUNCH_SPLIT_BNB(1);
 #undef PFST_LAUNCH_SPLIT_BNB
   } else {
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, 0>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
-                       Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs());
+    static const int diag = getenv("PFST_SPLIT_DIAG") ? atoi(getenv("PFST_SPLIT_DIAG")) : 0;
+    if (BM == 128 && diag) {
+#define PFST_DIAG_CASE(D_)                                                                                                                  \
+  case D_:                                                                                                                                  \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, D_>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, \
+                       C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});                                           \
+    PFST_CHECK_LAUNCH();                                                                                                                    \
+    return PFST_OK;
+      switch (diag) {
+        PFST_DIAG_CASE(1) PFST_DIAG_CASE(2) PFST_DIAG_CASE(3) PFST_DIAG_CASE(4) PFST_DIAG_CASE(5) PFST_DIAG_CASE(6)
+        default: break;
+      }
+#undef PFST_DIAG_CASE
+    }
+    if (BM == 128 && pipe)
+      hipLaunchKernelGGL(conv_igemm_split_pipe_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, Wi,
+                         M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+    else
+      hipLaunchKernelGGL((conv_igemm_split_kernel<BM, 0>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
+                         Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs());
   }
   PFST_CHECK_LAUNCH();
   return PFST_OK;
