@@ -335,7 +335,9 @@ __device__ __forceinline__ void split_op(const float (&v)[8], SplitState& s) {
   }
 }
 __device__ __forceinline__ uint4 split_piece(const SplitState& s, int pl) { return make_uint4(s.hp[pl][0], s.hp[pl][1], s.hp[pl][2], s.hp[pl][3]); }
-template <int BNB>
+// SHAPE16: timing experiment only (WRONG results): every 32x32x16 MFMA replaced by two 16x16x32 MFMAs on the same operand registers,
+// to see which clock the chip holds for that shape (MI355X guide, DVFS give-back item 7)
+template <int BNB, bool SHAPE16 = false>
 __device__ __forceinline__ void conv_igemm_split_pipe_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -451,7 +453,16 @@ __device__ __forceinline__ void conv_igemm_split_pipe_body(
     static_for<24>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (SHAPE16) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 lo = __builtin_shufflevector(acc[i][j], acc[i][j], 0, 1, 2, 3), hi = __builtin_shufflevector(acc[i][j], acc[i][j], 4, 5, 6, 7);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], lo, 0, 0, 0);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], hi, 0, 0, 0);
+        acc[i][j][0] = lo[0]; acc[i][j][1] = lo[1]; acc[i][j][2] = lo[2]; acc[i][j][3] = lo[3];
+        acc[i][j][4] = hi[0]; acc[i][j][5] = hi[1]; acc[i][j][6] = hi[2]; acc[i][j][7] = hi[3];
+      } else {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      }
       if constexpr (m < 8) read_frag(4 + m);
       if constexpr (LOAD) {
         if constexpr (m < 8) breg[m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff, b_soff + m * b_chan, 0));
@@ -506,6 +517,13 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_split_pipe_kernel(
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
   conv_igemm_split_pipe_body<0>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                 PfstBnbArgs());
+}
+__global__ __launch_bounds__(256, 3) void conv_igemm_split_pipe_shape16_diag_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+  conv_igemm_split_pipe_body<0, true>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats,
+                                      stats_T, PfstBnbArgs());
 }
 template <int BNB>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_pipe_bnb_kernel(
@@ -1044,7 +1062,10 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
       }
 #undef PFST_DIAG_CASE
     }
-    if (BM == 128 && pipe)
+    if (BM == 128 && diag == 7)
+      hipLaunchKernelGGL(conv_igemm_split_pipe_shape16_diag_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs,
+                         C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+    else if (BM == 128 && pipe)
       hipLaunchKernelGGL(conv_igemm_split_pipe_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, Wi,
                          M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
     else

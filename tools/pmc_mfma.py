@@ -57,7 +57,9 @@ def main():
                  mfma_share_of_vector_issue_if_valu_includes_mfma=round(64 * mf / (64 * mf + 4 * other_excl), 4),
                  mfma_busy_cycles=round(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)), sq_busy_cycles=round(v.get('SQ_BUSY_CYCLES', 0.0)),
                  sq_wave_cycles=round(v.get('SQ_WAVE_CYCLES', 0.0)), grbm_gui_active=round(gui),
-                 mfma_busy_frac=round(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8.0 * 1024.0), 4) if gui > 0 else None)
+                 mfma_busy_frac=round(v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8.0 * 1024.0), 4) if gui > 0 else None,
+                 # effective shader clock of the dispatch (guide, DVFS give-back: GRBM_GUI_ACTIVE / 8 / wall time; reads high on short ones)
+                 eff_clock_ghz=round(gui / 8.0 / (dur[k] / n * 1e6), 3) if gui > 0 and dur[k] > 0 else None)
         rows.append((dur[k], k, r))
     for _, k, r in sorted(rows, reverse=True):
         rec[k] = r

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pfst_amd import hip_ops as ops
 
-NAMES = {0: 'full', 1: 'no split+LDS store', 2: 'no global loads', 3: 'no MFMA', 4: 'no LDS fragment reads', 5: 'no in-loop barrier', 6: 'phase stamps'}
+NAMES = {0: 'full', 1: 'no split+LDS store', 2: 'no global loads', 3: 'no MFMA', 4: 'no LDS fragment reads', 5: 'no in-loop barrier', 6: 'phase stamps', 7: 'pipelined, 16x16x32 MFMA shape'}
 
 
 def timeit(fn, reps=5):
