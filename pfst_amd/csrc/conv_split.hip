@@ -534,212 +534,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_pipe_bnb_kernel(
                                   bnb);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The large-layer variant: 256 x 128 tile, 8 waves (one workgroup per CU, two waves per SIMD), K = 32 per step on
-// v_mfma_f32_16x16x32_bf16.  Why: with the pipelined loop above the matrix pipe is 0.76 busy on the large layers and what is left is
-// the clock the chip holds (DVFS give-back); the 16x16x32 shape holds a higher one (guide; 7-9 % measured here with PFST_SPLIT_DIAG=7).
-// LDS image of one K-step: [piece 3][k-quarter 4][row][8 x bf16] -- 48 KB of weights + 24 KB of activations, double-buffered (144 KB).
-// The packed weights keep their [k16-group][piece][half][row] layout: a K-step is two consecutive groups, chunk (g, piece, half) goes
-// to quarter 2 g + half.  A wave owns 64 x 64 = 4 x 4 accumulator tiles; 96 MFMAs per step, each followed by at most one memory / LDS
-// instruction and one VALU: slots 0-13 the next tile's global loads, 0-18 this step's remaining fragment reads (five before the first
-// MFMA), 48-91 the 44 split instructions, 86-94 the LDS stores.  The epilogue re-lays the accumulators through LDS (free after the loop) into
-// the 32x32 layout and reuses conv_epilogue with all its variants.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int K32_BM = 256, K32_BN = 128, K32_THREADS = 512;
-constexpr int K32_LDS_BYTES = 2 * (NP * 4 * K32_BM + NP * 4 * K32_BN) * 16;       // 147456
-
-template <int BNB>
-__device__ __forceinline__ void conv_igemm_split_k32_body(
-    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
-    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, const PfstBnbArgs& bnb) {
-  constexpr int BM = K32_BM, BNT = K32_BN, WAVES_N = 2;
-  extern __shared__ uint4 k32_smem[];
-  uint4* const As0 = k32_smem;                                   // [2][NP * 4 * BM]
-  uint4* const Bs0 = k32_smem + 2 * NP * 4 * BM;                 // [2][NP * 4 * BNT]
-  constexpr int A_BUF = NP * 4 * BM, B_BUF = NP * 4 * BNT;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wid / WAVES_N) * 64, wn0 = (wid % WAVES_N) * 64;
-  const int P = Ho * Wo, HiWi = Hi * Wi;
-  int bx, by;
-  {
-    const int gx = (P + BNT - 1) / BNT, gy = (M + BM - 1) / BM;
-    const int lin = blockIdx.x;
-    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      bx = lin - by * gx;
-    }
-  }
-  const int p0 = bx * BNT, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
-  const int spt = C / 32;                                // K-steps per filter tap
-  const int KT16 = (C / 16) * ks * ks;
-  in += (i64)n * in_bs;
-  out += (i64)n * out_bs;
-
-  const int pix = tid & (BNT - 1), kq = tid >> 7;        // B staging: this thread's pixel and k-quarter (8 channels)
-  const int p = p0 + pix;
-  const bool pvalid = p < P;
-  const int oy = pvalid ? p / Wo : 0;
-  const int ox = pvalid ? p - oy * Wo : 0;
-
-  constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk6) + (i64)blockIdx.y * KT16 * 2 * NP * M, 0,
-                                                                         KT16 * 2 * NP * M * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
-  // weight chunk c = tid + 512 i: row tid % 256, segment (tid / 256) + 2 i of the 12 = [k16-group 2][piece 3][half 2] of this K-step
-  const int arow = tid & (BM - 1), ah = tid >> 8;
-  const unsigned a_voff = (m0 + arow < M) ? 16u * ((unsigned)ah * (unsigned)M + (unsigned)(m0 + arow)) : OOB;
-  unsigned b_voff;
-  const int a_chunk = 2 * M * 16, b_chan = HiWi * 4;
-  auto set_tap = [&](int ty, int tx) {
-    int sy, sx;
-    const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
-    b_voff = ok ? 4u * ((unsigned)(kq * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
-  };
-
-  uint4 areg[6];
-  float breg[8];
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int a_step = 2 * 2 * NP * M * 16;                // bytes of one K-step (two k16 groups) of the weight image
-  int a_soff = 0;
-  // LDS slot of weight chunk i: i = g * 3 + piece -> ((piece * 4 + 2 g) * BM) + (ah * BM + arow) = ... + tid
-  auto a_lds = [&](int i) { return ((i % 3) * 4 + 2 * (i / 3)) * BM + tid; };
-  auto load_a = [&](int i) { areg[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + i * a_chunk, 0)); };
-  auto load_b = [&](int i, int b_soff) {
-    breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff, b_soff + i * b_chan, 0));
-  };
-
-  // prologue: tile 0 through the plain split
-  set_tap(0, 0);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) load_a(i);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) load_b(i, 0);
-  a_soff += a_step;
-  {
-    uint4 q0, q1, q2;
-    split8(breg, q0, q1, q2);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) As0[a_lds(i)] = areg[i];
-    Bs0[(0 * 4 + kq) * BNT + pix] = q0;
-    Bs0[(1 * 4 + kq) * BNT + pix] = q1;
-    Bs0[(2 * 4 + kq) * BNT + pix] = q2;
-  }
-  __syncthreads();
-
-  const int l15 = lane & 15, lq = lane >> 4;
-  int cur = 0;
-  auto step = [&](auto load_tag, int b_soff) {
-    constexpr bool LOAD = decltype(load_tag)::value;
-    const uint4* const Ac = As0 + cur * A_BUF;
-    const uint4* const Bc = Bs0 + cur * B_BUF;
-    uint4* const An = As0 + (cur ^ 1) * A_BUF;
-    uint4* const Bn = Bs0 + (cur ^ 1) * B_BUF;
-    bf16x8 af[4][NP], bf[4][NP];
-    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(bf16x8, Ac[(pl * 4 + lq) * BM + wm0 + i * 16 + l15]); };
-    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(bf16x8, Bc[(pl * 4 + lq) * BNT + wn0 + j * 16 + l15]); };
-    // fragment reads in the order the terms (a2 b0) (a1 b1) (a0 b2) need them; r = 0..23, the first five before the first MFMA
-    auto read_frag = [&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      if constexpr (r == 0) rd_a(0, 2);
-      else if constexpr (r < 5) rd_b(r - 1, 0);
-      else if constexpr (r < 8) rd_a(r - 4, 2);
-      else if constexpr (r == 8) rd_a(0, 1);
-      else if constexpr (r < 13) rd_b(r - 9, 1);
-      else if constexpr (r < 16) rd_a(r - 12, 1);
-      else if constexpr (r == 16) rd_a(0, 0);
-      else if constexpr (r < 21) rd_b(r - 17, 2);
-      else rd_a(r - 20, 0);
-    };
-    static_for<5>([&](auto rc) { read_frag(rc); });
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-    SplitState sp;
-    static_for<96>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int t = m >> 4, i = (m >> 2) & 3, j = m & 3;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-      if constexpr (m < 19) read_frag(std::integral_constant<int, 5 + m>());
-      if constexpr (LOAD) {
-        if constexpr (m < 8) load_b(m, b_soff);
-        else if constexpr (m < 14) load_a(m - 8);
-        if constexpr (m >= 48 && m < 92) split_op<m - 48>(breg, sp);
-        if constexpr (m >= 86 && m < 92) An[a_lds(m - 86)] = areg[m - 86];
-        if constexpr (m >= 92 && m < 95) Bn[((m - 92) * 4 + kq) * BNT + pix] = split_piece(sp, m - 92);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    if (LOAD) a_soff += a_step;
-    __syncthreads();
-    cur ^= 1;
-  };
-  const int chan_step = 32 * HiWi * 4;
-  for (int ty = 0; ty < ks; ++ty)
-    for (int tx = 0; tx < ks; ++tx) {
-      for (int sidx = 1; sidx < spt; ++sidx) step(std::true_type(), sidx * chan_step);
-      int nty = ty, ntx = tx + 1;                        // the last K-step of this tap fetches the first tile of the next one
-      if (ntx == ks) { ntx = 0; nty += 1; }
-      if (nty < ks) {
-        set_tap(nty, ntx);
-        step(std::true_type(), 0);
-      } else {
-        step(std::false_type(), 0);
-      }
-    }
-
-  // accumulators -> LDS (row-major 64 x 64 per wave, row stride 68 floats) -> the 32x32 MFMA layout conv_epilogue expects.
-  // D of v_mfma_f32_16x16x32: lane holds rows 4 (lane / 16) + r, column lane % 16 of its 16 x 16 tile.
-  float* const ws = reinterpret_cast<float*>(k32_smem) + wid * (64 * 68);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[i][j][r];
-  // (each wave reads back only what it wrote: no workgroup barrier needed, the LDS operations of a wave complete in order)
-  const int l31 = lane & 31, lh = lane >> 5;
-  pfst_f32x16 acc32[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc32[i][j][r] = ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
-  if (BNB != 0) {
-    __syncthreads();                                     // the reduction scratch below overlaps other waves' staging areas
-    conv_epilogue<2, 2, WAVES_N, BNT, BNB, true>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
-                                                 reinterpret_cast<float*>(k32_smem));
-  } else {
-    conv_epilogue<2, 2, WAVES_N, BNT>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
-  }
-}
-
-__global__ __launch_bounds__(K32_THREADS) void conv_igemm_split_k32_kernel(
-    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
-    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
-  conv_igemm_split_k32_body<0>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                               PfstBnbArgs());
-}
-template <int BNB>
-__global__ __launch_bounds__(K32_THREADS) void conv_igemm_split_k32_bnb_kernel(
-    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
-    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, PfstBnbArgs bnb) {
-  conv_igemm_split_k32_body<BNB>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T, bnb);
-}
-
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.
 // layout: [k/16][piece 3][k-half 2][row][8 x bf16]  (one uint4 per (k16-group, piece, half, row))
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __restrict__ wf, uint4* __restrict__ wd, int Cout, int Cin, int T) {
@@ -1240,44 +1034,6 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
   static const int pipe_env = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;        // 0: the un-pipelined main loop
   // measured per layer (bf16x6 train step): the pipelined loop wins from K = 512 up, loses 1-5 % on the short 1x1 / Winograd-domain GEMMs
   const bool pipe = pipe_env == 2 || (pipe_env == 1 && (i64)C * ks * ks >= 512);
-  // large layers: the 256 x 128 / K = 32 kernel on the 16x16x32 MFMA shape (one 144 KB workgroup per CU)
-  static const int k32_env = getenv("PFST_SPLIT_K32") ? atoi(getenv("PFST_SPLIT_K32")) : 1;
-  static const int k32_min_k = getenv("PFST_SPLIT_K32_MIN_K") ? atoi(getenv("PFST_SPLIT_K32_MIN_K")) : 4096;
-  if (BM == 128 && pipe && k32_env && M >= 256 && C % 32 == 0 && (M % K32_BM == 0 || M >= 4 * K32_BM) && (i64)C * ks * ks >= k32_min_k) {
-    static bool attr_done = false;
-#define PFST_K32_ATTR(call_)                                       \
-  do {                                                             \
-    hipError_t e_ = (call_);                                       \
-    if (e_ != hipSuccess) {                                        \
-      pfst_set_error(__FILE__, __LINE__, hipGetErrorString(e_));   \
-      return PFST_ERR_LAUNCH;                                      \
-    }                                                              \
-  } while (0)
-    if (!attr_done) {
-      PFST_K32_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_split_k32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, K32_LDS_BYTES));
-      PFST_K32_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_split_k32_bnb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, K32_LDS_BYTES));
-      PFST_K32_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_split_k32_bnb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, K32_LDS_BYTES));
-      PFST_K32_ATTR(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_split_k32_bnb_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, K32_LDS_BYTES));
-      attr_done = true;
-    }
-#undef PFST_K32_ATTR
-    dim3 g32(cdiv((i64)Ho * Wo, K32_BN) * cdiv(M, K32_BM), groups, N);
-    if (bnb && bnb->x) {
-      PFST_CHECK_ARG(M % K32_BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
-#define PFST_LAUNCH_K32_BNB(MODE_)                                                                                                          \
-      hipLaunchKernelGGL((conv_igemm_split_k32_bnb_kernel<MODE_>), g32, dim3(K32_THREADS), K32_LDS_BYTES, s, in, in_bs, (const uint4*)wk6, bias, out, \
-                         out_bs, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
-      if (!bnb->relu) PFST_LAUNCH_K32_BNB(3);
-      else if (bnb->y) PFST_LAUNCH_K32_BNB(2);
-      else PFST_LAUNCH_K32_BNB(1);
-#undef PFST_LAUNCH_K32_BNB
-    } else {
-      hipLaunchKernelGGL(conv_igemm_split_k32_kernel, g32, dim3(K32_THREADS), K32_LDS_BYTES, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C,
-                         Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-    }
-    PFST_CHECK_LAUNCH();
-    return PFST_OK;
-  }
   if (bnb && bnb->x) {
     PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_SPLIT_BNB(MODE_)                                                                                              \

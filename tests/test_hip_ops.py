@@ -56,6 +56,11 @@ CONV_CASES = [
     (1, 16, 32, 9, 16, 3, 1, 1, 1),      # one K-step per row: every step is an edge step
     (2, 64, 256, 32, 32, 1, 1, 1, 0),    # 8 pixel tiles: the XCD-aware tile order + the buffer-store epilogue on full tiles
     (1, 32, 160, 32, 64, 3, 1, 2, 2),    # 16 pixel tiles, M = 128 + 32: fast and generic epilogue paths in one launch
+    # contractions >= 512 deep with more than 64 output rows: the software-pipelined bf16x6 loops (conv_split.hip) -- ragged pixel tile,
+    # ragged row tile + tap switches between the branch-free blocks, 6 K-steps per tap
+    (2, 512, 256, 16, 24, 1, 1, 1, 0),
+    (1, 64, 192, 20, 28, 3, 1, 2, 2),
+    (2, 96, 128, 12, 20, 3, 1, 1, 1),
 ]
 
 
