@@ -534,6 +534,214 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_pipe_bnb_kernel(
                                   bnb);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The pipelined loop on v_mfma_f32_16x16x32_bf16 (the shape that holds the higher clock): the two K=16 LDS tiles are ONE
+// K=32 step -- k-quarter q of the MFMA operand is (tile q / 2, half q % 2) of the unchanged [piece][half][row] images.  All 24 fragments of
+// a step live in registers (96), so the LDS image is free once they have landed: barrier A sits in the middle of the MFMA stream, the
+// next pair of tiles is loaded, split and stored in the gaps of the same 96 MFMAs, barrier B ends the step.  Two 48 KB workgroups per CU
+// (~240 registers).  The accumulators leave in the 16x16 layout and are re-laid through LDS, 32 rows per wave at a time, for conv_epilogue.
+template <int BNB>
+__device__ __forceinline__ void conv_igemm_split_pair_body(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, const PfstBnbArgs& bnb) {
+  constexpr int BM = 128, WAVES_N = 2;
+  constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
+  __shared__ uint4 smem[2 * TILE_A + 2 * TILE_B];
+  uint4* const As = smem;
+  uint4* const Bs = smem + 2 * TILE_A;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * 64, wn0 = (wid % WAVES_N) * 64;
+  const int P = Ho * Wo, HiWi = Hi * Wi;
+  int bx, by;
+  {
+    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int lin = blockIdx.x;
+    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    } else {
+      by = lin / gx;
+      bx = lin - by * gx;
+    }
+  }
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
+  const int spt = C / 32;                                // K=32 steps per filter tap
+  const int KT16 = (C / 16) * ks * ks;
+  in += (i64)n * in_bs;
+  out += (i64)n * out_bs;
+
+  const int pix = tid & (BN - 1), kh = tid >> 7;
+  const int p = p0 + pix;
+  const bool pvalid = p < P;
+  const int oy = pvalid ? p / Wo : 0;
+  const int ox = pvalid ? p - oy * Wo : 0;
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk6) + (i64)blockIdx.y * KT16 * 2 * NP * M, 0,
+                                                                         KT16 * 2 * NP * M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
+  unsigned a_voff, b_voff;
+  {
+    const int seg = tid / BM, row = tid - seg * BM;        // chunk c = tid + 256 i of a tile -> segment seg + 2 i, same row
+    a_voff = (m0 + row < M) ? 16u * ((unsigned)seg * (unsigned)M + (unsigned)(m0 + row)) : OOB;
+  }
+  const int a_chunk = 2 * M * 16, a_tile = 2 * NP * M * 16, b_chan = HiWi * 4;
+  auto set_tap = [&](int ty, int tx) {
+    int sy, sx;
+    const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+    b_voff = ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
+  };
+
+  uint4 areg[6];                                         // [tile 2][chunk 3]
+  float breg[2][8];                                      // [tile][channel kh * 8 + i of the tile's 16]
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int a_soff = 0;
+  // load v = 0..21 of the next tile pair: the 16 activations first (the split needs them early), then the 6 weight chunks
+  auto load_one = [&](auto vc, int b_soff) {
+    constexpr int v = decltype(vc)::value;
+    if constexpr (v < 16)
+      breg[v >> 3][v & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, b_voff, b_soff + ((v >> 3) * 16 + (v & 7)) * b_chan, 0));
+    else
+      areg[v - 16] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + ((v - 16) / 3) * a_tile + ((v - 16) % 3) * a_chunk, 0));
+  };
+
+  set_tap(0, 0);
+  static_for<22>([&](auto vc) { load_one(vc, 0); });
+  a_soff += 2 * a_tile;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    uint4 q0, q1, q2;
+    split8(breg[t], q0, q1, q2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) As[t * TILE_A + tid + 256 * i] = areg[t * 3 + i];
+    Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = q0;
+    Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = q1;
+    Bs[t * TILE_B + (2 * 2 + kh) * BN + pix] = q2;
+  }
+  __syncthreads();
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  // fragment of k-quarter lq: tile lq / 2, half lq % 2
+  const int a_frag = (lq >> 1) * TILE_A + (lq & 1) * BM + wm0 + l15;
+  const int b_frag = (lq >> 1) * TILE_B + (lq & 1) * BN + wn0 + l15;
+  auto step = [&](auto load_tag, int b_soff) {
+    constexpr bool LOAD = decltype(load_tag)::value;
+    bf16x8 af[4][NP], bf[4][NP];
+    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(bf16x8, As[a_frag + pl * 2 * BM + i * 16]); };
+    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(bf16x8, Bs[b_frag + pl * 2 * BN + j * 16]); };
+    // fragment reads in the order the terms (a2 b0) (a1 b1) (a0 b2) need them; r = 0..23, the first five before the first MFMA
+    auto read_frag = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r == 0) rd_a(0, 2);
+      else if constexpr (r < 5) rd_b(r - 1, 0);
+      else if constexpr (r < 8) rd_a(r - 4, 2);
+      else if constexpr (r == 8) rd_a(0, 1);
+      else if constexpr (r < 13) rd_b(r - 9, 1);
+      else if constexpr (r < 16) rd_a(r - 12, 1);
+      else if constexpr (r == 16) rd_a(0, 0);
+      else if constexpr (r < 21) rd_b(r - 17, 2);
+      else rd_a(r - 20, 0);
+    };
+    static_for<5>([&](auto rc) { read_frag(rc); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    SplitState s0, s1;
+    // slots: 0-18 the remaining fragment reads, 0-21 the next pair's global loads, 32 barrier A (every wave holds its fragments: the
+    // LDS image may be overwritten), 40-83 two split instructions each, 84-95 the twelve LDS stores; barrier B after the last MFMA
+    static_for<96>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m >> 4, i = (m >> 2) & 3, j = m & 3;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (m < 19) read_frag(std::integral_constant<int, 5 + m>());
+      if constexpr (m == 32) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads have landed
+        __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (LOAD) {
+        if constexpr (m < 22) load_one(mc, b_soff);
+        if constexpr (m >= 40 && m < 84) {
+          constexpr int k = (m - 40) * 2;
+          if constexpr (k < 44) { split_op<k>(breg[0], s0); split_op<k + 1>(breg[0], s0); }
+          else { split_op<k - 44>(breg[1], s1); split_op<k - 43>(breg[1], s1); }
+        }
+        if constexpr (m >= 84 && m < 90) As[((m - 84) / 3) * TILE_A + tid + 256 * ((m - 84) % 3)] = areg[m - 84];
+        if constexpr (m >= 90 && m < 93) Bs[((m - 90) * 2 + kh) * BN + pix] = split_piece(s0, m - 90);
+        if constexpr (m >= 93) Bs[TILE_B + ((m - 93) * 2 + kh) * BN + pix] = split_piece(s1, m - 93);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (LOAD) a_soff += 2 * a_tile;
+    __syncthreads();
+  };
+  const int chan_step = 32 * HiWi * 4;
+  for (int ty = 0; ty < ks; ++ty)
+    for (int tx = 0; tx < ks; ++tx) {
+      for (int sidx = 1; sidx < spt; ++sidx) step(std::true_type(), sidx * chan_step);
+      int nty = ty, ntx = tx + 1;                        // the last step of this tap fetches the first pair of the next one
+      if (ntx == ks) { ntx = 0; nty += 1; }
+      if (nty < ks) {
+        set_tap(nty, ntx);
+        step(std::true_type(), 0);
+      } else {
+        step(std::false_type(), 0);
+      }
+    }
+
+  // D of v_mfma_f32_16x16x32: lane holds rows 4 (lane / 16) + r, column lane % 16 of its 16 x 16 tile.  Two passes of 32 rows per wave
+  // through LDS (row stride 68 floats, 34 KB for the four waves) into the 32x32 layout conv_epilogue expects.
+  static_assert(sizeof(smem) >= 4 * 32 * 68 * sizeof(float), "re-layout scratch must fit into the tiles");
+  float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
+  const int l31 = lane & 31, lh = lane >> 5;
+  pfst_f32x16 acc32[2][2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r];
+    // (a wave reads back only what it wrote itself; its LDS operations complete in order)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
+  }
+  if (BNB != 0) {
+    __syncthreads();                                     // the reduction scratch overlaps other waves' re-layout areas
+    static_assert(sizeof(smem) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into the tiles");
+    conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
+                                                reinterpret_cast<float*>(smem));
+  } else {
+    conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_pair_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
+  conv_igemm_split_pair_body<0>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                                PfstBnbArgs());
+}
+template <int BNB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_split_pair_bnb_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T, PfstBnbArgs bnb) {
+  conv_igemm_split_pair_body<BNB>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T, bnb);
+}
+
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.
 // layout: [k/16][piece 3][k-half 2][row][8 x bf16]  (one uint4 per (k16-group, piece, half, row))
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __restrict__ wf, uint4* __restrict__ wd, int Cout, int Cin, int T) {
@@ -1034,6 +1242,25 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
   static const int pipe_env = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;        // 0: the un-pipelined main loop
   // measured per layer (bf16x6 train step): the pipelined loop wins from K = 512 up, loses 1-5 % on the short 1x1 / Winograd-domain GEMMs
   const bool pipe = pipe_env == 2 || (pipe_env == 1 && (i64)C * ks * ks >= 512);
+  // the K = 32 pairing on the 16x16x32 MFMA shape: whole 32-channel steps per tap
+  static const int pair_env = getenv("PFST_SPLIT_PAIR") ? atoi(getenv("PFST_SPLIT_PAIR")) : 1;
+  if (BM == 128 && pipe && pair_env && C % 32 == 0) {
+    if (bnb && bnb->x) {
+      PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
+#define PFST_LAUNCH_PAIR_BNB(MODE_)                                                                                                        \
+      hipLaunchKernelGGL((conv_igemm_split_pair_bnb_kernel<MODE_>), grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, \
+                         Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
+      if (!bnb->relu) PFST_LAUNCH_PAIR_BNB(3);
+      else if (bnb->y) PFST_LAUNCH_PAIR_BNB(2);
+      else PFST_LAUNCH_PAIR_BNB(1);
+#undef PFST_LAUNCH_PAIR_BNB
+    } else {
+      hipLaunchKernelGGL(conv_igemm_split_pair_kernel, grid, dim3(256), 0, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, Wi, M, Ho,
+                         Wo, ks, a, b, c, d, acc, stats, stats_T);
+    }
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   if (bnb && bnb->x) {
     PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_SPLIT_BNB(MODE_)                                                                                              \
