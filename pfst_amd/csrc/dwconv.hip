@@ -10,6 +10,7 @@
 // Algorithmic traffic = read plane + write plane = 8 B per output element.
 // The data gradient is the same stencil with mirrored taps; the weight gradient reuses the staging and reduces
 // 9 partial sums per block (wavefront shuffles, one atomic per tap per block).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/pfst_hip.h"
 
@@ -35,7 +36,19 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ plane, floa
   if ((W & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* t4 = reinterpret_cast<float4*>(tile);
-    for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) t4[i] = s4[i];
+    // eight 16-byte loads in flight per thread before the first LDS store (a 128x128 plane is exactly one batch of 512 threads): the
+    // plain copy loop compiles to load -> wait -> store, 16 KB in flight per CU, and is latency-bound at half the HBM rate
+    // (buffer loads: an offset past the staged rows returns zeros instead of needing a branch around the load)
+    const int n4 = n >> 2, bd = blockDim.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(s4), 0, n4 * 16, 0x00020000);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 8 * bd) {
+      float4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (i0 + u * bd), 0, 0));
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * bd < n4) t4[i0 + u * bd] = r[u];
+    }
   } else {
     for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = src[i];
   }
@@ -56,7 +69,17 @@ __device__ __forceinline__ float4 row4(const float* __restrict__ row, int sx, in
   return v;
 }
 
-// MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation
+// dilation 1: the three taps of one row from ONE aligned 16-byte read plus the two neighbouring elements (3 LDS reads instead of 12)
+__device__ __forceinline__ void row_taps_d1(const float* __restrict__ row, int c4, int W, float4& vl, float4& vc, float4& vr) {
+  vc = *reinterpret_cast<const float4*>(row + c4 * 4);
+  const float lw = c4 > 0 ? row[c4 * 4 - 1] : 0.f;
+  const float rx = c4 * 4 + 4 < W ? row[c4 * 4 + 4] : 0.f;
+  vl = make_float4(lw, vc.x, vc.y, vc.z);
+  vr = make_float4(vc.y, vc.z, vc.w, rx);
+}
+
+// MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation;
+// MODE 3: float4 outputs, dilation 1 (row_taps_d1)
 template <int MODE>
 __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
@@ -85,9 +108,11 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
         const int sy = yy + (ty - 1) * dil;
         if (sy < 0 || sy >= H) continue;
         const float* row = tile + (sy - s.lo) * W;
+        float4 tv[3];
+        if (MODE == 3) row_taps_d1(row, c4, W, tv[0], tv[1], tv[2]);
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          const float4 v = row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
+          const float4 v = MODE == 3 ? tv[tx] : row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
           const float k = wt[ty * 3 + tx];
           acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
         }
@@ -135,8 +160,72 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
   }
 }
 
+// Whole-plane variant (the plane fits the LDS budget: the 128x128 ASPP planes): a workgroup walks `cpb` consecutive channels of one image
+// and fetches the NEXT plane into registers (8 x 16 bytes per thread, issued right after the barrier) while it computes the current one
+// from LDS -- the load latency of a plane is hidden behind the stencil of the previous one instead of being exposed once per plane.
+// grid: (1, ceil(C / cpb), N), 512 threads, float4 outputs (MODE 1: dilation % 4 == 0, MODE 2: any dilation).
+template <int MODE>
+__global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
+                                                              float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int cpb,
+                                                              int flip, int accumulate, float* __restrict__ stats) {
+  extern __shared__ float tile[];
+  __shared__ double red[16];
+  const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
+  const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
+  float4 r[8];                                     // host: n4 <= 8 * 512
+  auto fetch = [&](int c) {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (i64)n * x_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * 512), 0, 0));
+  };
+  fetch(c0);
+  for (int c = c0; c < c1; ++c) {
+    float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+    __syncthreads();
+    if (c + 1 < c1) fetch(c + 1);
+    float wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
+    float* yp = y + (i64)n * y_bs + (i64)c * HW;
+    float st_s = 0.f, st_q = 0.f;
+    for (int i = tid; i < n4; i += 512) {
+      const int yy = i / W4, c4 = i - yy * W4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + sy * W;
+        float4 tv[3];
+        if (MODE == 3) row_taps_d1(row, c4, W, tv[0], tv[1], tv[2]);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 v = MODE == 3 ? tv[tx] : row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
+          const float k = wt[ty * 3 + tx];
+          acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
+        }
+      }
+      float4* out = reinterpret_cast<float4*>(yp) + i;
+      if (accumulate) { const float4 o = *out; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+      *out = acc;
+      st_s += (acc.x + acc.y) + (acc.z + acc.w);
+      st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
+    }
+    if (stats) {                                   // stats[c][n][2]: one strip per plane (pfst_dwconv_stats_slots == 1)
+      const double bs = block_sum_d((double)st_s, red);
+      const double bq = block_sum_d((double)st_q, red);
+      if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
+    }
+    __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
+  }
+}
+
 // dw[c][t] += sum_{n,p} dy[n][c][p] * x[n][c][p + off(t)]     VEC: W % 4 == 0 and 16-byte aligned planes
-template <bool VEC, bool ALIGNED>
+template <bool VEC, bool ALIGNED, bool D1 = false>
 __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy,
                                                               i64 dy_bs, float* __restrict__ dw, int C, int H, int W, int dil, int R) {
   extern __shared__ float tile[];
@@ -162,9 +251,11 @@ __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __res
         const int sy = yy + (ty - 1) * dil;
         if (sy < 0 || sy >= H) continue;
         const float* row = tile + (sy - s.lo) * W;
+        float4 tv[3];
+        if (D1) row_taps_d1(row, c4, W, tv[0], tv[1], tv[2]);
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
-          const float4 v = row4<ALIGNED>(row, c4 * 4 + (tx - 1) * dil, W);
+          const float4 v = D1 ? tv[tx] : row4<ALIGNED>(row, c4 * 4 + (tx - 1) * dil, W);
           acc[ty * 3 + tx] += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
         }
       }
@@ -235,17 +326,39 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     set = true;
   }
   const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0) && (x_bs % 4 == 0) && (y_bs % 4 == 0) &&
                    (((i64)H * W) % 4 == 0);
-  const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : 2);
+  const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
+  static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;   // channels per workgroup of the plane kernel, 0 = off
+  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0) {
+    static bool set2 = false;
+    if (!set2) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      set2 = true;
+    }
+    dim3 gp(1, cdiv(C, cpb), N);
+    if (mode == 1)
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<1>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+    else if (mode == 3)
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<3>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+    else
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<2>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   if (mode == 1)
     hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   else if (mode == 2)
     hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+  else if (mode == 3)
+    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   else
     hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   PFST_CHECK_LAUNCH();
@@ -263,6 +376,7 @@ extern "C" int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float*
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_wgrad_kernel<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     set = true;
   }
   const bool vec = (W % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0) && (x_bs % 4 == 0) && (dy_bs % 4 == 0) &&
@@ -271,6 +385,8 @@ extern "C" int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float*
   hipStream_t st = (hipStream_t)stream;
   if (vec && dil % 4 == 0)
     hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+  else if (vec && dil == 1)
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
   else if (vec)
     hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
   else

@@ -245,7 +245,8 @@ def test_conv_channel_slice_views(ops):
     assert float(big_out[:, :8].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('dil,H,W', [(1, 16, 20), (12, 32, 32), (36, 24, 40), (2, 7, 9)])
+# whole-plane kernel: dilation 1 (row_taps_d1), % 4 (16-byte taps), other, scalar; planes above 64 KB: strips + halo rows, same three tap forms
+@pytest.mark.parametrize('dil,H,W', [(1, 16, 20), (12, 32, 32), (36, 24, 40), (2, 7, 9), (3, 24, 32), (1, 136, 128), (4, 130, 132), (2, 132, 128)])
 def test_depthwise(ops, dil, H, W):
     n, c = 2, 24
     x = torch.randn(n, c, H, W, generator=g(1)).requires_grad_()
@@ -262,6 +263,8 @@ def test_depthwise(ops, dil, H, W):
     assert_close(mean, yr.mean((0, 2, 3)), 2e-5, 'dw stats mean')
     assert_close(invstd, 1.0 / torch.sqrt(yr.var((0, 2, 3), unbiased=False) + 1e-5), 2e-5, 'dw stats invstd')
     assert_close(ops.dwconv(dyd, wd, dil, flip=True), x.grad, 1e-5, 'dw dgrad')
+    acc = ops.dwconv(dyd, wd, dil, flip=True, out=xd.clone(), accumulate=True)
+    assert_close(acc, x.grad + x.detach(), 1e-5, 'dw dgrad accumulate')
     dw = torch.zeros_like(wd)
     ops.dwconv_wgrad_(dw, xd, dyd, dil)
     assert_close(dw, w.grad, 1e-4, 'dw wgrad')
