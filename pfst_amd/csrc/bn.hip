@@ -119,22 +119,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const int stride = gridDim.x * blockDim.x;
   if ((HW & 3) == 0 && (((uintptr_t)xp | (uintptr_t)yp | (uintptr_t)rp) & 15) == 0) {
     const int n4 = HW >> 2;
-    for (int i = bxi * blockDim.x + threadIdx.x; i < n4; i += stride) {
-      float4 v = reinterpret_cast<const float4*>(xp)[i];
-      v.x = __fmaf_rn(v.x, sc, sh); v.y = __fmaf_rn(v.y, sc, sh); v.z = __fmaf_rn(v.z, sc, sh); v.w = __fmaf_rn(v.w, sc, sh);
+    // four 16-byte loads per operand in flight per thread (buffer loads: offsets past the plane return zeros and their stores are dropped)
+    constexpr int U = 4;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xp), 0, HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rp ? rp : xp), 0, HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(yp, 0, HW * 4, 0x00020000);
+    for (int i0 = bxi * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+      float4 v[U], r[U];
+      unsigned off[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * stride;
+        off[u] = i < n4 ? 16u * (unsigned)i : OOB;
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[u], 0, 0));
+      }
       if (rp) {
-        const float4 r = reinterpret_cast<const float4*>(rp)[i];
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[u], 0, 0));
       }
-      if (mask) {
-        // ReLU bitmask for the backward pass (the host guarantees HW % 256 == 0, so all 64 lanes are here and hold 256
-        // consecutive elements): word [i >> 6][k] bit (lane) <-> component k of lane's float4, i.e. element 4*lane + k
-        const unsigned long long b0 = __ballot(v.x > 0.f), b1 = __ballot(v.y > 0.f), b2 = __ballot(v.z > 0.f), b3 = __ballot(v.w > 0.f);
-        const int l = threadIdx.x & 63;
-        if (l < 4) mask[((i64)n * C + c) * (HW >> 6) + (i64)(i >> 6) * 4 + l] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * stride;
+        float4 w = v[u];
+        w.x = __fmaf_rn(w.x, sc, sh); w.y = __fmaf_rn(w.y, sc, sh); w.z = __fmaf_rn(w.z, sc, sh); w.w = __fmaf_rn(w.w, sc, sh);
+        if (rp) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+        if (mask && i < n4) {
+          // ReLU bitmask for the backward pass (the host guarantees HW % 256 == 0, so all 64 lanes are here and hold 256
+          // consecutive elements): word [i >> 6][k] bit (lane) <-> component k of lane's float4, i.e. element 4*lane + k
+          const unsigned long long b0 = __ballot(w.x > 0.f), b1 = __ballot(w.y > 0.f), b2 = __ballot(w.z > 0.f), b3 = __ballot(w.w > 0.f);
+          const int l = threadIdx.x & 63;
+          if (l < 4) mask[((i64)n * C + c) * (HW >> 6) + (i64)(i >> 6) * 4 + l] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
+        }
+        if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), yr, off[u], 0, 0);
       }
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      reinterpret_cast<float4*>(yp)[i] = v;
     }
   } else {
     for (int i = bxi * blockDim.x + threadIdx.x; i < HW; i += stride) {

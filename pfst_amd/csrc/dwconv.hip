@@ -234,6 +234,17 @@ __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __res
   const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
   const float* gp = dy + (i64)n * dy_bs + (i64)c * H * W;
+  // the strip's output gradients: up to eight 16-byte loads per thread in flight beside the staging copy (a strip of at most 64 KB is
+  // exactly one batch; larger strips take further batches inside the loop)
+  const int W4v = W >> 2, totalv = (s.y1 - s.y0) * W4v;
+  float4 gq[8];
+  if (VEC) {
+    const __amdgpu_buffer_rsrc_t grs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gp + (i64)s.y0 * W), 0, totalv * 16, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      gq[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, 16 * (threadIdx.x + u * 512), 0, 0));
+  }
   stage_rows(xp, tile, s.lo, s.hi, W);
   __syncthreads();
   float acc[9];
@@ -242,7 +253,28 @@ __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __res
   if (VEC) {
     const int W4 = W >> 2;
     const int total = (s.y1 - s.y0) * W4;
-    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = threadIdx.x + u * 512;
+      if (i >= total) break;
+      const int r = i / W4, c4 = i - r * W4;
+      const int yy = s.y0 + r;
+      const float4 g = gq[u];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int sy = yy + (ty - 1) * dil;
+        if (sy < 0 || sy >= H) continue;
+        const float* row = tile + (sy - s.lo) * W;
+        float4 tv[3];
+        if (D1) row_taps_d1(row, c4, W, tv[0], tv[1], tv[2]);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const float4 v = D1 ? tv[tx] : row4<ALIGNED>(row, c4 * 4 + (tx - 1) * dil, W);
+          acc[ty * 3 + tx] += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+        }
+      }
+    }
+    for (int i = threadIdx.x + 8 * 512; i < total; i += blockDim.x) {
       const int r = i / W4, c4 = i - r * W4;
       const int yy = s.y0 + r;
       const float4 g = *(reinterpret_cast<const float4*>(gp + (i64)yy * W) + c4);
