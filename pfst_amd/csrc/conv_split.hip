@@ -744,7 +744,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_split_pair_bnb_kernel(
 
 // w[Cout][Cin][T] -> split K-major images.  fprop: k = t*Cin+ci, row m = co;  dgrad: k = t*Cout+co, row m = ci.
 // layout: [k/16][piece 3][k-half 2][row][8 x bf16]  (one uint4 per (k16-group, piece, half, row))
-__global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __restrict__ wf, uint4* __restrict__ wd, int Cout, int Cin, int T) {
+// blockIdx.y: filter set (the (m+2)^2 transform-domain sets of a Winograd layer: `set_in` floats / `set_out` 16-byte chunks apart; 0 otherwise)
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __restrict__ wf, uint4* __restrict__ wd, int Cout, int Cin, int T,
+                                         i64 set_in = 0, i64 set_out = 0) {
+  w += blockIdx.y * set_in;
+  if (wf) wf += blockIdx.y * set_out;
+  if (wd) wd += blockIdx.y * set_out;
   const i64 nf = (i64)(T * Cin / 16) * 2 * Cout, nd = (i64)(T * Cout / 16) * 2 * Cin;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (i64)gridDim.x * blockDim.x) {
     const bool dg = i >= nf;
@@ -1395,17 +1400,19 @@ extern "C" int pfst_wino_pack_weight_split(const float* plain_f, const float* pl
   PFST_CHECK_ARG(((plain_f && U6_fprop) || (plain_d && U6_dgrad)) && (m == 2 || m == 4));
   PFST_CHECK_ARG(Cout > 0 && Cin > 0 && (!U6_fprop || Cin % 16 == 0) && (!U6_dgrad || Cout % 16 == 0));
   const i64 n = (i64)Cout * Cin, set = 6 * n;
-  for (int xi = 0; xi < (m + 2) * (m + 2); ++xi) {
-    if (U6_fprop) {
-      hipLaunchKernelGGL(pack_weight_split_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, plain_f + xi * n,
-                         (uint4*)((char*)U6_fprop + xi * set), (uint4*)nullptr, Cout, Cin, 1);
-      PFST_CHECK_LAUNCH();
-    }
-    if (U6_dgrad) {
-      hipLaunchKernelGGL(pack_weight_split_kernel, dim3(ew_grid(n / 8 + 1)), dim3(256), 0, (hipStream_t)stream, plain_d + xi * n,
-                         (uint4*)nullptr, (uint4*)((char*)U6_dgrad + xi * set), Cout, Cin, 1);
-      PFST_CHECK_LAUNCH();
-    }
+  const int nx = (m + 2) * (m + 2);
+  // one launch per layout for all (m+2)^2 sets (was one per set: 72 small launches per layer and step)
+  int gx = ew_grid(n / 8 + 1);
+  if (gx > 4096) gx = 4096;
+  if (U6_fprop) {
+    hipLaunchKernelGGL(pack_weight_split_kernel, dim3(gx, nx), dim3(256), 0, (hipStream_t)stream, plain_f, (uint4*)U6_fprop, (uint4*)nullptr, Cout,
+                       Cin, 1, n, set / 16);
+    PFST_CHECK_LAUNCH();
+  }
+  if (U6_dgrad) {
+    hipLaunchKernelGGL(pack_weight_split_kernel, dim3(gx, nx), dim3(256), 0, (hipStream_t)stream, plain_d, (uint4*)nullptr, (uint4*)U6_dgrad, Cout,
+                       Cin, 1, n, set / 16);
+    PFST_CHECK_LAUNCH();
   }
   return PFST_OK;
 }
