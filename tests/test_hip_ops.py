@@ -59,6 +59,8 @@ CONV_CASES = [
     # contractions >= 512 deep with more than 64 output rows: the software-pipelined bf16x6 loops (conv_split.hip) -- ragged pixel tile,
     # ragged row tile + tap switches between the branch-free blocks, 6 K-steps per tap
     (2, 512, 256, 16, 24, 1, 1, 1, 0),
+    (2, 512, 256, 15, 20, 1, 1, 1, 0),   # 300 pixels: ragged last pixel tile on the K = 32 pairing
+    (1, 560, 144, 12, 12, 1, 1, 1, 0),   # 560 channels (16 but not 32 per step): the K = 16 pipelined loop, ragged rows and pixels
     (1, 64, 192, 20, 28, 3, 1, 2, 2),
     (2, 96, 128, 12, 20, 3, 1, 1, 1),
 ]
