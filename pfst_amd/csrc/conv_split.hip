@@ -202,10 +202,9 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
         for (int j = 0; j < TN; ++j) { bf16x8 t = __builtin_bit_cast(bf16x8, areg[0]); asm volatile("" : "+v"(t)); bf[j][pl] = t; }
       }
     }
-    // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0).  (Placing the in-register split of the next K-step's
-    // activations between the two halves of the MFMA stream instead of after it was measured: no difference, the split is not on
-    // the critical path.  Counters, profiles/r02 notes in DESIGN.md: the matrix pipe is 58 % busy at ~2.0 GHz; 3 workgroups per CU
-    // of 154 registers / 49 KB LDS, one barrier per 768 MFMA-cycles, and 5.33 rounds of tiles rounded up to 6.)
+    // smallest terms first: (2,0) (1,1) (0,2) | (1,0) (0,1) | (0,0).  This loop (now used for contractions below 512 and the 64- / 32-row
+    // tiles) leaves the order of everything else to the compiler: all MFMAs back to back, then the split and the LDS stores.  Its matrix
+    // pipe is 0.54-0.58 busy; the phase stamps (DIAG 6) show why, and conv_igemm_split_pipe_body / _pair_body below are the answer.
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     if (DIAG == 6) {
