@@ -6,7 +6,7 @@ Sources:
   * synthetic_loader   -- seeded synthetic device batches (benchmarks, tests);
   * TileFolder         -- a folder dataset of converted tiles (rsiseg/datasets/custom.py:85-175, isprs.py) read with PIL and pushed
                           through the config's own pipeline list (pfst_amd/pipeline.py);
-  * UDADataset         -- the source/target pairing + rare-class sampling of the reference, same NumPy RNG stream;
+  * UDADataset / UDADatasetV2 -- the source/target pairings + rare-class sampling of the reference, same NumPy RNG stream;
   * epoch_indices / uda_batches -- the distributed sampler (samplers/distributed_sampler.py:11-70) and the collation."""
 import json
 import os
@@ -161,9 +161,36 @@ class UDADataset:
         return item
 
 
+class UDADatasetV2(UDADataset):
+    """The pairing of the season_net config (uda_dataset_v2.py:43-140): one item per SOURCE sample; the target index is drawn with
+    np.random.choice before the source item runs its pipeline (the order of draws from the global NumPy stream), rare-class sampling as in
+    UDADataset."""
+
+    def __len__(self):
+        return len(self.source)
+
+    def __getitem__(self, idx):
+        if self.rcs_enabled:
+            return self.rcs.draw(self.source, self.target)
+        j = np.random.choice(range(len(self.target)))
+        a = self.source[idx]
+        b = self.target[j]
+        item = {**a, 'target_img_metas': b['img_metas'], 'target_img': b['img']}
+        for key, name in (('img_strong_aug', 'target_img_strong_aug'), ('ori_img', 'target_img_ori')):
+            if key in b:
+                item[name] = b[key]
+        return item
+
+
+UDA_DATASET_TYPES = {'UDADataset': UDADataset, 'UDADatasetV2': UDADatasetV2}
+
+
 def build_uda_dataset(train_cfg):
-    """cfg.data.train of the PFST configs: dict(type='UDADataset', source=..., target=..., rare_class_sampling=...)"""
-    return UDADataset(TileFolder(train_cfg['source']), TileFolder(train_cfg['target']), train_cfg)
+    """cfg.data.train of the PFST configs: dict(type='UDADataset' | 'UDADatasetV2', source=..., target=..., rare_class_sampling=...)"""
+    kind = train_cfg.get('type', 'UDADataset')
+    if kind not in UDA_DATASET_TYPES:
+        raise KeyError(f'unknown UDA dataset type {kind!r} (have {sorted(UDA_DATASET_TYPES)})')
+    return UDA_DATASET_TYPES[kind](TileFolder(train_cfg['source']), TileFolder(train_cfg['target']), train_cfg)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -502,6 +502,40 @@ def gen_uda_dataset(ref):
     print('uda_dataset.npz', out['rcs_classes'], out['rcs_classprob'], out['rcs_sequence'][:5].tolist())
 
 
+def gen_uda_dataset_v2(ref):
+    """UDADatasetV2 (rsiseg/datasets/uda_dataset_v2.py:43-140, the season_net config's pairing): len = len(source), item idx pairs
+    source[idx] with a target drawn by np.random.choice BEFORE the source item is produced; records the pairs under a NumPy seed."""
+    pkg = types.ModuleType('rsiseg.datasets')
+    pkg.__path__ = []
+    sys.modules['rsiseg.datasets'] = pkg
+    bmod = types.ModuleType('rsiseg.datasets.builder')
+    bmod.DATASETS = sys.modules['mmcv.utils'].Registry('dataset')
+    sys.modules['rsiseg.datasets.builder'] = bmod
+    sys.modules['mmcv'].print_log = lambda *a, **k: None
+    ud = _load('rsiseg.datasets.uda_dataset_v2', 'rsiseg/datasets/uda_dataset_v2.py')
+    n_src, n_trg = 9, 4
+
+    class Toy(list):
+        ignore_index, CLASSES, PALETTE = 255, tuple('abcde'), None
+
+    class Source(Toy):
+        def __getitem__(self, i):
+            return dict(img=i, draw=int(np.random.randint(0, 1000)))      # a pipeline that consumes the global NumPy stream
+
+    src = Source(range(n_src))
+    src.img_infos = [dict(ann=dict(seg_map=f'dir/src_{i}.png')) for i in range(n_src)]
+    trg = Toy(dict(img=100 + j, img_metas=dict(j=j), img_strong_aug=200 + j, ori_img=300 + j) for j in range(n_trg))
+    ds = ud.UDADatasetV2(src, trg, dict(source=dict(data_root='.')))
+    np.random.seed(21)
+    rows = []
+    for rep in range(3):
+        for i in range(len(ds)):
+            s = ds[i]
+            rows.append((s['img'], s['draw'], s['target_img'], s['target_img_strong_aug'], s['target_img_ori'], s['target_img_metas']['j']))
+    np.savez_compressed(os.path.join(OUT, 'uda_dataset_v2.npz'), n_src=n_src, n_trg=n_trg, length=len(ds), pairs=np.array(rows))
+    print('uda_dataset_v2.npz', len(ds), rows[:4])
+
+
 def gen_segmentor(ref):
     """EncoderDecoder.forward_train + backward (BASELINE config #1 shape, reduced) and the
     teacher-style encode_decode.  Weights = pfst_amd.synthetic.fill_state_dict(seed=5), which the tests rebuild bit-identically."""
@@ -594,7 +628,7 @@ def gen_train_step(ref):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'seg', 'step']
     if 'options2' in which:
         gen_pfgst_options2(ref)
     if 'small' in which:
@@ -603,6 +637,8 @@ if __name__ == '__main__':
         gen_pfgst_options(ref)
     if 'dataset' in which:
         gen_uda_dataset(ref)
+    if 'dataset2' in which:
+        gen_uda_dataset_v2(ref)
     if 'seg' in which:
         gen_segmentor(ref)
     if 'step' in which:
