@@ -159,7 +159,7 @@ def pad_to(a, hw, value):
 # ----------------------------------------------------------------------------------------------------------------------
 _KNOWN = {'LoadImageFromFile', 'LoadAnnotations', 'LoadAnnotationsPseudoLabelsV2', 'Resize', 'RandomCrop', 'RandomRotate90',
           'RandomFlip', 'StrongAugmentation', 'PhotoMetricDistortion', 'Normalize', 'Pad', 'DefaultFormatBundle', 'Collect',
-          'ImageToTensor', 'MultiScaleFlipAug'}
+          'ImageToTensor', 'MultiScaleFlipAug', 'ClipNormalize', 'Uint82Float'}
 
 
 class Pipeline:
@@ -192,7 +192,9 @@ class Pipeline:
         out = {'img': img}
         if seg is not None and self.reduce_zero_label:
             seg = reduce_zero_label(seg)
-        norm_cfg = None
+        # LoadImageFromFile's default (loading.py:80-84): what the metas carry when the pipeline has no Normalize step (season_net)
+        nch = 1 if img.ndim < 3 else img.shape[2]
+        norm_cfg = dict(mean=[0.0] * nch, std=[1.0] * nch, to_rgb=False)
         for t, k in self.steps:
             if t == 'Resize':
                 scale = k.get('img_scale')
@@ -249,6 +251,20 @@ class Pipeline:
                 for key in ('img', 'img_strong_aug'):
                     if key in out:
                         out[key] = normalize(out[key], k['mean'], k['std'], k.get('to_rgb', True))
+            elif t == 'ClipNormalize':          # season_net pipelines (transforms.py:1166-1212): [mean - 2 std, mean + 2 std] -> [0, 1]
+                mean = np.array(k['mean']).astype(np.float32).reshape(1, 1, -1)
+                std = np.array(k['std']).astype(np.float32).reshape(1, 1, -1)
+                lo, hi = mean - 2 * std, mean + 2 * std
+                img = np.clip((out['img'].astype(np.float32) - lo) / (hi - lo), 0, 1)
+                if k.get('to_rgb', True):
+                    img = img[:, :, [2, 1, 0]]
+                if k.get('to_uint8', False):
+                    img = (img * 255).astype(np.uint8)
+                out['img'] = img
+            elif t == 'Uint82Float':            # transforms.py:1215-1221
+                for key in ('img', 'img_strong_aug'):
+                    if key in out:
+                        out[key] = out[key].astype(np.float32) / 255
             elif t == 'Pad':
                 if k.get('size') is None:
                     raise NotImplementedError('Pad(size_divisor) is outside the PFST configs')

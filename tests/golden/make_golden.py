@@ -536,6 +536,40 @@ def gen_uda_dataset_v2(ref):
     print('uda_dataset_v2.npz', len(ds), rows[:4])
 
 
+def gen_pipeline_steps(ref):
+    """ClipNormalize / Uint82Float of the season_net pipelines (rsiseg/datasets/pipelines/transforms.py:1166-1221) on seeded inputs:
+    pure NumPy classes; the module's other imports (mmcv helpers, skimage) are satisfied by empty stand-ins that these two never touch."""
+    pkg = types.ModuleType('rsiseg.datasets')
+    pkg.__path__ = []
+    sys.modules['rsiseg.datasets'] = pkg
+    sub = types.ModuleType('rsiseg.datasets.pipelines')
+    sub.__path__ = []
+    sys.modules['rsiseg.datasets.pipelines'] = sub
+    bmod = types.ModuleType('rsiseg.datasets.builder')
+    bmod.PIPELINES = sys.modules['mmcv.utils'].Registry('pipeline')
+    sys.modules['rsiseg.datasets.builder'] = bmod
+    sys.modules.setdefault('skimage', types.ModuleType('skimage'))
+    mu = sys.modules['mmcv.utils']
+    if not hasattr(mu, 'deprecated_api_warning'):
+        mu.deprecated_api_warning = lambda *a, **k: (lambda f: f)
+    if not hasattr(mu, 'is_tuple_of'):
+        mu.is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(v, t) for v in seq)
+    tf = _load('rsiseg.datasets.pipelines.transforms', 'rsiseg/datasets/pipelines/transforms.py')
+    rng = np.random.RandomState(17)
+    img = rng.randint(0, 6000, size=(21, 19, 3)).astype(np.uint16)
+    cfg = dict(mean=[817.83099309, 817.90637517, 613.89910777], std=[1152.3451639, 1081.4451218, 1107.54732507], to_rgb=True, to_uint8=True)
+    out = dict(img=img, mean=np.array(cfg['mean']), std=np.array(cfg['std']))
+    r = tf.ClipNormalize(**cfg)(dict(img=img.copy(), img_fields=['img']))
+    out['clip_u8'] = r['img']
+    r2 = tf.ClipNormalize(mean=cfg['mean'], std=cfg['std'], to_rgb=False, to_uint8=False)(dict(img=img.copy(), img_fields=['img']))
+    out['clip_f32_bgr'] = r2['img']
+    r3 = tf.Uint82Float()(dict(img=r['img'].copy(), aug=r['img'][::-1].copy(), img_fields=['img', 'aug']))
+    out['u8_to_float'] = r3['img']
+    out['u8_to_float_aug'] = r3['aug']
+    np.savez_compressed(os.path.join(OUT, 'pipeline_steps.npz'), **out)
+    print('pipeline_steps.npz', out['clip_u8'].dtype, out['clip_u8'][0, 0], out['clip_f32_bgr'].dtype, out['u8_to_float'].dtype)
+
+
 def gen_segmentor(ref):
     """EncoderDecoder.forward_train + backward (BASELINE config #1 shape, reduced) and the
     teacher-style encode_decode.  Weights = pfst_amd.synthetic.fill_state_dict(seed=5), which the tests rebuild bit-identically."""
@@ -628,7 +662,7 @@ def gen_train_step(ref):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step']
     if 'options2' in which:
         gen_pfgst_options2(ref)
     if 'small' in which:
@@ -639,6 +673,8 @@ if __name__ == '__main__':
         gen_uda_dataset(ref)
     if 'dataset2' in which:
         gen_uda_dataset_v2(ref)
+    if 'pipeline' in which:
+        gen_pipeline_steps(ref)
     if 'seg' in which:
         gen_segmentor(ref)
     if 'step' in which:

@@ -138,3 +138,45 @@ def test_tile_folder_and_uda_batches(tmp_path):
                                                           # prediction is resized back to ori_shape (encoder_decoder.py:300-310)
     gt = val.gt_seg_map(0)
     assert set(np.unique(gt)) <= {0, 1, 2, 3, 4, 5, 255} and gt.shape == (256, 256)
+
+
+def test_season_net_pipeline_steps_match_the_reference():
+    """ClipNormalize / Uint82Float (season_net config) against vectors from the executed reference classes
+    (tests/golden/pipeline_steps.npz, make_golden.py:gen_pipeline_steps), and the config's source pipeline list end to end."""
+    import os
+    from pfst_amd.pipeline import Pipeline
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pipeline_steps.npz'))
+    img, mean, std = z['img'], list(z['mean']), list(z['std'])
+
+    def run(steps, im):
+        return Pipeline(steps)(im)['img']            # float32 CHW
+
+    u8 = run([dict(type='ClipNormalize', mean=mean, std=std, to_rgb=True, to_uint8=True)], img)
+    assert np.array_equal(u8, z['clip_u8'].transpose(2, 0, 1).astype(np.float32))
+    f32 = run([dict(type='ClipNormalize', mean=mean, std=std, to_rgb=False, to_uint8=False)], img)
+    assert np.array_equal(f32, z['clip_f32_bgr'].transpose(2, 0, 1))
+    fl = run([dict(type='ClipNormalize', mean=mean, std=std, to_rgb=True, to_uint8=True), dict(type='Uint82Float')], img)
+    assert np.array_equal(fl, z['u8_to_float'].transpose(2, 0, 1))
+    # the source pipeline of configs/_base_/datasets/season_net_sp2fa.py:16-30 compiles and runs (loading is the dataset's job)
+    crop = (128, 128)
+    steps = [dict(type='LoadImageFromFile', imdecode_backend='tifffile'),
+             dict(type='LoadAnnotations', reduce_zero_label=True, imdecode_backend='tifffile'),
+             dict(type='ClipNormalize', mean=mean, std=std, to_rgb=True, to_uint8=True),
+             dict(type='Resize', img_scale=(120, 120), ratio_range=(0.5, 2.0)),
+             dict(type='RandomCrop', crop_size=crop, cat_max_ratio=0.75),
+             dict(type='RandomRotate90', prob=1.0),
+             dict(type='RandomFlip', flip_ratio=0.5, direction='vertical'),
+             dict(type='RandomFlip', flip_ratio=0.5, direction='horizontal'),
+             dict(type='PhotoMetricDistortion'),
+             dict(type='Uint82Float'),
+             dict(type='Pad', size=crop, pad_val=0, seg_pad_val=255),
+             dict(type='DefaultFormatBundle'),
+             dict(type='Collect', keys=['img', 'gt_semantic_seg'])]
+    rng = np.random.RandomState(3)
+    big = rng.randint(0, 6000, size=(120, 120, 3)).astype(np.uint16)
+    seg = rng.randint(0, 5, size=(120, 120)).astype(np.uint8)
+    np.random.seed(4)
+    out = Pipeline(steps)(big, seg)
+    assert out['img'].shape == (3, 128, 128) and out['gt_semantic_seg'].shape == (1, 128, 128)
+    assert 0.0 <= float(out['img'].min()) and float(out['img'].max()) <= 1.0
+    assert out['img_norm_cfg'] == dict(mean=[0.0] * 3, std=[1.0] * 3, to_rgb=False)       # loading.py:80-84
