@@ -187,10 +187,21 @@ class Pipeline:
             flat.append((t, s))
         self.steps = flat
         self.reduce_zero_label = any(k.get('reduce_zero_label') for t, k in flat if t.startswith('LoadAnnotations'))
+        # LoadAnnotationsPseudoLabelsV2(pseudo_labels_dir=None) (loading.py:463-468, the shipped target pipelines): the target's label map is
+        # all `ignore`.  It is never forwarded (uda_dataset.py:127-133) but RandomCrop(cat_max_ratio < 1) walks its ten retries on it, so the
+        # crop that is kept is the ELEVENTH box drawn: the map has to exist for the NumPy stream to match.
+        self.blank_labels = False
+        for t, k in flat:
+            if t == 'LoadAnnotationsPseudoLabelsV2':
+                if k.get('pseudo_labels_dir') is not None:
+                    raise NotImplementedError('pseudo labels from .h5 files (pseudo_labels_dir) are outside the PFST configs')
+                self.blank_labels = True
 
     def __call__(self, img, seg=None):
         out = {'img': img}
-        if seg is not None and self.reduce_zero_label:
+        if seg is None and self.blank_labels:
+            seg = np.full(img.shape[:2], IGNORE, np.uint8)
+        elif seg is not None and self.reduce_zero_label:
             seg = reduce_zero_label(seg)
         # LoadImageFromFile's default (loading.py:80-84): what the metas carry when the pipeline has no Normalize step (season_net)
         nch = 1 if img.ndim < 3 else img.shape[2]

@@ -180,3 +180,26 @@ def test_season_net_pipeline_steps_match_the_reference():
     assert out['img'].shape == (3, 128, 128) and out['gt_semantic_seg'].shape == (1, 128, 128)
     assert 0.0 <= float(out['img'].min()) and float(out['img'].max()) <= 1.0
     assert out['img_norm_cfg'] == dict(mean=[0.0] * 3, std=[1.0] * 3, to_rgb=False)       # loading.py:80-84
+
+
+def test_target_crop_is_the_eleventh_box_when_labels_are_blank():
+    """LoadAnnotationsPseudoLabelsV2(pseudo_labels_dir=None) gives the target an all-ignore label map (loading.py:463-468); RandomCrop with
+    cat_max_ratio < 1 then never accepts a box and keeps the one drawn after its ten retries (transforms.py RandomCrop.__call__)."""
+    from pfst_amd.pipeline import Pipeline
+    steps = [dict(type='LoadImageFromFile'),
+             dict(type='LoadAnnotationsPseudoLabelsV2', pseudo_labels_dir=None, load_feats=False, reduce_zero_label=False, pseudo_ratio=0.3),
+             dict(type='RandomCrop', crop_size=(16, 16), cat_max_ratio=0.75)]
+    img = np.arange(40 * 48 * 3, dtype=np.uint32).reshape(40, 48, 3).astype(np.uint8)
+    ramp = np.arange(40 * 48).reshape(40, 48)
+    np.random.seed(11)
+    out = Pipeline(steps)(np.dstack([ramp % 251, ramp // 251, ramp * 0]).astype(np.uint8))
+    np.random.seed(11)
+    for _ in range(11):
+        oy, ox = np.random.randint(0, 40 - 16 + 1), np.random.randint(0, 48 - 16 + 1)
+    got = out['img'][:, 0, 0]                       # the crop's top-left pixel identifies the box
+    want = ramp[oy, ox]
+    assert (int(got[0]), int(got[1])) == (want % 251, want // 251)
+    assert out['gt_semantic_seg'].shape == (1, 16, 16) and int(out['gt_semantic_seg'].min()) == 255
+    import pytest
+    with pytest.raises(NotImplementedError):
+        Pipeline([dict(type='LoadAnnotationsPseudoLabelsV2', pseudo_labels_dir='/x')])
