@@ -52,6 +52,11 @@ class TileFolder:
 
     def __init__(self, cfg, test_mode=False):
         cfg = dict(cfg)
+        if 'img_dir' not in cfg:
+            # EODataset configs (inria_da, season_net) read through Dataset4EO datapipes (rsiseg/datasets/custom.py:18, third party, not
+            # available offline): their tiles have to be exported to img_dir / ann_dir folders first
+            raise NotImplementedError(f"dataset type {cfg.get('type')!r} (datapipe {cfg.get('datapipe')!r}) reads through Dataset4EO; "
+                                      "TileFolder needs 'img_dir' (+ 'ann_dir') folders of tiles")
         root = cfg.get('data_root') or ''
         self.img_dir = os.path.join(root, cfg['img_dir'])
         self.ann_dir = os.path.join(root, cfg['ann_dir']) if cfg.get('ann_dir') else None

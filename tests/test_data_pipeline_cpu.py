@@ -203,3 +203,10 @@ def test_target_crop_is_the_eleventh_box_when_labels_are_blank():
     import pytest
     with pytest.raises(NotImplementedError):
         Pipeline([dict(type='LoadAnnotationsPseudoLabelsV2', pseudo_labels_dir='/x')])
+
+
+def test_datapipe_datasets_fail_loudly():
+    import pytest
+    from pfst_amd.data import TileFolder
+    with pytest.raises(NotImplementedError, match='Dataset4EO'):
+        TileFolder(dict(type='EODataset', datapipe='season_net', data_root='x', split='train', pipeline=[]))
