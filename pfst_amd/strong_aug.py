@@ -31,6 +31,8 @@ def apply_strong_aug(mixed_img, img_metas, jitter_draw, jitter_p, jitter_s, blur
         return mixed_img
     dev = mixed_img.device
     if jitter_draw > jitter_p:
+        if denorm_type not in ('mean_std', 'none'):          # dacs_transforms.py:69-74, raised where the reference raises it
+            raise ValueError('No such denorm type!')
         s = jitter_s if isinstance(jitter_s, dict) else dict(brightness=jitter_s, contrast=jitter_s, saturation=jitter_s, hue=jitter_s)
         prm = torch.empty(n, 8)
         for i in range(n):                      # the reference builds one ColorJitter per image (pfgst.py:287-294)

@@ -112,3 +112,11 @@ def test_strong_aug_entry_point_respects_draws():
     assert z.shape == x.shape and bool(torch.isfinite(z).all()) and not torch.equal(z, x)
     ten = torch.randn(2, 10, 32, 32).cuda()
     assert apply_strong_aug(ten, metas, 0.9, 0.2, 0.2, 0.9) is ten   # != 3 channels: skipped like the reference
+    import pytest
+    with pytest.raises(ValueError, match='No such denorm type'):      # raised only when the jitter actually runs (dacs_transforms.py:69-74)
+        apply_strong_aug(x.clone(), metas, 0.9, 0.2, 0.2, 0.3, denorm_type='minmax')
+    assert torch.equal(apply_strong_aug(x.clone(), metas, 0.1, 0.2, 0.2, 0.3, denorm_type='minmax'), x)
+    w01 = torch.rand(2, 3, 64, 64).cuda()                              # season_net: images already in [0, 1], no de-normalisation
+    unit = [dict(img_norm_cfg=dict(mean=[0.0] * 3, std=[1.0] * 3, to_rgb=False))] * 2
+    j = apply_strong_aug(w01.clone(), unit, 0.9, 0.2, 0.2, 0.3, denorm_type='none')
+    assert bool(torch.isfinite(j).all()) and float(j.min()) >= -1e-6 and float(j.max()) <= 1.0 + 1e-6
