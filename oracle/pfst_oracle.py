@@ -398,7 +398,7 @@ class OraclePFGST:
     def __init__(self, student_sd, alpha=0.999, pseudo_threshold=0.98, trg_loss_weight=1.0,
                  aux_weights=None, lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01, teacher_sd=None,
                  blur=False, downscale=0.5, thre_type='all', loss_opts=None, feat_level=None, ignore_top=0, ignore_bottom=0,
-                 proj=None):
+                 proj=None, apply_no_mix=False):
         self.student = OrderedDict((k, v.clone()) for k, v in student_sd.items())
         self.teacher = OrderedDict((k, v.clone()) for k, v in (teacher_sd or student_sd).items())
         self.pkeys = param_keys(self.student)
@@ -418,6 +418,7 @@ class OraclePFGST:
         self.feat_level = feat_level
         self.thre_type = thre_type
         self.ignore_top, self.ignore_bottom = ignore_top, ignore_bottom      # pseudo_weight_ignore_top / _bottom (pfgst.py:273-276)
+        self.apply_no_mix = apply_no_mix             # pfgst.py:283-289: masks zeroed after they were drawn, the un-augmented target image
         self.local_iter = 0
 
     def train_step(self, batch, masks=None, drop_masks=None, return_extras=False, pseudo_override=None):
@@ -448,7 +449,9 @@ class OraclePFGST:
             pw[:, -self.ignore_bottom:, :] = 0
         if masks is None:
             masks = class_masks(gt)
-        mixed_img, mixed_lbl, mixed_w = class_mix(masks, img, trg_aug, gt, pl, pw)
+        if self.apply_no_mix:
+            masks = [torch.zeros_like(m) for m in masks] if isinstance(masks, (list, tuple)) else torch.zeros_like(masks)
+        mixed_img, mixed_lbl, mixed_w = class_mix(masks, img, trg if self.apply_no_mix else trg_aug, gt, pl, pw)
         mlosses, _, mix_logits, _, _ = segmentor_forward_train(
             self.student, mixed_img, mixed_lbl, mixed_w, dm.get('mix', (None, None)))
         mix_loss, lv = parse_losses(OrderedDict(('mix.' + k, v) for k, v in mlosses.items()))

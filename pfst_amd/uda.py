@@ -197,7 +197,7 @@ class PFGST(UDADecorator):
         assert self.mix == 'class'
         bad = dict(fdist=self.fdist_lambda > 0, thre_type=self.thre_type not in ('all', 'part'),
                    ps_rows=self.psweight_ignore_top < 0 or self.psweight_ignore_bottom < 0,
-                   apply_no_mix=self.apply_no_mix, print_grad=self.print_grad_magnitude)
+                   print_grad=self.print_grad_magnitude)
         bad = [k for k, v in bad.items() if v]
         if bad:
             raise NotImplementedError(f'PFGST options outside the shipped PFST configs: {bad}')
@@ -417,8 +417,10 @@ class PFGST(UDADecorator):
         classes = self._choose_mix_classes(presence_host.numpy(), batch_size)
         classes_dev = torch.from_numpy(np.ascontiguousarray(classes)).to(dev, non_blocking=True)
         mix_masks = ops.class_mask(gt8, classes_dev)
+        if self.apply_no_mix:                          # pfgst.py:283-289: the classes were drawn (same RNG stream), then nothing is pasted
+            mix_masks.zero_()
         mixed_img, mixed_lbl8, mixed_lbl64, mixed_w = ops.class_mix(
-            img.contiguous(), target_img_strong_aug.contiguous(), gt8, pl8, mix_masks, conf_count,
+            img.contiguous(), (target_img if self.apply_no_mix else target_img_strong_aug).contiguous(), gt8, pl8, mix_masks, conf_count,
             want_i64=self.return_vis_states or dbg is not None, trg_weight=trg_weight)
         if apply_strong_aug is not None:
             mixed_img = apply_strong_aug(mixed_img, img_metas, jitter_draw, self.color_jitter_p, self.color_jitter_s,

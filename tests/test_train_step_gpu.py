@@ -502,3 +502,39 @@ def test_step_with_trainable_projection():
     assert rel(proj.bias.grad, ex['proj_grads'][1]) < 2e-2
     assert not torch.equal(proj.weight.detach().cpu(), pw)                     # AdamW stepped it
     assert rel(proj.weight, oracle.proj[0]) < 1e-3
+
+
+def test_step_with_apply_no_mix():
+    """apply_no_mix (pfgst.py:283-289): the mix classes are still drawn (same NumPy stream), the masks are zeroed and the UN-augmented target
+    image is used, so the 'mixed' pass is a pure target pass under pseudo labels; one full step against the oracle."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    cfg = preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0, pseudo_threshold=0.3)
+    cfg['apply_no_mix'] = True
+    model = UDA.build(cfg)
+    both, student, teacher = seeded_pfgst_state(O, 12)
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    batch = synth_batch(2, 128, 6, seed=41)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.3, teacher_sd=teacher, apply_no_mix=True)
+    random.seed(5); np.random.seed(5)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    state_after = np.random.get_state()[1][:4].copy()
+    random.seed(5); np.random.seed(5)
+    model.debug = {}
+    out = model.train_step(to_dev(batch, 'cuda'), opt)
+    assert np.array_equal(np.random.get_state()[1][:4], state_after)          # the classes were drawn all the same
+    dbg = model.debug
+    assert int(dbg['mix_masks'].abs().sum()) == 0 and int(ex['masks'].abs().sum()) == 0
+    assert torch.equal(dbg['mixed_img'].cpu(), batch['target_img'])           # not the strongly augmented copy
+    assert torch.equal(ex['mixed_img'], batch['target_img'])
+    same = dbg['mixed_lbl'].cpu() == ex['mixed_lbl']
+    assert 1 - same.float().mean() < 5e-3
+    for k, v in olog.items():
+        tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
+        assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
