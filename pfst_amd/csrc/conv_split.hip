@@ -1246,6 +1246,42 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
   static const int pipe_env = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;        // 0: the un-pipelined main loop
   // measured per layer (bf16x6 train step): the pipelined loop wins from K = 512 up, loses 1-5 % on the short 1x1 / Winograd-domain GEMMs
   const bool pipe = pipe_env == 2 || (pipe_env == 1 && (i64)C * ks * ks >= 512);
+  // timing diagnostics (tools/split_ablation.py): take precedence over every dispatch rule below; plain launches without bias / statistics
+  static const int diag = getenv("PFST_SPLIT_DIAG") ? atoi(getenv("PFST_SPLIT_DIAG")) : 0;
+  if (diag != 0) {
+    if (!getenv("PFST_DIAG_WRONG_RESULTS_OK")) {                  // the ablated variants compute WRONG results: never by accident
+      pfst_set_error(__FILE__, __LINE__, "PFST_SPLIT_DIAG selects timing-only kernels with wrong results; set PFST_DIAG_WRONG_RESULTS_OK=1 as well");
+      return PFST_ERR_UNSUPPORTED;
+    }
+    if (BM == 128 && !(bnb && bnb->x)) {
+#define PFST_DIAG_CASE(D_)                                                                                                                  \
+  case D_:                                                                                                                                  \
+    hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, D_>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, \
+                       C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});                                           \
+    PFST_CHECK_LAUNCH();                                                                                                                    \
+    return PFST_OK;
+      switch (diag) {
+        PFST_DIAG_CASE(1) PFST_DIAG_CASE(2) PFST_DIAG_CASE(3) PFST_DIAG_CASE(4) PFST_DIAG_CASE(5) PFST_DIAG_CASE(6)
+        case 7:
+          hipLaunchKernelGGL(conv_igemm_split_pipe_shape16_diag_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out,
+                             out_bs, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+          PFST_CHECK_LAUNCH();
+          return PFST_OK;
+        case 8:                                                   // reference points of the ablation: the two un-ablated loops by name
+          hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, 0>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs,
+                             C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});
+          PFST_CHECK_LAUNCH();
+          return PFST_OK;
+        case 9:
+          hipLaunchKernelGGL(conv_igemm_split_pipe_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
+                             Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
+          PFST_CHECK_LAUNCH();
+          return PFST_OK;
+        default: break;
+      }
+#undef PFST_DIAG_CASE
+    }
+  }
   // the K = 32 pairing on the 16x16x32 MFMA shape: whole 32-channel steps per tap
   static const int pair_env = getenv("PFST_SPLIT_PAIR") ? atoi(getenv("PFST_SPLIT_PAIR")) : 1;
   if (BM == 128 && pipe && pair_env && C % 32 == 0) {
@@ -1279,24 +1315,7 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
     else PFST_LAUNCH_SPLIT_BNB(1);
 #undef PFST_LAUNCH_SPLIT_BNB
   } else {
-    static const int diag = getenv("PFST_SPLIT_DIAG") ? atoi(getenv("PFST_SPLIT_DIAG")) : 0;
-    if (BM == 128 && diag) {
-#define PFST_DIAG_CASE(D_)                                                                                                                  \
-  case D_:                                                                                                                                  \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, D_>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, \
-                       C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});                                           \
-    PFST_CHECK_LAUNCH();                                                                                                                    \
-    return PFST_OK;
-      switch (diag) {
-        PFST_DIAG_CASE(1) PFST_DIAG_CASE(2) PFST_DIAG_CASE(3) PFST_DIAG_CASE(4) PFST_DIAG_CASE(5) PFST_DIAG_CASE(6)
-        default: break;
-      }
-#undef PFST_DIAG_CASE
-    }
-    if (BM == 128 && diag == 7)
-      hipLaunchKernelGGL(conv_igemm_split_pipe_shape16_diag_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs,
-                         C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-    else if (BM == 128 && pipe)
+    if (BM == 128 && pipe)
       hipLaunchKernelGGL(conv_igemm_split_pipe_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi, Wi,
                          M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
     else

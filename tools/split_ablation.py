@@ -1,12 +1,15 @@
-"""Timing ablation of the bf16x6 implicit-GEMM main loop (PFST_SPLIT_DIAG=1..5, see conv_split.hip): which part of the loop the time
+"""Timing ablation of the bf16x6 implicit-GEMM main loop (PFST_SPLIT_DIAG, see conv_split.hip: 1-6 ablate / stamp the un-pipelined loop (8),
+7 swaps the MFMA shape in the K=16 pipelined loop (9); 0 is what the product launches): which part of the loop the time
 goes to.  The ablated variants compute wrong results on purpose; this tool only times them.  Run on the GPU box:
-    for D in 0 1 2 3 4 5; do PFST_SPLIT_DIAG=$D python tools/split_ablation.py; done"""
+    for D in 0 8 1 2 3 4 5 6 9 7; do PFST_SPLIT_DIAG=$D python tools/split_ablation.py; done
+(the tool sets PFST_DIAG_WRONG_RESULTS_OK=1 itself: the library refuses PFST_SPLIT_DIAG without it)"""
 import os, sys
+os.environ.setdefault('PFST_DIAG_WRONG_RESULTS_OK', '1')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pfst_amd import hip_ops as ops
 
-NAMES = {0: 'full', 1: 'no split+LDS store', 2: 'no global loads', 3: 'no MFMA', 4: 'no LDS fragment reads', 5: 'no in-loop barrier', 6: 'phase stamps', 7: 'pipelined, 16x16x32 MFMA shape'}
+NAMES = {0: 'product dispatch (K=32 pairing)', 8: 'un-pipelined loop', 9: 'K=16 pipelined loop', 1: 'no split+LDS store', 2: 'no global loads', 3: 'no MFMA', 4: 'no LDS fragment reads', 5: 'no in-loop barrier', 6: 'phase stamps', 7: 'pipelined, 16x16x32 MFMA shape'}
 
 
 def timeit(fn, reps=5):
