@@ -15,7 +15,7 @@ constexpr int BN_SPLIT_TARGET = 2048;  // aim for this many blocks in the reduct
 // grid: (splits, C, N); each block reduces a contiguous chunk of one (image, channel) plane
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, i64 x_bs, int HW, int chunk,
                                                        double* __restrict__ ws) {
-  __shared__ double sm[16];
+  __shared__ double sm[32];
   const int c = blockIdx.y, n = blockIdx.z;
   const float* xp = x + (i64)n * x_bs + (i64)c * HW;
   const int beg = blockIdx.x * chunk;
@@ -34,8 +34,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
       ss += (double)v * (double)v;
     }
   }
-  s = block_sum_d(s, sm);
-  ss = block_sum_d(ss, sm);
+  block_sum2_d(s, ss, sm);
   if (threadIdx.x == 0) {
     atomicAdd(&ws[2 * c], s);
     atomicAdd(&ws[2 * c + 1], ss);
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
                                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                                     float momentum, float eps, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float4* __restrict__ coef) {
-  __shared__ double sm[16];
+  __shared__ double sm[32];
   const int c = blockIdx.x;
   const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
   double s = 0.0, ss = 0.0;
@@ -85,8 +84,7 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
     s += (double)v.x;
     ss += (double)v.y;
   }
-  s = block_sum_d(s, sm);
-  ss = block_sum_d(ss, sm);
+  block_sum2_d(s, ss, sm);
   if (threadIdx.x == 0) {
     const double m = s / count;
     double var = ss / count - m * m;
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int HW, int chunk, int relu, const unsigned long long* __restrict__ mask,
                                                             double* __restrict__ ws, int rev) {
-  __shared__ double sm[16];
+  __shared__ double sm[32];
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const float mu = mean[c], is = invstd[c];
@@ -239,8 +237,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       sx += (double)dz * (double)xh;
     }
   }
-  s = block_sum_d(s, sm);
-  sx = block_sum_d(sx, sm);
+  block_sum2_d(s, sx, sm);
   if (threadIdx.x == 0) {
     atomicAdd(&ws[2 * c], s);
     atomicAdd(&ws[2 * c + 1], sx);
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 // part = (sum dz, sum dz * x):  sum dz * xhat = invstd * (sum dz*x - mean * sum dz), in fp64
 __global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __restrict__ part, int T, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, double* __restrict__ ws) {
-  __shared__ double sm[16];
+  __shared__ double sm[32];
   const int c = blockIdx.x;
   const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
   double s = 0.0, sx = 0.0;
@@ -260,8 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __res
     s += (double)v.x;
     sx += (double)v.y;
   }
-  s = block_sum_d(s, sm);
-  sx = block_sum_d(sx, sm);
+  block_sum2_d(s, sx, sm);
   if (threadIdx.x == 0) {
     ws[2 * c] = s;
     ws[2 * c + 1] = (double)invstd[c] * (sx - (double)mean[c] * s);

@@ -65,6 +65,30 @@ __device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 do
   return r;
 }
 
+// two block-wide sums at once (the (sum, sum of squares) pairs of the fused BatchNorm statistics): one pair of barriers instead of two;
+// results valid in thread 0.  smem >= 32 doubles.
+// WAVE_F32: the 64 lane values are added in fp32 (DPP), the per-wave results in fp64 -- for per-thread partials that are fp32 anyway
+template <bool WAVE_F32 = false>
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double* smem) {
+  if (WAVE_F32) {
+    a = (double)wave_sum((float)a);
+    b = (double)wave_sum((float)b);
+  } else {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { smem[wid] = a; smem[16 + wid] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    double ra = 0.0, rb = 0.0;
+    for (int i = 0; i < nw; ++i) { ra += smem[i]; rb += smem[16 + i]; }
+    a = ra; b = rb;
+  }
+}
+
 // torch's area_pixel_compute_source_index for bilinear, align_corners=False (ATen/native/UpSample.h):
 // src = max(0, scale*(dst+0.5)-0.5).  The arithmetic is PINNED (explicit fma / rn intrinsics, immune to -ffp-contract) to
 // what torch's kernels evaluate, determined bit-for-bit against F.interpolate (tests/test_hip_ops.py): the source index is one

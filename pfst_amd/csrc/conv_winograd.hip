@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           WinoGeom g, int accumulate, int vec, float* __restrict__ stats) {
   constexpr int R = M + 2;
   typedef float vecM __attribute__((ext_vector_type(M)));
-  __shared__ double red[16];
+  __shared__ double red[32];
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of the outputs this block writes (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
   float* yp = y + (i64)n * y_bs + (i64)c * g.H * g.W;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
   }
   if (stats) {                                       // stats[c][n * gridDim.x + blockIdx.x][2] for pfst_bn_finalize_partials
-    const double bs = block_sum_d((double)st_s, red);
-    const double bq = block_sum_d((double)st_q, red);
+    double bs = (double)st_s, bq = (double)st_q;
+    block_sum2_d<true>(bs, bq, red);
     if (threadIdx.x == 0) {
       const i64 T = (i64)gridDim.x * gridDim.z;
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);

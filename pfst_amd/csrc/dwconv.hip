@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
                                                         int flip, int accumulate, float* __restrict__ stats) {
   extern __shared__ float tile[];
-  __shared__ double red[16];
+  __shared__ double red[32];
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of this block's outputs (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
   const Strip s = make_strip(blockIdx.x, R, H, dil);
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
   // per-(channel, strip, image) partial sums for pfst_bn_finalize_partials: stats[c][n * gridDim.x + strip][2]  (the kernel is
   // HBM-bound, the arithmetic is free; saves the separate bn_stats read of the depthwise output)
   if (stats) {
-    const double bs = block_sum_d((double)st_s, red);
-    const double bq = block_sum_d((double)st_q, red);
+    double bs = (double)st_s, bq = (double)st_q;
+    block_sum2_d<true>(bs, bq, red);
     if (threadIdx.x == 0) {
       const i64 T = (i64)gridDim.x * gridDim.z;
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
                                                               float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int cpb,
                                                               int flip, int accumulate, float* __restrict__ stats) {
   extern __shared__ float tile[];
-  __shared__ double red[16];
+  __shared__ double red[32];
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
   const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
   float4 r[8];                                     // host: n4 <= 8 * 512
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
       st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
     }
     if (stats) {                                   // stats[c][n][2]: one strip per plane (pfst_dwconv_stats_slots == 1)
-      const double bs = block_sum_d((double)st_s, red);
-      const double bq = block_sum_d((double)st_q, red);
+      double bs = (double)st_s, bq = (double)st_q;
+      block_sum2_d<true>(bs, bq, red);
       if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
     }
     __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
