@@ -348,6 +348,10 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         assert tape is None, 'eval-mode BN is inference only'
         mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS)
     else:
+        if pre.shape[0] * pre.shape[2] * pre.shape[3] == 1:
+            # torch.nn.functional.batch_norm's own check: the image-pool BatchNorm of the ASPP head sees N x C x 1 x 1, so a per-GPU batch of
+            # one cannot train; same exception type and text as the reference raises
+            raise ValueError(f'Expected more than 1 value per channel when training, got input size {torch.Size(pre.shape)}')
         want_coef = tape is not None and FUSE_BN_BWD
         gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
         if fused_stats:

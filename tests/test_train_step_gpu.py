@@ -538,3 +538,19 @@ def test_step_with_apply_no_mix():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+
+
+def test_batch_of_one_fails_like_the_reference():
+    """The ASPP image-pool BatchNorm normalises over the batch only (N x 512 x 1 x 1): with one sample per GPU torch's batch_norm raises
+    'Expected more than 1 value per channel when training'; so does this path, before any statistics are formed."""
+    import pytest
+    import pfst_amd  # noqa: F401
+    from pfst_amd.optim import build_optimizer
+    from pfst_amd.presets import uda_cfg as preset_cfg
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    model = UDA.build(preset_cfg(6, 3, dropout=0.0, blur=False, color_jitter_probability=2.0))
+    model.cuda()
+    opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
+    with pytest.raises(ValueError, match='Expected more than 1 value per channel when training'):
+        model.train_step(to_dev(synth_batch(1, 64, 6, seed=3), 'cuda'), opt)
