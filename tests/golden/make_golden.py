@@ -659,10 +659,37 @@ def gen_train_step(ref):
     np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
 
 
+def gen_train_step_no_mix(ref):
+    """One PFGST.train_step with apply_no_mix=True (pfgst.py:283-289): mix masks zeroed after the draw, the un-augmented target image."""
+    torch.manual_seed(0)
+    C, S, b = 6, 128, 2
+    cfg = uda_cfg(C, dropout=0.0)
+    cfg['apply_no_mix'] = True
+    model = ref.builder.UDA.build(cfg)
+    sd = model.state_dict()
+    fill_state_dict(sd, 9)
+    model.load_state_dict(sd)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    random.seed(3)
+    np.random.seed(3)
+    batch = synth_batch(b, S, C, seed=77)
+    model.pseudo_threshold = 0.30
+    res = model.train_step(batch, opt)
+    lv = res['log_vars']
+    st = res['states']
+    out = dict(log_keys=np.array(list(lv.keys())), log_vals=np.array([float(v) for v in lv.values()], dtype=np.float64),
+               mixed_lbl=st['vis|seg_mask_mix'][1].numpy().astype(np.int64), np_state_after=np.random.get_state()[1][:8].copy())
+    g = {n: p.grad for n, p in model.model.named_parameters()}
+    out['grad_norms'] = np.array([float(v.norm()) for v in g.values()])
+    np.savez_compressed(os.path.join(OUT, 'train_step_no_mix.npz'), **out)
+    print('train_step_no_mix.npz', lv)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step', 'nomix']
     if 'options2' in which:
         gen_pfgst_options2(ref)
     if 'small' in which:
@@ -679,3 +706,5 @@ if __name__ == '__main__':
         gen_segmentor(ref)
     if 'step' in which:
         gen_train_step(ref)
+    if 'nomix' in which:
+        gen_train_step_no_mix(ref)
