@@ -659,37 +659,52 @@ def gen_train_step(ref):
     np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
 
 
-def gen_train_step_no_mix(ref):
-    """One PFGST.train_step with apply_no_mix=True (pfgst.py:283-289): mix masks zeroed after the draw, the un-augmented target image."""
-    torch.manual_seed(0)
-    C, S, b = 6, 128, 2
-    cfg = uda_cfg(C, dropout=0.0)
-    cfg['apply_no_mix'] = True
-    model = ref.builder.UDA.build(cfg)
-    sd = model.state_dict()
-    fill_state_dict(sd, 9)
-    model.load_state_dict(sd)
-    model.train()
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
-    random.seed(3)
-    np.random.seed(3)
-    batch = synth_batch(b, S, C, seed=77)
-    model.pseudo_threshold = 0.30
-    res = model.train_step(batch, opt)
-    lv = res['log_vars']
-    st = res['states']
-    out = dict(log_keys=np.array(list(lv.keys())), log_vals=np.array([float(v) for v in lv.values()], dtype=np.float64),
-               mixed_lbl=st['vis|seg_mask_mix'][1].numpy().astype(np.int64), np_state_after=np.random.get_state()[1][:8].copy())
-    g = {n: p.grad for n, p in model.model.named_parameters()}
-    out['grad_norms'] = np.array([float(v.norm()) for v in g.values()])
-    np.savez_compressed(os.path.join(OUT, 'train_step_no_mix.npz'), **out)
-    print('train_step_no_mix.npz', lv)
+STEP_VARIANTS = {
+    # name: (PFGST cfg overrides, PFGSTLoss overrides, pseudo_threshold)
+    'no_mix': (dict(apply_no_mix=True), {}, 0.30),
+    'thre_part': (dict(thre_type='part'), {}, 0.30),
+    'ignore_rows': (dict(pseudo_weight_ignore_top=16, pseudo_weight_ignore_bottom=8), {}, 0.30),
+    'feat_level2': (dict(use_decoded_feats=False), dict(feat_level=2), 0.30),
+    'trg_weight': (dict(trg_loss_weight=0.5), {}, 0.30),
+}
+
+
+def gen_train_step_variants(ref, only=None):
+    """One PFGST.train_step of the reference per PFGST-level option (pfgst.py:229-231,255-257,259-276,283-289,310): apply_no_mix,
+    thre_type='part', pseudo_weight_ignore_top/bottom, use_decoded_feats=False + PFGSTLoss(feat_level), trg_loss_weight."""
+    for name, (over, loss_over, tau) in STEP_VARIANTS.items():
+        if only and name not in only:
+            continue
+        torch.manual_seed(0)
+        C, S, b = 6, 128, 2
+        cfg = uda_cfg(C, dropout=0.0)
+        cfg.update(over)
+        cfg['aux_losses'][0].update(loss_over)
+        model = ref.builder.UDA.build(cfg)
+        sd = model.state_dict()
+        fill_state_dict(sd, 9)
+        model.load_state_dict(sd)
+        model.train()
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+        random.seed(3)
+        np.random.seed(3)
+        batch = synth_batch(b, S, C, seed=77)
+        model.pseudo_threshold = tau
+        res = model.train_step(batch, opt)
+        lv = res['log_vars']
+        st = res['states']
+        out = dict(log_keys=np.array(list(lv.keys())), log_vals=np.array([float(v) for v in lv.values()], dtype=np.float64),
+                   mixed_lbl=st['vis|seg_mask_mix'][1].numpy().astype(np.int64), np_state_after=np.random.get_state()[1][:8].copy())
+        g = {n: p.grad for n, p in model.model.named_parameters()}
+        out['grad_norms'] = np.array([float(v.norm()) for v in g.values()])
+        np.savez_compressed(os.path.join(OUT, f'train_step_{name}.npz'), **out)
+        print(f'train_step_{name}.npz', lv)
 
 
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step', 'nomix']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step', 'variants']
     if 'options2' in which:
         gen_pfgst_options2(ref)
     if 'small' in which:
@@ -706,5 +721,5 @@ if __name__ == '__main__':
         gen_segmentor(ref)
     if 'step' in which:
         gen_train_step(ref)
-    if 'nomix' in which:
-        gen_train_step_no_mix(ref)
+    if 'variants' in which:
+        gen_train_step_variants(ref)
