@@ -399,23 +399,41 @@ class EncoderDecoder(nn.Module):
     # ------------------------------------------------------------------ test time (encoder_decoder.py:265-353)
     def inference(self, img, img_meta=None, rescale=True):
         """whole-image inference in eval mode -> (argmax label map uint8 [N,H,W], low-res logits).  The softmax of the
-        reference (`F.softmax(seg_logit)` then `argmax`) does not change the arg-max, so the fused
-        upsample+softmax+argmax kernel is used."""
+        reference (`F.softmax(seg_logit)` then `argmax`) is what the fused upsample+softmax+argmax kernel evaluates (its tie rule: §7).
+        As in the reference the logits are first resized to the INPUT size (encode_decode, encoder_decoder.py:77-81) and, when `rescale`
+        asks for another `ori_shape`, resized a second time from there (whole_inference :269-280); flipped inputs are flipped back
+        (:314-325)."""
         if self.test_cfg is not None and self.test_cfg.get('mode', 'whole') != 'whole':
             raise NotImplementedError('slide inference is outside the PFST configs (test_cfg.mode="whole")')
         self.repack_weights(need_dgrad=False)
         with bn_eval():
             x = self.extract_feat(img.contiguous(), None)
             logits = self.decode_head(x, return_features=False, tape=None, training=False)
-        size = tuple(img.shape[2:])
+        in_size = tuple(img.shape[2:])
+        size = in_size
         if rescale and img_meta is not None and 'ori_shape' in img_meta[0]:
+            assert all(tuple(m['ori_shape']) == tuple(img_meta[0]['ori_shape']) for m in img_meta)
             size = tuple(img_meta[0]['ori_shape'][:2])
-        _, lab8, _ = ops.pseudo_label(logits.data, size, 2.0, want_i64=False)
+        src = logits.data if size == in_size else ops.resize_bilinear(logits.data, in_size)
+        _, lab8, _ = ops.pseudo_label(src, size, 2.0, want_i64=False)
+        if img_meta is not None and img_meta[0].get('flip'):
+            direction = img_meta[0]['flip_direction']
+            for d in (direction if isinstance(direction, list) else [direction]):
+                assert d in ('horizontal', 'vertical')
+                lab8 = lab8.flip(dims=(2,) if d == 'horizontal' else (1,))
+            lab8 = lab8.contiguous()
+        self._last_states = dict(feats=[v.data for v in x], seg_logits=logits.data)
         return lab8, logits.data
 
     def simple_test(self, img, img_meta=None, rescale=True):
+        """-> (list of per-image label maps, list of per-image state dicts), the fork's contract (encoder_decoder.py:329-353; consumed as
+        `result, state = model(return_loss=False, **data)` by apis/test.py:97).  The states hold the backbone features and the low-res
+        logits of each image (device tensors; the reference copies them to the host)."""
         lab8, _ = self.inference(img, img_meta, rescale)
-        return list(lab8.cpu().numpy())
+        st = self._last_states
+        states = [dict(feats=[f[i] for f in st['feats']], seg_logits=st['seg_logits'][i]) for i in range(lab8.shape[0])]
+        self._last_states = None
+        return list(lab8.cpu().numpy()), states
 
     def forward_test(self, imgs, img_metas=None, **kwargs):
         if isinstance(imgs, (list, tuple)):

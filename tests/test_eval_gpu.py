@@ -32,7 +32,8 @@ def test_inference_eval_mode_and_miou():
         feats = O.backbone_forward(student, batch['img'], train=False)
         logits, _ = O.decode_head_forward(student, feats, train=False)
         ref = F.interpolate(logits, size=(128, 128), mode='bilinear', align_corners=False).softmax(1).argmax(1)
-    out = model(batch['img'].cuda(), batch['img_metas'], return_loss=False)
+    out, states = model(batch['img'].cuda(), batch['img_metas'], return_loss=False)      # the fork's (predictions, states) contract
+    assert len(states) == 2 and len(states[0]['feats']) == 4 and states[0]['seg_logits'].shape[0] == 6
     pred = torch.from_numpy(np.stack(out)).long()
     assert pred.shape == ref.shape
     assert (pred != ref).float().mean() < 2e-3
@@ -138,3 +139,34 @@ def test_train_cli_on_tile_folders_with_validation_and_test_cli(tmp_path):
     work2 = tmp_path / 'work2'
     train_cli.main([str(cfg_path), '--work-dir', str(work2), '--seed', '0', '--no-validate'])
     assert not [l for l in map(json.loads, open(work2 / 'log.json')) if l['mode'] == 'val']
+
+
+def test_inference_rescale_and_flip_follow_the_reference():
+    """encoder_decoder.py:72-84,265-327: logits -> input size -> (rescale) ori_shape, two bilinear steps; a flipped input's prediction is
+    flipped back.  Against torch on the oracle's eval-mode logits."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    model = UDA.build(uda_cfg())
+    both, student, _ = seeded_pfgst_state(O, 9)
+    student = {k[6:]: v for k, v in both.items() if k.startswith('model.')}
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    batch = synth_batch(2, 128, 6, seed=5)
+    with torch.no_grad():
+        feats = O.backbone_forward(student, batch['img'], train=False)
+        logits, _ = O.decode_head_forward(student, feats, train=False)
+        full = F.interpolate(logits, size=(128, 128), mode='bilinear', align_corners=False)
+        ref = F.interpolate(full, size=(100, 144), mode='bilinear', align_corners=False).softmax(1).argmax(1)
+    metas = [dict(ori_shape=(100, 144, 3), flip=False)] * 2
+    lab, _ = model.get_model().inference(batch['img'].cuda(), metas, rescale=True)
+    assert tuple(lab.shape) == (2, 100, 144)
+    assert (lab.cpu().long() != ref).float().mean() < 2e-3
+    one_step = F.interpolate(logits, size=(100, 144), mode='bilinear', align_corners=False).argmax(1)
+    assert (ref != one_step).float().mean() > 0          # the two-step resize is not the one-step one: the distinction is real
+    flipped = [dict(ori_shape=(100, 144, 3), flip=True, flip_direction=['horizontal', 'vertical'])] * 2
+    lab_f, _ = model.get_model().inference(batch['img'].cuda(), flipped, rescale=True)
+    assert torch.equal(lab_f, lab.flip(dims=(2,)).flip(dims=(1,)))
+    lab_n, _ = model.get_model().inference(batch['img'].cuda(), metas, rescale=False)
+    assert tuple(lab_n.shape) == (2, 128, 128)
