@@ -80,7 +80,10 @@ class IterBasedRunner:
         if not (self.work_dir and is_main()):
             return None
         path = os.path.join(self.work_dir, f'iter_{self.iter}.pth')
-        torch.save(dict(meta=dict(iter=self.iter, CLASSES=getattr(self.model, 'CLASSES', None)),
+        # meta as mmcv's runner writes / reads it back on resume (epoch + iter) plus what tools/train.py:228-236 adds (CLASSES, PALETTE)
+        meta = dict(iter=self.iter, epoch=getattr(self, 'epoch', 0), time=time.asctime(), CLASSES=getattr(self.model, 'CLASSES', None),
+                    PALETTE=getattr(self.model, 'PALETTE', None))
+        torch.save(dict(meta=meta,
                         state_dict=OrderedDict((k, v.cpu() if torch.is_tensor(v) else v) for k, v in self.model.state_dict().items()),
                         optimizer=self.optimizer.state_dict()), path)
         latest = os.path.join(self.work_dir, 'latest.pth')

@@ -134,6 +134,7 @@ def main(argv=None):
         # img_scale / ratio_range / crop_size / reduce_zero_label / flips / photometric steps all come from the config's pipelines
         dataset = build_uda_dataset(data_cfg['train'])
         model.CLASSES = dataset.CLASSES
+        model.PALETTE = dataset.PALETTE
         loader = uda_batches(dataset, bs, dev, seed=cfg.get('seed') or 0, rank=rank, world=world)
     runner.run(iter(loader))
     runner.save_checkpoint()
