@@ -203,7 +203,8 @@ def test_every_backward_link_as_wired(wino, math):
     for op, name, k, worst, nrm, fe, de, _ in sorted(rows, key=lambda r: -r[3])[:25]:
         print(f'   {worst:8.3f} {nrm:9.2e}  fwd {fe:8.1e}  chain-dy {de:8.1e}  {name}:{k} [{op}]')
     print(f'   {n_fused[0]} BatchNorm layers had received fused backward sums from the launch completing their gradient')
-    assert n_fused[0] >= (20 if math == 'f32' else 0)      # layers.FUSE_BN_BWD_MIN_K = 512: the MFMA-bound fp32 data-gradient launches only
+    if layers.FUSE_BN_BWD and layers.FUSE_BN_BWD_MIN_K <= 512:                     # the defaults (not PFST_FUSE_BN_BWD=0 / a higher threshold)
+        assert n_fused[0] >= (20 if math == 'f32' else 0)  # layers.FUSE_BN_BWD_MIN_K = 512: the MFMA-bound fp32 data-gradient launches only
     checked_ops = {r[0] for r in rows}
     assert {'conv_bn_act', 'conv', 'maxpool', 'resize', 'gap', 'broadcast', 'ce'} <= checked_ops, checked_ops
     n_bn = sum(1 for m in model.modules() if isinstance(m, layers.BatchNorm2dP))
