@@ -4,6 +4,9 @@
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts exactly that torch.distributed.run command
+                                         as a fresh child process BEFORE any GPU call and relays rank 0's JSON line;
+                                         --dry-run prints the child command instead -- what tools/dist_train.sh:8-17 does)
 
 One "step" = one full PFGST.train_step (student fwd/bwd on source + mixed batch, EMA-teacher forward, pseudo labels,
 class mix, PFGSTLoss, backward, gradient all-reduce, AdamW) on a synthetic batch of 8 x 1024x1024x3 tiles per GPU that
@@ -195,6 +198,31 @@ def cpu_baseline(num_classes, threads, timed_steps=3):
                        f'equivalents per step), mean {mean:.1f} s/step, torch-CPU fp32 oracle on {threads} threads')
 
 
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` without a torch.distributed.run environment: start N ranks (one process per GPU, RCCL over xGMI) the way
+    the reference's launcher does (tools/dist_train.sh:8-17: `python -m torch.distributed.launch --nproc_per_node=$GPUS
+    --master_port=$PORT train.py --launcher pytorch`).  This process has made no GPU call (importing torch makes none), starts the
+    launcher as a CHILD -- never an exec: a process that has touched the GPU must not be replaced -- relays its output and exits with
+    its code.  The port is taken from --master-port / MASTER_PORT or picked free on 127.0.0.1."""
+    import socket
+    import subprocess
+    port = args.master_port or int(os.environ.get('MASTER_PORT', 0))
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+    child_args = [a for a in argv if a != '--dry-run']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + child_args
+    if args.dry_run:
+        print(json.dumps({'launcher': 'child process', 'cmd': cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -206,11 +234,42 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--per-layer', action='store_true', help='debug: per-layer conv timing table on stderr')
     ap.add_argument('--no-alt-math', action='store_true', help='skip the informational bf16x6 pass (N=1 only)')
+    ap.add_argument('--master-port', type=int, default=None, help='rendezvous port when bench.py starts the ranks itself')
+    ap.add_argument('--rendezvous-only', action='store_true', help='launch-path check: join the process group, one all-reduce, no kernels')
+    ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no WORLD_SIZE: print the child command and exit')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        print(json.dumps({'launcher': 'none (single process)' if args.gpus == 1 else 'torch.distributed.run environment present',
+                          'cmd': [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != '--dry-run']}), flush=True)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.rendezvous_only:
+        # launch-path check (no kernels): every rank joins the group the bench would use -- RCCL when each rank has its own GPU,
+        # gloo otherwise (the CPU test of the launcher) -- and takes part in one all-reduce; rank 0 prints the group it saw
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        use_rccl = torch.cuda.device_count() >= world and torch.cuda.is_available()
+        if world > 1:
+            if use_rccl:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            else:
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+            t = torch.ones(4, device=torch.device('cuda', local_rank) if use_rccl else 'cpu') * (rank + 1)
+            dist.all_reduce(t)
+            assert float(t[0]) == world * (world + 1) / 2
+        if rank == 0:
+            print(json.dumps({'rendezvous': 'ok', 'n_gpus': args.gpus, 'rccl_ranks': dist.get_world_size() if world > 1 else 1,
+                              'backend': dist.get_backend() if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -289,7 +348,7 @@ def main():
         value = global_batch * args.steps / elapsed
         res = {
             'metric': 'PFST train-step images/s on 1024\u00b2 IRRG tiles', 'value': value, 'unit': 'images/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
+            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': WORKLOAD, 'global_batch': global_batch, 'per_gpu_batch': b, 'tile': f'{S}x{S}x{w["in_channels"]}',
                        'num_classes': w['num_classes'], 'parallelism': f'dp{world}', 'weights': 'seeded random init',

@@ -60,12 +60,23 @@ __device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31
 // combined with one lane ^ 16 exchange.  Same contract as half_wave_transpose_sum<16>.  `ws`: this wave's 64 * 20 floats; the
 // caller has put a workgroup barrier between the main loop's last LDS reads and the first call.
 constexpr int PFST_ROWSUM_LDS_FLOATS = 64 * 20;
+// Lanes of ONE wave exchange values through LDS: the hardware completes a wave's LDS operations in order, but the compiler may
+// move may-alias accesses; a wavefront-scope release/acquire fence + wave barrier (no instructions at run time) pins the order
+// between a store phase and the loads of other lanes' values (and between a load phase and the next store phase).
+__device__ __forceinline__ void wave_lds_phase_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float half_wave_rowsum_lds(const float (&v)[16], float* __restrict__ ws, int lane) {
   float4* wr = reinterpret_cast<float4*>(ws + lane * 20);
+  wave_lds_phase_fence();        // a previous call's reads of `ws` (sv, then sq on the same scratch) come before these stores
   wr[0] = make_float4(v[0], v[1], v[2], v[3]);
   wr[1] = make_float4(v[4], v[5], v[6], v[7]);
   wr[2] = make_float4(v[8], v[9], v[10], v[11]);
   wr[3] = make_float4(v[12], v[13], v[14], v[15]);
+  wave_lds_phase_fence();        // every lane's values are in LDS before any lane reads its neighbours'
   const int l31 = lane & 31;
   const float* rd = ws + ((lane & 32) + (l31 >> 4)) * 20 + (l31 & 15);
   float s = 0.f;

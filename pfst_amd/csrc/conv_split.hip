@@ -710,11 +710,14 @@ __device__ __forceinline__ void conv_igemm_split_pair_body(
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r];
-    // (a wave reads back only what it wrote itself; its LDS operations complete in order)
+    // a wave reads back only what its own lanes wrote and its LDS operations complete in order; the fence keeps the compiler from
+    // moving the loads of other lanes' values above the stores (and the next pass's stores above these loads)
+    wave_lds_phase_fence();
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
+    wave_lds_phase_fence();
   }
   if (BNB != 0) {
     __syncthreads();                                     // the reduction scratch overlaps other waves' re-layout areas

@@ -75,6 +75,33 @@ def broadcast_module_state_(module, src=0, group=None):
             t.detach().copy_(buf)
 
 
+def broadcast_bn_buffers_(module, src=0, group=None):
+    """DistEvalHook._do_evaluate (rsiseg/core/evaluation/eval_hooks.py:95-107): BatchNorm running statistics are never reduced in
+    training (plain BN, rank-local batches), so before a distributed validation pass every rank takes rank `src`'s `running_var` /
+    `running_mean` -- all ranks then score their image shard with the SAME model, the one `save_checkpoint` writes from rank 0.
+    The reference issues two broadcasts per BatchNorm module (2 x 140 for student + teacher); here the buffers travel as one flat
+    tensor.  Returns the number of BatchNorm modules synchronised (0 when not distributed)."""
+    if not is_distributed():
+        return 0
+    bufs = []
+    for _, m in module.named_modules():
+        rm, rv = getattr(m, 'running_mean', None), getattr(m, 'running_var', None)
+        if torch.is_tensor(rm) and torch.is_tensor(rv):
+            bufs += [rv, rm]
+    if not bufs:
+        return 0
+    on_gpu = dist.get_backend(group) == 'nccl'
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')   # the backend's device
+    flat = torch.cat([b.detach().reshape(-1).to(dev, torch.float32) for b in bufs])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.detach().copy_(flat[off:off + n].view(b.shape))
+        off += n
+    return len(bufs) // 2
+
+
 class GradReducer:
     """Bucketed gradient all-reduce overlapped with the backward sweep (what MMDistributedDataParallel's reducer does in the
     reference: rsiseg/apis/train.py:104-112, fired from total_loss.backward(), pfgst.py:344).

@@ -92,6 +92,11 @@ def build_eval_fn(val_cfg, num_classes, device, metric='mIoU', max_images=None):
         seg = model.get_model() if hasattr(model, 'get_model') else model
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
+        if world > 1:
+            # eval_hooks.py:95-107: rank 0's BatchNorm running statistics on every rank (of `runner.model`, i.e. student AND teacher),
+            # so the summed histograms describe ONE model -- the one rank 0 checkpoints and tools/test.py scores
+            from .dist import broadcast_bn_buffers_
+            broadcast_bn_buffers_(model)
         acc = AreaAccumulator(num_classes, dataset.ignore_index, device)
         n = len(dataset) if max_images is None else min(len(dataset), max_images)
         for i in range(rank, n, world):
@@ -99,6 +104,8 @@ def build_eval_fn(val_cfg, num_classes, device, metric='mIoU', max_images=None):
             pred8, _ = seg.inference(item['img'][None].to(device), [item['img_metas']], rescale=True)
             gt = torch.from_numpy(dataset.gt_seg_map(i)).to(device)
             acc.update(pred8.reshape(gt.shape), gt)
+        if hasattr(seg, '_last_states'):
+            seg._last_states = None          # do not keep the last tile's feature maps (~0.3 GB at 1024^2) alive through training
         if world > 1:
             dist.all_reduce(acc.hist)
         m = total_area_to_metrics(*acc.areas(), metrics=metrics)

@@ -333,7 +333,12 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
     (then the returned Var is expected to be obtained from the concat Var's .slice())."""
     xd = x.data
-    fused_stats = FUSE_BN_STATS and not _BN_EVAL
+    # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
+    # cancellation: var = E[x^2] - mean^2 from the epilogue's fp32 partial sums of squares loses what torch's two-pass variance keeps
+    # (per-link test: 1.3e-3 on that layer's backward against 6e-5 for torch-fp32).  Those tiny layers take the stand-alone statistics
+    # kernel, whose sums of exact fp64 squares are exact for fp32 inputs.
+    tiny = xd.shape[0] * xd.shape[2] * xd.shape[3] <= 64
+    fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
     if conv.depthwise:
         if fused_stats:                            # batch statistics come out of the producing kernel in every case
             pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True)

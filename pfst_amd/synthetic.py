@@ -9,12 +9,16 @@ NORM_CFG = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375])
 
 def synth_batch(b, S, num_classes, cin=3, seed=1234, block=None, device='cpu'):
     """One PFST batch dict (keys of rsiseg/datasets/uda_dataset.py:120-132 after collation):
-    N(0,1) images, strong-aug = target + 0.1 N(0,1), blocky labels with a 255 ignore patch."""
+    N(0,1) images, strong-aug = target + 0.1 N(0,1), blocky labels with a 255 ignore patch.
+
+    Label blocks are 64 px ("repeat-interleave x64") from S = 128 up: PFGSTLoss's target-side mask needs all nine
+    dilation-2 neighbours on the 1/8 grid un-mixed (pfgst_loss.py:64-71), which blocks of one or two grid pixels never give --
+    with 8-px blocks `loss_sim_pos/neg` and their gradient were identically zero in every S=128 parity step."""
     g = torch.Generator().manual_seed(seed)
     img = torch.randn(b, cin, S, S, generator=g)
     trg = torch.randn(b, cin, S, S, generator=g)
     trg_aug = trg + 0.1 * torch.randn(b, cin, S, S, generator=g)
-    block = block or max(S // 16, 1)
+    block = block or (min(64, S // 2) if S >= 128 else max(S // 16, 1))
     lab = torch.randint(0, num_classes, (b, 1, S // block, S // block), generator=g)
     gt = lab.repeat_interleave(block, 2).repeat_interleave(block, 3).contiguous()
     e = max(block // 8, 1) * 2

@@ -127,7 +127,11 @@ class PFGSTLoss(nn.Module):
                 if not acc:
                     ops.fill_(buf, 0.0)
                 ops.cross_prob_bwd_(buf, prob, gP, d, self.ds, self.unfold_grad)
-            tape.record(bwd)
+            # tagged like every closure of the network, so a Tape observer (the per-link backward test) sees the link as wired:
+            # it writes dL/dx_src (first writer of that buffer in the sweep) and dL/dlogits_trg, into which the mixed pass's CE
+            # backward accumulates afterwards
+            tape.record(bwd, tag=dict(op='pfgst_loss', out=None, module=self, logits_trg=lt, x_src=raw_src, x_ema=raw_ema,
+                                      gt_src=gt8, mix_masks=mm8))
         if self.src_loss_type == 'mean_std':
             out = OrderedDict(loss_src_pos_mean=l4[0:1], loss_src_neg_mean=l4[1:2], loss_src_pos_std=l4[2:3], loss_src_neg_std=l4[3:4])
         else:                                           # pfgst_loss.py:116-131
@@ -222,11 +226,12 @@ class PFGST(UDADecorator):
     # ------------------------------------------------------------------ test hooks (never set by configs / the trainer)
     class _TestHooks:
         """debug: dict that captures intermediates; injected_mix_classes: the class choice; injected_pseudo: (uint8 label map,
-        confident-pixel count) -- decouples the student-gradient check from 1-ulp arg-max ties in the teacher logits"""
-        __slots__ = ('debug', 'injected_mix_classes', 'injected_pseudo')
+        confident-pixel count) -- decouples the student-gradient check from 1-ulp arg-max ties in the teacher logits;
+        tape_observer: engine.Tape(observer=...) for the step's single backward sweep (tests/test_layer_backward_gpu.py)"""
+        __slots__ = ('debug', 'injected_mix_classes', 'injected_pseudo', 'tape_observer')
 
         def __init__(self):
-            self.debug = self.injected_mix_classes = self.injected_pseudo = None
+            self.debug = self.injected_mix_classes = self.injected_pseudo = self.tape_observer = None
 
     def _hook(self, name, value=None, set_=False):
         if set_:
@@ -243,6 +248,7 @@ class PFGST(UDADecorator):
     debug = property(lambda self: self._hook('debug'), lambda self, v: self._hook('debug', v, True))
     injected_mix_classes = property(lambda self: self._hook('injected_mix_classes'), lambda self, v: self._hook('injected_mix_classes', v, True))
     injected_pseudo = property(lambda self: self._hook('injected_pseudo'), lambda self, v: self._hook('injected_pseudo', v, True))
+    tape_observer = property(lambda self: self._hook('tape_observer'), lambda self, v: self._hook('tape_observer', v, True))
 
     # ------------------------------------------------------------------ state
     def get_extra_state(self):
@@ -350,7 +356,7 @@ class PFGST(UDADecorator):
         presence_evt = torch.cuda.Event()
         presence_evt.record()
 
-        tape = Tape()
+        tape = Tape(hooks.tape_observer if hooks is not None else None)
         scalars = OrderedDict()
 
         # ---- teacher on target, optionally forked onto a second stream (layers.FORK_TEACHER): it is independent of the

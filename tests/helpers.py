@@ -49,3 +49,14 @@ def seeded_pfgst_state(oracle_mod, seed, num_classes=6, in_channels=3):
 
 def to_dev(batch, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def assert_live_target_side(log, ex=None, min_frac=0.15):
+    """A whole-step parity input must exercise the target-side half of PFGSTLoss (pfgst_loss.py:62-71,203-234): a valid region
+    (source label != 255 AND all nine dilated neighbours un-mixed) of at least `min_frac` of the loss grid, so that loss_sim_pos/neg
+    and their gradient into the mixed-pass logits are non-zero (with <= 1 valid pixel the reference returns zeros(1)).
+    log: the step's log_vars; ex: the oracle's extras (holds the mask) when the test ran the oracle."""
+    assert log['loss_sim_pos'] != 0.0 and log['loss_sim_neg'] != 0.0, ('dead target side', log['loss_sim_pos'], log['loss_sim_neg'])
+    if ex is not None:
+        frac = float(ex['mask'].float().mean())
+        assert frac >= min_frac, f'valid target region is {frac:.3f} of the grid'

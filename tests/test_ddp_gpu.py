@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from helpers import seeded_pfgst_state, to_dev, uda_cfg
+from helpers import assert_live_target_side, seeded_pfgst_state, to_dev, uda_cfg
 
 pytestmark = pytest.mark.gpu
 
@@ -26,8 +26,9 @@ def _one_step(rank, seed_rng=True):
     model.load_state_dict(both, strict=False)
     model.cuda()
     opt = build_optimizer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01))
-    random.seed(50 + rank); np.random.seed(50 + rank)
+    random.seed(52 + 2 * rank); np.random.seed(52 + 2 * rank)
     out = model.train_step(to_dev(synth_batch(2, 128, 6, seed=1234 + rank), 'cuda'), opt)
+    assert_live_target_side(out['log_vars'])      # every rank's step runs the whole loss graph (64-px label blocks, synthetic.py)
     a = model.student_arena
     return out, a.grad.clone().cpu(), a.data.clone().cpu(), model._teacher_arena.data.clone().cpu()
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import seeded_pfgst_state, to_dev, uda_cfg
+from helpers import assert_live_target_side, seeded_pfgst_state, to_dev, uda_cfg
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), 'golden')
@@ -74,11 +74,11 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
             sync.update(('ema_model.' + k, v.detach()) for k, v in oracle.teacher.items())
             model.load_state_dict(sync, strict=False)
         # --- oracle (fp32 CPU restatement of the reference), consuming the global python/numpy RNG like the reference
-        random.seed(100 + it); np.random.seed(100 + it)
+        random.seed(101 + it); np.random.seed(101 + it)
         olog, ex = oracle.train_step(batch, return_extras=True)
         # --- HIP product with the same RNG stream.  Its own pseudo-label map is checked below; the student passes
         # then use the oracle's map so that gradient parity is not polluted by arg-max near-ties (see below).
-        random.seed(100 + it); np.random.seed(100 + it)
+        random.seed(101 + it); np.random.seed(101 + it)
         model.debug = {}
         model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
         out = model.train_step(to_dev(batch, 'cuda'), opt)
@@ -114,6 +114,8 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
         assert rel(dbg['mixed_w'], ex['mixed_w']) < 1e-5
         for k in olog:
             assert abs(lv[k] - olog[k]) <= TOL * max(abs(olog[k]), 1e-2), (it, k, lv[k], olog[k])
+        assert_live_target_side(olog, ex)
+        assert_live_target_side(lv)
         if it == 0:
             # Gradients.  With random-init weights the backward pass through ~70 train-mode BN layers is badly
             # conditioned: the reference's OWN fp32 CPU path differs from exact (fp64) arithmetic by 2-5 % per tensor
@@ -126,7 +128,7 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
                                 pseudo_threshold=0.30,
                                 teacher_sd={k: (v.double() if v.is_floating_point() else v) for k, v in teacher.items()})
             b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
-            random.seed(100 + it); np.random.seed(100 + it)
+            random.seed(101 + it); np.random.seed(101 + it)
             _, ex64 = o64.train_step(b64, masks=ex['masks'], return_extras=True,
                                      pseudo_override=(ex['pseudo_label'], ex['n_conf']))
             rows = []
@@ -168,6 +170,20 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
     assert rel(g, torch.from_numpy(gold['it0_grad|decode_head.conv_seg.weight'])) < 5 * TOL
     g = arena.view(arena.grad, 'backbone.stem.0.weight')
     assert rel(g, torch.from_numpy(gold['it0_grad|backbone.stem.0.weight'])) < 0.1   # fp32 conditioning, see above
+    # the reference's own step had a live target side (92 of 512 grid pixels un-mixed with all nine neighbours) ...
+    assert float(gold['it0_ignore_mask_trg'].mean()) >= 0.15 and float(vals[keys.index('loss_sim_pos')]) != 0.0
+    assert_live_target_side(out['log_vars'])
+    # ... and the layers right below the mixed-pass logits carry its gradient (PFGSTLoss -> softmax(logits_trg) -> conv_seg <- CE),
+    # against the executed reference: 1e-3 on the classifier (measured 2e-6), 2e-2 one BatchNorm layer down (measured 3e-4 / 5e-3);
+    # from two BN layers down the comparison is in the conditioning regime of the stem gradient above (the reference's own fp32
+    # gradient is 2.3e-2 from fp64 on the flat vector; this run also uses its OWN pseudo labels, a few near-tie pixels apart) --
+    # measured 2-4e-2, bound 0.1.  The per-link test (tests/test_layer_backward_gpu.py) is the tight bound.
+    for k in gold.files:
+        if k.startswith('it0_grad|') and k[9:] not in ('decode_head.conv_seg.weight', 'backbone.stem.0.weight'):
+            gg = arena.view(arena.grad, k[9:])
+            e = rel(gg.reshape(gg.shape[0], -1)[:32, :64], torch.from_numpy(gold[k]))
+            print(f'   golden gradient sample {k[9:]}: rel err {e:.2e}')
+            assert e < (TOL if 'conv_seg' in k else 2e-2 if 'sep_bottleneck.1' in k else 0.1), (k, e)
 
 
 def test_pfgst_loss_downscale1_matches_oracle():
@@ -228,6 +244,7 @@ def test_seasonnet_like_step_10band_33class():
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
     assert rel(model.debug['mix_logits'], ex['mix_logits']) < TOL
     assert (model.debug['own_pseudo_label'].cpu() != ex['pseudo_label']).float().mean() < 5e-3
+    assert_live_target_side(olog, ex)
 
 
 def test_inria_like_binary_step_with_part_threshold():
@@ -263,6 +280,7 @@ def test_inria_like_binary_step_with_part_threshold():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
 
 
 def test_step_with_pfgst_loss_option_variants():
@@ -292,6 +310,7 @@ def test_step_with_pfgst_loss_option_variants():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
 
 
 @pytest.mark.parametrize('level', [3, 1])
@@ -331,6 +350,7 @@ def test_step_with_backbone_feature_level(level):
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
     # backward: the loss gradient enters the backbone at feature map `level`; the tensor producing that map must carry it --
     # the HIP gradient is far closer to the feature-level oracle than the decoded-feature oracle's gradient is
     name = {3: 'backbone.layer4.2.bn3.weight', 1: 'backbone.layer2.3.bn3.weight'}[level]
@@ -362,7 +382,7 @@ def test_stream_overlap_options_do_not_change_the_step():
         model.debug = {}
         layers.set_overlap(overlap, overlap)
         try:
-            random.seed(100); np.random.seed(100)
+            random.seed(106); np.random.seed(106)      # a class draw that leaves a live target region (helpers.assert_live_target_side)
             log0 = model.train_step(batch, opt)['log_vars']
             grad0 = model.student_arena.grad.clone().cpu()
             pl0 = model.debug['pseudo_label'].cpu()
@@ -376,6 +396,7 @@ def test_stream_overlap_options_do_not_change_the_step():
     (a0, p0, g0, a1, t0), (b0, p1, g1, b1, t1) = runs
     assert torch.equal(p0, p1), 'pseudo labels'
     assert list(a0) == list(b0)
+    assert_live_target_side(a0)
     for k in a0:
         assert abs(a0[k] - b0[k]) <= 1e-5 * max(abs(a0[k]), 1e-2), (k, a0[k], b0[k])
         assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
@@ -397,7 +418,7 @@ def test_fused_bn_backward_does_not_change_the_step():
         layers.FUSE_BN_BWD = fuse
         try:
             model, opt, _, _ = _build(0.30)
-            random.seed(100); np.random.seed(100)
+            random.seed(106); np.random.seed(106)      # a class draw that leaves a live target region (helpers.assert_live_target_side)
             log0 = model.train_step(batch, opt)['log_vars']
             grad0 = model.student_arena.grad.clone().cpu()
             random.seed(101); np.random.seed(101)
@@ -406,6 +427,7 @@ def test_fused_bn_backward_does_not_change_the_step():
             layers.FUSE_BN_BWD = prev
         runs.append((log0, grad0, log1))
     (a0, g0, a1), (b0, g1, b1) = runs
+    assert_live_target_side(a0)           # the whole loss graph is alive: the target-side PFGSTLoss gradient runs through the fused sums too
     for k in a0:
         assert abs(a0[k] - b0[k]) <= 1e-6 * max(abs(a0[k]), 1e-2), (k, a0[k], b0[k])       # forward is untouched
         assert abs(a1[k] - b1[k]) <= 5e-3 * max(abs(a1[k]), 1e-1), (k, a1[k], b1[k])
@@ -462,6 +484,7 @@ def test_pseudo_weight_ignore_rows_and_invalid_labels():
     assert float(ex['mixed_w'][:, :16][ex['masks'][:, 0, :16] == 0].abs().max()) == 0.0          # the rows really are zeroed
     for k, v in olog.items():
         assert abs(out['log_vars'][k] - v) <= TOL * max(abs(v), 1e-2), (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
     bad = to_dev(synth_batch(2, 128, 6, seed=56), 'cuda')
     bad['gt_semantic_seg'][0, 0, 40:44, 40:44] = 7
     with pytest.raises(ValueError, match='outside'):
@@ -497,6 +520,7 @@ def test_step_with_trainable_projection():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
     proj = model.aux_losses[0].proj_net
     assert rel(proj.weight.grad, ex['proj_grads'][0]) < 2e-2, rel(proj.weight.grad, ex['proj_grads'][0])     # one BN layer above the features
     assert rel(proj.bias.grad, ex['proj_grads'][1]) < 2e-2
@@ -538,6 +562,7 @@ def test_step_with_apply_no_mix():
     for k, v in olog.items():
         tol = 100.0 * 40 / (2 * 128 * 128) if k.endswith('acc_seg') else 5e-3 * max(abs(v), 1e-2)
         assert abs(out['log_vars'][k] - v) <= tol, (k, out['log_vars'][k], v)
+    assert_live_target_side(olog, ex)
 
 
 def test_batch_of_one_fails_like_the_reference():
