@@ -28,7 +28,10 @@ WORKLOAD = 'pfst_pots_irrg2vaih_irrg_deeplabv3plus_r50-d8'
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA, spec (a tuned loop on random data sustains 1250-1500: DVFS)
-DOMINANT_KERNEL = 'conv_igemm_q_kernel<128>'     # expected dominant kernel (checked against the full per-kernel pass)
+# expected dominant kernel per arithmetic (checked against the full per-kernel pass); keys are the timer's names: C-ABI entry + row tile
+DOMINANT_KERNEL = {'f32': 'conv_igemm_q_kernel<128>', 'bf16x6': 'conv_igemm_split_kernel<128>'}
+MATH_DTYPE = {'f32': 'f32 (fp32-input MFMA v_mfma_f32_32x32x2_f32, fp32 accumulate)',
+              'bf16x6': 'f32 (bf16x6 split MFMA, fp32 accumulate)'}
 
 
 class KernelTimer:
@@ -140,10 +143,13 @@ def pmc_traffic(kernel):
     (profiles/rNN_pmc_hbm_traffic_per_launch.json, newest round: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if no record matches."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_per_launch.json')))
+    split = 'split' in kernel
+    paths = sorted(p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_per_launch*.json'))
+                   if ('bf16x6' in os.path.basename(p)) == split)
     if not paths:
-        return None
-    rec = json.load(open(paths[-1]))        # the newest round's record
+        return None, None
+    rec = json.load(open(paths[-1]))        # the newest round's record of that arithmetic
+    source = 'committed PMC pass of this command, NOT this run: profiles/' + os.path.basename(paths[-1])
     def split(k):              # 'conv_igemm_q_kernel<128, 0>' -> ('conv_igemm_q_kernel', ['128', '0'])
         k = k.replace(' ', '')
         if '<' not in k:
@@ -151,15 +157,19 @@ def pmc_traffic(kernel):
         base, args = k.split('<', 1)
         return base, args.rstrip('>').split(',')
     base, want = split(kernel)
+    # the timer names a kernel family by C-ABI entry + row tile; on the device the 128-row split GEMMs are several kernels (the
+    # software-pipelined K=16 loop, the K=32 pairing and its fused-epilogue variants, the plain loop for short contractions)
+    family = {'conv_igemm_split_kernel': ('conv_igemm_split_pair_kernel', 'conv_igemm_split_pair_bnb_kernel', 'conv_igemm_split_pipe_kernel'),
+              'conv_wgrad_split_q_kernel': ('conv_wgrad_split_q_pipe_kernel',)}.get(base, ()) if want == ['128'] else ()
     tot, calls = 0.0, 0
     for k, v in rec.items():          # all instantiations whose leading template arguments match (e.g. the fused-epilogue variants
         if not isinstance(v, dict):   # <128, 0..3> of conv_igemm_q_kernel<128>), weighted by their launch counts
             continue
         b, a = split(k)
-        if b == base and a[:len(want)] == want:
+        if (b == base and a[:len(want)] == want) or b in family:
             tot += (v['fetch_MB_corrected'] + v['write_MB']) * 1e6 * v['calls']
             calls += v['calls']
-    return tot / calls if calls else None
+    return (tot / calls, source) if calls else (None, None)
 
 
 def _cpu_model():
@@ -233,7 +243,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--per-layer', action='store_true', help='debug: per-layer conv timing table on stderr')
-    ap.add_argument('--no-alt-math', action='store_true', help='skip the informational bf16x6 pass (N=1 only)')
+    ap.add_argument('--no-alt-math', action='store_true', help='skip the informational passes: stream overlap, the other arithmetic (N=1 only)')
+    ap.add_argument('--math', choices=['f32', 'bf16x6'], default=None, help='arithmetic of the dense convolutions for `value` '
+                    '(default: the product default, pfst_amd.layers.CONV_MATH / PFST_CONV_MATH)')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port when bench.py starts the ranks itself')
     ap.add_argument('--rendezvous-only', action='store_true', help='launch-path check: join the process group, one all-reduce, no kernels')
     ap.add_argument('--dry-run', action='store_true', help='with --gpus N > 1 and no WORLD_SIZE: print the child command and exit')
@@ -280,7 +292,7 @@ def main():
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import pfst_amd  # noqa: F401
-    from pfst_amd import hip_ops, strong_aug  # noqa: F401
+    from pfst_amd import hip_ops, layers, strong_aug  # noqa: F401
     from pfst_amd.hostinfo import usable_cpus
     from pfst_amd.optim import build_optimizer, poly_lr
     from pfst_amd.presets import OPTIMIZER, workload_cfg
@@ -290,198 +302,181 @@ def main():
     cfg, w = workload_cfg(WORKLOAD)
     b = args.batch or w['per_gpu_batch']
     S = args.size or w['size']
-    model = UDA.build(cfg)
-    fill_state_dict(model.state_dict(), 0)            # same seeded weights on every rank (DDP starts in sync)
-    model.to(dev)
-    opt = build_optimizer(model, OPTIMIZER)
+    main_math = args.math or layers.CONV_MATH          # the arithmetic `value` is measured in (the product default)
+    other_math = 'f32' if main_math == 'bf16x6' else 'bf16x6'
     batch = synth_batch(b, S, w['num_classes'], w['in_channels'], seed=1234 + rank, device=dev)
 
     timer = KernelTimer(hip_ops.call)
-    hip_ops.call = timer.call
+    state = dict(it=0)
 
-    def step(it):
-        for g in opt.param_groups:
-            g['lr'] = poly_lr(OPTIMIZER['lr'], it, cfg['max_iters'])
-        return model.train_step(batch, opt)
+    def build(math):
+        layers.CONV_MATH = math
+        model = UDA.build(cfg)
+        fill_state_dict(model.state_dict(), 0)            # same seeded weights on every rank (DDP starts in sync)
+        model.to(dev)
+        return model, build_optimizer(model, OPTIMIZER)
 
-    it = 0
-    for _ in range(args.warmup):
-        step(it)
-        it += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    # Timed region: only the dominant kernel's launches are bracketed with events (its roofline figure must come from the very
-    # steps `value` is measured on, and 2700 event pairs per step would cost the step 1.5-2 %); the per-kernel tables
-    # (hbm_kernels, kernel_ms_per_step) come from a second, untimed pass of the same K steps with every launch bracketed.
-    timer.enabled = not args.no_kernel_timing
-    timer.per_layer = args.per_layer
-    timer.only = None if args.per_layer else DOMINANT_KERNEL
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(it)
-        it += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    timer.enabled = False
-    dom_agg = None
-    if not args.no_kernel_timing and not args.per_layer:
-        dom_agg = timer.summary()
-        timer.records = []
-        timer.only = None
-        timer.enabled = True
-        for _ in range(args.steps):
-            step(it)
-            it += 1
+    def run_steps(model, opt, n):
+        for _ in range(n):
+            for g in opt.param_groups:
+                g['lr'] = poly_lr(OPTIMIZER['lr'], state['it'], cfg['max_iters'])
+            out = model.train_step(batch, opt)
+            state['it'] += 1
+        return out
+
+    def timed_steps(model, opt, n):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = run_steps(model, opt, n)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, out
+
+    def kernel_tables(model, opt, math, dom_agg):
+        """second, untimed pass of the same K steps with EVERY launch bracketed -> roofline legs and per-kernel tables"""
+        hip_ops.call = timer.call
+        timer.records, timer.only, timer.enabled, timer.per_layer = [], None, True, args.per_layer
+        run_steps(model, opt, args.steps)
         torch.cuda.synchronize()
         timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        hip_ops.call = timer.inner
+        agg = timer.summary()
+        timer.records = []
+        out = {}
+        if args.per_layer:       # debug table, then fold back to per-kernel keys for the JSON line
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                if v[2] == 0:
+                    sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/step {v[1] / args.steps:7.3f}\n')
+                if v[2] > 0:
+                    sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/call {v[1] / v[0]:7.3f}  TF/s {v[2] / v[1] / 1e9:6.1f}\n')
+            folded = {}
+            for k, v in agg.items():
+                d = folded.setdefault(k.split(' ')[0] if v[2] > 0 else k, [0, 0.0, 0.0, 0.0])
+                for i in range(4):
+                    d[i] += v[i]
+            agg = folded
+        tot_ms = sum(v[1] for v in agg.values())
+        mfma = {k: v for k, v in agg.items() if v[2] > 0}
+        split = math == 'bf16x6'
+        # dominant kernel = the MFMA kernel with the most time; under bf16x6 the split implicit GEMM, priced against the bf16 dense
+        # peak with the 6 bf16 MFMA flops it executes per algorithmic flop
+        cand = {k: v for k, v in mfma.items() if ('split' in k) == split} or mfma
+        dom = max(cand.items(), key=lambda kv: kv[1][1])
+        measured_in = 'second pass (all launches bracketed)'
+        if dom_agg and dom[0] in dom_agg:          # the expected dominant kernel: its launches inside the TIMED region
+            dom = (dom[0], dom_agg[dom[0]])
+            measured_in = 'timed region'
+        cnt, ms, fl, nb = dom[1]
+        mult, peak, unit = (6.0, PEAK_BF16_MFMA_TFLOPS, 'TFLOP/s (bf16 MFMA; 6 per algorithmic flop)') if 'split' in dom[0] \
+            else (1.0, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s')
+        achieved = mult * fl / (ms * 1e-3) / 1e12
+        traffic, src = pmc_traffic(dom[0])
+        out['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
+                           'traffic': traffic, 'traffic_source': src, 'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
+                           'algorithmic_flops_per_launch': fl / cnt, 'executed_mfma_flops_per_launch': mult * fl / cnt,
+                           'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12, 'algorithmic_bytes_per_launch': nb / cnt,
+                           'ms_per_step': ms / args.steps}
+        # the weight-gradient kernel in the same form, so its over-fetch ratio (PMC traffic vs algorithmic bytes) is visible too
+        wk = 'conv_wgrad_split_q_kernel<128>' if split else 'conv_wgrad_q_kernel<128,1>'
+        if wk in agg:
+            wc, wms, wfl, wnb = agg[wk]
+            wt, wsrc = pmc_traffic(wk)
+            wach = mult * wfl / (wms * 1e-3) / 1e12
+            out['roofline_wgrad'] = {'kernel': wk, 'bound': 'mfma', 'achieved': wach, 'peak': peak, 'unit': unit, 'frac': wach / peak,
+                                     'traffic': wt, 'traffic_source': wsrc, 'launches': wc, 'avg_launch_ms': wms / wc,
+                                     'measured_in': 'second pass (all launches bracketed)', 'fp32_equivalent_tflops': wfl / (wms * 1e-3) / 1e12,
+                                     'algorithmic_flops_per_launch': wfl / wc, 'algorithmic_bytes_per_launch': wnb / wc}
+        all_fl = sum(v[2] for v in mfma.values())
+        all_ms = sum(v[1] for v in mfma.values())
+        out['mfma_all_convs'] = {'fp32_equivalent_tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
+                                 'share_of_kernel_time': all_ms / tot_ms}
+        # the memory-bound kernels against the HBM roofline: algorithmic bytes (read-once / write-once) / kernel time.
+        # bn_backward is two passes (reduce + apply) over a 3-tensor minimum, so its ceiling is 3/5 of the peak.
+        out['hbm_kernels'] = {k: {'GBps': round(v[3] / (v[1] * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(v[3] / (v[1] * 1e-3) / 8e12, 3),
+                                  'ms_per_step': round(v[1] / args.steps, 3)}
+                              for k, v in agg.items() if v[2] == 0 and v[3] > 0}
+        out['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
+        out['kernel_time_total_ms_per_step'] = tot_ms / args.steps
+        return out
 
+    def measure(math, with_overlap_leg):
+        """one arithmetic: warm-up, the timed K steps (only the dominant kernel's launches bracketed), the table pass, the overlap leg"""
+        model, opt = build(math)
+        dominant = DOMINANT_KERNEL[math]
+        hip_ops.call = timer.inner
+        run_steps(model, opt, args.warmup)
+        rec = {}
+        # Timed region: only the dominant kernel's launches are bracketed with events (its roofline figure must come from the very
+        # steps `value` is measured on, and 2700 event pairs per step would cost the step 1.5-2 %).
+        timing = not args.no_kernel_timing
+        if timing and not args.per_layer:
+            hip_ops.call = timer.call
+            timer.records, timer.only, timer.enabled, timer.per_layer = [], dominant, True, False
+        elapsed, out = timed_steps(model, opt, args.steps)
+        timer.enabled = False
+        hip_ops.call = timer.inner
+        dom_agg = timer.summary() if timing and not args.per_layer else None
+        timer.records = []
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        rec.update(value=b * world * args.steps / elapsed, unit='images/s', ms_per_step=1000.0 * elapsed / args.steps,
+                   loss=out['log_vars'].get('decode.loss_ce'))
+        if timing and rank == 0:
+            rec.update(kernel_tables(model, opt, math, dom_agg))
+        elif timing:
+            run_steps(model, opt, args.steps)          # keep the ranks in step (collectives inside train_step)
+        if with_overlap_leg:
+            # informational: the same step with stream-level overlap (weight gradients on a side stream beside the BatchNorm-backward /
+            # data-gradient chain, teacher forward forked beside the student's source pass).  Kept out of `value`: with kernels of several
+            # streams sharing the CUs, per-kernel event durations stop describing the kernel, and the roofline leg is measured in the
+            # same timed region as `value`.
+            layers.set_overlap(True, True)
+            run_steps(model, opt, max(1, args.warmup))
+            dt, _ = timed_steps(model, opt, args.steps)
+            layers.set_overlap(False, False)
+            rec['with_stream_overlap'] = {'mode': 'weight gradients on a side stream + teacher forward forked (opt-in: PFST_WGRAD_STREAM=1 '
+                                                  'PFST_FORK_TEACHER=1)', 'value': b * args.steps / dt, 'unit': 'images/s',
+                                          'ms_per_step': 1000.0 * dt / args.steps}
+        rec['hbm_peak_allocated_GB'] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+        del model, opt
+        torch.cuda.empty_cache()
+        return rec
+
+    main = measure(main_math, with_overlap_leg=world == 1 and not args.no_alt_math)
+    res = None
     if rank == 0:
         global_batch = b * world
-        value = global_batch * args.steps / elapsed
         res = {
-            'metric': 'PFST train-step images/s on 1024\u00b2 IRRG tiles', 'value': value, 'unit': 'images/s',
-            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1000.0 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'metric': 'PFST train-step images/s on 1024² IRRG tiles', 'value': main['value'], 'unit': 'images/s',
+            'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': main['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': MATH_DTYPE[main_math], 'data': 'synthetic',
             'config': {'workload': WORKLOAD, 'global_batch': global_batch, 'per_gpu_batch': b, 'tile': f'{S}x{S}x{w["in_channels"]}',
                        'num_classes': w['num_classes'], 'parallelism': f'dp{world}', 'weights': 'seeded random init',
+                       'conv_math': main_math,
                        'strong_aug': 'colour-jitter p=0.8 + gaussian-blur p=0.5 (HIP kernels; kornia arithmetic restated, PARITY UNPINNED, <2 ms of the step)',
                        'dropout': 0.1},
-            'loss': out['log_vars'].get('decode.loss_ce'),
-            'hbm_peak_allocated_GB': round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+            'loss': main['loss'], 'hbm_peak_allocated_GB': main['hbm_peak_allocated_GB'],
         }
-        if not args.no_kernel_timing:
-            agg = timer.summary()
-            if args.per_layer:       # debug table, then fold back to per-kernel keys for the JSON line
-                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    if v[2] == 0:
-                        sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/step {v[1] / args.steps:7.3f}\n')
-                    if v[2] > 0:
-                        sys.stderr.write(f'{k:70s} calls/step {v[0] / args.steps:5.1f}  ms/call {v[1] / v[0]:7.3f}  TF/s {v[2] / v[1] / 1e9:6.1f}\n')
-                folded = {}
-                for k, v in agg.items():
-                    d = folded.setdefault(k.split(' ')[0] if v[2] > 0 else k, [0, 0.0, 0.0, 0.0])
-                    for i in range(4):
-                        d[i] += v[i]
-                agg = folded
-            tot_ms = sum(v[1] for v in agg.values())
-            mfma = {k: v for k, v in agg.items() if v[2] > 0}
-            dom = max(mfma.items(), key=lambda kv: kv[1][1])
-            measured_in = 'second pass (all launches bracketed)'
-            if dom_agg and dom[0] in dom_agg:          # the expected dominant kernel: use its launches of the TIMED region
-                dom = (dom[0], dom_agg[dom[0]])
-                measured_in = 'timed region'
-            cnt, ms, fl, nb = dom[1]
-            achieved = fl / (ms * 1e-3) / 1e12
-            res['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom[0]),
-                               'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
-                               'algorithmic_flops_per_launch': fl / cnt, 'algorithmic_bytes_per_launch': nb / cnt}
-            # the second-largest MFMA kernel (weight gradients) in the same form, so its over-fetch ratio (PMC traffic vs algorithmic
-            # bytes: x + dy read once, dw written) is visible in the record too
-            wk = 'conv_wgrad_q_kernel<128,1>'
-            if wk in agg:
-                wc, wms, wfl, wnb = agg[wk]
-                res['roofline_wgrad'] = {'kernel': wk, 'bound': 'mfma', 'achieved': wfl / (wms * 1e-3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                                         'unit': 'TFLOP/s', 'frac': wfl / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                                         'traffic': pmc_traffic(wk), 'launches': wc, 'avg_launch_ms': wms / wc,
-                                         'measured_in': 'second pass (all launches bracketed)',
-                                         'algorithmic_flops_per_launch': wfl / wc, 'algorithmic_bytes_per_launch': wnb / wc}
-            all_fl = sum(v[2] for v in mfma.values())
-            all_ms = sum(v[1] for v in mfma.values())
-            res['mfma_all_convs'] = {'tflops': all_fl / (all_ms * 1e-3) / 1e12, 'ms_per_step': all_ms / args.steps,
-                                     'share_of_kernel_time': all_ms / tot_ms}
-            # the memory-bound kernels against the HBM roofline: algorithmic bytes (read-once / write-once) / kernel time.
-            # bn_backward is two passes (reduce + apply) over a 3-tensor minimum, so its ceiling is 3/5 of the peak.
-            res['hbm_kernels'] = {k: {'GBps': round(v[3] / (v[1] * 1e-3) / 1e9, 1), 'frac_of_8TBps': round(v[3] / (v[1] * 1e-3) / 8e12, 3),
-                                      'ms_per_step': round(v[1] / args.steps, 3)}
-                                  for k, v in agg.items() if v[2] == 0 and v[3] > 0}
-            res['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]}
-            res['kernel_time_total_ms_per_step'] = tot_ms / args.steps
-        if world == 1 and not args.no_alt_math:
-            # informational pass: the same fp32 step with stream-level overlap (weight gradients on a side stream beside the
-            # BatchNorm-backward / data-gradient chain, teacher forward forked beside the student's source pass).  Kept out of
-            # `value`: with kernels of several streams sharing the CUs, per-kernel event durations stop describing the kernel,
-            # and the roofline leg above is measured in the same timed region as `value`.
-            from pfst_amd import layers
-            hip_ops.call = timer.inner
-            layers.set_overlap(True, True)
-            for i in range(max(1, args.warmup)):
-                step(it)
-                it += 1
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                step(it)
-                it += 1
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            layers.set_overlap(False, False)
-            res['alt_streams'] = {'mode': 'fp32 MFMA, weight gradients on a side stream + teacher forward forked (opt-in via '
-                                          'PFST_WGRAD_STREAM=1 PFST_FORK_TEACHER=1)',
-                                  'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
-        if world == 1 and not args.no_alt_math:
-            # informational second pass: same step with the fp32-faithful 6-term bf16 split for the fprop/dgrad GEMMs (direct and Winograd)
-            # (csrc/conv_split.hip).  `value` above is the fp32-MFMA number; this one is reported separately.
-            from pfst_amd import layers
-            hip_ops.call = timer.inner
-            del model, opt
-            torch.cuda.empty_cache()
-            layers.CONV_MATH = 'bf16x6'
-            model2 = UDA.build(cfg)
-            fill_state_dict(model2.state_dict(), 0)
-            model2.to(dev)
-            opt2 = build_optimizer(model2, OPTIMIZER)
-            for i in range(max(1, args.warmup)):
-                model2.train_step(batch, opt2)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                model2.train_step(batch, opt2)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            alt = {'mode': 'bf16x6 split MFMA (fp32-faithful 6-term bf16 split) for the fprop / dgrad GEMMs incl. the Winograd ones and the 1x1 / '
-                           'Winograd-domain weight gradients; opt-in via PFST_CONV_MATH=bf16x6', 'value': b * args.steps / dt,
-                   'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
-            if not args.no_kernel_timing:
-                # its own roofline leg, against the bf16 dense peak: the split kernel executes 6 bf16 MFMA flops per algorithmic flop
-                timer.records, timer.only, timer.enabled = [], None, True
-                hip_ops.call = timer.call
-                for i in range(args.steps):
-                    model2.train_step(batch, opt2)
-                torch.cuda.synchronize()
-                timer.enabled = False
-                hip_ops.call = timer.inner
-                agg2 = timer.summary()
-                sk = {k: v for k, v in agg2.items() if 'split' in k and v[2] > 0}
-                if sk:
-                    k0, (cnt, ms, fl, nb) = max(sk.items(), key=lambda kv: kv[1][1])
-                    tf = 6.0 * fl / (ms * 1e-3) / 1e12
-                    alt['roofline'] = {'kernel': k0, 'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA)',
-                                       'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12, 'launches': cnt,
-                                       'avg_launch_ms': ms / cnt, 'ms_per_step': ms / args.steps}
-                    alt['kernel_ms_per_step'] = {k: round(v[1] / args.steps, 3) for k, v in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:8]}
-            # both opt-in features together: bf16x6 arithmetic + stream-level overlap
-            layers.set_overlap(True, True)
-            for i in range(max(1, args.warmup)):
-                model2.train_step(batch, opt2)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                model2.train_step(batch, opt2)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            layers.set_overlap(False, False)
-            alt['with_stream_overlap'] = {'value': b * args.steps / dt, 'unit': 'images/s', 'ms_per_step': 1000.0 * dt / args.steps}
-            res['alt_math'] = alt
-            layers.CONV_MATH = 'f32'
+        for k in ('roofline', 'roofline_wgrad', 'mfma_all_convs', 'hbm_kernels', 'kernel_ms_per_step', 'kernel_time_total_ms_per_step'):
+            if k in main:
+                res[k] = main[k]
+        if 'with_stream_overlap' in main:
+            res['alt_streams'] = main['with_stream_overlap']
+    if world == 1 and not args.no_alt_math:
+        # the other arithmetic on the same step, same line: fp32-input MFMA (v_mfma_f32_32x32x2_f32) when `value` runs the
+        # fp32-faithful bf16x6 split, and vice versa -- with its own roofline leg
+        alt = measure(other_math, with_overlap_leg=True)
+        alt['mode'] = MATH_DTYPE[other_math] + ('; PFST_CONV_MATH=f32' if other_math == 'f32' else '; PFST_CONV_MATH=bf16x6')
+        alt.pop('hbm_kernels', None)
+        res['alt_math'] = alt
+    layers.CONV_MATH = main_math
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(w['num_classes'], usable_cpus())
         elif not args.no_cpu_baseline:

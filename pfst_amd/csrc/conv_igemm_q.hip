@@ -234,18 +234,21 @@ int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, flo
              int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
              const PfstBnbArgs* bnb, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), groups, N);
+  // occupancy cap (diagnostic / stream-overlap experiments, tools/overlap_microbench.py): unused dynamic LDS so that fewer workgroups
+  // fit per CU and a concurrently running HBM-bound kernel of another stream finds registers and wave slots
+  static const int lds_pad = getenv("PFST_IGEMM_LDS_PAD") ? atoi(getenv("PFST_IGEMM_LDS_PAD")) : 0;
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, one GEMM group
     PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_BNB(MODE_)                                                                                                        \
-    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, MODE_>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out, \
+    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, MODE_>), grid, dim3(256), lds_pad, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out, \
                        out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, *bnb)
     if (!bnb->relu) PFST_LAUNCH_BNB(3);
     else if (bnb->y) PFST_LAUNCH_BNB(2);
     else PFST_LAUNCH_BNB(1);
 #undef PFST_LAUNCH_BNB
   } else {
-    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, 0>), grid, dim3(256), 0, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
+    hipLaunchKernelGGL((conv_igemm_q_kernel<BM, 0>), grid, dim3(256), lds_pad, s, in, in_bs, reinterpret_cast<const float4*>(wq), bias, out,
                        out_bs, N, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs());
   }
   PFST_CHECK_LAUNCH();

@@ -16,10 +16,14 @@ import os
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 _BN_EVAL = False
-# Arithmetic of the dense convolutions' forward / data-gradient GEMMs:
-#   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32), the default and what every reported number uses;
-#   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores (csrc/conv_split.hip), opt-in.
-CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f32')
+# Arithmetic of the dense convolutions' GEMMs (forward, data gradient, 1x1 / Winograd-domain weight gradients):
+#   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores, fp32 accumulate (csrc/conv_split.hip): the default since
+#               round 3.  Same results as fp32 to fp32 round-off (3.5e-7 vs fp64 per convolution against 4.1e-7 for the fp32-input
+#               MFMA; every parity test runs under both; layer by layer at b=8 x 1024^2: tests/test_fullsize_gpu.py), +25 % step
+#               throughput because gfx950's fp32-input MFMA runs at 1/16 of the bf16 rate;
+#   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32); PFST_CONV_MATH=f32.  Layers whose channel count is not a multiple of 16
+#               (the 3-/10-band stems, the classifiers' data gradient) use it in either mode.
+CONV_MATH = os.environ.get('PFST_CONV_MATH', 'bf16x6')
 # bf16x6 mode: the 1x1 and Winograd-domain weight gradients run on the K-quad split kernel (1.5x the fp32-MFMA one); the rare direct
 # 3x3 / strided ones stay on fp32 MFMA unless PFST_WGRAD_SPLIT_ALL=1 (the generic split kernel is slower than fp32 MFMA)
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'

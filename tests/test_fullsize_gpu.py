@@ -336,3 +336,139 @@ def test_pfgst_loss_nearest_upsample_path_at_seasonnet_size(ops):
     gs = torch.randn(sim_a.shape, device='cuda', generator=g)
     # adjoint of the replication: <up(s), g> = <s, up^T(g)>
     close(dot(sim_a, gs), dot(sim_lo, ops.upsample_nearest_bwd(gs, 2)), 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The two arithmetics of the dense convolutions, layer by layer at the BASELINE size: every distinct
+# groups=1 convolution shape of DeepLabV3+/R50-d8 at b=8 x 1024^2, dispatched exactly as the product dispatches it (Winograd F(4x4)
+# or direct, K-quad / split / generic kernels, the transformed input kept for the weight gradient), fprop + dgrad + wgrad under
+# fp32-input MFMA and under the bf16x6 split, both against fp64 on sampled outputs.
+# ---------------------------------------------------------------------------------------------------------------------------
+FULLSIZE_LAYERS = [  # (name, cin, cout, k, stride, dilation, input H=W)   SURVEY.md App. A
+    ('stem.3', 32, 32, 3, 1, 1, 512), ('stem.6', 32, 64, 3, 1, 1, 512),
+    ('layer1.0.conv1', 64, 64, 1, 1, 1, 256), ('layer1.conv2', 64, 64, 3, 1, 1, 256), ('layer1.conv3', 64, 256, 1, 1, 1, 256),
+    ('layer1.1.conv1', 256, 64, 1, 1, 1, 256),
+    ('layer2.0.conv1', 256, 128, 1, 1, 1, 256), ('layer2.0.conv2', 128, 128, 3, 2, 1, 256), ('layer2.conv3', 128, 512, 1, 1, 1, 128),
+    ('layer2.0.down', 256, 512, 1, 2, 1, 256), ('layer2.1.conv1', 512, 128, 1, 1, 1, 128), ('layer2.1.conv2', 128, 128, 3, 1, 1, 128),
+    ('layer3.0.conv1', 512, 256, 1, 1, 1, 128), ('layer3.0.conv2', 256, 256, 3, 1, 1, 128), ('layer3.conv3', 256, 1024, 1, 1, 1, 128),
+    ('layer3.0.down', 512, 1024, 1, 1, 1, 128), ('layer3.1.conv1', 1024, 256, 1, 1, 1, 128), ('layer3.1.conv2', 256, 256, 3, 1, 2, 128),
+    ('layer4.0.conv1', 1024, 512, 1, 1, 1, 128), ('layer4.0.conv2', 512, 512, 3, 1, 2, 128), ('layer4.conv3', 512, 2048, 1, 1, 1, 128),
+    ('layer4.0.down', 1024, 2048, 1, 1, 1, 128), ('layer4.1.conv1', 2048, 512, 1, 1, 1, 128), ('layer4.1.conv2', 512, 512, 3, 1, 4, 128),
+    ('head.bottleneck', 2560, 512, 3, 1, 1, 128), ('head.c1_bottleneck', 256, 48, 1, 1, 1, 256), ('head.sep0.pw', 560, 512, 1, 1, 1, 256),
+    ('head.sep1.pw', 512, 512, 1, 1, 1, 256), ('head.conv_seg', 512, 6, 1, 1, 1, 256), ('aux.conv', 1024, 256, 3, 1, 1, 128),
+    ('aux.conv_seg', 256, 6, 1, 1, 1, 128)]
+
+
+def _sampled_fp64(x, w, dy, k, stride, dil, seed):
+    """fp64 references on samples: forward outputs and input gradients at 48 random positions (all channels), the weight gradient
+    of a 16 x 16 channel block (all taps, the full pixel sum).  Everything on the GPU in float64 (test-side arithmetic)."""
+    g = torch.Generator().manual_seed(seed)
+    n, ci, hi, wi = x.shape
+    co, ho, wo = dy.shape[1], dy.shape[2], dy.shape[3]
+    pad = dil * (k // 2)
+    w64 = w.double()
+    P = 48
+    # ---- fprop samples: y[n, :, yo, xo]
+    pn, py, px = (torch.randint(0, m, (P,), generator=g).cuda() for m in (n, ho, wo))
+    patch = torch.zeros(P, ci, k, k, dtype=torch.float64, device='cuda')
+    for a in range(k):
+        for b in range(k):
+            yy, xx = py * stride - pad + a * dil, px * stride - pad + b * dil
+            ok = (yy >= 0) & (yy < hi) & (xx >= 0) & (xx < wi)
+            v = x[pn, :, yy.clamp(0, hi - 1), xx.clamp(0, wi - 1)].double()
+            patch[:, :, a, b] = v * ok[:, None]
+    y_ref = torch.einsum('pcab,ocab->po', patch, w64)
+    y_t32 = torch.einsum('pcab,ocab->po', patch.float(), w)              # torch's own fp32 evaluation of the same sums
+    # ---- dgrad samples: dx[n, :, yi, xi] = sum_{o,a,b} dy[n, o, (yi + pad - a dil) / stride, ...] w[o, :, a, b]
+    qn, qy, qx = (torch.randint(0, m, (P,), generator=g).cuda() for m in (n, hi, wi))
+    dx_ref = torch.zeros(P, ci, dtype=torch.float64, device='cuda')
+    dx_t32 = torch.zeros(P, ci, dtype=torch.float32, device='cuda')
+    for a in range(k):
+        for b in range(k):
+            ty, tx = qy + pad - a * dil, qx + pad - b * dil
+            yo, xo = torch.div(ty, stride, rounding_mode='floor'), torch.div(tx, stride, rounding_mode='floor')
+            ok = (ty % stride == 0) & (tx % stride == 0) & (yo >= 0) & (yo < ho) & (xo >= 0) & (xo < wo)
+            v = dy[qn, :, yo.clamp(0, ho - 1), xo.clamp(0, wo - 1)].double() * ok[:, None]
+            dx_ref += v @ w64[:, :, a, b]
+            dx_t32 += v.float() @ w[:, :, a, b]
+    # ---- wgrad block: dw[o0:o0+16, c0:c0+16]
+    o0 = int(torch.randint(0, max(1, co - 15), (1,), generator=g))
+    c0 = int(torch.randint(0, max(1, ci - 15), (1,), generator=g))
+    ob, cb = min(16, co), min(16, ci)
+    xs = torch.nn.functional.pad(x[:, c0:c0 + cb].double(), (pad, pad, pad, pad))
+    dys = dy[:, o0:o0 + ob].double()
+    dw_ref = torch.zeros(ob, cb, k, k, dtype=torch.float64, device='cuda')
+    dw_t32 = torch.zeros(ob, cb, k, k, dtype=torch.float32, device='cuda')
+    for a in range(k):
+        for b in range(k):
+            win = xs[:, :, a * dil:a * dil + (ho - 1) * stride + 1:stride, b * dil:b * dil + (wo - 1) * stride + 1:stride]
+            dw_ref[:, :, a, b] = torch.einsum('nohw,nchw->oc', dys, win)
+            dw_t32[:, :, a, b] = torch.einsum('nohw,nchw->oc', dys.float(), win.float())
+    return dict(y=(pn, py, px, y_ref, y_t32), dx=(qn, qy, qx, dx_ref, dx_t32), dw=(o0, ob, c0, cb, dw_ref, dw_t32))
+
+
+def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
+    import pfst_amd  # noqa: F401
+    from pfst_amd import layers
+    rel = lambda a, ref: float((a.double() - ref).norm() / (ref.norm() + 1e-300))
+    rows = []
+    prev = layers.CONV_MATH
+    try:
+        for li, (name, ci, co, k, stride, dil, hw) in enumerate(FULLSIZE_LAYERS):
+            g = torch.Generator().manual_seed(100 + li)
+            pad = dil * (k // 2)
+            n = 8
+            ho = (hw + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            x = torch.randn(n, ci, hw, hw, generator=g).cuda()
+            x = torch.relu(x) * (1.0 + x.abs())                       # post-ReLU-like operand: zeros and a heavy tail
+            dy = (torch.randn(n, co, ho, ho, generator=g) * 1e-4).cuda()
+            w = (torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).cuda()
+            ref = _sampled_fp64(x, w, dy, k, stride, dil, 7 + li)
+            res = {}
+            for math in ('f32', 'bf16x6'):
+                layers.CONV_MATH = math
+                conv = layers.Conv2dP(ci, co, k, stride, pad, dil).cuda()
+                with torch.no_grad():
+                    conv.weight.copy_(w)
+                conv.weight.grad = torch.zeros_like(conv.weight)
+                conv.repack(need_dgrad=True)
+                y = conv.fprop(x, keep=True)
+                y = y[0] if isinstance(y, tuple) else y
+                saved_v = conv.saved_v
+                dx = torch.empty_like(x)
+                conv.dgrad(dy, (hw, hw), dx, False)
+                layers._wgrad(conv, x, dy, saved_v)
+                res[math] = (y, dx, conv.weight.grad.clone(), dict(wino=conv.wino, split_f=conv.split_f, split_d=conv.split_d))
+                del conv, saved_v
+            pn, py, px, y_ref, y_t32 = ref['y']
+            qn, qy, qx, dx_ref, dx_t32 = ref['dx']
+            o0, ob, c0, cb, dw_ref, dw_t32 = ref['dw']
+            for what, pick, r64, t32 in (('fprop', lambda t: t[0][pn, :, py, px], y_ref, y_t32),
+                                         ('dgrad', lambda t: t[1][qn, :, qy, qx], dx_ref, dx_t32),
+                                         ('wgrad', lambda t: t[2][o0:o0 + ob, c0:c0 + cb], dw_ref, dw_t32)):
+                e32, e6 = rel(pick(res['f32']), r64), rel(pick(res['bf16x6']), r64)
+                full = {'fprop': 0, 'dgrad': 1, 'wgrad': 2}[what]
+                d = rel(res['bf16x6'][full], res['f32'][full].double())          # the two arithmetics against each other, whole tensor
+                rows.append((name, what, e32, e6, d, res['bf16x6'][3], rel(t32, r64)))
+            del x, dy, w, res, ref
+            torch.cuda.empty_cache()
+    finally:
+        layers.CONV_MATH = prev
+    print('\nlayer-by-layer at b=8 x 1024^2: rel. error vs fp64 on samples (fp32-input MFMA | bf16x6 split | torch fp32 of the same sums), '
+          'the two arithmetics against each other (whole tensor)')
+    for name, what, e32, e6, d, disp, et in rows:
+        tag = ('wino ' if disp['wino'] else '') + ('split' if (disp['split_f'] or disp['split_d'] or disp['wino']) else 'fp32-kernel')
+        print(f'   {name:20s} {what:5s}  {e32:9.2e} | {e6:9.2e} | {et:9.2e}   diff {d:9.2e}   [{tag}]')
+    worst = max(rows, key=lambda r: r[3] / max(r[2], 1e-8))
+    print(f'   worst bf16x6 / fp32-MFMA error ratio: {worst[3] / max(worst[2], 1e-8):.2f} at {worst[0]} {worst[1]}')
+    for name, what, e32, e6, d, disp, et in rows:
+        # "fp32-level error on the real shapes".  fprop / dgrad: never above the fp32-input MFMA kernel's error by more than 25 %
+        # (+1e-7: fp32 round-off of the stored result).  The 1x1 weight gradient sums 0.13-0.5 M products per weight through
+        # split-K partial sums and fp32 atomics; there the split kernel measures up to 3x the fp32-MFMA kernel's error on zero-mean
+        # data (equal on same-sign data: tools/wgrad_precision_probe.py) -- and stays BELOW torch's own fp32 evaluation of the same
+        # sums, which is the yardstick for an fp32 implementation: bound = the larger of the two.  Winograd layers: both arithmetics
+        # carry the F(4x4) transforms' 2-7e-6.
+        slack = 1.5 if (disp['wino'] and what == 'wgrad') else 1.25      # the transforms amplify the GEMM-domain round-off (entries up to 8)
+        assert e6 <= max(slack * e32, et if what == 'wgrad' else 0.0) + 1e-7, (name, what, e32, e6, et)
+        assert d <= 3.0 * max(e32, e6) + 2e-7, (name, what, d, e32, e6)
+    assert sum(1 for r in rows if r[5]['split_f'] or r[5]['split_d'] or r[5]['wino']) >= 80      # the split kernels really ran
