@@ -36,7 +36,23 @@ def _stale(obj, src):
     return any(os.path.getmtime(d) > t for d in _deps(src))
 
 
+CPU_LIB = os.path.join(HERE, 'libpfst_cpu.so')
+
+
+def build_cpu(force=False, verbose=True):
+    """libpfst_cpu.so: the data pipeline's pixel kernels (csrc/pipeline_cpu.c), plain C with gcc.  -ffp-contract=off: no fused
+    multiply-adds, so every float operation rounds like the NumPy expression it mirrors (bit-identical results)."""
+    src = os.path.join(CSRC, 'pipeline_cpu.c')
+    if force or not os.path.exists(CPU_LIB) or os.path.getmtime(src) > os.path.getmtime(CPU_LIB):
+        cmd = [os.environ.get('CC', 'gcc'), '-O3', '-msse4.1', '-fPIC', '-shared', '-std=c99', '-ffp-contract=off', '-fno-fast-math', '-o', CPU_LIB, src, '-lm']
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return CPU_LIB
+
+
 def build(force=False, verbose=True):
+    build_cpu(force, verbose)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)

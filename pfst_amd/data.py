@@ -13,6 +13,7 @@ import os
 
 import numpy as np
 import torch
+import torch.utils.data
 
 from .pipeline import Pipeline, reduce_zero_label
 from .synthetic import synth_batch
@@ -228,11 +229,165 @@ def collate(items, device):
 
 
 def uda_batches(dataset, batch_size, device='cuda', seed=0, rank=0, world=1, start_epoch=0):
-    """infinite iterator of collated device batches, epoch after epoch (drop_last=True like rsiseg/datasets/builder.py:107);
-    single-process loading -- `workers_per_gpu` worker processes are a deployment concern outside the hot path"""
+    """infinite iterator of collated device batches, epoch after epoch (drop_last=True like rsiseg/datasets/builder.py:107), loaded
+    inline on the calling thread from the caller's global NumPy stream (the golden-vector tests pin the draw order this way);
+    training uses `build_loader` below"""
     epoch = start_epoch
     while True:
         idx = epoch_indices(len(dataset), world, rank, epoch, seed)
         for b in range(len(idx) // batch_size):
             yield collate([dataset[i] for i in idx[b * batch_size:(b + 1) * batch_size]], device)
         epoch += 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# worker-process loader (rsiseg/datasets/builder.py:100-193: DataLoader(num_workers=workers_per_gpu, pin_memory, persistent
+# workers, worker_init_fn) behind a DistributedSampler)
+# ----------------------------------------------------------------------------------------------------------------------
+def sample_seed(seed, epoch, position, rank=0, world=1):
+    """32-bit seed of ONE sample: a function of (run seed, epoch, the sample's position in the epoch's global order) only"""
+    x = (int(seed) * 0x9E3779B1 + int(epoch) * 0x85EBCA77 + (int(position) * world + rank) * 0xC2B2AE3D + 0x27D4EB2F) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 33
+    x = (x * 0xFF51AFD7ED558CCD) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 33
+    return int(x & 0xFFFFFFFF)
+
+
+class _SeededItems(torch.utils.data.Dataset):
+    """dataset[(seed, idx)]: the item `idx` drawn from a NumPy / Python stream seeded for this sample.  The caller's global streams
+    are put back afterwards: loaded inline (workers = 0) the pipeline must not consume the training thread's NumPy stream, which
+    PFGST draws its class-mix choices from (dacs_transforms.py:110-126) -- in the reference those draws live in worker processes."""
+
+    def __init__(self, dataset, reseed):
+        self.dataset, self.reseed = dataset, reseed
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, key):
+        import random
+        seed, idx = key
+        if not self.reseed:
+            return self.dataset[idx]
+        saved = (np.random.get_state(), random.getstate())
+        try:
+            np.random.seed(seed)
+            random.seed(seed)
+            return self.dataset[idx]
+        finally:
+            np.random.set_state(saved[0])
+            random.setstate(saved[1])
+
+
+class _EpochBatches(torch.utils.data.Sampler):
+    """infinite batch sampler: the rank's share of one seeded permutation per epoch (epoch_indices), drop_last, every index paired
+    with its sample seed"""
+
+    def __init__(self, n, batch_size, seed, rank, world, start_epoch=0):
+        self.n, self.batch_size, self.seed, self.rank, self.world, self.epoch = n, batch_size, seed, rank, world, start_epoch
+
+    def __iter__(self):
+        while True:
+            idx = epoch_indices(self.n, self.world, self.rank, self.epoch, self.seed)
+            for b in range(len(idx) // self.batch_size):
+                yield [(sample_seed(self.seed, self.epoch, b * self.batch_size + j, self.rank, self.world), idx[b * self.batch_size + j])
+                       for j in range(self.batch_size)]
+            self.epoch += 1
+
+
+def _collate_cpu(items):
+    batch = {}
+    for key in ('img', 'gt_semantic_seg', 'target_img', 'target_img_strong_aug'):
+        if key in items[0]:
+            batch[key] = torch.stack([it[key] for it in items])
+    batch['img_metas'] = [it['img_metas'] for it in items]
+    batch['target_img_metas'] = [it['target_img_metas'] for it in items]
+    return batch
+
+
+def _worker_init(worker_id, num_workers, rank, seed, seeding):
+    import random
+    torch.set_num_threads(1)                 # the pipeline is NumPy / C per sample; parallelism comes from the worker processes
+    if seeding == 'worker':                  # rsiseg/datasets/builder.py:170-181, verbatim arithmetic
+        worker_seed = num_workers * rank + worker_id + seed
+        np.random.seed(worker_seed)
+        random.seed(worker_seed)
+
+
+def build_loader(dataset, batch_size, device='cuda', seed=0, rank=0, world=1, workers=0, prefetch=2, seeding='sample', start_epoch=0,
+                 pin_memory=None):
+    """Infinite iterator of device batches fed by `workers` processes (cfg.data.workers_per_gpu), the counterpart of the reference's
+    build_dataloader (rsiseg/datasets/builder.py:100-193): torch DataLoader with persistent workers, a bounded prefetch queue
+    (`prefetch` batches per worker), pinned host buffers, and the host -> device copy of the NEXT batch issued on a copy stream while
+    the current step runs (`device_prefetch`).
+
+    seeding='sample' (default): every sample draws from its own stream, seeded by (seed, epoch, position) -- the batches are then
+    identical for ANY worker count, 0 included, and reproducible across runs; within a sample the pipeline makes the reference's
+    draws in the reference's order.  seeding='worker': the reference's worker_init_fn (one stream per worker process, seeded
+    num_workers * rank + worker_id + seed), whose batches depend on the worker count like the reference's do.
+    Workers are started with 'spawn': a forked child of a process that has initialised the GPU would inherit its device handles."""
+    from functools import partial
+    if seeding not in ('sample', 'worker'):
+        raise ValueError(f'seeding={seeding!r}')
+    items = _SeededItems(dataset, reseed=seeding == 'sample')
+    sampler = _EpochBatches(len(dataset), batch_size, seed, rank, world, start_epoch)
+    on_gpu = torch.device(device).type == 'cuda'
+    kw = {}
+    if workers > 0:
+        kw = dict(multiprocessing_context='spawn', persistent_workers=True, prefetch_factor=prefetch,
+                  worker_init_fn=partial(_worker_init, num_workers=workers, rank=rank, seed=seed, seeding=seeding))
+    elif seeding == 'worker':
+        _worker_init(0, 0, rank, seed, seeding)
+    loader = torch.utils.data.DataLoader(items, batch_sampler=sampler, num_workers=workers, collate_fn=_collate_cpu,
+                                         pin_memory=on_gpu if pin_memory is None else pin_memory, **kw)
+    return BatchLoader(loader, device if on_gpu else None)
+
+
+class BatchLoader:
+    """the iterator `build_loader` returns: next() -> one batch dict; close() stops the worker processes (also on deletion)"""
+
+    def __init__(self, loader, device):
+        self._loader = loader
+        self._it = iter(loader)
+        self._gen = device_prefetch(self._it, device) if device is not None else self._it
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return next(self._gen)
+
+    def close(self):
+        it, self._it, self._gen, self._loader = self._it, None, None, None
+        if it is not None and hasattr(it, '_shutdown_workers'):
+            it._shutdown_workers()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_prefetch(cpu_batches, device):
+    """batch k is handed out once its copy has been ordered before the caller's stream; the copy of batch k+1 (from pinned memory, on
+    a separate copy stream) is already in flight behind it while step k runs"""
+    copy_stream = torch.cuda.Stream(device)
+
+    def start(b):
+        with torch.cuda.stream(copy_stream):
+            moved = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+            evt = torch.cuda.Event()
+            evt.record(copy_stream)
+        return moved, evt, b                      # the pinned source stays referenced until the copy has been waited for
+
+    pending = start(next(cpu_batches))
+    while True:
+        moved, evt, _src = pending
+        pending = start(next(cpu_batches))
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(evt)
+        for v in moved.values():
+            if torch.is_tensor(v):
+                v.record_stream(cur)
+        yield moved

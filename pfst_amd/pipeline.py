@@ -21,6 +21,47 @@ import numpy as np
 
 IGNORE = 255
 
+# ----------------------------------------------------------------------------------------------------------------------
+# native pixel kernels (csrc/pipeline_cpu.c -> libpfst_cpu.so, built by pfst_amd.build): same results bit for bit as the NumPy
+# expressions below (which stay as the readable restatement and as the checker: tests/test_data_loader_cpu.py), 5-10x faster.
+# PFST_PIPELINE_NATIVE=0 or a missing library selects NumPy -- both are CPU code of the data path, not the GPU hot path.
+# ----------------------------------------------------------------------------------------------------------------------
+import ctypes
+import os
+
+_NATIVE = None
+
+
+def native():
+    global _NATIVE
+    if _NATIVE is None:
+        _NATIVE = False
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libpfst_cpu.so')
+        if os.environ.get('PFST_PIPELINE_NATIVE', '1') == '1' and os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+            lib.pfst_cpu_resize_window_u8.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+            lib.pfst_cpu_bgr2hsv_u8.argtypes = [vp, i64, vp]
+            lib.pfst_cpu_hsv2bgr_u8.argtypes = [vp, i64, vp]
+            lib.pfst_cpu_convert_u8.argtypes = [vp, i64, i32, f32, f32, vp]
+            lib.pfst_cpu_hue_shift_u8.argtypes = [vp, i64, i32]
+            lib.pfst_cpu_normalize_u8.argtypes = [vp, i64, vp, vp, i32, vp]
+            for f in ('resize_window_u8', 'bgr2hsv_u8', 'hsv2bgr_u8', 'convert_u8', 'hue_shift_u8', 'normalize_u8'):
+                getattr(lib, 'pfst_cpu_' + f).restype = None
+            _NATIVE = lib
+    return _NATIVE
+
+
+def set_native(on):
+    """tests: switch the native kernels off / on again"""
+    global _NATIVE
+    _NATIVE = None if on else False
+    return native() if on else False
+
+
+def _u8c(a):
+    return a if (a.dtype == np.uint8 and a.flags['C_CONTIGUOUS']) else np.ascontiguousarray(a, np.uint8)
+
 
 # ----------------------------------------------------------------------------------------------------------------------
 # pixel operations
@@ -67,6 +108,47 @@ def resize_bilinear_u8(img, out_hw):
     return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
+class LazyResize:
+    """A bilinear resize that has not been computed yet.  The shipped training pipelines resize a 1024^2 tile by a ratio of up
+    to 2 (12.6 M output pixels x 3 channels in float arithmetic) and then keep a 512^2 RandomCrop of it: only the crop window is ever
+    needed, and a window of the resize is the same arithmetic on the window's rows and columns (same source indices, same weights),
+    so `window()` returns exactly the pixels `resize_bilinear_u8(img, hw)[y1:y2, x1:x2]` would.  8-16x less work per sample."""
+
+    def __init__(self, img, out_hw):
+        self.img, self.hw = img, (int(out_hw[0]), int(out_hw[1]))
+
+    @property
+    def shape(self):
+        return self.hw + self.img.shape[2:]
+
+    def window(self, y1, y2, x1, x2):
+        h, w = self.img.shape[:2]
+        H, W = self.hw
+        y2, x2 = min(y2, H), min(x2, W)
+        if (H, W) == (h, w):
+            return self.img[y1:y2, x1:x2]
+        y0, y1i, fy = (a[y1:y2] for a in _src_index(H, h))
+        x0, x1i, fx = (a[x1:x2] for a in _src_index(W, w))
+        lib = native()
+        if lib and self.img.ndim == 3 and self.img.shape[2] == 3:
+            src = _u8c(self.img)
+            out = np.empty((len(y0), len(x0), 3), np.uint8)
+            idx = [np.ascontiguousarray(v) for v in (y0, y1i, fy, x0, x1i, fx)]
+            lib.pfst_cpu_resize_window_u8(src.ctypes.data, h, w, *(v.ctypes.data for v in idx), len(y0), len(x0), out.ctypes.data)
+            return out
+        ylo, yhi = int(min(y0.min(), y1i.min())), int(max(y0.max(), y1i.max())) + 1
+        xlo, xhi = int(min(x0.min(), x1i.min())), int(max(x0.max(), x1i.max())) + 1
+        a = self.img[ylo:yhi, xlo:xhi].astype(np.float32)          # only the source rows / columns the window reads
+        y0, y1i, x0, x1i = y0 - ylo, y1i - ylo, x0 - xlo, x1i - xlo
+        top = a[y0][:, x0] * (1 - fx)[None, :, None] + a[y0][:, x1i] * fx[None, :, None]
+        bot = a[y1i][:, x0] * (1 - fx)[None, :, None] + a[y1i][:, x1i] * fx[None, :, None]
+        out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+        return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+    def materialize(self):
+        return resize_bilinear_u8(self.img, self.hw)
+
+
 def resize_nearest(seg, out_hw):
     """cv2.resize(INTER_NEAREST): src = floor(dst * in/out)"""
     h, w = seg.shape[:2]
@@ -80,6 +162,16 @@ def resize_nearest(seg, out_hw):
 
 def bgr2hsv_u8(img):
     """cv2.cvtColor(BGR2HSV) for 8-bit images: H in [0, 180), S, V in [0, 255]"""
+    lib = native()
+    if lib:
+        src = _u8c(img)
+        out = np.empty(src.shape, np.uint8)
+        lib.pfst_cpu_bgr2hsv_u8(src.ctypes.data, src.size // 3, out.ctypes.data)
+        return out
+    return bgr2hsv_np(img)
+
+
+def bgr2hsv_np(img):
     b, g, r = [img[..., i].astype(np.float32) for i in range(3)]
     v = np.maximum(np.maximum(b, g), r)
     mn = np.minimum(np.minimum(b, g), r)
@@ -94,6 +186,16 @@ def bgr2hsv_u8(img):
 
 
 def hsv2bgr_u8(hsv):
+    lib = native()
+    if lib:
+        src = _u8c(hsv)
+        out = np.empty(src.shape, np.uint8)
+        lib.pfst_cpu_hsv2bgr_u8(src.ctypes.data, src.size // 3, out.ctypes.data)
+        return out
+    return hsv2bgr_np(hsv)
+
+
+def hsv2bgr_np(hsv):
     h = hsv[..., 0].astype(np.float32) * 2.0
     s = hsv[..., 1].astype(np.float32) / 255.0
     v = hsv[..., 2].astype(np.float32)
@@ -112,6 +214,11 @@ def hsv2bgr_u8(hsv):
 
 def _convert(img, alpha=1.0, beta=0.0):
     """transforms.py:975-979: float multiply-add, clip, truncate to uint8"""
+    lib = native()
+    if lib and img.dtype == np.uint8 and img.flags['C_CONTIGUOUS']:
+        out = np.empty(img.shape, np.uint8)
+        lib.pfst_cpu_convert_u8(img.ctypes.data, img.size, 1, alpha, beta, out.ctypes.data)
+        return out
     return np.clip(img.astype(np.float32) * alpha + beta, 0, 255).astype(np.uint8)
 
 
@@ -126,11 +233,21 @@ def photometric_distortion(img, brightness_delta=32, contrast_range=(0.5, 1.5), 
         img = _convert(img, alpha=rnd.uniform(*contrast_range))
     if rnd.randint(2):
         hsv = bgr2hsv_u8(img)
-        hsv[..., 1] = _convert(hsv[..., 1], alpha=rnd.uniform(*saturation_range))
+        alpha = rnd.uniform(*saturation_range)
+        lib = native()
+        if lib:         # the saturation channel of the interleaved image, in place
+            lib.pfst_cpu_convert_u8(hsv.ctypes.data + 1, hsv.size // 3, 3, alpha, 0.0, hsv.ctypes.data + 1)
+        else:
+            hsv[..., 1] = _convert(hsv[..., 1], alpha=alpha)
         img = hsv2bgr_u8(hsv)
     if rnd.randint(2):
         hsv = bgr2hsv_u8(img)
-        hsv[..., 0] = (hsv[..., 0].astype(int) + rnd.randint(-hue_delta, hue_delta)) % 180
+        delta = rnd.randint(-hue_delta, hue_delta)
+        lib = native()
+        if lib:
+            lib.pfst_cpu_hue_shift_u8(hsv.ctypes.data, hsv.size // 3, int(delta))
+        else:
+            hsv[..., 0] = (hsv[..., 0].astype(int) + delta) % 180
         img = hsv2bgr_u8(hsv)
     if mode == 0 and rnd.randint(2):
         img = _convert(img, alpha=rnd.uniform(*contrast_range))
@@ -139,6 +256,13 @@ def photometric_distortion(img, brightness_delta=32, contrast_range=(0.5, 1.5), 
 
 def normalize(img, mean, std, to_rgb=True):
     """mmcv.imnormalize: (BGR -> RGB,) subtract mean, divide by std, float32"""
+    lib = native()
+    if lib and img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3 and len(mean) == 3:
+        src = _u8c(img)
+        m, sd = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+        out = np.empty(src.shape, np.float32)
+        lib.pfst_cpu_normalize_u8(src.ctypes.data, src.size // 3, m.ctypes.data, sd.ctypes.data, int(bool(to_rgb)), out.ctypes.data)
+        return out
     a = img.astype(np.float32)
     if to_rgb:
         a = a[..., ::-1]
@@ -165,6 +289,8 @@ _KNOWN = {'LoadImageFromFile', 'LoadAnnotations', 'LoadAnnotationsPseudoLabelsV2
 class Pipeline:
     """steps: the reference's list of dict(type=..., **kw).  __call__(img_bgr_u8, seg_u8 | None) -> dict with float32 CHW arrays
     `img` (+ `img_strong_aug`), uint8 `gt_semantic_seg` [1,H,W] and `img_norm_cfg`."""
+
+    lazy_resize = True          # Resize followed by RandomCrop computes the crop window only (LazyResize); False: the eager order
 
     def __init__(self, steps):
         flat = []
@@ -199,7 +325,8 @@ class Pipeline:
 
     def __call__(self, img, seg=None):
         out = {'img': img}
-        if seg is None and self.blank_labels:
+        blank = seg is None and self.blank_labels      # an all-ignore label map: its resizes / crop histograms are known without computing
+        if blank:
             seg = np.full(img.shape[:2], IGNORE, np.uint8)
         elif seg is not None and self.reduce_zero_label:
             seg = reduce_zero_label(seg)
@@ -207,6 +334,9 @@ class Pipeline:
         nch = 1 if img.ndim < 3 else img.shape[2]
         norm_cfg = dict(mean=[0.0] * nch, std=[1.0] * nch, to_rgb=False)
         for t, k in self.steps:
+            if isinstance(out['img'], LazyResize) and t not in ('RandomCrop', 'Resize', 'LoadImageFromFile', 'LoadAnnotations',
+                                                                'LoadAnnotationsPseudoLabelsV2'):
+                out['img'] = out['img'].materialize()          # a step other than the crop needs the pixels
             if t == 'Resize':
                 scale = k.get('img_scale')
                 scale = tuple(scale[0]) if isinstance(scale, (list, tuple)) and isinstance(scale[0], (list, tuple)) else tuple(scale)
@@ -218,9 +348,10 @@ class Pipeline:
                     hw = rescale_size(out['img'].shape[:2], scale)
                 else:
                     hw = (scale[1], scale[0])
-                out['img'] = resize_bilinear_u8(out['img'], hw)
+                img_now = out['img'].materialize() if isinstance(out['img'], LazyResize) else out['img']
+                out['img'] = LazyResize(img_now, hw) if self.lazy_resize and img_now.ndim == 3 else resize_bilinear_u8(img_now, hw)
                 if seg is not None:
-                    seg = resize_nearest(seg, hw)
+                    seg = np.full(hw, IGNORE, np.uint8) if blank else resize_nearest(seg, hw)
             elif t == 'RandomCrop':
                 ch, cw = k['crop_size']
                 ratio, ign = k.get('cat_max_ratio', 1.0), k.get('ignore_index', IGNORE)
@@ -232,12 +363,16 @@ class Pipeline:
                 y1, y2, x1, x2 = bbox()
                 if ratio < 1.0 and seg is not None:
                     for _ in range(10):
-                        labels, cnt = np.unique(seg[y1:y2, x1:x2], return_counts=True)
-                        cnt = cnt[labels != ign]
+                        if blank:                 # no class besides `ignore`: the test below can never pass, the ten boxes are drawn
+                            y1, y2, x1, x2 = bbox()
+                            continue
+                        hist = np.bincount(seg[y1:y2, x1:x2].ravel(), minlength=256)      # = np.unique(..., return_counts=True) on uint8
+                        labels = np.nonzero(hist)[0]
+                        cnt = hist[labels][labels != ign]
                         if len(cnt) > 1 and np.max(cnt) / np.sum(cnt) < ratio:
                             break
                         y1, y2, x1, x2 = bbox()
-                out['img'] = out['img'][y1:y2, x1:x2]
+                out['img'] = out['img'].window(y1, y2, x1, x2) if isinstance(out['img'], LazyResize) else out['img'][y1:y2, x1:x2]
                 if seg is not None:
                     seg = seg[y1:y2, x1:x2]
             elif t == 'RandomRotate90':
@@ -284,6 +419,8 @@ class Pipeline:
                         out[key] = pad_to(out[key], k['size'], k.get('pad_val', 0))
                 if seg is not None:
                     seg = pad_to(seg, out['img'].shape[:2], k.get('seg_pad_val', IGNORE))
+        if isinstance(out['img'], LazyResize):
+            out['img'] = out['img'].materialize()
         res = {key: np.ascontiguousarray(out[key].transpose(2, 0, 1), dtype=np.float32) for key in ('img', 'img_strong_aug') if key in out}
         if seg is not None:
             res['gt_semantic_seg'] = np.ascontiguousarray(seg, dtype=np.uint8)[None]

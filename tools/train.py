@@ -39,6 +39,10 @@ def parse_args(argv=None):
     p.add_argument('--max-iters', type=int, default=None)
     p.add_argument('--batch-size', type=int, default=None)
     p.add_argument('--crop-size', type=int, default=None)
+    p.add_argument('--workers', type=int, default=None, help='data-loading worker processes per GPU (default: cfg.data.workers_per_gpu)')
+    p.add_argument('--seeding', choices=['sample', 'worker'], default='sample',
+                   help="'sample': one RNG stream per sample (batches independent of the worker count); 'worker': the reference's "
+                        'worker_init_fn (rsiseg/datasets/builder.py:170-181)')
     args = p.parse_args(argv)
     if args.options and args.cfg_options:
         raise ValueError('--options and --cfg-options cannot be both specified')
@@ -75,7 +79,7 @@ def main(argv=None):
     import torch.distributed as dist
     import pfst_amd  # noqa: F401
     from pfst_amd import dist as pdist
-    from pfst_amd.data import build_uda_dataset, synthetic_loader, uda_batches
+    from pfst_amd.data import build_loader, build_uda_dataset, synthetic_loader
     from pfst_amd.evaluation import build_eval_fn
     from pfst_amd.optim import build_optimizer
     from pfst_amd.registry import build_train_model
@@ -135,9 +139,14 @@ def main(argv=None):
         dataset = build_uda_dataset(data_cfg['train'])
         model.CLASSES = dataset.CLASSES
         model.PALETTE = dataset.PALETTE
-        loader = uda_batches(dataset, bs, dev, seed=cfg.get('seed') or 0, rank=rank, world=world)
+        # the RESOLVED seed (--seed / cfg.seed / the broadcast random one) drives the sampler's shuffle (apis/train.py:74-89 passes
+        # cfg.seed to build_dataloader) and the per-sample streams; the data side never touches the training thread's NumPy stream
+        workers = args.workers if args.workers is not None else int(data_cfg.get('workers_per_gpu', 0))
+        loader = build_loader(dataset, bs, dev, seed=seed, rank=rank, world=world, workers=workers, seeding=args.seeding)
     runner.run(iter(loader))
     runner.save_checkpoint()
+    if hasattr(loader, 'close'):
+        loader.close()                       # stop the data-loading worker processes
     if distributed:
         dist.destroy_process_group()
 
