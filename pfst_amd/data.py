@@ -306,8 +306,13 @@ def _collate_cpu(items):
 
 
 def _worker_init(worker_id, num_workers, rank, seed, seeding):
+    import atexit
     import random
     torch.set_num_threads(1)                 # the pipeline is NumPy / C per sample; parallelism comes from the worker processes
+    # A spawned worker ends through sys.exit -> interpreter finalisation -> C++ static destructors, where torch's runtime can call
+    # std::terminate ("terminate called without an active exception", exit code -6; a forked worker leaves through os._exit and
+    # never runs them).  The worker's queues are already closed by then (torch's worker loop), so leave the same way.
+    atexit.register(os._exit, 0)
     if seeding == 'worker':                  # rsiseg/datasets/builder.py:170-181, verbatim arithmetic
         worker_seed = num_workers * rank + worker_id + seed
         np.random.seed(worker_seed)

@@ -132,14 +132,15 @@ class IterBasedRunner:
                 avg = OrderedDict((k, float(np.mean(v))) for k, v in self.buffer.items())
                 eta = it_time * (max_iters - self.iter)
                 mem = torch.cuda.max_memory_allocated() // (1024 * 1024) if torch.cuda.is_available() else 0
+                data_time = avg.pop('data_time')
                 msg = (f'Iter [{self.iter}/{max_iters}]\tlr: {self.optimizer.param_groups[0]["lr"]:.3e}, eta: {eta / 3600:.2f} h, '
-                       f'time: {it_time:.3f}, data_time: {avg.pop("data_time"):.3f}, memory: {mem}, ')
+                       f'time: {it_time:.3f}, data_time: {data_time:.3f}, memory: {mem}, ')
                 msg += ', '.join(f'{k}: {v:.4f}' for k, v in avg.items())
                 self.log(msg)
                 if self.work_dir:
                     with open(os.path.join(self.work_dir, 'log.json'), 'a') as f:
                         f.write(json.dumps(dict(mode='train', iter=self.iter, lr=self.optimizer.param_groups[0]['lr'],
-                                                time=it_time, **avg)) + '\n')
+                                                time=it_time, data_time=data_time, memory=mem, **avg)) + '\n')     # mmcv's TextLoggerHook keys
                 self.buffer.clear()
             if self.ckpt_interval and self.iter % self.ckpt_interval == 0:
                 self.save_checkpoint()
