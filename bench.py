@@ -29,9 +29,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 PEAK_HBM_GBPS = 8000.0
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA, spec (a tuned loop on random data sustains 1250-1500: DVFS)
 # expected dominant kernel per arithmetic (checked against the full per-kernel pass); keys are the timer's names: C-ABI entry + row tile
-DOMINANT_KERNEL = {'f32': 'conv_igemm_q_kernel<128>', 'bf16x6': 'conv_igemm_split_kernel<128>'}
+DOMINANT_KERNEL = {'f32': 'conv_igemm_q_kernel<128>', 'bf16x6': 'conv_igemm_split_kernel<128>', 'f16x3': 'conv_igemm_f16x3_kernel'}
 MATH_DTYPE = {'f32': 'f32 (fp32-input MFMA v_mfma_f32_32x32x2_f32, fp32 accumulate)',
-              'bf16x6': 'f32 (bf16x6 split MFMA, fp32 accumulate)'}
+              'bf16x6': 'f32 (bf16x6 split MFMA, fp32 accumulate)',
+              'f16x3': 'f32 (f16x3 split MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)'}
 
 
 class KernelTimer:
@@ -66,6 +67,15 @@ class KernelTimer:
             bm = 128 if m > 64 else (64 if m > 32 else 32)
             px = ho * wo if mode == 0 else hi * wi
             return f'conv_igemm_split_kernel<{bm}>', 2.0 * n * m * c * ks * ks * px, 4.0 * (n * c * hi * wi + n * m * ho * wo) + 6.0 * c * ks * ks * m
+        if name == 'pfst_conv_igemm_f16x3':
+            n, c, hi, wi, m, ho, wo, ks, mode = a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[19]
+            px = ho * wo if mode == 0 else hi * wi
+            return 'conv_igemm_f16x3_kernel', 2.0 * n * m * c * ks * ks * px, 4.0 * (n * c * hi * wi + n * m * ho * wo) + 4.0 * c * ks * ks * m
+        if name == 'pfst_wino_gemm_f16x3':
+            n, k, m, t, nx = a[5], a[6], a[7], a[8], (a[9] + 2) ** 2
+            return 'conv_igemm_f16x3_kernel', 2.0 * nx * n * m * k * t, 4.0 * nx * (n * k * t + n * m * t) + 4.0 * nx * k * m
+        if name == 'pfst_absmax':
+            return name, 0.0, 4.0 * a[1] * a[2]
         if name == 'pfst_wino_gemm_split':
             n, k, m, t, nx = a[3], a[4], a[5], a[6], (a[7] + 2) ** 2
             bm = 128 if m > 64 else (64 if m > 32 else 32)
@@ -118,7 +128,8 @@ class KernelTimer:
             idx = {'pfst_conv_igemm': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad': (5, 6, 7, 9, 12, 14),
                    'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7),
                    'pfst_conv_igemm_split': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad_split': (5, 6, 7, 9, 12, 14),
-                   'pfst_wino_gemm_split': (3, 4, 5, 6)}[name]
+                   'pfst_wino_gemm_split': (3, 4, 5, 6), 'pfst_conv_igemm_f16x3': (8, 9, 10, 12, 15, 17, 19, 20),
+                   'pfst_wino_gemm_f16x3': (5, 6, 7, 8)}[name]
             key = key + (' wino ' if 'wino' in name else ' ') + ' '.join(str(args[i]) for i in idx)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -143,9 +154,9 @@ def pmc_traffic(kernel):
     (profiles/rNN_pmc_hbm_traffic_per_launch.json, newest round: FETCH_SIZE and WRITE_SIZE collected in separate runs, KiB units,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md).  None if no record matches."""
     import glob
-    split = 'split' in kernel
+    tag = 'f16x3' if 'f16x3' in kernel else 'bf16x6' if 'split' in kernel else 'f32'
     paths = sorted(p for p in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic_per_launch*.json'))
-                   if ('bf16x6' in os.path.basename(p)) == split)
+                   if ('f16x3' if 'f16x3' in os.path.basename(p) else 'bf16x6' if 'bf16x6' in os.path.basename(p) else 'f32') == tag)
     if not paths:
         return None, None
     rec = json.load(open(paths[-1]))        # the newest round's record of that arithmetic
@@ -244,7 +255,7 @@ def main():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--per-layer', action='store_true', help='debug: per-layer conv timing table on stderr')
     ap.add_argument('--no-alt-math', action='store_true', help='skip the informational passes: stream overlap, the other arithmetic (N=1 only)')
-    ap.add_argument('--math', choices=['f32', 'bf16x6'], default=None, help='arithmetic of the dense convolutions for `value` '
+    ap.add_argument('--math', choices=['f32', 'bf16x6', 'f16x3'], default=None, help='arithmetic of the dense convolutions for `value` '
                     '(default: the product default, pfst_amd.layers.CONV_MATH / PFST_CONV_MATH)')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port when bench.py starts the ranks itself')
     ap.add_argument('--rendezvous-only', action='store_true', help='launch-path check: join the process group, one all-reduce, no kernels')
@@ -303,7 +314,7 @@ def main():
     b = args.batch or w['per_gpu_batch']
     S = args.size or w['size']
     main_math = args.math or layers.CONV_MATH          # the arithmetic `value` is measured in (the product default)
-    other_math = 'f32' if main_math == 'bf16x6' else 'bf16x6'
+    other_math = 'f32' if main_math != 'f32' else 'bf16x6'     # the line always carries the fp32-input MFMA step beside a split arithmetic
     batch = synth_batch(b, S, w['num_classes'], w['in_channels'], seed=1234 + rank, device=dev)
 
     timer = KernelTimer(hip_ops.call)
@@ -360,18 +371,20 @@ def main():
             agg = folded
         tot_ms = sum(v[1] for v in agg.values())
         mfma = {k: v for k, v in agg.items() if v[2] > 0}
-        split = math == 'bf16x6'
-        # dominant kernel = the MFMA kernel with the most time; under bf16x6 the split implicit GEMM, priced against the bf16 dense
-        # peak with the 6 bf16 MFMA flops it executes per algorithmic flop
-        cand = {k: v for k, v in mfma.items() if ('split' in k) == split} or mfma
+        split = math != 'f32'
+        # dominant kernel = the MFMA kernel with the most time; a split implicit GEMM is priced against the bf16 / fp16 dense peak with
+        # the MFMA flops it EXECUTES per algorithmic flop (6 for bf16x6, 3 for f16x3)
+        fam = {'f32': lambda k: 'split' not in k and 'f16x3' not in k, 'bf16x6': lambda k: 'split' in k, 'f16x3': lambda k: 'f16x3' in k}[math]
+        cand = {k: v for k, v in mfma.items() if fam(k)} or mfma
         dom = max(cand.items(), key=lambda kv: kv[1][1])
         measured_in = 'second pass (all launches bracketed)'
         if dom_agg and dom[0] in dom_agg:          # the expected dominant kernel: its launches inside the TIMED region
             dom = (dom[0], dom_agg[dom[0]])
             measured_in = 'timed region'
         cnt, ms, fl, nb = dom[1]
-        mult, peak, unit = (6.0, PEAK_BF16_MFMA_TFLOPS, 'TFLOP/s (bf16 MFMA; 6 per algorithmic flop)') if 'split' in dom[0] \
-            else (1.0, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s')
+        mult, peak, unit = (3.0, PEAK_BF16_MFMA_TFLOPS, 'TFLOP/s (fp16 MFMA; 3 per algorithmic flop)') if 'f16x3' in dom[0] else \
+            (6.0, PEAK_BF16_MFMA_TFLOPS, 'TFLOP/s (bf16 MFMA; 6 per algorithmic flop)') if 'split' in dom[0] else \
+            (1.0, PEAK_FP32_MFMA_TFLOPS, 'TFLOP/s')
         achieved = mult * fl / (ms * 1e-3) / 1e12
         traffic, src = pmc_traffic(dom[0])
         out['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
@@ -384,7 +397,8 @@ def main():
         if wk in agg:
             wc, wms, wfl, wnb = agg[wk]
             wt, wsrc = pmc_traffic(wk)
-            wach = mult * wfl / (wms * 1e-3) / 1e12
+            wmult = 6.0 if 'split' in wk else 1.0
+            wach = wmult * wfl / (wms * 1e-3) / 1e12
             out['roofline_wgrad'] = {'kernel': wk, 'bound': 'mfma', 'achieved': wach, 'peak': peak, 'unit': unit, 'frac': wach / peak,
                                      'traffic': wt, 'traffic_source': wsrc, 'launches': wc, 'avg_launch_ms': wms / wc,
                                      'measured_in': 'second pass (all launches bracketed)', 'fp32_equivalent_tflops': wfl / (wms * 1e-3) / 1e12,
@@ -472,7 +486,7 @@ def main():
         # the other arithmetic on the same step, same line: fp32-input MFMA (v_mfma_f32_32x32x2_f32) when `value` runs the
         # fp32-faithful bf16x6 split, and vice versa -- with its own roofline leg
         alt = measure(other_math, with_overlap_leg=True)
-        alt['mode'] = MATH_DTYPE[other_math] + ('; PFST_CONV_MATH=f32' if other_math == 'f32' else '; PFST_CONV_MATH=bf16x6')
+        alt['mode'] = MATH_DTYPE[other_math] + '; PFST_CONV_MATH=' + other_math
         alt.pop('hbm_kernels', None)
         res['alt_math'] = alt
     layers.CONV_MATH = main_math

@@ -112,6 +112,20 @@ int pfst_wino_pack_weight_split(const float* plain_f, const float* plain_d, void
                                 int m, pfst_stream_t stream);
 int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 
+/* ---- the same GEMMs with the fp32-faithful TWO-piece fp16 split (csrc/conv_f16x3.hip): three fp16 MFMAs per product instead of
+ * six bf16 ones.  Every operand tensor is scaled by the power of two its absolute maximum implies; the maxima are device
+ * scalars (fp32 slots) written by pfst_absmax or by the kernels that produce the operands -- never read back to the host.
+ * Replaces the same reference calls as pfst_conv_igemm (F.conv2d / its data gradient inside mmcv ConvModule:
+ * rsiseg/models/backbones/resnet.py:273-305, decode_heads/aspp_head.py:34-42,85-92).  Needs C % 32 == 0 and M > 64 (-3 otherwise). */
+int pfst_absmax(const float* x, long long n, int planes, long long plane_stride, int slot_stride, float* slots, pfst_stream_t stream);
+int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void* wk4_dgrad, int Cout, int Cin, int T, int sets,
+                                const float* amax, pfst_stream_t stream);
+int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
+                          const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
+                          int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, pfst_stream_t stream);
+int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
+                         int M, int T, int m, pfst_stream_t stream);
+
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
 int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,

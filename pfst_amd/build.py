@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpfst_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_igemm_q.hip', 'conv_wgrad_q.hip', 'conv_winograd.hip', 'conv_split.hip', 'dwconv.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'pfgst_loss.hip', 'optim.hip', 'strong_aug.hip', 'api.cpp']
+SOURCES = ['conv_mfma.hip', 'conv_igemm_q.hip', 'conv_wgrad_q.hip', 'conv_winograd.hip', 'conv_split.hip', 'conv_f16x3.hip', 'dwconv.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'pfgst_loss.hip', 'optim.hip', 'strong_aug.hip', 'api.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
 
 

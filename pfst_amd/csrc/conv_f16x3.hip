@@ -1,0 +1,432 @@
+// fp32-faithful convolution on the fp16 matrix cores with THREE MFMAs per product term instead of six (conv_split.hip: bf16x6).
+//
+// A bf16 piece carries 8 significand bits, so an fp32 value needs three pieces and a product six piece-products.  An fp16 piece
+// carries 11 bits: two pieces h + l hold 22 bits (|x - h - l| <= 2^-22 |x|, remainders computed exactly) and the product is
+//     a*b ~= ah*bh + ah*bl + al*bh            (dropped: al*bl <= 2^-22 |ab|, zero-mean; round-off of the pieces 2^-22)
+// accumulated in fp32 by v_mfma_f32_16x16x32_f16, which runs at the bf16 rate -- half the matrix work of bf16x6.  What fp16 lacks is
+// exponent range (5 bits), so every operand tensor is scaled by a power of two taken from its absolute maximum:
+//     s = 2^(14 - floor(log2 max|x|))  ->  max|x s| < 2^15 (no overflow), both pieces of every element down to 2^-18 of the tensor's
+//     maximum are fp16 NORMALS (full 22 bits), smaller elements keep an absolute error <= 2^-25 / s = 2^-40 of the maximum;
+// the accumulator is multiplied by 1 / (s_a s_b), an exact power of two, in the epilogue.  The absolute maxima are device scalars
+// (one fp32 slot per tensor, or per transform-domain plane of a Winograd layer) written by the kernels that PRODUCE the tensors
+// (atomicMax on the bit pattern) or by pfst_absmax; nothing is read back to the host.  Emulation against fp64:
+// 3.6e-7 at K = 2048 against 5.0e-7 for bf16x6 and 5.6e-7 for an fp32 fma chain -- fewer roundings per accumulated product.
+//
+// This file: the K=32 "pair" loop of conv_split.hip re-scheduled for 48 MFMAs per step (fprop / dgrad / the grouped Winograd-domain
+// GEMM), the weight packing and the absmax reduction.  Layers it does not cover (Cin % 32 != 0, fewer than 65 output channels) stay
+// on the bf16x6 or fp32-input MFMA kernels.
+#include "conv_epilogue.h"
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+#include "../../include/pfst_hip.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BN = 128;
+constexpr int NP = 2;      // pieces: 0 = h (high 11 bits), 1 = l (next 11 bits)
+
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_seq(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_seq(std::make_integer_sequence<int, N>(), static_cast<F&&>(f));
+}
+
+__device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, int div, int lim, int& s) {
+  const int v = o * a + t * b + c0;
+  const int odd = v & (div - 1);
+  s = v >> (div >> 1);
+  return (odd == 0) & (s >= 0) & (s < lim);
+}
+
+// biased exponent of an absolute maximum, clamped so that both the scale 2^(268 - E - 127) and its inverse are normal floats
+__device__ __forceinline__ int amax_exponent(float amax) {
+  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+  return e < 16 ? 16 : (e > 254 ? 254 : e);            // zero / denormal maxima: any scale will do (the tensor is ~0)
+}
+__device__ __forceinline__ float scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(268 - e) << 23); }       // 2^(14 - (e - 127))
+__device__ __forceinline__ float unscale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - 14) << 23); }      // 2^((e - 127) - 14)
+
+// ---- absolute maximum of a tensor into one fp32 slot (bit pattern of a non-negative float: unsigned atomicMax orders it)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, i64 n, i64 plane_stride, int slot_stride,
+                                                     unsigned* __restrict__ slot) {
+  // blockIdx.y: plane; a plane is n contiguous floats, planes `plane_stride` apart; plane y goes to slot y * slot_stride (0: all planes
+  // into one slot, e.g. the per-image blocks of a channel slice of a concat buffer)
+  const float* p = x + (i64)blockIdx.y * plane_stride;
+  float m = 0.f;
+  const i64 n4 = (((uintptr_t)p & 15) == 0) ? n / 4 : 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (i64)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(p)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (i64 i = n4 * 4 + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot + (i64)blockIdx.y * slot_stride, __builtin_bit_cast(unsigned, m));
+}
+
+// two-piece fp16 split of 8 values already multiplied by the tensor's scale (plain code: prologue and packing)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], float s, uint4& ph, uint4& pl) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float t0 = v[2 * q] * s, t1 = v[2 * q + 1] * s;
+    const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;                 // round to nearest even
+    const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);   // the remainders are exact in fp32
+    h[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | (unsigned)__builtin_bit_cast(unsigned short, h1) << 16;
+    l[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | (unsigned)__builtin_bit_cast(unsigned short, l1) << 16;
+  }
+  ph = make_uint4(h[0], h[1], h[2], h[3]);
+  pl = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// The same split as 24 single VALU instructions pinned in place (volatile asm, like split_op of conv_split.hip), K = 0..23 on the
+// eight values: per pair q six instructions -- two scale multiplies, v_cvt_pk_f16_f32 (h), two v_fma_mix_f32 computing
+// x s - h in one exact step straight from the packed halves, v_cvt_pk_f16_f32 (l).  The scale sits in an SGPR.
+struct SplitF16 {
+  unsigned h[4], l[4];
+  float t0[4], t1[4];
+};
+template <int K>
+__device__ __forceinline__ void split_op_f16(const float (&v)[8], float s, SplitF16& st) {
+  constexpr int q = K / 6, op = K % 6;
+  if constexpr (op == 0) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(st.t0[q]) : "s"(s), "v"(v[2 * q]));
+  else if constexpr (op == 1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(st.t1[q]) : "s"(s), "v"(v[2 * q + 1]));
+  else if constexpr (op == 2) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.h[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
+  else if constexpr (op == 3)
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(st.t0[q]) : "v"(v[2 * q]), "s"(s), "v"(st.h[q]));
+  else if constexpr (op == 4)
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(st.t1[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
+  else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.l[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
+}
+
+// w[Cout][Cin][T] -> two-piece K-major images, scaled by the set's power of two.
+// layout: [k/16][piece 2][k-half 2][row][8 x f16]  (one uint4 per (k16-group, piece, half, row)); fprop: k = t*Cin+ci, row = co;
+// dgrad: k = t*Cout+co, row = ci.  blockIdx.y: filter set (Winograd transform index), `set_in` floats / `set_out` chunks apart.
+__global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __restrict__ wf, uint4* __restrict__ wd, int Cout, int Cin, int T,
+                                         i64 set_in, i64 set_out, const float* __restrict__ amax) {
+  w += blockIdx.y * set_in;
+  if (wf) wf += blockIdx.y * set_out;
+  if (wd) wd += blockIdx.y * set_out;
+  const float s = scale_of(amax_exponent(amax[blockIdx.y]));
+  const i64 nf = (i64)(T * Cin / 16) * 2 * Cout, nd = (i64)(T * Cout / 16) * 2 * Cin;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (i64)gridDim.x * blockDim.x) {
+    const bool dg = i >= nf;
+    const i64 e = dg ? i - nf : i;
+    const int M = dg ? Cin : Cout, Cq = dg ? Cout : Cin;
+    if ((dg ? wd : wf) == nullptr) continue;
+    if (Cq % 16 != 0) continue;
+    const int row = (int)(e % M);
+    const i64 gh = e / M;
+    const int h = (int)(gh & 1);
+    const int g = (int)(gh >> 1);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = g * 16 + h * 8 + j;
+      const int t = k / Cq, c = k - t * Cq;
+      const int co = dg ? c : row, ci = dg ? row : c;
+      v[j] = w[((i64)co * Cin + ci) * T + t];
+    }
+    uint4 ph, pl;
+    split8_f16(v, s, ph, pl);
+    uint4* dst = dg ? wd : wf;
+    const i64 base = (i64)g * 2 * NP * M;
+    dst[base + (i64)(0 * 2 + h) * M + row] = ph;
+    dst[base + (i64)(1 * 2 + h) * M + row] = pl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The implicit GEMM.  Workgroup tile 128 x 128, four waves of 64 x 64 = 4 x 4 accumulators of v_mfma_f32_16x16x32_f16; one step
+// consumes K = 32 (two K=16 LDS tiles of [piece][half][row] images, k-quarter q of the MFMA operand = tile q / 2, half q % 2): 16
+// fragments in registers, 48 MFMAs (al bh | ah bl | ah bh, smallest terms first).  One LDS buffer: barrier A sits in the MFMA stream
+// once every wave holds its fragments, the next pair is split and stored behind it, barrier B ends the step.  The activations of pair
+// k+2 are loaded (16 scalar buffer loads per thread, alternating register sets) while pair k+1 is split and pair k multiplied, so a
+// load has a whole step to land; the four pre-split weight chunks of pair k+1 are loaded in the first slots and stored in the last.
+// Issue order is fixed slot by slot (one MFMA + at most two fillers, a scheduling barrier after each slot).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int DUMMY>
+__device__ __forceinline__ void conv_igemm_f16x3_body(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
+  constexpr int BM = 128, WAVES_N = 2;
+  constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
+  constexpr int SMEM_CHUNKS = (2 * TILE_A + 2 * TILE_B) > (4 * 32 * 68 / 4) ? (2 * TILE_A + 2 * TILE_B) : (4 * 32 * 68 / 4);
+  __shared__ uint4 smem[SMEM_CHUNKS];                           // the tiles (32 KB); the epilogue's re-layout scratch needs 34 KB
+  uint4* const As = smem;
+  uint4* const Bs = smem + 2 * TILE_A;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * 64, wn0 = (wid % WAVES_N) * 64;
+  const int P = Ho * Wo, HiWi = Hi * Wi;
+  int bx, by;
+  {
+    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
+    const int lin = blockIdx.x;
+    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    } else {
+      by = lin / gx;
+      bx = lin - by * gx;
+    }
+  }
+  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
+  const int spt = C / 32;                                // K=32 steps per filter tap
+  const int KP = spt * ks * ks;                          // steps in all
+  const int KT16 = (C / 16) * ks * ks;
+  in += (i64)n * in_bs;
+  out += (i64)n * out_bs;
+
+  const int ea = amax_exponent(w_amax[blockIdx.y]);
+  const int eb = amax_exponent(in_amax[blockIdx.y * in_amax_stride]);
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));    // an SGPR
+
+  const int pix = tid & (BN - 1), kh = tid >> 7;
+  const int p = p0 + pix;
+  const bool pvalid = p < P;
+  const int oy = pvalid ? p / Wo : 0;
+  const int ox = pvalid ? p - oy * Wo : 0;
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk4) + (i64)blockIdx.y * KT16 * 2 * NP * M, 0,
+                                                                         KT16 * 2 * NP * M * 16, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
+  unsigned a_voff;
+  {
+    const int seg = tid / BM, row = tid - seg * BM;        // chunk c = tid + 256 i of a tile -> segment seg + 2 i, same row
+    a_voff = (m0 + row < M) ? 16u * ((unsigned)seg * (unsigned)M + (unsigned)(m0 + row)) : OOB;
+  }
+  const int a_chunk = 2 * M * 16, a_tile = 2 * NP * M * 16, b_chan = HiWi * 4;
+  const int chan_step = 32 * HiWi * 4;
+  // activation voffset of the pixel for filter tap `tap` (0 .. ks*ks-1): constant while the tap does not change
+  auto tap_voff = [&](int tap) -> unsigned {
+    const int ty = tap / ks, tx = tap - ty * ks;
+    int sy, sx;
+    const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+    return ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
+  };
+
+  uint4 areg[4];                                         // [tile 2][piece 2] of the NEXT pair
+  float breg[2][2][8];                                   // [register set][tile][channel kh * 8 + i of the tile's 16]
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // loads of pair q: activations into register set SET (v = 0..15), weights into areg (v = 16..19)
+  auto load_b = [&](auto vc, auto setc, unsigned voff, int soff) {
+    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;
+    breg[SET][v >> 3][v & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, soff + ((v >> 3) * 16 + (v & 7)) * b_chan, 0));
+  };
+  auto load_a = [&](auto vc, int a_soff) {
+    constexpr int v = decltype(vc)::value;                // 0..3: tile v / 2, piece v % 2
+    areg[v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / 2) * a_tile + (v % 2) * a_chunk, 0));
+  };
+  auto pair_addr = [&](int q, unsigned& voff, int& soff) {     // pair q = (tap, channel block)
+    const int tap = q / spt, sidx = q - tap * spt;
+    voff = tap_voff(tap);
+    soff = sidx * chan_step;
+  };
+
+  // ---- prologue: pair 0 through the plain split into LDS, pair 1 into register set 1 (+ its weights into areg)
+  {
+    unsigned voff; int soff;
+    pair_addr(0, voff, soff);
+    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff, soff); });
+    static_for<4>([&](auto vc) { load_a(vc, 0); });
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      uint4 ph, pl;
+      split8_f16(breg[0][t], sb, ph, pl);
+      As[t * TILE_A + tid] = areg[t * 2 + 0];
+      As[t * TILE_A + tid + 256] = areg[t * 2 + 1];
+      Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
+      Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
+    }
+    if (KP > 1) {
+      pair_addr(1, voff, soff);
+      static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff, soff); });
+    }
+  }
+  __syncthreads();
+
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int a_frag = (lq >> 1) * TILE_A + (lq & 1) * BM + wm0 + l15;
+  const int b_frag = (lq >> 1) * TILE_B + (lq & 1) * BN + wn0 + l15;
+
+  // one step on pair k: SETN = (k + 1) & 1 holds pair k+1 (split and stored here), pair k+2 is loaded into set k & 1
+  auto step = [&](auto setn_c, int k) {
+    constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
+    const bool have2 = k + 2 < KP;
+    f16x8 af[4][NP], bf[4][NP];
+    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(f16x8, As[a_frag + pl * 2 * BM + i * 16]); };
+    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(f16x8, Bs[b_frag + pl * 2 * BN + j * 16]); };
+    // fragment reads in the order the terms (al bh) (ah bl) (ah bh) need them; r = 0..15, the first five before the first MFMA
+    auto read_frag = [&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if constexpr (r == 0) rd_a(0, 1);
+      else if constexpr (r < 5) rd_b(r - 1, 0);
+      else if constexpr (r < 8) rd_a(r - 4, 1);
+      else if constexpr (r == 8) rd_a(0, 0);
+      else if constexpr (r < 13) rd_b(r - 9, 1);
+      else rd_a(r - 12, 0);
+    };
+    unsigned voff2 = OOB; int soff2 = 0;
+    if (have2) pair_addr(k + 2, voff2, soff2);
+    const int a_soff1 = (k + 1) * 2 * a_tile;
+    static_for<5>([&](auto rc) { read_frag(rc); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+    SplitF16 s0, s1;
+    // slots: 0-10 the remaining fragment reads; 0-3 the weight chunks of pair k+1; 4-19 the activations of pair k+2; 11-34 two split
+    // instructions each (pair k+1); 16 barrier A; 40-47 the eight LDS stores; barrier B after the last MFMA
+    static_for<48>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m >> 4, i = (m >> 2) & 3, j = m & 3;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (m < 11) read_frag(std::integral_constant<int, 5 + m>());
+      // (past the last pair the offsets are out of the buffers' ranges: the loads return zeros, no branches in the stream)
+      if constexpr (m < 4) load_a(mc, a_soff1);
+      if constexpr (m >= 4 && m < 20) load_b(std::integral_constant<int, m - 4>(), std::integral_constant<int, SETL>(), voff2, soff2);
+      if constexpr (m == 16) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads have landed
+        __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (m >= 11 && m < 35) {
+        constexpr int kk = (m - 11) * 2;
+        if constexpr (kk < 24) { split_op_f16<kk>(breg[SETN][0], sb, s0); split_op_f16<kk + 1>(breg[SETN][0], sb, s0); }
+        else { split_op_f16<kk - 24>(breg[SETN][1], sb, s1); split_op_f16<kk - 23>(breg[SETN][1], sb, s1); }
+      }
+      if constexpr (m >= 40 && m < 44) As[((m - 40) / 2) * TILE_A + tid + 256 * ((m - 40) % 2)] = areg[m - 40];
+      if constexpr (m == 44) Bs[(0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+      if constexpr (m == 45) Bs[(1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      if constexpr (m == 46) Bs[TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+      if constexpr (m == 47) Bs[TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  for (int k = 0; k < KP; k += 2) {
+    step(std::integral_constant<int, 1>(), k);
+    if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
+  }
+
+  // un-scale (an exact power of two, in two factors so that neither over- nor underflows) and hand over to the common epilogue
+  const float ua = unscale_of(ea), ub = unscale_of(eb);
+  float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
+  const int l31 = lane & 31, lh = lane >> 5;
+  pfst_f32x16 acc32[2][2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r] * ua * ub;
+    wave_lds_phase_fence();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
+    wave_lds_phase_fence();
+  }
+  conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
+  conv_igemm_f16x3_body<0>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                           w_amax, in_amax, in_amax_stride);
+}
+
+}  // namespace
+
+// max |x| of `planes` planes of `n` floats (plane_stride apart) into slots[plane * slot_stride]; the slots must have been zeroed (or
+// hold an earlier maximum to extend).  pfst_absmax is the stand-alone form; producers of GEMM operands write their slots themselves.
+extern "C" int pfst_absmax(const float* x, long long n, int planes, long long plane_stride, int slot_stride, float* slots,
+                           pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && slots && n > 0 && planes > 0 && planes <= 65535 && (slot_stride == 0 || slot_stride == 1));
+  int gx = (int)((n / 4 + 255) / 256);
+  if (gx < 1) gx = 1;
+  const int cap = planes > 1 ? 256 : 2048;
+  if (gx > cap) gx = cap;
+  hipLaunchKernelGGL(absmax_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, x, (i64)n, (i64)plane_stride, slot_stride,
+                     reinterpret_cast<unsigned*>(slots));
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// w [sets][Cout][Cin][T] -> two-piece fp16 K-major images (4 bytes per weight per layout), scaled per set by the power of two that
+// amax[set] implies.  sets > 1: the transform-domain filter sets of a Winograd layer (T = 1, `set` floats apart).
+extern "C" int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void* wk4_dgrad, int Cout, int Cin, int T, int sets,
+                                           const float* amax, pfst_stream_t stream) {
+  PFST_CHECK_ARG(w && amax && (wk4_fprop || wk4_dgrad) && Cout > 0 && Cin > 0 && (T == 1 || T == 9) && sets >= 1 && sets <= 65535);
+  PFST_CHECK_ARG(!wk4_fprop || Cin % 16 == 0);
+  PFST_CHECK_ARG(!wk4_dgrad || Cout % 16 == 0);
+  PFST_CHECK_ARG(sets == 1 || T == 1);
+  const i64 n = (i64)Cout * Cin * T;
+  int gx = ew_grid(n / 8 + 1);
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3(gx, sets), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wk4_fprop, (uint4*)wk4_dgrad,
+                     Cout, Cin, T, n, 4 * n / 16, amax);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 and M > 64.
+extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
+                                     const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
+                                     int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, pfst_stream_t stream) {
+  PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
+  PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
+  if (C % 32 != 0 || M <= 64) {
+    pfst_set_error(__FILE__, __LINE__, "f16x3 kernel needs C % 32 == 0 and more than 64 output channels (use pfst_conv_igemm_split)");
+    return PFST_ERR_UNSUPPORTED;
+  }
+  const int span = (ksize - 1) * dil;
+  if (mode == 0) {
+    PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
+  } else {
+    PFST_CHECK_ARG(Hi == (Ho + 2 * pad - span - 1) / stride + 1 && Wi == (Wo + 2 * pad - span - 1) / stride + 1);
+  }
+  int a, b, c, d;
+  if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
+  const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
+  dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, 128), 1, N);
+  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                     (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// the (m+2)^2 transform-domain GEMMs of a Winograd layer as one grouped launch: V [X][N][K][T], U4 [X] packed sets, amax slots per set
+extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
+                                    int M, int T, int m, pfst_stream_t stream) {
+  PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
+  const int nx = (m + 2) * (m + 2);
+  PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
+  dim3 grid(cdiv((i64)T, BN) * cdiv(M, 128), nx, N);
+  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
+                     Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 1);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}

@@ -18,7 +18,7 @@ class Var:
     runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed')
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -27,6 +27,7 @@ class Var:
         self.parent, self.c0, self.c1 = parent, c0, c1
         self.bn = None
         self._claimed = self._sealed = False
+        self.amax = None          # device slot with max |data| (scale of the two-piece fp16 split, layers.CONV_MATH == 'f16x3'), set on first use
 
     def claim_first_use(self):
         """forward: called by every consumer that may fuse; True for the first caller only (= the last gradient writer)"""

@@ -188,6 +188,74 @@ def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out
     return (out, st, slots) if want_stats else out
 
 
+# ---------------------------------------------------------------- fp32-faithful two-piece fp16 split (csrc/conv_f16x3.hip)
+def absmax(x, planes=1, out=None):
+    """max |x| -> fp32 device slot(s).  planes = 1: one slot for the whole tensor (a dense tensor, or a dense-plane NCHW view such as a
+    channel slice of a concat buffer); planes > 1: x is dense and viewed as `planes` equal contiguous parts, one slot each.
+    out: slots to extend (already zeroed or holding an earlier maximum)"""
+    if out is None:
+        out = torch.zeros(planes, dtype=F32, device=x.device)
+    if planes == 1 and x.dim() == 4 and not x.is_contiguous():
+        n, c, h, w = x.shape
+        call('pfst_absmax', x.data_ptr(), c * h * w, n, _bs(x), 0, out.data_ptr(), _stream())
+        return out
+    _dense(x)
+    n = x.numel() // planes
+    assert n * planes == x.numel()
+    call('pfst_absmax', x.data_ptr(), n, planes, n, 1, out.data_ptr(), _stream())
+    return out
+
+
+def f16x3_eligible(cin, cout):
+    """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks and more than 64 output rows"""
+    return cin % 32 == 0 and cout > 64
+
+
+def pack_weight_f16x2(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, amax=None, sets=1):
+    """w [Cout][Cin][k][k] (or `sets` plain [Cout][Cin] Winograd-domain filter sets) -> two-piece fp16 K-major images (uint8 buffers of
+    4 bytes per weight per layout) + the slots with max |w| per set that fixed their scales"""
+    _dense(w)
+    if sets == 1:
+        co, ci, kh, kw = w.shape
+        t = kh * kw
+    else:
+        assert w.dim() == 3 and w.shape[0] == sets
+        _, co, ci = w.shape
+        t = 1
+    nbytes = 4 * sets * co * ci * t
+    wf = (out_f if out_f is not None else torch.empty(nbytes, dtype=U8, device=w.device)) if want_fprop else None
+    wd = (out_d if out_d is not None else torch.empty(nbytes, dtype=U8, device=w.device)) if want_dgrad else None
+    if amax is None:
+        amax = absmax(w, sets)
+    call('pfst_conv_pack_weight_f16x2', w.data_ptr(), _p(wf), _p(wd), co, ci, t, sets, amax.data_ptr(), _stream())
+    return wf, wd, amax
+
+
+def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
+    n, c, hi, wi = x.shape
+    ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
+    assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout)
+    if out is None:
+        out = torch.empty(n, cout, ho, wo, device=x.device)
+    slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
+    st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
+    call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+    return (out, st, slots) if want_stats else out
+
+
+def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+    n, co, ho, wo = dy.shape
+    hi, wi = in_hw
+    assert wk4_d.numel() == 4 * ksize * ksize * co * cin and f16x3_eligible(co, cin)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(n, cin, hi, wi, device=dy.device)
+    call('pfst_conv_igemm_f16x3', dy.data_ptr(), _bs(dy), wk4_d.data_ptr(), w_amax.data_ptr(), dy_amax.data_ptr(), 0, out.data_ptr(), _bs(out),
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
+    return out
+
+
 def _bnb_struct(bnb, n, cin, hi, wi, co, dev):
     """-> (ctypes struct kept alive by the caller, partials tensor, slots) for a fused BatchNorm-backward data-gradient launch"""
     pre, y, coef, relu = bnb
@@ -306,14 +374,33 @@ def wino_pack_weight_split(w, want_fprop=True, want_dgrad=True, out_f=None, out_
     return uf, ud
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None):
+def wino_pack_weight_f16(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, m=None):
+    """transform-domain filters for the f16x3 GEMM: X two-piece fp16 sets (uint8 buffers of X * 4 * Cout * Cin bytes) + the X slots with
+    each set's absolute maximum; -> (uf, ud, amax_f, amax_d)"""
+    _dense(w)
+    m, nx = _wino_m(m)
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    n = co * ci
+    pf = _wino_ws(w.device, 'Pf', nx * n) if want_fprop else None
+    pd = _wino_ws(w.device, 'Pd', nx * n) if want_dgrad else None
+    call('pfst_wino_filter_plain', w.data_ptr(), _p(pf), _p(pd), co, ci, m, _stream())
+    uf = ud = af = ad = None
+    if want_fprop:
+        uf, _, af = pack_weight_f16x2(pf[:nx * n].view(nx, co, ci), True, False, out_f=out_f, sets=nx)
+    if want_dgrad:
+        _, ud, ad = pack_weight_f16x2(pd[:nx * n].view(nx, co, ci), False, True, out_d=out_d, sets=nx)
+    return uf, ud, af, ad
+
+
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
     (288 GB of HBM: keeping it resident beats re-transforming the input in backward)."""
     n, c, h, w = x.shape
     m, nx = _wino_m(m)
     t = wino_tiles(h, w, dil, m)
-    assert u.numel() == nx * c * cout * (6 if u.dtype == U8 else 1), 'filter set was packed for another tile size'
+    assert u.numel() == nx * c * cout * ((4 if u_amax is not None else 6) if u.dtype == U8 else 1), 'filter set was packed for another tile size'
     v = torch.empty(nx * n * c * t, dtype=F32, device=x.device) if keep_v else _wino_ws(x.device, 'V', nx * n * c * t)
     mb = _wino_ws(x.device, 'M', nx * n * cout * t)
     if out is None:
@@ -321,8 +408,12 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
         out = torch.empty(n, cout, h, w, device=x.device)
     assert tuple(out.shape) == (n, cout, h, w)
     call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _stream())
-    gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
-    call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
+    if u_amax is not None:              # two-piece fp16 filter sets -> f16x3 GEMM; the scale of every transform-domain plane from its own maximum
+        v_amax = absmax(v[:nx * n * c * t], planes=nx)
+        call('pfst_wino_gemm_f16x3', v.data_ptr(), u.data_ptr(), u_amax.data_ptr(), v_amax.data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
+    else:
+        gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
+        call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
     slots, st = 0, None
     if want_stats:                      # BN partial sums of the output come out of the output transform
         slots = n * lib().pfst_wino_stats_slots(h, w, dil, m)

@@ -23,7 +23,21 @@ _BN_EVAL = False
 #               throughput because gfx950's fp32-input MFMA runs at 1/16 of the bf16 rate;
 #   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32); PFST_CONV_MATH=f32.  Layers whose channel count is not a multiple of 16
 #               (the 3-/10-band stems, the classifiers' data gradient) use it in either mode.
+#   'f16x3'  -- fp32-faithful TWO-piece fp16 split, three fp16 MFMAs per product instead of six, every operand tensor scaled by the
+#               power of two its absolute maximum implies (csrc/conv_f16x3.hip); covers contractions over whole 32-channel blocks with
+#               more than 64 output rows, the other layers run as under 'bf16x6'.
 CONV_MATH = os.environ.get('PFST_CONV_MATH', 'bf16x6')
+
+
+def _split_mode():
+    return CONV_MATH in ('bf16x6', 'f16x3')
+
+
+def amax_of(v):
+    """device slot with max |v.data| of a Var (computed once, kept on the Var: an activation usually feeds several GEMMs)"""
+    if v.amax is None:
+        v.amax = ops.absmax(v.data)
+    return v.amax
 # bf16x6 mode: the 1x1 and Winograd-domain weight gradients run on the K-quad split kernel (1.5x the fp32-MFMA one); the rare direct
 # 3x3 / strided ones stay on fp32 MFMA unless PFST_WGRAD_SPLIT_ALL=1 (the generic split kernel is slower than fp32 MFMA)
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
@@ -88,6 +102,8 @@ class Conv2dP(nn.Module):
         self.uf = self.ud = None        # Winograd transform-domain filters
 
     split_f = split_d = False
+    f16_f = f16_d = wino_f16 = False          # this layer's fprop / dgrad / Winograd-domain GEMMs run on the f16x3 kernel
+    w4f = w4d = w_amax = uf_amax = ud_amax = None
     wino = False
     saved_v = None
 
@@ -103,16 +119,21 @@ class Conv2dP(nn.Module):
     def wino_wgrad_ok(self, h, w):
         return self.wino and self.cin * self.cout >= WINO_MIN_CC_WGRAD and ops.wino_tiles(h, w, self.dilation) % 4 == 0
 
-    def fprop(self, xd, out=None, bias=None, want_stats=False, keep=False):
-        """keep: training forward -- the Winograd path keeps its transformed input for the weight gradient (self.saved_v)"""
+    def fprop(self, xd, out=None, bias=None, want_stats=False, keep=False, x_amax=None):
+        """keep: training forward -- the Winograd path keeps its transformed input for the weight gradient (self.saved_v);
+        x_amax: the slot with max |xd| when the caller has it (f16x3 layers; computed here otherwise)"""
         self.saved_v = None
         if self.wino and bias is None:
             keep_v = keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3])
-            res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats)
+            res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats,
+                                u_amax=self.uf_amax if self.wino_f16 else None)
             if keep_v:
                 self.saved_v = res[-1]
                 res = res[:-1] if len(res) > 2 else res[0]
             return res                                     # (y, stats, slots) with want_stats, else y
+        if self.f16_f:
+            return ops.conv_fprop_f16x3(xd, self.w4f, self.w_amax, x_amax if x_amax is not None else ops.absmax(xd), self.cout, self.k,
+                                        self.stride, self.dilation, self.padding, bias=bias, out=out, want_stats=want_stats)
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                                         want_stats=want_stats)
@@ -122,13 +143,20 @@ class Conv2dP(nn.Module):
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
         min_k = FUSE_BN_BWD_MIN_K_SPLIT if self.split_d else FUSE_BN_BWD_MIN_K
+        if self.f16_d:
+            return False                  # the f16x3 data-gradient kernel has no fused-sums epilogue: the two-pass BatchNorm backward runs
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
     def dgrad(self, dy, in_hw, out, accumulate, bn=None):
         """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient"""
         if self.wino:
-            return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate)
+            return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
+                                 u_amax=self.ud_amax if self.wino_f16 else None)
+        if self.f16_d:
+            assert bn is None
+            return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, ops.absmax(dy), self.cin, in_hw, self.k, self.stride, self.dilation,
+                                        self.padding, out=out, accumulate=accumulate)
         if self.split_d:
             if bn is not None:
                 _, bn.partials, bn.slots = ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation,
@@ -148,17 +176,24 @@ class Conv2dP(nn.Module):
         if self.depthwise:
             return
         self.wino = self._wino_eligible()
+        f16 = CONV_MATH == 'f16x3'
+        self.wino_f16 = self.f16_f = self.f16_d = False
         if self.wino:
-            split = CONV_MATH == 'bf16x6'           # transform-domain GEMMs on the bf16x6 kernel: split-packed filter sets
-            n = (ops.WINO_TILE + 2) ** 2 * (self.weight.numel() // 9) * (6 if split else 1)
+            split = _split_mode()                   # transform-domain GEMMs on a split kernel: split-packed filter sets
+            self.wino_f16 = f16 and ops.f16x3_eligible(self.cin, self.cout) and (not need_dgrad or ops.f16x3_eligible(self.cout, self.cin))
+            n = (ops.WINO_TILE + 2) ** 2 * (self.weight.numel() // 9) * ((4 if self.wino_f16 else 6) if split else 1)
             dt = torch.uint8 if split else torch.float32
             if self.uf is None or self.uf.device != self.weight.device or self.uf.dtype != dt or self.uf.numel() != n:
                 self.uf = torch.empty(n, dtype=dt, device=self.weight.device)
                 self.ud = None
             if need_dgrad and self.ud is None:
                 self.ud = torch.empty(n, dtype=dt, device=self.weight.device)
-            pack = ops.wino_pack_weight_split if split else ops.wino_pack_weight
-            pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
+            if self.wino_f16:
+                _, _, self.uf_amax, self.ud_amax = ops.wino_pack_weight_f16(self.weight.data, True, need_dgrad, self.uf,
+                                                                            self.ud if need_dgrad else None)
+            else:
+                pack = ops.wino_pack_weight_split if split else ops.wino_pack_weight
+                pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
             if self.bias is None:
                 return                    # the direct-convolution packings are not needed
         if self.wf is None or self.wf.device != self.weight.device:
@@ -167,8 +202,18 @@ class Conv2dP(nn.Module):
         if need_dgrad and self.wd is None:
             self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
         ops.pack_weight(self.weight.data, True, need_dgrad, self.wf, self.wd if need_dgrad else None)
-        self.split_f = CONV_MATH == 'bf16x6' and self.cin % 16 == 0
-        self.split_d = CONV_MATH == 'bf16x6' and self.cout % 16 == 0 and need_dgrad
+        self.f16_f = f16 and ops.f16x3_eligible(self.cin, self.cout)
+        self.f16_d = f16 and need_dgrad and ops.f16x3_eligible(self.cout, self.cin)
+        if self.f16_f or self.f16_d:
+            nbytes = 4 * self.weight.numel()
+            if self.f16_f and (self.w4f is None or self.w4f.device != self.weight.device):
+                self.w4f = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+            if self.f16_d and (self.w4d is None or self.w4d.device != self.weight.device):
+                self.w4d = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+            _, _, self.w_amax = ops.pack_weight_f16x2(self.weight.data, self.f16_f, self.f16_d, self.w4f if self.f16_f else None,
+                                                      self.w4d if self.f16_d else None)
+        self.split_f = _split_mode() and self.cin % 16 == 0 and not self.f16_f
+        self.split_d = _split_mode() and self.cout % 16 == 0 and need_dgrad and not self.f16_d
         if self.split_f or self.split_d:
             nbytes = 6 * self.weight.numel()
             if self.split_f and (self.w6f is None or self.w6f.device != self.weight.device):
@@ -225,7 +270,8 @@ def conv_forward(x, conv, tape, out=None):
         assert conv.k == 3 and conv.stride == 1 and conv.padding == conv.dilation
         y = ops.dwconv(xd, conv.weight.data, conv.dilation, out=out)
     else:
-        y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data, keep=tape is not None)
+        y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data, keep=tape is not None,
+                       x_amax=amax_of(x) if conv.f16_f else None)
     saved_v = None if conv.depthwise else conv.saved_v
     yv = Var(y, tape is not None)
     if tape is not None:
@@ -290,7 +336,7 @@ def join_side_stream():
 def _wgrad(conv, xd, dy, saved_v):
     """weight gradient of a dense convolution into conv.weight.grad (fp32 atomics): Winograd-domain, 1x1 / 3x3 K-quad or generic
     kernel; in bf16x6 mode the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 matrix cores"""
-    split = CONV_MATH == 'bf16x6' and WGRAD_SPLIT
+    split = _split_mode() and WGRAD_SPLIT
     if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
         ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v, split=split)
     elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
@@ -349,9 +395,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         else:
             pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
-        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None)
+        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if conv.f16_f else None)
     else:
-        pre = conv.fprop(xd, keep=tape is not None)
+        pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if conv.f16_f else None)
     saved_v = None if conv.depthwise else conv.saved_v
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'

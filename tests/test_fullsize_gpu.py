@@ -184,7 +184,7 @@ def test_class_mix_identities_full_size(ops):
     assert torch.equal(mi, 0.0 * img + trg) and torch.equal(ml[:, 0], pl) and bool((mw == float(q)).all())
 
 
-@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
 def test_whole_train_step_at_baseline_size(math):
     import pfst_amd  # noqa: F401
     from pfst_amd import layers
@@ -407,7 +407,8 @@ def _sampled_fp64(x, w, dy, k, stride, dil, seed):
     return dict(y=(pn, py, px, y_ref, y_t32), dx=(qn, qy, qx, dx_ref, dx_t32), dw=(o0, ob, c0, cb, dw_ref, dw_t32))
 
 
-def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
+@pytest.mark.parametrize('split_math', ['bf16x6', 'f16x3'])
+def test_split_arithmetic_matches_fp32_mfma_layer_by_layer_at_baseline_size(split_math):
     import pfst_amd  # noqa: F401
     from pfst_amd import layers
     rel = lambda a, ref: float((a.double() - ref).norm() / (ref.norm() + 1e-300))
@@ -425,7 +426,7 @@ def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
             w = (torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).cuda()
             ref = _sampled_fp64(x, w, dy, k, stride, dil, 7 + li)
             res = {}
-            for math in ('f32', 'bf16x6'):
+            for math in ('f32', split_math):
                 layers.CONV_MATH = math
                 conv = layers.Conv2dP(ci, co, k, stride, pad, dil).cuda()
                 with torch.no_grad():
@@ -438,7 +439,8 @@ def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
                 dx = torch.empty_like(x)
                 conv.dgrad(dy, (hw, hw), dx, False)
                 layers._wgrad(conv, x, dy, saved_v)
-                res[math] = (y, dx, conv.weight.grad.clone(), dict(wino=conv.wino, split_f=conv.split_f, split_d=conv.split_d))
+                res[math] = (y, dx, conv.weight.grad.clone(),
+                             dict(wino=conv.wino, split_f=conv.split_f, split_d=conv.split_d, f16=(conv.f16_f, conv.f16_d, conv.wino_f16)))
                 del conv, saved_v
             pn, py, px, y_ref, y_t32 = ref['y']
             qn, qy, qx, dx_ref, dx_t32 = ref['dx']
@@ -446,21 +448,23 @@ def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
             for what, pick, r64, t32 in (('fprop', lambda t: t[0][pn, :, py, px], y_ref, y_t32),
                                          ('dgrad', lambda t: t[1][qn, :, qy, qx], dx_ref, dx_t32),
                                          ('wgrad', lambda t: t[2][o0:o0 + ob, c0:c0 + cb], dw_ref, dw_t32)):
-                e32, e6 = rel(pick(res['f32']), r64), rel(pick(res['bf16x6']), r64)
+                e32, e6 = rel(pick(res['f32']), r64), rel(pick(res[split_math]), r64)
                 full = {'fprop': 0, 'dgrad': 1, 'wgrad': 2}[what]
-                d = rel(res['bf16x6'][full], res['f32'][full].double())          # the two arithmetics against each other, whole tensor
-                rows.append((name, what, e32, e6, d, res['bf16x6'][3], rel(t32, r64)))
+                d = rel(res[split_math][full], res['f32'][full].double())          # the two arithmetics against each other, whole tensor
+                rows.append((name, what, e32, e6, d, res[split_math][3], rel(t32, r64)))
             del x, dy, w, res, ref
             torch.cuda.empty_cache()
     finally:
         layers.CONV_MATH = prev
-    print('\nlayer-by-layer at b=8 x 1024^2: rel. error vs fp64 on samples (fp32-input MFMA | bf16x6 split | torch fp32 of the same sums), '
+    print(f'\nlayer-by-layer at b=8 x 1024^2: rel. error vs fp64 on samples (fp32-input MFMA | {split_math} | torch fp32 of the same sums), '
           'the two arithmetics against each other (whole tensor)')
     for name, what, e32, e6, d, disp, et in rows:
-        tag = ('wino ' if disp['wino'] else '') + ('split' if (disp['split_f'] or disp['split_d'] or disp['wino']) else 'fp32-kernel')
+        on16 = disp['f16'][2] if disp['wino'] else disp['f16'][{'fprop': 0, 'dgrad': 1, 'wgrad': 0}[what]] and what != 'wgrad'
+        tag = ('wino ' if disp['wino'] else '') + ('f16x3' if on16 else 'bf16x6' if (disp['split_f'] or disp['split_d'] or disp['wino'] or
+                                                                                   disp['f16'][0]) else 'fp32-kernel')
         print(f'   {name:20s} {what:5s}  {e32:9.2e} | {e6:9.2e} | {et:9.2e}   diff {d:9.2e}   [{tag}]')
     worst = max(rows, key=lambda r: r[3] / max(r[2], 1e-8))
-    print(f'   worst bf16x6 / fp32-MFMA error ratio: {worst[3] / max(worst[2], 1e-8):.2f} at {worst[0]} {worst[1]}')
+    print(f'   worst {split_math} / fp32-MFMA error ratio: {worst[3] / max(worst[2], 1e-8):.2f} at {worst[0]} {worst[1]}')
     for name, what, e32, e6, d, disp, et in rows:
         # "fp32-level error on the real shapes".  fprop / dgrad: never above the fp32-input MFMA kernel's error by more than 25 %
         # (+1e-7: fp32 round-off of the stored result).  The 1x1 weight gradient sums 0.13-0.5 M products per weight through
@@ -471,4 +475,6 @@ def test_bf16x6_matches_fp32_mfma_layer_by_layer_at_baseline_size():
         slack = 1.5 if (disp['wino'] and what == 'wgrad') else 1.25      # the transforms amplify the GEMM-domain round-off (entries up to 8)
         assert e6 <= max(slack * e32, et if what == 'wgrad' else 0.0) + 1e-7, (name, what, e32, e6, et)
         assert d <= 3.0 * max(e32, e6) + 2e-7, (name, what, d, e32, e6)
-    assert sum(1 for r in rows if r[5]['split_f'] or r[5]['split_d'] or r[5]['wino']) >= 80      # the split kernels really ran
+    assert sum(1 for r in rows if r[5]['split_f'] or r[5]['split_d'] or r[5]['wino'] or any(r[5]['f16'])) >= 80      # the split kernels really ran
+    if split_math == 'f16x3':
+        assert sum(1 for r in rows if any(r[5]['f16'])) >= 60                                                        # ... and the f16x3 ones

@@ -42,7 +42,7 @@ def _grad_of(v):
     return None if g is None else g.clone()
 
 
-@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('wino', [True, False])
 def test_every_backward_link_as_wired(wino, math):
     import pfst_amd  # noqa: F401

@@ -46,9 +46,9 @@ def assert_elementwise(a, ref, what, rtol=TOL, atol_rel=TOL):
     assert worst <= 1.0, f'{what}: worst element at {worst:.2f}x the bound'
 
 
-@pytest.fixture(params=['f32', 'bf16x6'])
+@pytest.fixture(params=['f32', 'bf16x6', 'f16x3'])
 def conv_math(request):
-    """run the end-to-end parity under both convolution arithmetics (fp32 MFMA default; fp32-faithful bf16 split)"""
+    """run the end-to-end parity under every convolution arithmetic (fp32-input MFMA; the fp32-faithful bf16x6 and f16x3 splits)"""
     from pfst_amd import layers
     prev, layers.CONV_MATH = layers.CONV_MATH, request.param
     yield request.param
