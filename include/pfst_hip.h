@@ -95,13 +95,15 @@ int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, in
  *   wgrad : pfst_wino_input(x) -> V;  pfst_wino_dy(dy) -> dM;  pfst_wino_wgrad(V, dM, scratch dU[X*Cout*Cin]) : dw += ... */
 int pfst_wino_tiles(int H, int W, int dil, int m);
 int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
-int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, pfst_stream_t stream);
+int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
+                    pfst_stream_t stream);   /* v_amax: NULL, or the slot group (1024 floats, zeroed; csrc/amax.h) that receives max |V| (f16x3 scale) */
 int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
                      float* stats, int m, pfst_stream_t stream);
 /* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2] */
 int pfst_wino_stats_slots(int H, int W, int dil, int m);
-int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, pfst_stream_t stream);
+int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
+                 pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
                     int split, pfst_stream_t stream);
 /* split != 0: the transform-domain products with the fp32-faithful bf16x6 split on the bf16 matrix cores */
@@ -153,7 +155,8 @@ int pfst_bn_finalize_partials(const float* partials, int T, int C, double count,
  * 1 bit per element instead of the fp32 output y in both of its passes. */
 int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  int N, int C, int HW, int relu, unsigned long long* relu_mask, pfst_stream_t stream);
+                  int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, pfst_stream_t stream);
+/* y_amax: NULL, or the slot group (1024 floats, zeroed) that receives max |y|: the scale of an f16x3 GEMM reading y */
 /* backward of the above: dz = dy * (y > 0 if relu); dres (+)= dz; dgamma += sum dz*xhat; dbeta += sum dz;
  * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles.  The ReLU gate comes from relu_mask (as written by
  * pfst_bn_apply), else from the saved output y; if both are NULL and beta != NULL (layer without residual) it is recomputed from
@@ -162,7 +165,7 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                      float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                      float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                     double* ws, const float* bwd_partials, int bwd_slots, pfst_stream_t stream);
+                     double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, pfst_stream_t stream);
 /* bwd_partials != NULL: (sum dz, sum dz*x) were already produced by the launch that wrote dy (pfst_bnb_fuse_t, [C][bwd_slots][2]); the
  * reduction pass over dy and x is skipped and only the partials are summed (fp64). */
 

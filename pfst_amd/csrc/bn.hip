@@ -6,6 +6,7 @@
 // Statistics are accumulated in fp64 (per-thread fp32 loads, fp64 sums), one atomic pair per block.
 #include <stdlib.h>
 #include "common.h"
+#include "amax.h"
 #include "../../include/pfst_hip.h"
 
 namespace {
@@ -105,8 +106,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        i64 res_bs, float* __restrict__ y, i64 y_bs,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       int C, int HW, int relu, unsigned long long* __restrict__ mask, int rev) {
+                                                       int C, int HW, int relu, unsigned long long* __restrict__ mask, int rev,
+                                                       float* __restrict__ amax) {
   // rev: walk the tensor from its end (planes, images and blocks in descending order) -- see pfst_bn_order()
+  // amax != NULL: max |y| of what this launch writes goes to that slot group (amax.h): the scale of the next f16x3 GEMM's operand
+  float am = 0.f;
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   float sc, sh;
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
           if (l < 4) mask[((i64)n * C + c) * (HW >> 6) + (i64)(i >> 6) * 4 + l] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
         }
         if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        if (i < n4) am = fmaxf(fmaxf(am, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), yr, off[u], 0, 0);
       }
     }
@@ -158,9 +163,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       float v = __fmaf_rn(xp[i], sc, sh);
       if (rp) v += rp[i];
       if (relu) v = fmaxf(v, 0.f);
+      am = fmaxf(am, fabsf(v));
       yp[i] = v;
     }
   }
+  if (amax) amax_publish(amax, am);
 }
 
 // ReLU gate of element i of a plane: from the bitmask bn_apply wrote (layout there), else from the saved output y, else
@@ -274,9 +281,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dres, i64 dres_bs, int dres_acc,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int C, int HW, double inv_count, int relu,
-                                                           const unsigned long long* __restrict__ mask, const double* __restrict__ ws, int rev) {
+                                                           const unsigned long long* __restrict__ mask, const double* __restrict__ ws, int rev,
+                                                           float* __restrict__ amax) {
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  float am = 0.f;                                      // max |dx| written here -> slot group `amax` (f16x3 scale of the gradient operand)
   const float mu = mean[c], is = invstd[c];
   // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
   const double m1 = ws[2 * c] * inv_count, m2 = ws[2 * c + 1] * inv_count;
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o.z = (float)(gs * ((double)g.z - m1 - (((double)xv.z - (double)mu) * (double)is) * m2));
       o.w = (float)(gs * ((double)g.w - m1 - (((double)xv.w - (double)mu) * (double)is) * m2));
       reinterpret_cast<float4*>(dxp)[i4] = o;
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
       if (drp) {
         if (dres_acc) {
           const float4 old = reinterpret_cast<const float4*>(drp)[i4];
@@ -327,10 +337,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float xv = xp[i];
       if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
       const double xh = ((double)xv - (double)mu) * (double)is;
-      dxp[i] = (float)(gs * ((double)dz - m1 - xh * m2));
+      const float o = (float)(gs * ((double)dz - m1 - xh * m2));
+      dxp[i] = o;
+      am = fmaxf(am, fabsf(o));
       if (drp) drp[i] = dres_acc ? drp[i] + dz : dz;
     }
   }
+  if (amax) amax_publish(amax, am);
 }
 
 // split one HW plane into `splits` chunks (multiples of 4) so the reduction launches ~BN_SPLIT_TARGET blocks
@@ -385,7 +398,7 @@ static int pfst_bn_order() {
 
 extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                             int N, int C, int HW, int relu, unsigned long long* relu_mask, pfst_stream_t stream) {
+                             int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && y && mean && invstd && gamma && beta && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   // the bitmask comes out of the float4 path only: whole 256-element groups per wave, 16-byte aligned planes
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0 && ((x_bs | y_bs | (residual ? res_bs : 0)) & 3) == 0 &&
@@ -393,7 +406,7 @@ extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residu
   int gx = cdiv(HW, 256 * 4 * 4);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, residual, res_bs, y, y_bs, mean,
-                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1);
+                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1, y_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -402,7 +415,7 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                                 float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                                double* ws, const float* bwd_partials, int bwd_slots, pfst_stream_t stream) {
+                                double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0));
   PFST_CHECK_ARG(!relu || relu_mask || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
@@ -423,13 +436,13 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
                          beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
-                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1);
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax);
   } else {
     if (!fused)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
                          beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
-                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1);
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax);
   }
   PFST_CHECK_LAUNCH();
   return PFST_OK;

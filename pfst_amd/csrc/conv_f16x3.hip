@@ -16,6 +16,7 @@
 // GEMM), the weight packing and the absmax reduction.  Layers it does not cover (Cin % 32 != 0, fewer than 65 output channels) stay
 // on the bf16x6 or fp32-input MFMA kernels.
 #include "conv_epilogue.h"
+#include "amax.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -54,11 +55,11 @@ __device__ __forceinline__ int amax_exponent(float amax) {
 __device__ __forceinline__ float scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(268 - e) << 23); }       // 2^(14 - (e - 127))
 __device__ __forceinline__ float unscale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - 14) << 23); }      // 2^((e - 127) - 14)
 
-// ---- absolute maximum of a tensor into one fp32 slot (bit pattern of a non-negative float: unsigned atomicMax orders it)
+// ---- absolute maximum of a tensor into its slot group (amax.h)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, i64 n, i64 plane_stride, int slot_stride,
-                                                     unsigned* __restrict__ slot) {
-  // blockIdx.y: plane; a plane is n contiguous floats, planes `plane_stride` apart; plane y goes to slot y * slot_stride (0: all planes
-  // into one slot, e.g. the per-image blocks of a channel slice of a concat buffer)
+                                                     float* __restrict__ slots) {
+  // blockIdx.y: plane; a plane is n contiguous floats, planes `plane_stride` apart; plane y goes to group y * slot_stride (0: all planes
+  // into one group, e.g. the per-image blocks of a channel slice of a concat buffer)
   const float* p = x + (i64)blockIdx.y * plane_stride;
   float m = 0.f;
   const i64 n4 = (((uintptr_t)p & 15) == 0) ? n / 4 : 0;
@@ -67,9 +68,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
   for (i64 i = n4 * 4 + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot + (i64)blockIdx.y * slot_stride, __builtin_bit_cast(unsigned, m));
+  amax_publish(slots + (i64)blockIdx.y * slot_stride * PFST_AMAX_SUB, m);
 }
 
 // two-piece fp16 split of 8 values already multiplied by the tensor's scale (plain code: prologue and packing)
@@ -115,7 +114,7 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __r
   w += blockIdx.y * set_in;
   if (wf) wf += blockIdx.y * set_out;
   if (wd) wd += blockIdx.y * set_out;
-  const float s = scale_of(amax_exponent(amax[blockIdx.y]));
+  const float s = scale_of(amax_exponent(amax_read(amax + (i64)blockIdx.y * PFST_AMAX_SUB)));
   const i64 nf = (i64)(T * Cin / 16) * 2 * Cout, nd = (i64)(T * Cout / 16) * 2 * Cin;
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (i64)gridDim.x * blockDim.x) {
     const bool dg = i >= nf;
@@ -189,8 +188,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   in += (i64)n * in_bs;
   out += (i64)n * out_bs;
 
-  const int ea = amax_exponent(w_amax[blockIdx.y]);
-  const int eb = amax_exponent(in_amax[blockIdx.y * in_amax_stride]);
+  const int ea = amax_exponent(amax_read(w_amax + (i64)blockIdx.y * PFST_AMAX_SUB));
+  const int eb = amax_exponent(amax_read(in_amax + (i64)blockIdx.y * in_amax_stride * PFST_AMAX_SUB));
   const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));    // an SGPR
 
   const int pix = tid & (BN - 1), kh = tid >> 7;
@@ -359,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
 
 }  // namespace
 
-// max |x| of `planes` planes of `n` floats (plane_stride apart) into slots[plane * slot_stride]; the slots must have been zeroed (or
-// hold an earlier maximum to extend).  pfst_absmax is the stand-alone form; producers of GEMM operands write their slots themselves.
+// max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the
+// groups must have been zeroed (or hold an earlier maximum to extend).  pfst_absmax is the stand-alone form; producers of GEMM operands write their slots themselves.
 extern "C" int pfst_absmax(const float* x, long long n, int planes, long long plane_stride, int slot_stride, float* slots,
                            pfst_stream_t stream) {
   PFST_CHECK_ARG(x && slots && n > 0 && planes > 0 && planes <= 65535 && (slot_stride == 0 || slot_stride == 1));
@@ -368,8 +367,7 @@ extern "C" int pfst_absmax(const float* x, long long n, int planes, long long pl
   if (gx < 1) gx = 1;
   const int cap = planes > 1 ? 256 : 2048;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL(absmax_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, x, (i64)n, (i64)plane_stride, slot_stride,
-                     reinterpret_cast<unsigned*>(slots));
+  hipLaunchKernelGGL(absmax_kernel, dim3(gx, planes), dim3(256), 0, (hipStream_t)stream, x, (i64)n, (i64)plane_stride, slot_stride, slots);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -418,7 +416,9 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   return PFST_OK;
 }
 
-// the (m+2)^2 transform-domain GEMMs of a Winograd layer as one grouped launch: V [X][N][K][T], U4 [X] packed sets, amax slots per set
+// the (m+2)^2 transform-domain GEMMs of a Winograd layer as one grouped launch: V [X][N][K][T] with ONE slot group (max over all planes:
+// the planes of a transformed activation lie within ~2^7 of each other, far inside the 2^18 full-precision window), U4 [X] packed sets
+// with a group per set
 extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                                     int M, int T, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
@@ -426,7 +426,7 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
   dim3 grid(cdiv((i64)T, BN) * cdiv(M, 128), nx, N);
   hipLaunchKernelGGL(conv_igemm_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                     Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 1);
+                     Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

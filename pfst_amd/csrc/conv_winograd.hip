@@ -17,6 +17,7 @@
 //           A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // fp32 error against an fp64 direct convolution (512 channels): 3e-6 (m = 2), 3e-5 max / 5e-6 rms (m = 4) of the mean |y|.
 #include "common.h"
+#include "amax.h"
 #include "../../include/pfst_hip.h"
 
 namespace {
@@ -143,7 +144,9 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 // vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M interior columns of a patch row are one wide load
 template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
-                                                         WinoGeom g, int vec) {
+                                                         WinoGeom g, int vec, float* __restrict__ amax) {
+  // amax != NULL: max |V| over everything this launch writes -> that slot group (amax.h; the f16x3 GEMM's scale of V)
+  float am = 0.f;
   constexpr int R = M + 2;
   typedef float vecM __attribute__((ext_vector_type(M)));
   const int c = blockIdx.y, n = blockIdx.z;
@@ -199,8 +202,10 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::bt(j, k), r[i][k]);
         vp[(i64)(i * R + j) * plane + t] = a;
+        am = fmaxf(am, fabsf(a));
       }
   }
+  if (amax) amax_publish(amax, am);
 }
 
 // ---- output transform Y = A^T m A (M x M per tile), optional accumulate.   grid: (blocks over T, Cout, N)
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 // ---- adjoint of the output transform: dM = A dY A^T (R x R per tile) for the weight gradient.   grid: (blocks over T, Cout, N)
 template <int M>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dM, int N, int Cout,
-                                                      WinoGeom g) {
+                                                      WinoGeom g, float* __restrict__ amax) {
+  float am = 0.f;                                            // max |dM| -> slot group `amax` when given
   constexpr int R = M + 2;
   const int c = blockIdx.y, n = blockIdx.z;
   const float* gp = dy + (i64)n * dy_bs + (i64)c * g.H * g.W;
@@ -322,8 +328,10 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < M; ++j) s = cmac(s, Wino<M>::at(j, b), r[a][j]);
         mp[(i64)(a * R + b) * plane + t] = s;
+        am = fmaxf(am, fabsf(s));
       }
   }
+  if (amax) amax_publish(amax, am);
 }
 
 // ---- dW += G^T dU G.   dU [R*R][Cout][Cin] (row-major as the 1x1 wgrad kernel writes it).  One thread per (co, ci)
@@ -397,14 +405,15 @@ extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_d
   return PFST_OK;
 }
 
-extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, pfst_stream_t stream) {
+extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
+                               pfst_stream_t stream) {
   PFST_CHECK_ARG(x && V && N > 0 && N <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0 && dil >= 1 && x_bs >= (i64)C * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const int vec = dil == 1 && W % m == 0 && x_bs % m == 0 && ((uintptr_t)x & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), C, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec),
-              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax),
+              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -436,13 +445,14 @@ extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int
   return PFST_OK;
 }
 
-extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, pfst_stream_t stream) {
+extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
+                            pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && dM && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && dy_bs >= (i64)Cout * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const dim3 grid(tile_blocks(g.T), Cout, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g),
-              hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax),
+              hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

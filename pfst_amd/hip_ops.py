@@ -189,12 +189,29 @@ def conv_fprop_split(x, wk6, cout, ksize, stride=1, dil=1, pad=0, bias=None, out
 
 
 # ---------------------------------------------------------------- fp32-faithful two-piece fp16 split (csrc/conv_f16x3.hip)
+AMAX_SUB = 1024        # floats per slot group (csrc/amax.h)
+_amax_arena = {}
+
+
+def amax_slots(dev, groups=1):
+    """`groups` zeroed slot groups (groups x 1024 fp32) carved out of a zero-filled arena block: one memset per 4096 groups instead of one
+    per tensor.  A block that is used up is replaced by a fresh one; the old one lives as long as views of it do."""
+    need = groups * AMAX_SUB
+    blk = _amax_arena.get(dev)
+    if blk is None or blk[1] + need > blk[0].numel():
+        blk = [torch.zeros(max(1 << 22, need), dtype=F32, device=dev), 0]
+        _amax_arena[dev] = blk
+    out = blk[0][blk[1]:blk[1] + need]
+    blk[1] += need
+    return out
+
+
 def absmax(x, planes=1, out=None):
-    """max |x| -> fp32 device slot(s).  planes = 1: one slot for the whole tensor (a dense tensor, or a dense-plane NCHW view such as a
+    """max |x| -> device slot group(s) of 1024 fp32 (csrc/amax.h).  planes = 1: one group for the whole tensor (a dense tensor, or a dense-plane NCHW view such as a
     channel slice of a concat buffer); planes > 1: x is dense and viewed as `planes` equal contiguous parts, one slot each.
     out: slots to extend (already zeroed or holding an earlier maximum)"""
     if out is None:
-        out = torch.zeros(planes, dtype=F32, device=x.device)
+        out = amax_slots(x.device, planes)
     if planes == 1 and x.dim() == 4 and not x.is_contiguous():
         n, c, h, w = x.shape
         call('pfst_absmax', x.data_ptr(), c * h * w, n, _bs(x), 0, out.data_ptr(), _stream())
@@ -407,9 +424,9 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
         assert not accumulate
         out = torch.empty(n, cout, h, w, device=x.device)
     assert tuple(out.shape) == (n, cout, h, w)
-    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _stream())
-    if u_amax is not None:              # two-piece fp16 filter sets -> f16x3 GEMM; the scale of every transform-domain plane from its own maximum
-        v_amax = absmax(v[:nx * n * c * t], planes=nx)
+    v_amax = amax_slots(x.device) if u_amax is not None else None       # the input transform publishes max |V|: the f16x3 GEMM's scale
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _p(v_amax), _stream())
+    if u_amax is not None:              # two-piece fp16 filter sets -> f16x3 GEMM
         call('pfst_wino_gemm_f16x3', v.data_ptr(), u.data_ptr(), u_amax.data_ptr(), v_amax.data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
     else:
         gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
@@ -437,9 +454,9 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False):
     du = _wino_ws(x.device, 'U', nx * co * ci)
     if v is None:
         v = _wino_ws(x.device, 'V', nx * n * ci * t)
-        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _stream())
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, 0, _stream())
     assert v.numel() >= nx * n * ci * t
-    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _stream())
+    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, 0, _stream())
     call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m, int(split), _stream())
     return dw
 
@@ -491,7 +508,7 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gam
     return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False):
+def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False, amax=None):
     """want_mask: also return the ReLU gate as a bitmask (int64 words) for bn_backward, or None where the kernel cannot
     produce it (plane size not a multiple of 256, unaligned slices) -- the caller then keeps using y."""
     n, c, h, w = x.shape
@@ -504,12 +521,12 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, w
         mask = torch.empty(n * c * h * w // 64, dtype=torch.int64, device=x.device)
     call('pfst_bn_apply', x.data_ptr(), _bs(x), _p(residual), 0 if residual is None else _bs(residual), out.data_ptr(), _bs(out),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _p(mask),
-         _stream())
+         _p(amax), _stream())
     return (out, mask) if want_mask else out
 
 
 def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None,
-                mask=None, partials=None, slots=0):
+                mask=None, partials=None, slots=0, amax=None):
     """mask: the bitmask bn_apply(..., want_mask=True) returned; replaces y as the source of the ReLU gate.
     partials / slots: the (sum dz, sum dz*x) partials the launch that wrote dy emitted (conv_dgrad(bnb=...)): no reduction pass"""
     n, c, h, w = x.shape
@@ -520,7 +537,7 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
     call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _p(beta), dx.data_ptr(), _bs(dx),
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
-         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _stream())
+         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _p(amax), _stream())
     return dx
 
 

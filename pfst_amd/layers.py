@@ -34,10 +34,22 @@ def _split_mode():
 
 
 def amax_of(v):
-    """device slot with max |v.data| of a Var (computed once, kept on the Var: an activation usually feeds several GEMMs)"""
+    """device slot group with max |v.data| of a Var: published by the kernel that produced the tensor (bn_apply, the Winograd
+    transforms) or, failing that, computed once here; kept on the Var -- an activation usually feeds several GEMMs"""
     if v.amax is None:
         v.amax = ops.absmax(v.data)
     return v.amax
+
+
+def _amax_target(yv, dev):
+    """where the kernel producing Var `yv` publishes max |y| in f16x3 mode: the Var's own slot group.  Channel slices of a concat
+    buffer get none: other kernels (resize, broadcast) write slices too, so a shared group would not cover the buffer; whoever reads
+    such a buffer through an f16x3 GEMM computes the maximum itself (amax_of)."""
+    if CONV_MATH != 'f16x3' or yv.parent is not None:
+        return None
+    if yv.amax is None:
+        yv.amax = ops.amax_slots(dev)
+    return yv.amax
 # bf16x6 mode: the 1x1 and Winograd-domain weight gradients run on the K-quad split kernel (1.5x the fp32-MFMA one); the rare direct
 # 3x3 / strided ones stay on fp32 MFMA unless PFST_WGRAD_SPLIT_ALL=1 (the generic split kernel is slower than fp32 MFMA)
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
@@ -148,14 +160,16 @@ class Conv2dP(nn.Module):
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
-    def dgrad(self, dy, in_hw, out, accumulate, bn=None):
-        """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient"""
+    def dgrad(self, dy, in_hw, out, accumulate, bn=None, dy_amax=None):
+        """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient;
+        dy_amax: slot group with max |dy| (f16x3 layers; computed here when the producer did not publish it)"""
         if self.wino:
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
                                  u_amax=self.ud_amax if self.wino_f16 else None)
         if self.f16_d:
             assert bn is None
-            return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, ops.absmax(dy), self.cin, in_hw, self.k, self.stride, self.dilation,
+            return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, dy_amax if dy_amax is not None else ops.absmax(dy), self.cin, in_hw,
+                                        self.k, self.stride, self.dilation,
                                         self.padding, out=out, accumulate=accumulate)
         if self.split_d:
             if bn is not None:
@@ -345,17 +359,18 @@ def _wgrad(conv, xd, dy, saved_v):
         ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
 
 
-def _dgrad_into(x, conv, dy, final):
+def _dgrad_into(x, conv, dy, final, dy_amax=None):
     """data gradient of `conv` into x's gradient buffer; when this launch completes the gradient of a conv -> BN layer's output
     (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
     fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward()
     buf, acc = x.grad_target(final=fuse)
-    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None)
+    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax)
 
 
-def conv_backward(x, conv, dy, saved_v=None, final=False):
+def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
     """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward;
-    final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use)"""
+    final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use);
+    dy_amax: the slot group the kernel that produced dy published max |dy| to (f16x3)"""
     xd = x.data
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
@@ -364,7 +379,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False):
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
-            _dgrad_into(x, conv, dy, final)
+            _dgrad_into(x, conv, dy, final, dy_amax)
         return
     if conv.depthwise:
         ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
@@ -376,7 +391,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False):
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
-            _dgrad_into(x, conv, dy, final)
+            _dgrad_into(x, conv, dy, final, dy_amax)
 
 
 def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
@@ -422,14 +437,17 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         out_var, out = out, out.data
     # residual layers: the ReLU gate goes to the backward pass as a bitmask (1 bit instead of 4 bytes per element, read twice)
     want_mask = tape is not None and relu and residual is not None
+    # f16x3: the normalisation pass publishes max |y| for the GEMMs that will read y (no separate pass over the tensor)
+    yv = out_var if out_var is not None else Var(None, tape is not None)
     y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
-                     None if residual is None else residual.data, out=out, want_mask=want_mask)
+                     None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device))
     gate = None
     if want_mask:
         y, gate = y
+    if out_var is None:
+        yv.data = y
     if tape is None:
-        return out_var if out_var is not None else Var(y, False)
-    yv = out_var if out_var is not None else Var(y, True)
+        return yv
     final = x.claim_first_use()
     if residual is not None:
         residual.claim_first_use()
@@ -446,9 +464,10 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
         part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
+        dpre_amax = ops.amax_slots(pre.device) if (conv.f16_d and x.requires_grad) else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots)
-        conv_backward(x, conv, dpre, saved_v, final)
+                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax)
+        conv_backward(x, conv, dpre, saved_v, final, dy_amax=dpre_amax)
         if yv.parent is None:
             yv.free_grad()
     tape.record(bwd, dict(op='conv_bn_act', conv=conv, bn=bn, x=x, residual=residual, relu=relu, out=yv))
