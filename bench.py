@@ -74,6 +74,9 @@ class KernelTimer:
         if name == 'pfst_wino_gemm_f16x3':
             n, k, m, t, nx = a[5], a[6], a[7], a[8], (a[9] + 2) ** 2
             return 'conv_igemm_f16x3_kernel', 2.0 * nx * n * m * k * t, 4.0 * nx * (n * k * t + n * m * t) + 4.0 * nx * k * m
+        if name == 'pfst_conv_wgrad_f16x3':
+            n, ci, co, hw = a[5], a[6], a[7], a[8]
+            return 'conv_wgrad_f16x3_kernel', 2.0 * n * co * ci * hw, 4.0 * (n * ci * hw + n * co * hw + 2 * co * ci)
         if name == 'pfst_absmax':
             return name, 0.0, 4.0 * a[1] * a[2]
         if name == 'pfst_wino_gemm_split':
@@ -93,7 +96,7 @@ class KernelTimer:
         if name == 'pfst_wino_wgrad':
             n, ci, co, t, nx = a[4], a[5], a[6], a[7], (a[8] + 2) ** 2
             bm = 128 if co > 64 else (64 if co > 32 else 32)
-            kern = f'conv_wgrad_split_q_kernel<{bm}>' if a[9] else f'conv_wgrad_q_kernel<{bm},1>'
+            kern = 'conv_wgrad_f16x3_kernel' if (a[9] == 2 and co > 64) else f'conv_wgrad_split_q_kernel<{bm}>' if a[9] else f'conv_wgrad_q_kernel<{bm},1>'
             return kern, 2.0 * nx * n * co * ci * t, 4.0 * nx * (n * ci * t + n * co * t + 2 * co * ci)
         if name in ('pfst_wino_input', 'pfst_wino_dy'):          # read the image once, write X transform planes of T = HW/m^2 tiles
             return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * (1.0 + (a[8] + 2) ** 2 / a[8] ** 2)
@@ -129,7 +132,7 @@ class KernelTimer:
                    'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7),
                    'pfst_conv_igemm_split': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad_split': (5, 6, 7, 9, 12, 14),
                    'pfst_wino_gemm_split': (3, 4, 5, 6), 'pfst_conv_igemm_f16x3': (8, 9, 10, 12, 15, 17, 19, 20),
-                   'pfst_wino_gemm_f16x3': (5, 6, 7, 8)}[name]
+                   'pfst_wino_gemm_f16x3': (5, 6, 7, 8), 'pfst_conv_wgrad_f16x3': (5, 6, 7, 8)}[name]
             key = key + (' wino ' if 'wino' in name else ' ') + ' '.join(str(args[i]) for i in idx)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
@@ -393,11 +396,11 @@ def main():
                            'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12, 'algorithmic_bytes_per_launch': nb / cnt,
                            'ms_per_step': ms / args.steps}
         # the weight-gradient kernel in the same form, so its over-fetch ratio (PMC traffic vs algorithmic bytes) is visible too
-        wk = 'conv_wgrad_split_q_kernel<128>' if split else 'conv_wgrad_q_kernel<128,1>'
+        wk = 'conv_wgrad_f16x3_kernel' if math == 'f16x3' else 'conv_wgrad_split_q_kernel<128>' if split else 'conv_wgrad_q_kernel<128,1>'
         if wk in agg:
             wc, wms, wfl, wnb = agg[wk]
             wt, wsrc = pmc_traffic(wk)
-            wmult = 6.0 if 'split' in wk else 1.0
+            wmult = 3.0 if 'f16x3' in wk else 6.0 if 'split' in wk else 1.0
             wach = wmult * wfl / (wms * 1e-3) / 1e12
             out['roofline_wgrad'] = {'kernel': wk, 'bound': 'mfma', 'achieved': wach, 'peak': peak, 'unit': unit, 'frac': wach / peak,
                                      'traffic': wt, 'traffic_source': wsrc, 'launches': wc, 'avg_launch_ms': wms / wc,

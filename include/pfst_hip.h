@@ -105,8 +105,9 @@ int pfst_wino_stats_slots(int H, int W, int dil, int m);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
                  pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
-                    int split, pfst_stream_t stream);
-/* split != 0: the transform-domain products with the fp32-faithful bf16x6 split on the bf16 matrix cores */
+                    int split, const float* v_amax, const float* dm_amax, pfst_stream_t stream);
+/* split = 1: the transform-domain products with the fp32-faithful bf16x6 split on the bf16 matrix cores; split = 2: with the f16x3 split,
+ * v_amax / dm_amax = the slot groups pfst_wino_input / pfst_wino_dy published the operands' absolute maxima to (NULL otherwise) */
 /* the same GEMMs on the fp32-faithful bf16x6 path: plain [X][Cout][Cin] filter sets (normal / flipped) -> X split-packed sets of
  * 6*Cout*Cin bytes each -> pfst_wino_gemm_split */
 int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
@@ -127,6 +128,8 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, pfst_stream_t stream);
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                          int M, int T, int m, pfst_stream_t stream);
+int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
+                          int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */

@@ -356,6 +356,163 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
                            w_amax, in_amax, in_amax_stride);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1 convolution / the grouped transform-domain products of a Winograd layer on the same arithmetic:
+//     dW[m][j] += sum_p dY[m][p] X[j][p]        (m: output channel, j: input channel, p: pixel or tile of one image)
+// Both operands are activations and pixel-contiguous: a thread stages 8 consecutive pixels of one row per operand (two 16-byte buffer
+// loads), both are split in registers (2 x 24 VALU per K=16 step) and written as [piece][k-half][row] images.  The loads run TWO tiles
+// ahead into alternating register sets (conv_wgrad_split_q_pipe_kernel's scheme): step k multiplies LDS buffer k & 1 (12 MFMAs
+// 32x32x16: al bh | ah bl | ah bh for the 2 x 2 blocks of a wave), splits tile k+1 in their gaps, stores it to the other buffer and
+// issues the loads of tile k+2.  Split-K over pixel chunks and images, fp32 atomics into dW, all tiles of a K slice on one XCD.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
+    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
+  constexpr int BM = 128, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ uint4 As[2][2 * NP * BM];
+  __shared__ uint4 Bs[2][2 * NP * BJ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  int bx, by, bz;
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * BJ, m0 = by * BM;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
+  const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
+  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
+
+  const int srow = tid >> 1, half = tid & 1;        // staging role: 8 consecutive pixels of one row per operand
+  const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
+  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
+
+  float la[2][8], lb[2][8];                         // two register sets of loaded tiles
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // load q = 0..3 of the tile starting at pixel pk0: (A, B) x (first, second quad); P % 4 == 0 and chunk_len % 16 == 0: a quad is
+  // entirely in or out
+  auto load_quad = [&](auto qc, auto setc, int pk0) {
+    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value;
+    const int p = pk0 + 8 * half + 4 * (q & 1);
+    const bool v = p < pend;
+    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(q < 2 ? a_rsrc : b_rsrc, v ? (q < 2 ? a_voff : b_voff) : OOB,
+                                                                                      pk0 * 4 + 16 * (q & 1), 0));
+    float (&dst)[8] = q < 2 ? la[SET] : lb[SET];
+    dst[4 * (q & 1) + 0] = t.x; dst[4 * (q & 1) + 1] = t.y; dst[4 * (q & 1) + 2] = t.z; dst[4 * (q & 1) + 3] = t.w;
+  };
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // prologue: tile 0 through the plain split into buffer 0, tile 1 into register set 1
+  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
+  {
+    uint4 ph, pl;
+    split8_f16(la[0], sa, ph, pl);
+    As[0][(0 * 2 + half) * BM + srow] = ph; As[0][(1 * 2 + half) * BM + srow] = pl;
+    split8_f16(lb[0], sb, ph, pl);
+    Bs[0][(0 * 2 + half) * BJ + srow] = ph; Bs[0][(1 * 2 + half) * BJ + srow] = pl;
+  }
+  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 16); });
+  __syncthreads();
+
+  // one K-step on LDS buffer CUR = k & 1.  Issue order, a full scheduling barrier after each slot: 4 fragment reads, then 12 slots of
+  // one MFMA + fillers -- slots 0-3 one fragment read and one global load of tile k+2, 0-11 four split instructions of tile k+1 (dy in
+  // slots 0-5, x in 6-11), 6 / 11 (after the MFMA) the LDS stores of the dy / x pieces.
+  auto step = [&](auto curc, int kt) {
+    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+    f16x8 af[TM][NP], bf[TN][NP];
+    // r = 0..7: al0 bh0 | bh1 al1 | ah0 bl0 | bl1 ah1   (what the MFMAs need, in their order)
+    auto read_frag = [&](int r) {
+      const int e = r & 1, pa = r < 4;                      // first four: the (al, bh) pair
+      if (r == 0 || r == 3) af[r == 0 ? 0 : 1][1] = __builtin_bit_cast(f16x8, As[CUR][(1 * 2 + lh) * BM + wm0 + (r == 0 ? 0 : 1) * 32 + l31]);
+      else if (r == 1 || r == 2) bf[r - 1][0] = __builtin_bit_cast(f16x8, Bs[CUR][(0 * 2 + lh) * BJ + wn0 + (r - 1) * 32 + l31]);
+      else if (r == 4 || r == 7) af[r == 4 ? 0 : 1][0] = __builtin_bit_cast(f16x8, As[CUR][(0 * 2 + lh) * BM + wm0 + (r == 4 ? 0 : 1) * 32 + l31]);
+      else bf[r - 5][1] = __builtin_bit_cast(f16x8, Bs[CUR][(1 * 2 + lh) * BJ + wn0 + (r - 5) * 32 + l31]);
+      (void)e; (void)pa;
+    };
+    static_for<4>([&](auto rc) { read_frag(decltype(rc)::value); });
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PA[3] = {1, 0, 0};
+    constexpr int PB[3] = {0, 1, 0};
+    SplitF16 s_a, s_b;
+    const int pk2 = pbeg + (kt + 2) * 16;
+    static_for<12>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+      if constexpr (m < 4) read_frag(4 + m);
+      static_for<4>([&](auto kc) {
+        constexpr int k = m * 4 + decltype(kc)::value;
+        if constexpr (k < 24) split_op_f16<k>(la[NXT], sa, s_a);
+        else split_op_f16<k - 24>(lb[NXT], sb, s_b);
+      });
+      // (the loads of tile k+2 overwrite set CUR: its values were split during the previous step)
+      if constexpr (m < 4) load_quad(mc, curc, pk2);
+      if constexpr (m == 6) {
+        As[NXT][(0 * 2 + half) * BM + srow] = make_uint4(s_a.h[0], s_a.h[1], s_a.h[2], s_a.h[3]);
+        As[NXT][(1 * 2 + half) * BM + srow] = make_uint4(s_a.l[0], s_a.l[1], s_a.l[2], s_a.l[3]);
+      }
+      if constexpr (m == 11) {
+        Bs[NXT][(0 * 2 + half) * BJ + srow] = make_uint4(s_b.h[0], s_b.h[1], s_b.h[2], s_b.h[3]);
+        Bs[NXT][(1 * 2 + half) * BJ + srow] = make_uint4(s_b.l[0], s_b.l[1], s_b.l[2], s_b.l[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  const int KT = (pend - pbeg + 15) / 16;
+  for (int kt = 0; kt < KT; kt += 2) {
+    step(std::integral_constant<int, 0>(), kt);
+    if (kt + 1 < KT) step(std::integral_constant<int, 1>(), kt + 1);
+  }
+  const float ua = unscale_of(ea), ub = unscale_of(eb);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r] * ua * ub);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the
@@ -429,4 +586,41 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
                      Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
+}
+
+// internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
+int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
+                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, hipStream_t s) {
+  const int tiles = cdiv(J, 128) * cdiv(M, 128) * groups;
+  // split-K chunking: whole rounds of resident workgroups (2 per CU)
+  const double slots = 256.0 * 2;
+  int chunks = 1;
+  double best = -1.0;
+  for (int c = 1; c <= 64 && (c == 1 || P / c >= 512); ++c) {
+    const double rounds = (double)tiles * N * c / slots;
+    const double eff = rounds < 2.0 ? 0.45 * rounds : rounds / ceil(rounds);
+    if (eff > best + 0.02) { best = eff; chunks = c; }
+    if (eff >= 0.93) break;
+  }
+  int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
+  chunks = cdiv(P, chunk_len);
+  const int gx = cdiv(J, 128), gy = cdiv(M, 128), gz = N * groups * chunks;
+  PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
+  hipLaunchKernelGGL(conv_wgrad_f16x3_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
+                     x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// dw[co][ci] += sum_{n,p} dy[n][co][p] x[n][ci][p]: the weight gradient of a stride-1 1x1 convolution (atomic fp32 adds)
+extern "C" int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
+                                     int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && dy && dw && x_amax && dy_amax && N > 0 && Cin > 0 && Cout > 0 && HW > 0);
+  PFST_CHECK_ARG(x_bs >= (i64)Cin * HW && dy_bs >= (i64)Cout * HW && (x_bs & 3) == 0 && (dy_bs & 3) == 0);
+  PFST_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && (i64)Cin * HW * 4 < (1ll << 31) && (i64)Cout * HW * 4 < (1ll << 31));
+  if (HW % 4 != 0 || Cout <= 64) {
+    pfst_set_error(__FILE__, __LINE__, "f16x3 weight gradient needs HW % 4 == 0 and more than 64 output channels (use pfst_conv_wgrad_split)");
+    return PFST_ERR_UNSUPPORTED;
+  }
+  return pfst_wgrad_f16x3_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, HW, 1, 0, 0, 0, x_amax, dy_amax, (hipStream_t)stream);
 }

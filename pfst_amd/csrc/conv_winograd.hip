@@ -460,8 +460,9 @@ extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, 
 // dU[xi][Cout][Cin] = sum_{n,t} dM[xi][n][Cout][T] V[xi][n][Cin][T]  (one grouped launch of the 1x1 K-quad wgrad), then dW += G^T dU G.
 // dU is scratch of (m+2)^2*Cout*Cin floats (zeroed here).
 extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
-                               int split, pfst_stream_t stream) {
+                               int split, const float* v_amax, const float* dm_amax, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && dM && dU && dw && N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && T % 4 == 0);
+  PFST_CHECK_ARG(split != 2 || (v_amax && dm_amax && Cout > 64));
   PFST_CHECK_TILE(m);
   hipStream_t s = (hipStream_t)stream;
   const i64 uc = (i64)Cout * Cin;
@@ -469,7 +470,10 @@ extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float
   if (hipMemsetAsync(dU, 0, nx * uc * sizeof(float), s) != hipSuccess) return PFST_ERR_LAUNCH;
   // the per-transform-index products as ONE grouped launch: enough workgroups without splitting the tile range further
   // split != 0: the products on the bf16 matrix cores with the fp32-faithful 6-term split (conv_split.hip)
-  const int rc = split ? pfst_wgrad_split_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, Cout, T, nx, (i64)N * Cin * T,
+  // split == 2: the two-piece fp16 split (conv_f16x3.hip), scales from the slot groups the transforms published max |V| / max |dM| to
+  const int rc = split == 2 ? pfst_wgrad_f16x3_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, Cout, T, nx, (i64)N * Cin * T,
+                                                      (i64)N * Cout * T, uc, v_amax, dm_amax, s)
+                 : split ? pfst_wgrad_split_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, Cout, T, nx, (i64)N * Cin * T,
                                                    (i64)N * Cout * T, uc, s)
                        : pfst_wgrad_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, 1, T, Cout, 1, T, 1, 1, 0, nx, (i64)N * Cin * T,
                                              (i64)N * Cout * T, uc, s);

@@ -261,6 +261,16 @@ def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0
     return (out, st, slots) if want_stats else out
 
 
+def conv_wgrad_f16x3_(dw, x, dy, x_amax, dy_amax):
+    """dw += dL/dw of a stride-1 1x1 convolution with the f16x3 split (fp32 atomics)"""
+    n, ci, h, w = x.shape
+    co = dy.shape[1]
+    assert dy.shape == (n, co, h, w) and dw.numel() == co * ci
+    call('pfst_conv_wgrad_f16x3', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, ci, co, h * w,
+         x_amax.data_ptr(), dy_amax.data_ptr(), _stream())
+    return dw
+
+
 def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
@@ -438,11 +448,11 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     call('pfst_wino_output', mb.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), m, _stream())
     res = (out, st, slots) if want_stats else (out,)
     if keep_v:
-        res = res + (v,)
+        res = res + ((v, v_amax),)          # the transformed input and the slot group with its absolute maximum (None unless f16x3)
     return res if len(res) > 1 else res[0]
 
 
-def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False):
+def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None):
     """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass (same m);
     split: the transform-domain products with the fp32-faithful bf16x6 split instead of the fp32-input MFMA"""
     n, ci, h, w = x.shape
@@ -452,12 +462,18 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False):
     t = wino_tiles(h, w, dil, m)
     dm = _wino_ws(x.device, 'M', nx * n * co * t)
     du = _wino_ws(x.device, 'U', nx * co * ci)
+    f16 = split == 2 and co > 64           # split: False / 0 fp32-input MFMA, True / 1 bf16x6, 2 f16x3 (falls back to bf16x6 for <= 64 rows)
     if v is None:
         v = _wino_ws(x.device, 'V', nx * n * ci * t)
-        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, 0, _stream())
+        v_amax = amax_slots(x.device) if f16 else None
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _p(v_amax), _stream())
+    elif f16 and v_amax is None:
+        v_amax = absmax(v[:nx * n * ci * t])
     assert v.numel() >= nx * n * ci * t
-    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, 0, _stream())
-    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m, int(split), _stream())
+    dm_amax = amax_slots(x.device) if f16 else None
+    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _p(dm_amax), _stream())
+    call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m,
+         2 if f16 else int(bool(split)), _p(v_amax), _p(dm_amax), _stream())
     return dw
 
 

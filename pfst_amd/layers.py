@@ -347,12 +347,19 @@ def join_side_stream():
         torch.cuda.current_stream().wait_stream(_side_stream)
 
 
-def _wgrad(conv, xd, dy, saved_v):
+def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     """weight gradient of a dense convolution into conv.weight.grad (fp32 atomics): Winograd-domain, 1x1 / 3x3 K-quad or generic
-    kernel; in bf16x6 mode the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 matrix cores"""
+    kernel; in the split modes the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 / fp16 matrix cores.
+    saved_v: (transformed input, its amax slot group) kept from the forward pass; x_amax / dy_amax: slot groups when the caller has
+    them (f16x3)"""
     split = _split_mode() and WGRAD_SPLIT
+    f16 = split and CONV_MATH == 'f16x3' and conv.cout > 64
+    v, v_amax = saved_v if saved_v is not None else (None, None)
     if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=saved_v, split=split)
+        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16 else split, v_amax=v_amax)
+    elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
+        ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
+                              dy_amax if dy_amax is not None else ops.absmax(dy))
     elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
         ops.conv_wgrad_split_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
     else:
@@ -372,10 +379,14 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
     final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use);
     dy_amax: the slot group the kernel that produced dy published max |dy| to (f16x3)"""
     xd = x.data
+    f16w = CONV_MATH == 'f16x3' and not conv.depthwise and conv.cout > 64 and conv.k == 1 and conv.stride == 1
+    x_amax = amax_of(x) if f16w else None
+    if f16w and dy_amax is None:
+        dy_amax = ops.absmax(dy)
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
-            _wgrad(conv, xd, dy, saved_v)
-        _on_side_stream(wg, dy, xd, saved_v)
+            _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
+        _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0])
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
@@ -387,7 +398,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
             buf, acc = x.grad_target()
             ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
-        _wgrad(conv, xd, dy, saved_v)
+        _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
@@ -464,7 +475,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
         part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
-        dpre_amax = ops.amax_slots(pre.device) if (conv.f16_d and x.requires_grad) else None
+        need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1))
+        dpre_amax = ops.amax_slots(pre.device) if need_amax else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
                                relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax)
         conv_backward(x, conv, dpre, saved_v, final, dy_amax=dpre_amax)

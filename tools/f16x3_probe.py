@@ -73,7 +73,43 @@ def bench():
               f'f16x3 {t3:.3f} ms ({fl / t3 / 1e9:5.0f} TF-eq, {3 * fl / t3 / 1e12:.2f} PF f16)   absmax(x) {ta:.3f} ms', flush=True)
 
 
+def wgrad():
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    for (n, ci, co, hw) in [(2, 96, 160, 24), (8, 64, 256, 64), (8, 2048, 512, 128), (8, 512, 2048, 128), (8, 256, 1024, 128), (8, 512, 512, 256)]:
+        g = torch.Generator().manual_seed(ci)
+        x = torch.randn(n, ci, hw, hw, generator=g)
+        x = (torch.relu(x) * (1 + x.abs())).cuda()
+        dy = (torch.randn(n, co, hw, hw, generator=g) * 1e-5 * torch.exp(torch.randn(n, co, hw, hw, generator=g))).cuda()
+        ref = torch.einsum('nohw,nchw->oc', dy[:, :32].double(), x[:, :32].double())
+        outs = {}
+        for name, fn in (('fp32', lambda d: H.conv_wgrad_(d, x, dy, 1)), ('bf16x6', lambda d: H.conv_wgrad_split_(d, x, dy, 1)),
+                         ('f16x3', lambda d: H.conv_wgrad_f16x3_(d, x, dy, H.absmax(x), H.absmax(dy)))):
+            d = torch.zeros(co, ci, 1, 1, device='cuda')
+            fn(d)
+            outs[name] = rel(d[:32, :32, 0, 0], ref)
+        xa, da = H.absmax(x), H.absmax(dy)
+        d = torch.zeros(co, ci, 1, 1, device='cuda')
+        fl = 2.0 * n * ci * co * hw * hw
+        t6 = timeit(lambda: H.conv_wgrad_split_(d, x, dy, 1))
+        t3 = timeit(lambda: H.conv_wgrad_f16x3_(d, x, dy, xa, da))
+        print(f'wgrad {n}x{ci}->{co}@{hw}: err fp32 {outs["fp32"]:.2e} bf16x6 {outs["bf16x6"]:.2e} f16x3 {outs["f16x3"]:.2e} | '
+              f'bf16x6 {t6:.3f} ms ({fl / t6 / 1e9:4.0f} TF-eq)  f16x3 {t3:.3f} ms ({fl / t3 / 1e9:4.0f} TF-eq)', flush=True)
+
+
 if __name__ == '__main__':
+    if '--wgrad' in sys.argv:
+        wgrad()
+        sys.exit(0)
     if '--bench-only' not in sys.argv:
         accuracy()
     bench()
