@@ -492,6 +492,16 @@ def main():
         alt['mode'] = MATH_DTYPE[other_math] + '; PFST_CONV_MATH=' + other_math
         alt.pop('hbm_kernels', None)
         res['alt_math'] = alt
+        # the third arithmetic, timed only (no kernel tables): the step under the other split
+        third = ({'f32', 'bf16x6', 'f16x3'} - {main_math, other_math}).pop()
+        m3, o3 = build(third)
+        hip_ops.call = timer.inner
+        run_steps(m3, o3, args.warmup)
+        dt3, _ = timed_steps(m3, o3, args.steps)
+        res['alt_math_' + third] = {'mode': MATH_DTYPE[third] + '; PFST_CONV_MATH=' + third, 'value': b * args.steps / dt3, 'unit': 'images/s',
+                                    'ms_per_step': 1000.0 * dt3 / args.steps}
+        del m3, o3
+        torch.cuda.empty_cache()
     layers.CONV_MATH = main_math
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

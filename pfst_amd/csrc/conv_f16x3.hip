@@ -234,17 +234,23 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     constexpr int v = decltype(vc)::value;                // 0..3: tile v / 2, piece v % 2
     areg[v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / 2) * a_tile + (v % 2) * a_chunk, 0));
   };
-  auto pair_addr = [&](int q, unsigned& voff, int& soff) {     // pair q = (tap, channel block)
-    const int tap = q / spt, sidx = q - tap * spt;
-    voff = tap_voff(tap);
-    soff = sidx * chan_step;
+  // pairs are numbered (tap, channel block); the address of pair k+2 advances by one channel block per step, the pixel offset is
+  // recomputed only when the tap changes (never for a 1x1 convolution): no integer divisions in the loop
+  const int ntaps = ks * ks;
+  int tap2 = 0, sidx2 = 0;                               // (tap, channel block) of the pair whose activations are loaded next
+  unsigned voff2 = tap_voff(0);
+  auto advance = [&]() {
+    if (++sidx2 == spt) {
+      sidx2 = 0;
+      ++tap2;
+      voff2 = tap2 < ntaps ? tap_voff(tap2) : OOB;
+    }
   };
 
   // ---- prologue: pair 0 through the plain split into LDS, pair 1 into register set 1 (+ its weights into areg)
   {
-    unsigned voff; int soff;
-    pair_addr(0, voff, soff);
-    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff, soff); });
+    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
+    advance();
     static_for<4>([&](auto vc) { load_a(vc, 0); });
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -255,10 +261,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
       Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
     }
-    if (KP > 1) {
-      pair_addr(1, voff, soff);
-      static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff, soff); });
-    }
+    // pair 1 (past the end of a one-step contraction the offset is out of range: zeros)
+    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, sidx2 * chan_step); });
+    advance();
   }
   __syncthreads();
 
@@ -269,7 +274,6 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // one step on pair k: SETN = (k + 1) & 1 holds pair k+1 (split and stored here), pair k+2 is loaded into set k & 1
   auto step = [&](auto setn_c, int k) {
     constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
-    const bool have2 = k + 2 < KP;
     f16x8 af[4][NP], bf[4][NP];
     auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(f16x8, As[a_frag + pl * 2 * BM + i * 16]); };
     auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(f16x8, Bs[b_frag + pl * 2 * BN + j * 16]); };
@@ -283,8 +287,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       else if constexpr (r < 13) rd_b(r - 9, 1);
       else rd_a(r - 12, 0);
     };
-    unsigned voff2 = OOB; int soff2 = 0;
-    if (have2) pair_addr(k + 2, voff2, soff2);
+    const int soff2 = sidx2 * chan_step;
     const int a_soff1 = (k + 1) * 2 * a_tile;
     static_for<5>([&](auto rc) { read_frag(rc); });
     __builtin_amdgcn_sched_barrier(0);
@@ -317,6 +320,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       if constexpr (m == 47) Bs[TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
       __builtin_amdgcn_sched_barrier(0);
     });
+    advance();
     __syncthreads();
   };
   for (int k = 0; k < KP; k += 2) {

@@ -16,17 +16,17 @@ import os
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 _BN_EVAL = False
-# Arithmetic of the dense convolutions' GEMMs (forward, data gradient, 1x1 / Winograd-domain weight gradients):
-#   'bf16x6' -- fp32-faithful 6-term bf16 split on the bf16 matrix cores, fp32 accumulate (csrc/conv_split.hip): the default since
-#               round 3.  Same results as fp32 to fp32 round-off (3.5e-7 vs fp64 per convolution against 4.1e-7 for the fp32-input
-#               MFMA; every parity test runs under both; layer by layer at b=8 x 1024^2: tests/test_fullsize_gpu.py), +25 % step
-#               throughput because gfx950's fp32-input MFMA runs at 1/16 of the bf16 rate;
+# Arithmetic of the dense convolutions' GEMMs (forward, data gradient, 1x1 / Winograd-domain weight gradients).  All three give fp32
+# results to fp32 round-off; every parity test runs under each of them, and tests/test_fullsize_gpu.py compares them layer by layer at
+# b=8 x 1024^2 against fp64.  gfx950's fp32-input MFMA runs at 1/16 of the bf16 / fp16 rate, hence the splits:
+#   'f16x3'  -- TWO scaled fp16 pieces per operand, three fp16 MFMAs per product, fp32 accumulate (csrc/conv_f16x3.hip): the default
+#               (round 3).  Every operand tensor is scaled by the power of two its absolute maximum implies (device scalars published by
+#               the producing kernels).  Measured error vs fp64 at or below the fp32-input MFMA's on every layer; covers contractions
+#               over whole 32-channel blocks with more than 64 output rows, the other layers run as under 'bf16x6';
+#   'bf16x6' -- three bf16 pieces per operand, the six piece-products >= 2^-16 (csrc/conv_split.hip); PFST_CONV_MATH=bf16x6;
 #   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32); PFST_CONV_MATH=f32.  Layers whose channel count is not a multiple of 16
-#               (the 3-/10-band stems, the classifiers' data gradient) use it in either mode.
-#   'f16x3'  -- fp32-faithful TWO-piece fp16 split, three fp16 MFMAs per product instead of six, every operand tensor scaled by the
-#               power of two its absolute maximum implies (csrc/conv_f16x3.hip); covers contractions over whole 32-channel blocks with
-#               more than 64 output rows, the other layers run as under 'bf16x6'.
-CONV_MATH = os.environ.get('PFST_CONV_MATH', 'bf16x6')
+#               (the 3-/10-band stems, the classifiers' data gradient) use it in every mode.
+CONV_MATH = os.environ.get('PFST_CONV_MATH', 'f16x3')
 
 
 def _split_mode():
