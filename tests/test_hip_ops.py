@@ -205,7 +205,8 @@ def test_winograd_matches_direct_convolution(ops, case, m):
         ops.wino_wgrad_(dw, x.to(DEV), dy.to(DEV), d, m=m)
         assert_close(dw, dw_ref, 2 * tol, 'winograd wgrad')
         # with the transformed input kept from the forward pass, as the train step does
-        _, v = ops.wino_conv(x.to(DEV), uf, co, d, keep_v=True, m=m)
+        _, (v, v_amax) = ops.wino_conv(x.to(DEV), uf, co, d, keep_v=True, m=m)      # (V, its amax slot group: None outside f16x3)
+        assert v_amax is None
         dw2 = torch.zeros(co, ci, 3, 3, device=DEV)
         ops.wino_wgrad_(dw2, x.to(DEV), dy.to(DEV), d, v=v, m=m)
         assert_close(dw2, dw_ref, 2 * tol, 'winograd wgrad from the kept V')
@@ -232,6 +233,102 @@ def test_winograd_on_the_bf16x6_gemm(ops, case, m):
     assert uf.dtype == torch.uint8
     assert_close(ops.wino_conv(x.to(DEV), uf, co, d, m=m), ref, WINO_TOL[m], 'winograd/bf16x6 fprop')
     assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d, m=m), dx_ref, WINO_TOL[m], 'winograd/bf16x6 dgrad')
+
+
+F16_CASES = [c for c in CONV_CASES if c[1] % 32 == 0 and c[2] > 64]
+
+
+@pytest.mark.parametrize('spread', [0.0, 2.5])
+@pytest.mark.parametrize('case', F16_CASES)
+def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
+    """Two scaled fp16 pieces per operand, three fp16 MFMAs per product (csrc/conv_f16x3.hip): as close to fp64 as fp32 arithmetic, fprop
+    + dgrad + the 1x1 weight gradient.  spread > 0: log-normal magnitudes over ~6 decades and tensors far from 1 (1e-6 gradients, 3e4
+    activations): what the per-tensor power-of-two scales are for -- without them fp16 would flush or overflow."""
+    n, ci, co, H, W, k, s, d, p = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, k, k, generator=g(2)) * 0.1
+    if spread:
+        x = x * 3e4 * torch.exp(spread * torch.randn(x.shape, generator=g(7)))
+        w = w * 1e-3 * torch.exp(0.5 * spread * torch.randn(w.shape, generator=g(8)))
+    ref = F.conv2d(x.double(), w.double(), None, s, p, d)
+    xd, wd = x.to(DEV), w.to(DEV)
+    w4f, w4d, wa = ops.pack_weight_f16x2(wd, True, co % 32 == 0 and ci > 64)
+    xa = ops.absmax(xd)
+    assert float(xa.max()) == float(x.abs().max()) and float(wa.max()) == float(w.abs().max())       # the slot group holds the exact maximum
+    y = ops.conv_fprop_f16x3(xd, w4f, wa, xa, co, k, s, d, p)
+    assert_close(y, ref, 2e-6, 'f16x3 fprop')
+    # the bf16x6 kernel on the same data, for scale: f16x3 is not allowed to be worse than 1.5x + 1e-7
+    w6f, _ = ops.pack_weight_split(wd, True, False)
+    e6 = rel_err(ops.conv_fprop_split(xd, w6f, co, k, s, d, p), ref)
+    assert rel_err(y, ref) <= 1.5 * e6 + 1e-7
+    dy = torch.randn(ref.shape, generator=g(4))
+    if spread:
+        dy = dy * 1e-6 * torch.exp(spread * torch.randn(dy.shape, generator=g(9)))
+    if w4d is not None:
+        dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, p, d)
+        da = ops.absmax(dy.to(DEV))
+        dx = ops.conv_dgrad_f16x3(dy.to(DEV), w4d, wa, da, ci, (H, W), k, s, d, p)
+        assert_close(dx, dx_ref, 2e-6, 'f16x3 dgrad')
+        dx2 = ops.conv_dgrad_f16x3(dy.to(DEV), w4d, wa, da, ci, (H, W), k, s, d, p, out=dx.clone(), accumulate=True)
+        assert_close(dx2, 2 * dx_ref, 2e-6, 'f16x3 dgrad-acc')
+    if k == 1 and s == 1 and (H * W) % 4 == 0:
+        dw_ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 1, 1), dy.double(), 1, 0, 1)
+        dw = torch.zeros(co, ci, 1, 1, device=DEV)
+        ops.conv_wgrad_f16x3_(dw, xd, dy.to(DEV), xa, ops.absmax(dy.to(DEV)))
+        assert_close(dw, dw_ref, 3e-6, 'f16x3 wgrad')
+        ops.conv_wgrad_f16x3_(dw, xd, dy.to(DEV), xa, ops.absmax(dy.to(DEV)))           # accumulates (fp32 atomics)
+        assert_close(dw, 2 * dw_ref, 3e-6, 'f16x3 wgrad accumulate')
+
+
+def test_f16x3_refuses_shapes_it_does_not_cover(ops):
+    from pfst_amd._lib import PfstHipError
+    x = torch.randn(1, 48, 8, 8, device=DEV)
+    w = torch.randn(128, 48, 1, 1, device=DEV)
+    w4f, _, wa = ops.pack_weight_f16x2(w, True, False)
+    assert not ops.f16x3_eligible(48, 128) and not ops.f16x3_eligible(64, 64) and ops.f16x3_eligible(64, 96)
+    with pytest.raises((PfstHipError, AssertionError)):
+        ops.conv_fprop_f16x3(x, w4f, wa, ops.absmax(x), 128, 1)
+
+
+def test_absmax_slot_groups(ops):
+    """pfst_absmax: exact maxima per plane, channel slices of a concat buffer into one group, extension of an existing group, zeros"""
+    t = torch.randn(3, 40, 9, 11, generator=g(3)).to(DEV)
+    a = ops.absmax(t)
+    assert a.numel() == ops.AMAX_SUB and float(a.max()) == float(t.abs().max())
+    planes = ops.absmax(t, planes=3)
+    assert [float(planes[i * ops.AMAX_SUB:(i + 1) * ops.AMAX_SUB].max()) for i in range(3)] == [float(t[i].abs().max()) for i in range(3)]
+    sl = t[:, 8:24]                                                                  # dense planes, batch stride of the parent
+    assert float(ops.absmax(sl).max()) == float(sl.abs().max())
+    ext = ops.absmax(t[:1].contiguous())
+    ops.absmax(t[1:].contiguous() * 3.0, out=ext)
+    assert float(ext.max()) == max(float(t[:1].abs().max()), float((t[1:] * 3.0).abs().max()))
+    assert float(ops.absmax(torch.zeros(2, 4, 4, 4, device=DEV)).max()) == 0.0
+
+
+@pytest.mark.parametrize('m', [2, 4])
+@pytest.mark.parametrize('case', [(1, 96, 128, 16, 16, 1), (2, 128, 96, 12, 20, 2), (1, 128, 160, 16, 24, 4), (2, 96, 96, 9, 13, 1)])
+def test_winograd_on_the_f16x3_gemm(ops, case, m):
+    """The Winograd pipeline with the transform-domain GEMMs and weight-gradient products on the f16x3 kernels: filter sets scaled per
+    transform index, V / dM scaled by the maxima their transforms publish."""
+    n, ci, co, H, W, d = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1
+    dy = torch.randn(n, co, H, W, generator=g(4)) * 1e-5
+    ref = F.conv2d(x.double(), w.double(), None, 1, d, d)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d, d)
+    uf, ud, af, ad = ops.wino_pack_weight_f16(w.to(DEV), m=m)
+    assert uf.dtype == torch.uint8 and af.numel() == (m + 2) ** 2 * ops.AMAX_SUB
+    y, (v, v_amax) = ops.wino_conv(x.to(DEV), uf, co, d, m=m, u_amax=af, keep_v=True)
+    assert_close(y, ref, WINO_TOL[m], 'winograd/f16x3 fprop')
+    assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d, m=m, u_amax=ad), dx_ref, WINO_TOL[m], 'winograd/f16x3 dgrad')
+    if ops.wino_tiles(H, W, d, m) % 4 == 0:
+        dw_ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), dy.double(), 1, d, d)
+        dw = torch.zeros(co, ci, 3, 3, device=DEV)
+        ops.wino_wgrad_(dw, x.to(DEV), dy.to(DEV), d, v=v, m=m, split=2, v_amax=v_amax)
+        assert_close(dw, dw_ref, 2 * WINO_TOL[m], 'winograd/f16x3 wgrad from the kept V')
+        dw2 = torch.zeros(co, ci, 3, 3, device=DEV)
+        ops.wino_wgrad_(dw2, x.to(DEV), dy.to(DEV), d, m=m, split=2)
+        assert_close(dw2, dw_ref, 2 * WINO_TOL[m], 'winograd/f16x3 wgrad')
 
 
 def test_conv_channel_slice_views(ops):
