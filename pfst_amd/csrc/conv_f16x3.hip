@@ -149,10 +149,13 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __r
 // fragments in registers, 48 MFMAs (al bh | ah bl | ah bh, smallest terms first).  One LDS buffer: barrier A sits in the MFMA stream
 // once every wave holds its fragments, the next pair is split and stored behind it, barrier B ends the step.  The activations of pair
 // k+2 are loaded (16 scalar buffer loads per thread, alternating register sets) while pair k+1 is split and pair k multiplied, so a
-// load has a whole step to land; the four pre-split weight chunks of pair k+1 are loaded in the first slots and stored in the last.
+// load has a whole step to land; the four pre-split weight chunks run two pairs ahead as well (loaded behind the stores of the set that
+// is being written to LDS).
 // Issue order is fixed slot by slot (one MFMA + at most two fillers, a scheduling barrier after each slot).
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int DUMMY>
+// SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_f16 (48 per step) or 32 = v_mfma_f32_32x32x16_f16 (24 per step: half the MFMA
+// issue slots, accumulators already in the 32x32 layout of conv_epilogue -- no re-layout through LDS)
+template <int SHAPE>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -160,8 +163,11 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
   constexpr int BM = 128, WAVES_N = 2;
   constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
-  constexpr int SMEM_CHUNKS = (2 * TILE_A + 2 * TILE_B) > (4 * 32 * 68 / 4) ? (2 * TILE_A + 2 * TILE_B) : (4 * 32 * 68 / 4);
-  __shared__ uint4 smem[SMEM_CHUNKS];                           // the tiles (32 KB); the epilogue's re-layout scratch needs 34 KB
+  // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
+  // stores of pair k+1 go to the other buffer whenever their data is ready.  SHAPE 16: one buffer, barrier A in the MFMA stream.
+  constexpr int PAIR_CHUNKS = 2 * TILE_A + 2 * TILE_B;
+  constexpr int SMEM_CHUNKS = SHAPE == 32 ? 2 * PAIR_CHUNKS : (PAIR_CHUNKS > (4 * 32 * 68 / 4) ? PAIR_CHUNKS : (4 * 32 * 68 / 4));
+  __shared__ uint4 smem[SMEM_CHUNKS];                           // SHAPE 16: the tiles (32 KB); the epilogue's re-layout scratch needs 34 KB
   uint4* const As = smem;
   uint4* const Bs = smem + 2 * TILE_A;
 
@@ -217,22 +223,29 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     return ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
   };
 
-  uint4 areg[4];                                         // [tile 2][piece 2] of the NEXT pair
+  uint4 areg[2][4];                                      // [register set][tile 2][piece 2]: like the activations, two pairs ahead
   float breg[2][2][8];                                   // [register set][tile][channel kh * 8 + i of the tile's 16]
-  f32x4 acc[4][4];
+  f32x4 acc[4][4];                                       // SHAPE 16
+  pfst_f32x16 acc32[2][2];                               // SHAPE 32 (and the epilogue's layout)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
 
   // loads of pair q: activations into register set SET (v = 0..15), weights into areg (v = 16..19)
   auto load_b = [&](auto vc, auto setc, unsigned voff, int soff) {
     constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;
     breg[SET][v >> 3][v & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, soff + ((v >> 3) * 16 + (v & 7)) * b_chan, 0));
   };
-  auto load_a = [&](auto vc, int a_soff) {
-    constexpr int v = decltype(vc)::value;                // 0..3: tile v / 2, piece v % 2
-    areg[v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / 2) * a_tile + (v % 2) * a_chunk, 0));
+  auto load_a = [&](auto vc, auto setc, int a_soff) {
+    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;                // v = 0..3: tile v / 2, piece v % 2
+    areg[SET][v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / 2) * a_tile + (v % 2) * a_chunk, 0));
   };
   // pairs are numbered (tap, channel block); the address of pair k+2 advances by one channel block per step, the pixel offset is
   // recomputed only when the tap changes (never for a 1x1 convolution): no integer divisions in the loop
@@ -251,18 +264,19 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   {
     static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
     advance();
-    static_for<4>([&](auto vc) { load_a(vc, 0); });
+    static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 0>(), 0); });
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       uint4 ph, pl;
       split8_f16(breg[0][t], sb, ph, pl);
-      As[t * TILE_A + tid] = areg[t * 2 + 0];
-      As[t * TILE_A + tid + 256] = areg[t * 2 + 1];
+      As[t * TILE_A + tid] = areg[0][t * 2 + 0];
+      As[t * TILE_A + tid + 256] = areg[0][t * 2 + 1];
       Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
       Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
     }
     // pair 1 (past the end of a one-step contraction the offset is out of range: zeros)
     static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, sidx2 * chan_step); });
+    static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), 2 * a_tile); });
     advance();
   }
   __syncthreads();
@@ -288,7 +302,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       else rd_a(r - 12, 0);
     };
     const int soff2 = sidx2 * chan_step;
-    const int a_soff1 = (k + 1) * 2 * a_tile;
+    const int a_soff2 = (k + 2) * 2 * a_tile;
     static_for<5>([&](auto rc) { read_frag(rc); });
     __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[3] = {1, 0, 0};
@@ -302,7 +316,6 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
       if constexpr (m < 11) read_frag(std::integral_constant<int, 5 + m>());
       // (past the last pair the offsets are out of the buffers' ranges: the loads return zeros, no branches in the stream)
-      if constexpr (m < 4) load_a(mc, a_soff1);
       if constexpr (m >= 4 && m < 20) load_b(std::integral_constant<int, m - 4>(), std::integral_constant<int, SETL>(), voff2, soff2);
       if constexpr (m == 16) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads have landed
@@ -313,7 +326,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         if constexpr (kk < 24) { split_op_f16<kk>(breg[SETN][0], sb, s0); split_op_f16<kk + 1>(breg[SETN][0], sb, s0); }
         else { split_op_f16<kk - 24>(breg[SETN][1], sb, s1); split_op_f16<kk - 23>(breg[SETN][1], sb, s1); }
       }
-      if constexpr (m >= 40 && m < 44) As[((m - 40) / 2) * TILE_A + tid + 256 * ((m - 40) % 2)] = areg[m - 40];
+      if constexpr (m >= 36 && m < 40) As[((m - 36) / 2) * TILE_A + tid + 256 * ((m - 36) % 2)] = areg[SETN][m - 36];
+      if constexpr (m >= 40 && m < 44) load_a(std::integral_constant<int, m - 40>(), std::integral_constant<int, SETL>(), a_soff2);
       if constexpr (m == 44) Bs[(0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
       if constexpr (m == 45) Bs[(1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
       if constexpr (m == 46) Bs[TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
@@ -323,16 +337,85 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     advance();
     __syncthreads();
   };
+  // the same step on v_mfma_f32_32x32x16_f16: fragments [k16 tile][32-row block][piece] (lane l31 = row, lh = k-half), 24 MFMAs in the
+  // order product-major, tile-minor (al bh | ah bl | ah bh): slots 0-11 one fragment read each, 0-7 two activation loads each, 8-11 the
+  // weight stores of pair k+1 (to the OTHER LDS buffer: no barrier inside the step), 12-23 four split instructions each, 12-15 the weight
+  // loads of pair k+2, 18 / 23 the activation stores
+  const int l31 = lane & 31, lh = lane >> 5;
+  auto step32 = [&](auto setn_c, int k) {
+    constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
+    constexpr int CUR = SETL * PAIR_CHUNKS, NXT = SETN * PAIR_CHUNKS;       // pair k sits in LDS buffer k & 1 = SETL, pair k+1 goes to the other
+    f16x8 af[2][2][NP], bf[2][2][NP];
+    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR + t * TILE_A + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
+    auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR + t * TILE_B + (pl * 2 + lh) * BN + wn0 + j * 32 + l31]); };
+    // r = 0..15: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 a1, the MFMAs' order
+    auto read_frag = [&](auto rc) {
+      constexpr int r = decltype(rc)::value, grp = r >> 2, e = r & 3, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
+      if constexpr (e == 0) rd_a(t, 0, pa);
+      else if constexpr (e == 1) rd_b(t, 0, pb);
+      else if constexpr (e == 2) rd_b(t, 1, pb);
+      else rd_a(t, 1, pa);
+    };
+    const int soff2 = sidx2 * chan_step;
+    const int a_soff2 = (k + 2) * 2 * a_tile;
+    static_for<4>([&](auto rc) { read_frag(rc); });
+    __builtin_amdgcn_sched_barrier(0);
+    SplitF16 s0, s1;
+    static_for<24>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int prod = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
+      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+      acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc32[i][j], 0, 0, 0);
+      if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
+      if constexpr (m < 8) {
+        load_b(std::integral_constant<int, 2 * m>(), std::integral_constant<int, SETL>(), voff2, soff2);
+        load_b(std::integral_constant<int, 2 * m + 1>(), std::integral_constant<int, SETL>(), voff2, soff2);
+      }
+      if constexpr (m >= 8 && m < 12) As[NXT + ((m - 8) / 2) * TILE_A + tid + 256 * ((m - 8) % 2)] = areg[SETN][m - 8];
+      if constexpr (m >= 12) {
+        static_for<4>([&](auto kc) {
+          constexpr int kk = (m - 12) * 4 + decltype(kc)::value;
+          if constexpr (kk < 24) split_op_f16<kk>(breg[SETN][0], sb, s0);
+          else split_op_f16<kk - 24>(breg[SETN][1], sb, s1);
+        });
+      }
+      if constexpr (m >= 12 && m < 16) load_a(std::integral_constant<int, m - 12>(), std::integral_constant<int, SETL>(), a_soff2);
+      if constexpr (m == 18) {
+        Bs[NXT + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+        Bs[NXT + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      }
+      if constexpr (m == 23) {
+        Bs[NXT + TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+        Bs[NXT + TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    advance();
+    __syncthreads();
+  };
   for (int k = 0; k < KP; k += 2) {
-    step(std::integral_constant<int, 1>(), k);
-    if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
+    if constexpr (SHAPE == 32) {
+      step32(std::integral_constant<int, 1>(), k);
+      if (k + 1 < KP) step32(std::integral_constant<int, 0>(), k + 1);
+    } else {
+      step(std::integral_constant<int, 1>(), k);
+      if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
+    }
   }
 
   // un-scale (an exact power of two, in two factors so that neither over- nor underflows) and hand over to the common epilogue
   const float ua = unscale_of(ea), ub = unscale_of(eb);
+  if constexpr (SHAPE == 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = acc32[i][j][r] * ua * ub;
+    conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+    return;
+  }
   float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
-  const int l31 = lane & 31, lh = lane >> 5;
-  pfst_f32x16 acc32[2][2];
 #pragma unroll
   for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
@@ -351,12 +434,13 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
 }
 
+template <int SHAPE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
-  conv_igemm_f16x3_body<0>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+  conv_igemm_f16x3_body<SHAPE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                            w_amax, in_amax, in_amax_stride);
 }
 
@@ -517,6 +601,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
   }
 }
 
+int f16x3_shape() {
+  static const int v = getenv("PFST_F16X3_SHAPE") ? atoi(getenv("PFST_F16X3_SHAPE")) : 32;
+  return v == 16 ? 16 : 32;
+}
+
 }  // namespace
 
 // max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the
@@ -571,8 +660,12 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, 128), 1, N);
-  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                     (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
+  if (f16x3_shape() == 32)
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
+  else
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -586,8 +679,12 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
   dim3 grid(cdiv((i64)T, BN) * cdiv(M, 128), nx, N);
-  hipLaunchKernelGGL(conv_igemm_f16x3_kernel, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                     Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+  if (f16x3_shape() == 32)
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+  else
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
