@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_
 echo write done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_sq -o q -- python3 bench.py $ARGS > gpurun_out/pmc_q.log 2>&1
 echo sq done
-python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${R}_pmc_hbm_traffic_per_launch.json > /dev/null
+python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/${R}_pmc_hbm_traffic_per_launch_${MATH:-f16x3}.json > /dev/null
 python3 tools/pmc_mfma.py gpurun_out/pmc_sq gpurun_out/${R}_mfma_busy.json > /dev/null
 find gpurun_out/prof_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/${R}_kernel_stats.csv \;
 rm -rf gpurun_out/prof_stats gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
