@@ -125,7 +125,8 @@ int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void* wk4_dgrad
                                 const float* amax, pfst_stream_t stream);
 int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                           const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
-                          int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, pfst_stream_t stream);
+                          int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
+                          pfst_stream_t stream);
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                          int M, int T, int m, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,

@@ -155,12 +155,14 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __r
 // ---------------------------------------------------------------------------------------------------------------------------------
 // SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_f16 (48 per step) or 32 = v_mfma_f32_32x32x16_f16 (24 per step: half the MFMA
 // issue slots, accumulators already in the 32x32 layout of conv_epilogue -- no re-layout through LDS)
-template <int SHAPE>
+// BNB != 0 (SHAPE 32 only): the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h)
+template <int SHAPE, int BNB = 0>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride, const PfstBnbArgs& bnb) {
+  static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
   constexpr int BM = 128, WAVES_N = 2;
   constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
   // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
@@ -412,7 +414,14 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc32[i][j][r] = acc32[i][j][r] * ua * ub;
-    conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+    if constexpr (BNB != 0) {
+      __syncthreads();                                   // the reduction scratch overlaps the tiles other waves may still be reading
+      static_assert(sizeof(smem) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into the tiles");
+      conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
+                                                  reinterpret_cast<float*>(smem));
+    } else {
+      conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+    }
     return;
   }
   float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
@@ -441,7 +450,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
   conv_igemm_f16x3_body<SHAPE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                           w_amax, in_amax, in_amax_stride);
+                               w_amax, in_amax, in_amax_stride, PfstBnbArgs());
+}
+template <int BNB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_bnb_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride, PfstBnbArgs bnb) {
+  conv_igemm_f16x3_body<32, BNB>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                                 w_amax, in_amax, in_amax_stride, bnb);
 }
 
 
@@ -642,8 +660,10 @@ extern "C" int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void
 // fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 and M > 64.
 extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
-                                     int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, pfst_stream_t stream) {
+                                     int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
+                                     const pfst_bnb_fuse_t* bnb, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
   if (C % 32 != 0 || M <= 64) {
@@ -660,6 +680,19 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, 128), 1, N);
+  if (bnb && bnb->x) {
+    // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
+    PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);
+#define PFST_LAUNCH_F16_BNB(MODE_)                                                                                                          \
+    hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
+                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0, *bnb)
+    if (!bnb->relu) PFST_LAUNCH_F16_BNB(3);
+    else if (bnb->y) PFST_LAUNCH_F16_BNB(2);
+    else PFST_LAUNCH_F16_BNB(1);
+#undef PFST_LAUNCH_F16_BNB
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   if (f16x3_shape() == 32)
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);

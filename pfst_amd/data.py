@@ -362,6 +362,11 @@ class BatchLoader:
     def __next__(self):
         return next(self._gen)
 
+    @property
+    def epoch(self):
+        """the data epoch the sampler is drawing from (it runs ahead of the training loop by the prefetch depth)"""
+        return self._loader.batch_sampler.epoch if self._loader is not None else 0
+
     def close(self):
         it, self._it, self._gen, self._loader = self._it, None, None, None
         if it is not None and hasattr(it, '_shutdown_workers'):

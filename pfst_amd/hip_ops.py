@@ -257,7 +257,7 @@ def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0
     slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
     st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, _stream())
     return (out, st, slots) if want_stats else out
 
 
@@ -271,16 +271,21 @@ def conv_wgrad_f16x3_(dw, x, dy, x_amax, dy_amax):
     return dw
 
 
-def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False):
+def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False, bnb=None):
+    """bnb: as conv_dgrad (returns (out, partials, slots) then)"""
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
     assert wk4_d.numel() == 4 * ksize * ksize * co * cin and f16x3_eligible(co, cin)
     if out is None:
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)
+    fuse, part, slots, st = 0, None, 0, None
+    if bnb is not None:
+        st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
+        fuse = ctypes.addressof(st)
     call('pfst_conv_igemm_f16x3', dy.data_ptr(), _bs(dy), wk4_d.data_ptr(), w_amax.data_ptr(), dy_amax.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, _stream())
-    return out
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, _stream())
+    return (out, part, slots) if bnb is not None else out
 
 
 def _bnb_struct(bnb, n, cin, hi, wi, co, dev):

@@ -154,9 +154,9 @@ class Conv2dP(nn.Module):
 
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
-        min_k = FUSE_BN_BWD_MIN_K_SPLIT if self.split_d else FUSE_BN_BWD_MIN_K
-        if self.f16_d:
-            return False                  # the f16x3 data-gradient kernel has no fused-sums epilogue: the two-pass BatchNorm backward runs
+        min_k = FUSE_BN_BWD_MIN_K_SPLIT if (self.split_d or self.f16_d) else FUSE_BN_BWD_MIN_K
+        if self.f16_d and self.cin % 128 != 0:
+            return False                  # the f16x3 kernel's fused epilogue needs whole 128-row tiles
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
@@ -167,9 +167,13 @@ class Conv2dP(nn.Module):
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
                                  u_amax=self.ud_amax if self.wino_f16 else None)
         if self.f16_d:
-            assert bn is None
-            return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, dy_amax if dy_amax is not None else ops.absmax(dy), self.cin, in_hw,
-                                        self.k, self.stride, self.dilation,
+            amax = dy_amax if dy_amax is not None else ops.absmax(dy)
+            if bn is not None:
+                _, bn.partials, bn.slots = ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride,
+                                                                self.dilation, self.padding, out=out, accumulate=accumulate,
+                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu))
+                return out
+            return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride, self.dilation,
                                         self.padding, out=out, accumulate=accumulate)
         if self.split_d:
             if bn is not None:

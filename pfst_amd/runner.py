@@ -118,6 +118,7 @@ class IterBasedRunner:
             t0 = time.time()
             batch = next(data_iter)
             data_time = time.time() - t0
+            self.epoch = getattr(data_iter, 'epoch', 0)          # meta['epoch'] of the checkpoints (mmcv writes the data epoch)
             for g, lr in zip(self.optimizer.param_groups, self.current_lr()):
                 g['lr'] = lr
             out = self.model.train_step(batch, self.optimizer)

@@ -31,7 +31,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
+@pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('n,c,co,h,w,k,dil,mode,acc', CASES)
 def test_fused_bn_backward_sums_match_two_pass_and_autograd(ops, n, c, co, h, w, k, dil, mode, acc, math):
     g = torch.Generator().manual_seed(c + co + h)
@@ -66,9 +66,16 @@ def test_fused_bn_backward_sums_match_two_pass_and_autograd(ops, n, c, co, h, w,
     if math == 'f32':
         _, wd = ops.pack_weight(wc.to(DEV))
         dgrad = ops.conv_dgrad
-    else:                                   # the fp32-faithful bf16x6 data-gradient kernel carries the same fused epilogue
+    elif math == 'bf16x6':                  # the fp32-faithful bf16x6 data-gradient kernel carries the same fused epilogue
         _, wd = ops.pack_weight_split(wc.to(DEV))
         dgrad = ops.conv_dgrad_split
+    else:                                   # ... and so does the f16x3 one (whole 128-row tiles, contraction over whole 32-channel blocks)
+        if not (ops.f16x3_eligible(co, c) and c % 128 == 0):
+            pytest.skip('shape outside the f16x3 kernel')
+        _, wd, wa = ops.pack_weight_f16x2(wc.to(DEV), False, True)
+
+        def dgrad(dy, w4, cin, hw, ks, s, d, p, out, accumulate, bnb):
+            return ops.conv_dgrad_f16x3(dy, w4, wa, ops.absmax(dy), cin, hw, ks, s, d, p, out=out, accumulate=accumulate, bnb=bnb)
     outs = {}
     for fused in (False, True):
         buf = old.to(DEV).clone() if acc else torch.empty(n, c, h, w, device=DEV)
