@@ -197,10 +197,13 @@ def amax_slots(dev, groups=1):
     """`groups` zeroed slot groups (groups x 1024 fp32) carved out of a zero-filled arena block: one memset per 4096 groups instead of one
     per tensor.  A block that is used up is replaced by a fresh one; the old one lives as long as views of it do."""
     need = groups * AMAX_SUB
-    blk = _amax_arena.get(dev)
+    # one arena per (device, stream): a block is zero-filled on the stream that allocates it, and the first kernel to touch a group
+    # (the producer publishing into it) runs on that same stream; consumers on other streams are ordered behind the producer anyway
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    blk = _amax_arena.get(key)
     if blk is None or blk[1] + need > blk[0].numel():
         blk = [torch.zeros(max(1 << 22, need), dtype=F32, device=dev), 0]
-        _amax_arena[dev] = blk
+        _amax_arena[key] = blk
     out = blk[0][blk[1]:blk[1] + need]
     blk[1] += need
     return out
