@@ -219,7 +219,7 @@ def cpu_baseline(num_classes, threads, timed_steps=3):
     spread = round((max(dts) - min(dts)) / mean, 3)
     return dict(value=tiles / mean, unit='images/s', cores=threads, kind='port', cpu_model=_cpu_model(),
                 step_seconds=[round(d, 2) for d in dts], spread=spread,
-                note=('spread of the timed steps above 10 %: shared host, treat the value as +-%d %%' % round(100 * spread)) if spread > 0.1 else None,
+                note=f'spread of the timed steps above 10 %: shared host, treat the value as +-{round(100 * spread)} %' if spread > 0.1 else None,
                 sample=f'{timed_steps} steps after 1 warm-up: PFGST.train_step, b={b}, {S}x{S} crops (={tiles:.2f} 1024^2-tile '
                        f'equivalents per step), mean {mean:.1f} s/step, torch-CPU fp32 oracle on {threads} threads')
 
