@@ -96,16 +96,19 @@ int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, in
 int pfst_wino_tiles(int H, int W, int dil, int m);
 int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
 int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
-                    pfst_stream_t stream);   /* v_amax: NULL, or the slot group (1024 floats, zeroed; csrc/amax.h) that receives max |V| (f16x3 scale) */
+                    const float* pack_x_amax, pfst_stream_t stream);
+/* v_amax: NULL, or the slot group (1024 floats, zeroed; csrc/amax.h) that receives max |V| (f16x3 scale).  pack_x_amax != NULL: V is
+ * written PRE-SPLIT for the f16x3 GEMMs (one dword per element: the two fp16 pieces of V s), scaled from the slot group holding max |x|
+ * through the transform's norm bound, and v_amax receives that bound (pass v_packed = 1 / packed = 1 to the consumers) */
 int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
                      float* stats, int m, pfst_stream_t stream);
 /* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2] */
 int pfst_wino_stats_slots(int H, int W, int dil, int m);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
-                 pfst_stream_t stream);
+                 const float* pack_dy_amax, pfst_stream_t stream);
 int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
-                    int split, const float* v_amax, const float* dm_amax, pfst_stream_t stream);
+                    int split, const float* v_amax, const float* dm_amax, int packed, pfst_stream_t stream);
 /* split = 1: the transform-domain products with the fp32-faithful bf16x6 split on the bf16 matrix cores; split = 2: with the f16x3 split,
  * v_amax / dm_amax = the slot groups pfst_wino_input / pfst_wino_dy published the operands' absolute maxima to (NULL otherwise) */
 /* the same GEMMs on the fp32-faithful bf16x6 path: plain [X][Cout][Cin] filter sets (normal / flipped) -> X split-packed sets of
@@ -128,7 +131,7 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
                           pfst_stream_t stream);
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
-                         int M, int T, int m, pfst_stream_t stream);
+                         int M, int T, int m, int v_packed, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
                           int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream);
 

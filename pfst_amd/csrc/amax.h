@@ -39,3 +39,18 @@ __device__ __forceinline__ float amax_read(const float* __restrict__ group) {
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
 }
+
+// biased exponent of an absolute maximum, clamped so that both the scale 2^(268 - E - 127) and its inverse are normal floats
+__device__ __forceinline__ int amax_exponent(float amax) {
+  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+  return e < 16 ? 16 : (e > 254 ? 254 : e);            // zero / denormal maxima: any scale will do (the tensor is ~0)
+}
+__device__ __forceinline__ float scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(268 - e) << 23); }       // 2^(14 - (e - 127))
+__device__ __forceinline__ float unscale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - 14) << 23); }      // 2^((e - 127) - 14)
+
+// x s as two fp16 pieces h + l in one dword (h in the low half): the storage format of a pre-split GEMM operand
+__device__ __forceinline__ unsigned pack_f16x2_pieces(float xs) {
+  const _Float16 h = (_Float16)xs;                       // round to nearest even
+  const _Float16 l = (_Float16)(xs - (float)h);          // the remainder is exact in fp32
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | (unsigned)__builtin_bit_cast(unsigned short, l) << 16;
+}

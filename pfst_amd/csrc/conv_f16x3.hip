@@ -47,14 +47,6 @@ __device__ __forceinline__ bool src_coord(int o, int t, int a, int b, int c0, in
   return (odd == 0) & (s >= 0) & (s < lim);
 }
 
-// biased exponent of an absolute maximum, clamped so that both the scale 2^(268 - E - 127) and its inverse are normal floats
-__device__ __forceinline__ int amax_exponent(float amax) {
-  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
-  return e < 16 ? 16 : (e > 254 ? 254 : e);            // zero / denormal maxima: any scale will do (the tensor is ~0)
-}
-__device__ __forceinline__ float scale_of(int e) { return __builtin_bit_cast(float, (unsigned)(268 - e) << 23); }       // 2^(14 - (e - 127))
-__device__ __forceinline__ float unscale_of(int e) { return __builtin_bit_cast(float, (unsigned)(e - 14) << 23); }      // 2^((e - 127) - 14)
-
 // ---- absolute maximum of a tensor into its slot group (amax.h)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, i64 n, i64 plane_stride, int slot_stride,
                                                      float* __restrict__ slots) {
@@ -86,6 +78,22 @@ __device__ __forceinline__ void split8_f16(const float (&v)[8], float s, uint4& 
   pl = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// a PRE-SPLIT operand (the Winograd transforms write V / dM that way: one dword per element, h in the low half, l in the high half):
+// the two piece vectors of 8 values are byte permutes of the 8 loaded dwords -- 8 instructions instead of 24
+__device__ __forceinline__ void unpack8_f16(const float (&v)[8], uint4& ph, uint4& pl) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned d0 = __builtin_bit_cast(unsigned, v[2 * q]), d1 = __builtin_bit_cast(unsigned, v[2 * q + 1]);
+    h[q] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+    l[q] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+  }
+  ph = make_uint4(h[0], h[1], h[2], h[3]);
+  pl = make_uint4(l[0], l[1], l[2], l[3]);
+}
+struct SplitF16;
+template <int K> __device__ __forceinline__ void unpack_op_f16(const float (&v)[8], SplitF16& st);
+
 // The same split as 24 single VALU instructions pinned in place (volatile asm, like split_op of conv_split.hip), K = 0..23 on the
 // eight values: per pair q six instructions -- two scale multiplies, v_cvt_pk_f16_f32 (h), two v_fma_mix_f32 computing
 // x s - h in one exact step straight from the packed halves, v_cvt_pk_f16_f32 (l).  The scale sits in an SGPR.
@@ -104,6 +112,14 @@ __device__ __forceinline__ void split_op_f16(const float (&v)[8], float s, Split
   else if constexpr (op == 4)
     asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(st.t1[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
   else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.l[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
+}
+
+// K = 0..7: permute number K of unpack8_f16 as one pinned instruction (h pairs first)
+template <int K>
+__device__ __forceinline__ void unpack_op_f16(const float (&v)[8], SplitF16& st) {
+  constexpr int q = K & 3;
+  if constexpr (K < 4) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(st.h[q]) : "v"(v[2 * q + 1]), "v"(v[2 * q]), "s"(0x05040100u));
+  else asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(st.l[q]) : "v"(v[2 * q + 1]), "v"(v[2 * q]), "s"(0x07060302u));
 }
 
 // w[Cout][Cin][T] -> two-piece K-major images, scaled by the set's power of two.
@@ -156,13 +172,15 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __r
 // SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_f16 (48 per step) or 32 = v_mfma_f32_32x32x16_f16 (24 per step: half the MFMA
 // issue slots, accumulators already in the 32x32 layout of conv_epilogue -- no re-layout through LDS)
 // BNB != 0 (SHAPE 32 only): the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h)
-template <int SHAPE, int BNB = 0>
+// BPACK: the activation operand is stored pre-split (Winograd-domain V written by pfst_wino_input in packed mode)
+template <int SHAPE, int BNB = 0, bool BPACK = false>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride, const PfstBnbArgs& bnb) {
   static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
+  static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
   constexpr int BM = 128, WAVES_N = 2;
   constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
   // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
@@ -270,7 +288,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       uint4 ph, pl;
-      split8_f16(breg[0][t], sb, ph, pl);
+      if constexpr (BPACK) unpack8_f16(breg[0][t], ph, pl);
+      else split8_f16(breg[0][t], sb, ph, pl);
       As[t * TILE_A + tid] = areg[0][t * 2 + 0];
       As[t * TILE_A + tid + 256] = areg[0][t * 2 + 1];
       Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
@@ -377,8 +396,13 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       if constexpr (m >= 12) {
         static_for<4>([&](auto kc) {
           constexpr int kk = (m - 12) * 4 + decltype(kc)::value;
-          if constexpr (kk < 24) split_op_f16<kk>(breg[SETN][0], sb, s0);
-          else split_op_f16<kk - 24>(breg[SETN][1], sb, s1);
+          if constexpr (BPACK) {                                  // 16 permutes (slots 12-15) instead of 48 split instructions
+            if constexpr (kk < 8) unpack_op_f16<kk>(breg[SETN][0], s0);
+            else if constexpr (kk < 16) unpack_op_f16<kk - 8>(breg[SETN][1], s1);
+          } else {
+            if constexpr (kk < 24) split_op_f16<kk>(breg[SETN][0], sb, s0);
+            else split_op_f16<kk - 24>(breg[SETN][1], sb, s1);
+          }
         });
       }
       if constexpr (m >= 12 && m < 16) load_a(std::integral_constant<int, m - 12>(), std::integral_constant<int, SETL>(), a_soff2);
@@ -443,13 +467,13 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
 }
 
-template <int SHAPE>
+template <int SHAPE, bool BPACK = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
-  conv_igemm_f16x3_body<SHAPE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+  conv_igemm_f16x3_body<SHAPE, 0, BPACK>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                w_amax, in_amax, in_amax_stride, PfstBnbArgs());
 }
 template <int BNB>
@@ -474,6 +498,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_bnb_kernel(
 // ---------------------------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// PACK: both operands are stored pre-split (the Winograd-domain V and dM): 2 x 8 permutes per step instead of 2 x 24 split instructions
+template <bool PACK>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
     int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
@@ -546,9 +572,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
   static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
   {
     uint4 ph, pl;
-    split8_f16(la[0], sa, ph, pl);
+    if constexpr (PACK) unpack8_f16(la[0], ph, pl);
+    else split8_f16(la[0], sa, ph, pl);
     As[0][(0 * 2 + half) * BM + srow] = ph; As[0][(1 * 2 + half) * BM + srow] = pl;
-    split8_f16(lb[0], sb, ph, pl);
+    if constexpr (PACK) unpack8_f16(lb[0], ph, pl);
+    else split8_f16(lb[0], sb, ph, pl);
     Bs[0][(0 * 2 + half) * BJ + srow] = ph; Bs[0][(1 * 2 + half) * BJ + srow] = pl;
   }
   static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 16); });
@@ -582,8 +610,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
       if constexpr (m < 4) read_frag(4 + m);
       static_for<4>([&](auto kc) {
         constexpr int k = m * 4 + decltype(kc)::value;
-        if constexpr (k < 24) split_op_f16<k>(la[NXT], sa, s_a);
-        else split_op_f16<k - 24>(lb[NXT], sb, s_b);
+        if constexpr (PACK) {
+          if constexpr (k < 8) unpack_op_f16<k>(la[NXT], s_a);
+          else if constexpr (k >= 24 && k < 32) unpack_op_f16<k - 24>(lb[NXT], s_b);
+        } else {
+          if constexpr (k < 24) split_op_f16<k>(la[NXT], sa, s_a);
+          else split_op_f16<k - 24>(lb[NXT], sb, s_b);
+        }
       });
       // (the loads of tile k+2 overwrite set CUR: its values were split during the previous step)
       if constexpr (m < 4) load_quad(mc, curc, pk2);
@@ -707,12 +740,16 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
 // the planes of a transformed activation lie within ~2^7 of each other, far inside the 2^18 full-precision window), U4 [X] packed sets
 // with a group per set
 extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
-                                    int M, int T, int m, pfst_stream_t stream) {
+                                    int M, int T, int m, int v_packed, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
   const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
   dim3 grid(cdiv((i64)T, BN) * cdiv(M, 128), nx, N);
-  if (f16x3_shape() == 32)
+  // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
+  if (v_packed)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+  else if (f16x3_shape() == 32)
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
                        Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
   else
@@ -724,7 +761,7 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
-                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, hipStream_t s) {
+                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
   const int tiles = cdiv(J, 128) * cdiv(M, 128) * groups;
   // split-K chunking: whole rounds of resident workgroups (2 per CU)
   const double slots = 256.0 * 2;
@@ -740,8 +777,12 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, 128), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  hipLaunchKernelGGL(conv_wgrad_f16x3_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
-                     x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+  if (packed)
+    hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<true>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
+                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+  else
+    hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<false>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
+                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -756,5 +797,5 @@ extern "C" int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float
     pfst_set_error(__FILE__, __LINE__, "f16x3 weight gradient needs HW % 4 == 0 and more than 64 output channels (use pfst_conv_wgrad_split)");
     return PFST_ERR_UNSUPPORTED;
   }
-  return pfst_wgrad_f16x3_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, HW, 1, 0, 0, 0, x_amax, dy_amax, (hipStream_t)stream);
+  return pfst_wgrad_f16x3_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, HW, 1, 0, 0, 0, x_amax, dy_amax, 0, (hipStream_t)stream);
 }

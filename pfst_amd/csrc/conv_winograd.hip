@@ -144,9 +144,22 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 // vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M interior columns of a patch row are one wide load
 template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
-                                                         WinoGeom g, int vec, float* __restrict__ amax) {
-  // amax != NULL: max |V| over everything this launch writes -> that slot group (amax.h; the f16x3 GEMM's scale of V)
+                                                         WinoGeom g, int vec, float* __restrict__ amax, const float* __restrict__ pack_amax,
+                                                         int pack_shift) {
+  // amax != NULL: max |V| over everything this launch writes -> that slot group (amax.h; the f16x3 GEMM's scale of V).
+  // pack_amax != NULL (f16x3): V is written PRE-SPLIT -- every element as the two fp16 pieces of V s in one dword (amax.h
+  // pack_f16x2_pieces), exactly what the GEMM's in-register split would produce, so the GEMMs that read V (forward product, weight
+  // gradient) skip their 24 split instructions per 8 values.  The scale has to be known before V exists: |B^T d B| <= 2^pack_shift max|d|
+  // (row sums of B^T: 10 for F(4x4), i.e. 100 < 2^7), so s derives from max|x| -- the slot group pack_amax -- and `amax` receives that
+  // BOUND (one store) instead of the measured maximum; the consumers derive the same exponent from it.
   float am = 0.f;
+  float ps = 0.f;
+  if (pack_amax) {
+    int e = amax_exponent(amax_read(pack_amax)) + pack_shift;
+    e = e > 254 ? 254 : e;
+    ps = scale_of(e);
+    if (amax && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) amax[0] = __builtin_bit_cast(float, (unsigned)e << 23);
+  }
   constexpr int R = M + 2;
   typedef float vecM __attribute__((ext_vector_type(M)));
   const int c = blockIdx.y, n = blockIdx.z;
@@ -201,11 +214,15 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::bt(j, k), r[i][k]);
-        vp[(i64)(i * R + j) * plane + t] = a;
-        am = fmaxf(am, fabsf(a));
+        if (pack_amax) {
+          reinterpret_cast<unsigned*>(vp)[(i64)(i * R + j) * plane + t] = pack_f16x2_pieces(a * ps);
+        } else {
+          vp[(i64)(i * R + j) * plane + t] = a;
+          am = fmaxf(am, fabsf(a));
+        }
       }
   }
-  if (amax) amax_publish(amax, am);
+  if (amax && !pack_amax) amax_publish(amax, am);
 }
 
 // ---- output transform Y = A^T m A (M x M per tile), optional accumulate.   grid: (blocks over T, Cout, N)
@@ -292,8 +309,15 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 // ---- adjoint of the output transform: dM = A dY A^T (R x R per tile) for the weight gradient.   grid: (blocks over T, Cout, N)
 template <int M>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dM, int N, int Cout,
-                                                      WinoGeom g, float* __restrict__ amax) {
+                                                      WinoGeom g, float* __restrict__ amax, const float* __restrict__ pack_amax, int pack_shift) {
   float am = 0.f;                                            // max |dM| -> slot group `amax` when given
+  float ps = 0.f;                                            // pack_amax: dM written pre-split (see wino_input_kernel); |A e A^T| <= 15^2 max|e| < 2^8
+  if (pack_amax) {
+    int e = amax_exponent(amax_read(pack_amax)) + pack_shift;
+    e = e > 254 ? 254 : e;
+    ps = scale_of(e);
+    if (amax && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) amax[0] = __builtin_bit_cast(float, (unsigned)e << 23);
+  }
   constexpr int R = M + 2;
   const int c = blockIdx.y, n = blockIdx.z;
   const float* gp = dy + (i64)n * dy_bs + (i64)c * g.H * g.W;
@@ -327,11 +351,15 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < M; ++j) s = cmac(s, Wino<M>::at(j, b), r[a][j]);
-        mp[(i64)(a * R + b) * plane + t] = s;
-        am = fmaxf(am, fabsf(s));
+        if (pack_amax) {
+          reinterpret_cast<unsigned*>(mp)[(i64)(a * R + b) * plane + t] = pack_f16x2_pieces(s * ps);
+        } else {
+          mp[(i64)(a * R + b) * plane + t] = s;
+          am = fmaxf(am, fabsf(s));
+        }
       }
   }
-  if (amax) amax_publish(amax, am);
+  if (amax && !pack_amax) amax_publish(amax, am);
 }
 
 // ---- dW += G^T dU G.   dU [R*R][Cout][Cin] (row-major as the 1x1 wgrad kernel writes it).  One thread per (co, ci)
@@ -406,14 +434,16 @@ extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_d
 }
 
 extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
-                               pfst_stream_t stream) {
+                               const float* pack_x_amax, pfst_stream_t stream) {
+  PFST_CHECK_ARG(!pack_x_amax || v_amax);
+  const int shift_in = m == 4 ? 7 : 3;                // (max row sum of |B^T|)^2: 100 for F(4x4), 4 for F(2x2)
   PFST_CHECK_ARG(x && V && N > 0 && N <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0 && dil >= 1 && x_bs >= (i64)C * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const int vec = dil == 1 && W % m == 0 && x_bs % m == 0 && ((uintptr_t)x & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), C, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax),
-              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in),
+              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -446,13 +476,15 @@ extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int
 }
 
 extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
-                            pfst_stream_t stream) {
+                            const float* pack_dy_amax, pfst_stream_t stream) {
+  PFST_CHECK_ARG(!pack_dy_amax || dm_amax);
+  const int shift_dy = m == 4 ? 8 : 2;                // (max row sum of |A|)^2: 225 for F(4x4), 4 for F(2x2)
   PFST_CHECK_ARG(dy && dM && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && dy_bs >= (i64)Cout * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const dim3 grid(tile_blocks(g.T), Cout, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax),
-              hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_dy_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax, pack_dy_amax, shift_dy),
+              hipLaunchKernelGGL(wino_dy_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dM, N, Cout, g, dm_amax, pack_dy_amax, shift_dy));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -460,9 +492,10 @@ extern "C" int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, 
 // dU[xi][Cout][Cin] = sum_{n,t} dM[xi][n][Cout][T] V[xi][n][Cin][T]  (one grouped launch of the 1x1 K-quad wgrad), then dW += G^T dU G.
 // dU is scratch of (m+2)^2*Cout*Cin floats (zeroed here).
 extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float* dw, int N, int Cin, int Cout, int T, int m,
-                               int split, const float* v_amax, const float* dm_amax, pfst_stream_t stream) {
+                               int split, const float* v_amax, const float* dm_amax, int packed, pfst_stream_t stream) {
   PFST_CHECK_ARG(V && dM && dU && dw && N > 0 && N <= 65535 && Cin > 0 && Cout > 0 && T > 0 && T % 4 == 0);
   PFST_CHECK_ARG(split != 2 || (v_amax && dm_amax && Cout > 64));
+  PFST_CHECK_ARG(!packed || split == 2);       // packed: V and dM are stored pre-split (pfst_wino_input / pfst_wino_dy packed modes)
   PFST_CHECK_TILE(m);
   hipStream_t s = (hipStream_t)stream;
   const i64 uc = (i64)Cout * Cin;
@@ -472,7 +505,7 @@ extern "C" int pfst_wino_wgrad(const float* V, const float* dM, float* dU, float
   // split != 0: the products on the bf16 matrix cores with the fp32-faithful 6-term split (conv_split.hip)
   // split == 2: the two-piece fp16 split (conv_f16x3.hip), scales from the slot groups the transforms published max |V| / max |dM| to
   const int rc = split == 2 ? pfst_wgrad_f16x3_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, Cout, T, nx, (i64)N * Cin * T,
-                                                      (i64)N * Cout * T, uc, v_amax, dm_amax, s)
+                                                      (i64)N * Cout * T, uc, v_amax, dm_amax, packed, s)
                  : split ? pfst_wgrad_split_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, Cout, T, nx, (i64)N * Cin * T,
                                                    (i64)N * Cout * T, uc, s)
                        : pfst_wgrad_q_launch(V, (i64)Cin * T, dM, (i64)Cout * T, dU, N, Cin, 1, T, Cout, 1, T, 1, 1, 0, nx, (i64)N * Cin * T,

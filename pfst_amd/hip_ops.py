@@ -428,7 +428,7 @@ def wino_pack_weight_f16(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=
     return uf, ud, af, ad
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None):
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
     (288 GB of HBM: keeping it resident beats re-transforming the input in backward)."""
@@ -442,10 +442,14 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
         assert not accumulate
         out = torch.empty(n, cout, h, w, device=x.device)
     assert tuple(out.shape) == (n, cout, h, w)
-    v_amax = amax_slots(x.device) if u_amax is not None else None       # the input transform publishes max |V|: the f16x3 GEMM's scale
-    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _p(v_amax), _stream())
+    # f16x3 (u_amax given): the input transform writes V PRE-SPLIT -- two fp16 pieces per element, scaled from max |x| (x_amax: the slot
+    # group the producer of x published, else computed here) through the transform's norm bound -- and v_amax receives that bound
+    v_amax = amax_slots(x.device) if u_amax is not None else None
+    if u_amax is not None and x_amax is None:
+        x_amax = absmax(x)
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _p(v_amax), _p(x_amax) if u_amax is not None else 0, _stream())
     if u_amax is not None:              # two-piece fp16 filter sets -> f16x3 GEMM
-        call('pfst_wino_gemm_f16x3', v.data_ptr(), u.data_ptr(), u_amax.data_ptr(), v_amax.data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
+        call('pfst_wino_gemm_f16x3', v.data_ptr(), u.data_ptr(), u_amax.data_ptr(), v_amax.data_ptr(), mb.data_ptr(), n, c, cout, t, m, 1, _stream())
     else:
         gemm = 'pfst_wino_gemm_split' if u.dtype == U8 else 'pfst_wino_gemm'        # split-packed filters -> bf16x6 GEMM
         call(gemm, v.data_ptr(), _dense(u, u.dtype).data_ptr(), mb.data_ptr(), n, c, cout, t, m, _stream())
@@ -460,7 +464,7 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     return res if len(res) > 1 else res[0]
 
 
-def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None):
+def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None, x_amax=None, dy_amax=None):
     """dw += dL/dw of the 'same' 3x3 stride-1 convolution; v: the transformed input kept from the forward pass (same m);
     split: the transform-domain products with the fp32-faithful bf16x6 split instead of the fp32-input MFMA"""
     n, ci, h, w = x.shape
@@ -470,18 +474,24 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None):
     t = wino_tiles(h, w, dil, m)
     dm = _wino_ws(x.device, 'M', nx * n * co * t)
     du = _wino_ws(x.device, 'U', nx * co * ci)
-    f16 = split == 2 and co > 64           # split: False / 0 fp32-input MFMA, True / 1 bf16x6, 2 f16x3 (falls back to bf16x6 for <= 64 rows)
+    # split: False / 0 fp32-input MFMA, True / 1 bf16x6, 2 f16x3 (falls back to bf16x6 for <= 64 rows).  f16x3: both operands PRE-SPLIT by
+    # their transforms (v given: the packed V and its bound group kept from the f16x3 forward pass)
+    f16 = split == 2 and co > 64
+    assert not (f16 and v is not None and v_amax is None), 'a kept V must come with the slot group of its scale bound'
+    assert f16 or v_amax is None, 'a packed V kept from an f16x3 forward pass needs the f16x3 weight gradient'
     if v is None:
         v = _wino_ws(x.device, 'V', nx * n * ci * t)
         v_amax = amax_slots(x.device) if f16 else None
-        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _p(v_amax), _stream())
-    elif f16 and v_amax is None:
-        v_amax = absmax(v[:nx * n * ci * t])
+        if f16 and x_amax is None:
+            x_amax = absmax(x)
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _p(v_amax), _p(x_amax) if f16 else 0, _stream())
     assert v.numel() >= nx * n * ci * t
     dm_amax = amax_slots(x.device) if f16 else None
-    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _p(dm_amax), _stream())
+    if f16 and dy_amax is None:
+        dy_amax = absmax(dy)
+    call('pfst_wino_dy', dy.data_ptr(), _bs(dy), dm.data_ptr(), n, co, h, w, dil, m, _p(dm_amax), _p(dy_amax) if f16 else 0, _stream())
     call('pfst_wino_wgrad', v.data_ptr(), dm.data_ptr(), du.data_ptr(), _dense(dw).data_ptr(), n, ci, co, t, m,
-         2 if f16 else int(bool(split)), _p(v_amax), _p(dm_amax), _stream())
+         2 if f16 else int(bool(split)), _p(v_amax), _p(dm_amax), int(f16), _stream())
     return dw
 
 

@@ -138,7 +138,7 @@ class Conv2dP(nn.Module):
         if self.wino and bias is None:
             keep_v = keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3])
             res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats,
-                                u_amax=self.uf_amax if self.wino_f16 else None)
+                                u_amax=self.uf_amax if self.wino_f16 else None, x_amax=x_amax if self.wino_f16 else None)
             if keep_v:
                 self.saved_v = res[-1]
                 res = res[:-1] if len(res) > 2 else res[0]
@@ -165,7 +165,7 @@ class Conv2dP(nn.Module):
         dy_amax: slot group with max |dy| (f16x3 layers; computed here when the producer did not publish it)"""
         if self.wino:
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
-                                 u_amax=self.ud_amax if self.wino_f16 else None)
+                                 u_amax=self.ud_amax if self.wino_f16 else None, x_amax=dy_amax if self.wino_f16 else None)
         if self.f16_d:
             amax = dy_amax if dy_amax is not None else ops.absmax(dy)
             if bn is not None:
@@ -289,7 +289,7 @@ def conv_forward(x, conv, tape, out=None):
         y = ops.dwconv(xd, conv.weight.data, conv.dilation, out=out)
     else:
         y = conv.fprop(xd, out=out, bias=None if conv.bias is None else conv.bias.data, keep=tape is not None,
-                       x_amax=amax_of(x) if conv.f16_f else None)
+                       x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
     saved_v = None if conv.depthwise else conv.saved_v
     yv = Var(y, tape is not None)
     if tape is not None:
@@ -360,7 +360,8 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     f16 = split and CONV_MATH == 'f16x3' and conv.cout > 64
     v, v_amax = saved_v if saved_v is not None else (None, None)
     if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16 else split, v_amax=v_amax)
+        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16 else split, v_amax=v_amax, x_amax=x_amax,
+                        dy_amax=dy_amax)
     elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
         ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                               dy_amax if dy_amax is not None else ops.absmax(dy))
@@ -384,8 +385,9 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
     dy_amax: the slot group the kernel that produced dy published max |dy| to (f16x3)"""
     xd = x.data
     f16w = CONV_MATH == 'f16x3' and not conv.depthwise and conv.cout > 64 and conv.k == 1 and conv.stride == 1
-    x_amax = amax_of(x) if f16w else None
-    if f16w and dy_amax is None:
+    wino16 = CONV_MATH == 'f16x3' and not conv.depthwise and conv.wino_f16
+    x_amax = amax_of(x) if (f16w or (wino16 and saved_v is None)) else None
+    if (f16w or wino16) and dy_amax is None:
         dy_amax = ops.absmax(dy)
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
@@ -425,9 +427,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         else:
             pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
-        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if conv.f16_f else None)
+        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
     else:
-        pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if conv.f16_f else None)
+        pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
     saved_v = None if conv.depthwise else conv.saved_v
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'
@@ -479,7 +481,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
         part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
-        need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1))
+        need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
+                                                                    or conv.wino_f16)
         dpre_amax = ops.amax_slots(pre.device) if need_amax else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
                                relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax)
