@@ -175,6 +175,8 @@ def pmc_traffic(kernel):
     # software-pipelined K=16 loop, the K=32 pairing and its fused-epilogue variants, the plain loop for short contractions)
     family = {'conv_igemm_split_kernel': ('conv_igemm_split_pair_kernel', 'conv_igemm_split_pair_bnb_kernel', 'conv_igemm_split_pipe_kernel'),
               'conv_wgrad_split_q_kernel': ('conv_wgrad_split_q_pipe_kernel',)}.get(base, ()) if want == ['128'] else ()
+    if base == 'conv_igemm_f16x3_kernel':          # + the variants with the fused BatchNorm-backward epilogue
+        family = ('conv_igemm_f16x3_bnb_kernel',)
     tot, calls = 0.0, 0
     for k, v in rec.items():          # all instantiations whose leading template arguments match (e.g. the fused-epilogue variants
         if not isinstance(v, dict):   # <128, 0..3> of conv_igemm_q_kernel<128>), weighted by their launch counts
