@@ -214,14 +214,19 @@ class Conv2dP(nn.Module):
                 pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
             if self.bias is None:
                 return                    # the direct-convolution packings are not needed
-        if self.wf is None or self.wf.device != self.weight.device:
-            self.wf = torch.empty(self.k * self.k * self.cin, self.cout, device=self.weight.device)
-            self.wd = None
-        if need_dgrad and self.wd is None:
-            self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
-        ops.pack_weight(self.weight.data, True, need_dgrad, self.wf, self.wd if need_dgrad else None)
         self.f16_f = f16 and ops.f16x3_eligible(self.cin, self.cout)
         self.f16_d = f16 and need_dgrad and ops.f16x3_eligible(self.cout, self.cin)
+        # the fp32 K-major images only for the directions that run on the fp32-input MFMA kernels (every layer under 'f32'; the stems
+        # and the classifiers' data gradient otherwise): 106 small launches per step less in the split modes
+        fp32_f = not (self.f16_f or (_split_mode() and self.cin % 16 == 0))
+        fp32_d = need_dgrad and not (self.f16_d or (_split_mode() and self.cout % 16 == 0))
+        if fp32_f or fp32_d:
+            if self.wf is None or self.wf.device != self.weight.device:
+                self.wf = torch.empty(self.k * self.k * self.cin, self.cout, device=self.weight.device)
+                self.wd = None
+            if fp32_d and self.wd is None:
+                self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
+            ops.pack_weight(self.weight.data, fp32_f, fp32_d, self.wf if fp32_f else None, self.wd if fp32_d else None)
         if self.f16_f or self.f16_d:
             nbytes = 4 * self.weight.numel()
             if self.f16_f and (self.w4f is None or self.w4f.device != self.weight.device):
