@@ -397,7 +397,9 @@ def main():
         out['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                            'traffic': traffic, 'traffic_source': src, 'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
                            'algorithmic_flops_per_launch': fl / cnt, 'executed_mfma_flops_per_launch': mult * fl / cnt,
-                           'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12, 'algorithmic_bytes_per_launch': nb / cnt,
+                           'fp32_equivalent_tflops': fl / (ms * 1e-3) / 1e12,
+                           'fp32_equivalent_vs_fp32_mfma_peak': fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                           'algorithmic_bytes_per_launch': nb / cnt,
                            'ms_per_step': ms / args.steps}
         # the weight-gradient kernel in the same form, so its over-fetch ratio (PMC traffic vs algorithmic bytes) is visible too
         wk = 'conv_wgrad_f16x3_kernel' if math == 'f16x3' else 'conv_wgrad_split_q_kernel<128>' if split else 'conv_wgrad_q_kernel<128,1>'
