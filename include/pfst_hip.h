@@ -126,6 +126,27 @@ int pfst_wino_gemm_split(const float* V, const void* U6, float* Mbuf, int N, int
 int pfst_absmax(const float* x, long long n, int planes, long long plane_stride, int slot_stride, float* slots, pfst_stream_t stream);
 int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void* wk4_dgrad, int Cout, int Cin, int T, int sets,
                                 const float* amax, pfst_stream_t stream);
+/* Batched weight preparation of a whole network (two launches per model and step instead of 2-5 tiny ones per convolution; the
+ * reference re-reads its weights inside every cuDNN call and has no such step).  A job table lives on the device; the host copy is
+ * passed beside it and checked (pointers, shapes, block prefix) before the launch.
+ *   pfst_weight_prep_batched:  m == 0: amax_f[0] (one slot group) <- max |src[Cout*Cin*T]|
+ *                              m == 2/4: src = 3x3 filters; dst_f / dst_d (either may be NULL) <- the X = (m+2)^2 plain transform-domain
+ *                              sets [X][Cout][Cin] of pfst_wino_filter_plain, amax_f / amax_d <- X consecutive slot groups with each set's maximum
+ *   pfst_conv_pack_weight_f16x2_batched: src [sets][Cout][Cin][T] -> dst_f / dst_d two-piece fp16 images exactly as
+ *                              pfst_conv_pack_weight_f16x2 writes them, scales from the `sets` consecutive slot groups at amax_f
+ * The slot groups must be zeroed before the prep launch.  first_block: prefix sum of pfst_weight_job_blocks over the table. */
+typedef struct pfst_weight_job {
+  const float* src;
+  void* dst_f;
+  void* dst_d;
+  float* amax_f;
+  float* amax_d;
+  int Cout, Cin, T, sets, m, first_block;
+} pfst_weight_job_t;
+int pfst_weight_job_blocks(const pfst_weight_job_t* job, int pack);     /* workgroups one job takes in the prep (0) / pack (1) launch */
+int pfst_weight_prep_batched(const pfst_weight_job_t* jobs_host, const pfst_weight_job_t* jobs_dev, int njobs, pfst_stream_t stream);
+int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs_host, const pfst_weight_job_t* jobs_dev, int njobs,
+                                        pfst_stream_t stream);
 int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                           const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,

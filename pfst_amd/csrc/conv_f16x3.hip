@@ -17,6 +17,7 @@
 // on the bf16x6 or fp32-input MFMA kernels.
 #include "conv_epilogue.h"
 #include "amax.h"
+#include "weight_jobs.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -157,6 +158,42 @@ __global__ void pack_weight_f16x2_kernel(const float* __restrict__ w, uint4* __r
     dst[base + (i64)(0 * 2 + h) * M + row] = ph;
     dst[base + (i64)(1 * 2 + h) * M + row] = pl;
   }
+}
+
+// the same images for every layer of a network in one launch (pfst_conv_pack_weight_f16x2_batched): whole workgroups per filter set
+__global__ __launch_bounds__(256) void pack_weight_f16x2_batched_kernel(const pfst_weight_job_t* __restrict__ jobs, int njobs) {
+  const pfst_weight_job_t J = jobs[weight_job_of_block(jobs, njobs, blockIdx.x)];
+  const int lb = blockIdx.x - J.first_block;
+  const int Cout = J.Cout, Cin = J.Cin, T = J.T;
+  const i64 nf = J.dst_f ? (i64)(T * Cin / 16) * 2 * Cout : 0, nd = J.dst_d ? (i64)(T * Cout / 16) * 2 * Cin : 0;
+  const int bps = (int)((nf + nd + 255) / 256);          // workgroups per set
+  const int set = lb / bps;
+  const i64 n = (i64)Cout * Cin * T;
+  const float s = scale_of(amax_exponent(amax_read(J.amax_f + (i64)set * PFST_AMAX_SUB)));     // every lane takes part
+  const i64 i = (i64)(lb - set * bps) * 256 + threadIdx.x;
+  if (i >= nf + nd) return;
+  const float* w = J.src + set * n;
+  const bool dg = i >= nf;
+  const i64 e = dg ? i - nf : i;
+  const int M = dg ? Cin : Cout, Cq = dg ? Cout : Cin;
+  const int row = (int)(e % M);
+  const i64 gh = e / M;
+  const int h = (int)(gh & 1);
+  const int g = (int)(gh >> 1);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = g * 16 + h * 8 + j;
+    const int t = k / Cq, c = k - t * Cq;
+    const int co = dg ? c : row, ci = dg ? row : c;
+    v[j] = w[((i64)co * Cin + ci) * T + t];
+  }
+  uint4 ph, pl;
+  split8_f16(v, s, ph, pl);
+  uint4* dst = reinterpret_cast<uint4*>(dg ? J.dst_d : J.dst_f) + set * (4 * n / 16);
+  const i64 base = (i64)g * 2 * NP * M;
+  dst[base + (i64)(0 * 2 + h) * M + row] = ph;
+  dst[base + (i64)(1 * 2 + h) * M + row] = pl;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -686,6 +723,22 @@ extern "C" int pfst_conv_pack_weight_f16x2(const float* w, void* wk4_fprop, void
   if (gx > 4096) gx = 4096;
   hipLaunchKernelGGL(pack_weight_f16x2_kernel, dim3(gx, sets), dim3(256), 0, (hipStream_t)stream, w, (uint4*)wk4_fprop, (uint4*)wk4_dgrad,
                      Cout, Cin, T, n, 4 * n / 16, amax);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs_host, const pfst_weight_job_t* jobs_dev, int njobs,
+                                                   pfst_stream_t stream) {
+  PFST_CHECK_ARG(jobs_host && jobs_dev && njobs > 0);
+  i64 blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const pfst_weight_job_t& J = jobs_host[j];
+    PFST_CHECK_ARG(J.src && J.amax_f && (J.dst_f || J.dst_d) && J.Cout > 0 && J.Cin > 0 && (J.T == 1 || J.T == 9) && J.sets >= 1);
+    PFST_CHECK_ARG((!J.dst_f || J.Cin % 16 == 0) && (!J.dst_d || J.Cout % 16 == 0) && (J.sets == 1 || J.T == 1) && J.first_block == blocks);
+    blocks += weight_job_blocks(J, 1);
+  }
+  PFST_CHECK_ARG(blocks < (1ll << 31));
+  hipLaunchKernelGGL(pack_weight_f16x2_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

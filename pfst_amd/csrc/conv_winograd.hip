@@ -18,7 +18,7 @@
 // fp32 error against an fp64 direct convolution (512 channels): 3e-6 (m = 2), 3e-5 max / 5e-6 rms (m = 4) of the mean |y|.
 #include "common.h"
 #include "amax.h"
-#include "../../include/pfst_hip.h"
+#include "weight_jobs.h"
 
 namespace {
 
@@ -393,6 +393,70 @@ __global__ void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__
   }
 }
 
+// ---- batched weight preparation (pfst_weight_prep_batched): one workgroup = 256 filters of one Winograd layer (transform to the plain
+// sets + every set's absolute maximum) or 4096 weights of one directly convolved layer (absolute maximum)
+template <int M>
+__device__ __forceinline__ void weight_prep_wino(const pfst_weight_job_t& J, int lb, float (*red)[36]) {
+  constexpr int R = M + 2, X = R * R;
+  const i64 total = (i64)J.Cout * J.Cin;
+  const i64 i = (i64)lb * 256 + threadIdx.x;
+  const bool live = i < total;
+  float g[3][3], gf[3][3], u[R][R];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      g[a][b] = live ? J.src[i * 9 + a * 3 + b] : 0.f;
+      gf[2 - a][2 - b] = g[a][b];
+    }
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    float* dst = reinterpret_cast<float*>(dir ? J.dst_d : J.dst_f);
+    float* amax = dir ? J.amax_d : J.amax_f;
+    if (!dst) continue;                                  // uniform over the launch's job
+    filter_tf<M>(dir ? gf : g, u);
+#pragma unroll
+    for (int xi = 0; xi < X; ++xi) {
+      const float v = u[xi / R][xi % R];                 // dead lanes transformed zeros
+      if (live) dst[(i64)xi * total + i] = v;
+      float m = fabsf(v);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][xi] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < X) {
+      const float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+      if (m > 0.f)
+        atomicMax(reinterpret_cast<unsigned*>(amax) + (i64)threadIdx.x * PFST_AMAX_SUB + (lb & (PFST_AMAX_SUB - 1)), __builtin_bit_cast(unsigned, m));
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const pfst_weight_job_t* __restrict__ jobs, int njobs) {
+  __shared__ float red[4][36];
+  const pfst_weight_job_t J = jobs[weight_job_of_block(jobs, njobs, blockIdx.x)];
+  const int lb = blockIdx.x - J.first_block;
+  if (J.m == 2) return weight_prep_wino<2>(J, lb, red);
+  if (J.m == 4) return weight_prep_wino<4>(J, lb, red);
+  const i64 n = (i64)J.Cout * J.Cin * J.T;
+  float m = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const i64 i = (i64)lb * 4096 + k * 256 + threadIdx.x;
+    if (i < n) m = fmaxf(m, fabsf(J.src[i]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][0] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(J.amax_f) + (lb & (PFST_AMAX_SUB - 1)), __builtin_bit_cast(unsigned, m));
+  }
+}
+
 inline int tile_blocks(int T) {
   int b = (T + 255) / 256;
   return b < 1 ? 1 : b;
@@ -429,6 +493,24 @@ extern "C" int pfst_wino_filter_plain(const float* w, float* P_fprop, float* P_d
   const dim3 grid(ew_grid((i64)Cout * Cin));
   PFST_WINO_M(m, hipLaunchKernelGGL((wino_filter_kernel<2, true>), grid, dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin),
               hipLaunchKernelGGL((wino_filter_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, w, P_fprop, P_dgrad, Cout, Cin));
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_weight_job_blocks(const pfst_weight_job_t* job, int pack) { return job ? weight_job_blocks(*job, pack) : 0; }
+
+extern "C" int pfst_weight_prep_batched(const pfst_weight_job_t* jobs_host, const pfst_weight_job_t* jobs_dev, int njobs, pfst_stream_t stream) {
+  PFST_CHECK_ARG(jobs_host && jobs_dev && njobs > 0);
+  i64 blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const pfst_weight_job_t& J = jobs_host[j];
+    PFST_CHECK_ARG(J.src && J.Cout > 0 && J.Cin > 0 && (J.m == 0 || J.m == 2 || J.m == 4) && J.first_block == blocks);
+    if (J.m == 0) PFST_CHECK_ARG(J.amax_f && (J.T == 1 || J.T == 9));
+    else PFST_CHECK_ARG(J.T == 9 && (J.dst_f || J.dst_d) && (!J.dst_f || J.amax_f) && (!J.dst_d || J.amax_d));
+    blocks += weight_job_blocks(J, 0);
+  }
+  PFST_CHECK_ARG(blocks < (1ll << 31));
+  hipLaunchKernelGGL(weight_prep_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, njobs);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

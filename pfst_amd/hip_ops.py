@@ -251,6 +251,32 @@ def pack_weight_f16x2(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=Non
     return wf, wd, amax
 
 
+class _WeightJob(ctypes.Structure):             # pfst_weight_job_t (include/pfst_hip.h)
+    _fields_ = [('src', ctypes.c_void_p), ('dst_f', ctypes.c_void_p), ('dst_d', ctypes.c_void_p), ('amax_f', ctypes.c_void_p),
+                ('amax_d', ctypes.c_void_p), ('Cout', ctypes.c_int), ('Cin', ctypes.c_int), ('T', ctypes.c_int), ('sets', ctypes.c_int),
+                ('m', ctypes.c_int), ('first_block', ctypes.c_int)]
+
+
+class WeightJobTable:
+    """a job table of the batched weight preparation: the host copy the library checks and its device copy the kernel reads.
+    jobs: dicts with the fields of pfst_weight_job_t (tensors or None for the pointers); pack: 0 = prep table, 1 = pack table"""
+
+    def __init__(self, jobs, pack, dev):
+        self.n = len(jobs)
+        self.host = (_WeightJob * self.n)()
+        first = 0
+        for j, d in zip(self.host, jobs):
+            j.src, j.dst_f, j.dst_d, j.amax_f, j.amax_d = (_p(d.get(k)) or None for k in ('src', 'dst_f', 'dst_d', 'amax_f', 'amax_d'))
+            j.Cout, j.Cin, j.T, j.sets, j.m, j.first_block = d['Cout'], d['Cin'], d['T'], d.get('sets', 1), d.get('m', 0), first
+            first += lib().pfst_weight_job_blocks(ctypes.addressof(j), pack)
+        self.blocks = first
+        self.dev = torch.frombuffer(bytearray(bytes(self.host)), dtype=U8).to(dev)
+        self.keep = [t for d in jobs for t in d.values() if torch.is_tensor(t)]     # the buffers the table points into
+
+    def run(self, name):
+        call(name, ctypes.addressof(self.host), self.dev.data_ptr(), self.n, _stream())
+
+
 def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
     n, c, hi, wi = x.shape
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)

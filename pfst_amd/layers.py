@@ -116,6 +116,7 @@ class Conv2dP(nn.Module):
     split_f = split_d = False
     f16_f = f16_d = wino_f16 = False          # this layer's fprop / dgrad / Winograd-domain GEMMs run on the f16x3 kernel
     w4f = w4d = w_amax = uf_amax = ud_amax = None
+    pf = pd = None                            # plain transform-domain filter sets (WeightBatch keeps them per layer)
     wino = False
     saved_v = None
 
@@ -190,7 +191,9 @@ class Conv2dP(nn.Module):
         return ops.conv_dgrad(dy, self.wd, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                               out=out, accumulate=accumulate)
 
-    def repack(self, need_dgrad):
+    def repack(self, need_dgrad, batch=None):
+        """batch: a WeightBatch collecting the f16x3 images of the whole network for its three launches (the other packings, a few
+        small layers, are launched here either way)"""
         if self.depthwise:
             return
         self.wino = self._wino_eligible()
@@ -206,7 +209,9 @@ class Conv2dP(nn.Module):
                 self.ud = None
             if need_dgrad and self.ud is None:
                 self.ud = torch.empty(n, dtype=dt, device=self.weight.device)
-            if self.wino_f16:
+            if self.wino_f16 and batch is not None:
+                batch.add_wino(self, need_dgrad)
+            elif self.wino_f16:
                 _, _, self.uf_amax, self.ud_amax = ops.wino_pack_weight_f16(self.weight.data, True, need_dgrad, self.uf,
                                                                             self.ud if need_dgrad else None)
             else:
@@ -233,8 +238,11 @@ class Conv2dP(nn.Module):
                 self.w4f = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
             if self.f16_d and (self.w4d is None or self.w4d.device != self.weight.device):
                 self.w4d = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
-            _, _, self.w_amax = ops.pack_weight_f16x2(self.weight.data, self.f16_f, self.f16_d, self.w4f if self.f16_f else None,
-                                                      self.w4d if self.f16_d else None)
+            if batch is not None:
+                batch.add_direct(self)
+            else:
+                _, _, self.w_amax = ops.pack_weight_f16x2(self.weight.data, self.f16_f, self.f16_d, self.w4f if self.f16_f else None,
+                                                          self.w4d if self.f16_d else None)
         self.split_f = _split_mode() and self.cin % 16 == 0 and not self.f16_f
         self.split_d = _split_mode() and self.cout % 16 == 0 and need_dgrad and not self.f16_d
         if self.split_f or self.split_d:
@@ -245,6 +253,76 @@ class Conv2dP(nn.Module):
                 self.w6d = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
             ops.pack_weight_split(self.weight.data, self.split_f, self.split_d, self.w6f if self.split_f else None,
                                   self.w6d if self.split_d else None)
+
+
+class WeightBatch:
+    """The f16x3 weight images of a whole network in three launches per step -- zero the slot groups, one preparation launch (absolute
+    maxima of the directly convolved layers; filter transform + per-set maxima of the Winograd layers), one packing launch -- instead
+    of two to five 5-12 us launches per convolution (~290 per step for student + teacher, 1 % of the b=8 step).  The job tables
+    (ops.WeightJobTable) are rebuilt only when a buffer or a mode changed.  PFST_BATCHED_PACK=0: the per-layer launches."""
+    enabled = os.environ.get('PFST_BATCHED_PACK', '1') != '0'
+
+    def __init__(self):
+        self.key = None
+        self.items = []
+
+    def begin(self):
+        self.items = []
+
+    def add_direct(self, conv):
+        self.items.append((conv, 0, False))
+
+    def add_wino(self, conv, need_dgrad):
+        n = (ops.WINO_TILE + 2) ** 2 * conv.cout * conv.cin
+        dev = conv.weight.device
+        if conv.pf is None or conv.pf.device != dev or conv.pf.numel() != n:      # plain transform-domain sets, resident per layer
+            conv.pf, conv.pd = torch.empty(n, device=dev), None
+        if need_dgrad and conv.pd is None:
+            conv.pd = torch.empty(n, device=dev)
+        self.items.append((conv, ops.WINO_TILE, need_dgrad))
+
+    def flush(self):
+        if not self.items:
+            return
+        key = tuple((id(c), m, dg, c.weight.data_ptr(), c.f16_f, c.f16_d) + tuple(ops._p(getattr(c, a)) for a in ('w4f', 'w4d', 'uf', 'ud', 'pf', 'pd'))
+                    for c, m, dg in self.items)
+        if key != self.key:
+            self._build()
+            self.key = key
+        for c, attr, view in self.views:      # a per-layer repack() in between may have replaced them
+            setattr(c, attr, view)
+        self.slots.zero_()
+        self.prep.run('pfst_weight_prep_batched')
+        self.pack.run('pfst_conv_pack_weight_f16x2_batched')
+
+    def _build(self):
+        dev = self.items[0][0].weight.device
+        groups = sum(1 if m == 0 else (m + 2) ** 2 * (2 if dg else 1) for _, m, dg in self.items)
+        self.slots = torch.empty(groups * ops.AMAX_SUB, device=dev)
+        self.views, prep, pack, at = [], [], [], 0
+
+        def take(g):
+            nonlocal at
+            v = self.slots[at * ops.AMAX_SUB:(at + g) * ops.AMAX_SUB]
+            at += g
+            return v
+        for c, m, dg in self.items:
+            dims = dict(Cout=c.cout, Cin=c.cin)
+            if m == 0:
+                a = take(1)
+                self.views.append((c, 'w_amax', a))
+                prep.append(dict(src=c.weight.data, amax_f=a, T=c.k * c.k, **dims))
+                pack.append(dict(src=c.weight.data, dst_f=c.w4f if c.f16_f else None, dst_d=c.w4d if c.f16_d else None, amax_f=a,
+                                 T=c.k * c.k, **dims))
+            else:
+                x = (m + 2) ** 2
+                af, ad = take(x), take(x) if dg else None
+                self.views += [(c, 'uf_amax', af), (c, 'ud_amax', ad)]
+                prep.append(dict(src=c.weight.data, dst_f=c.pf, dst_d=c.pd if dg else None, amax_f=af, amax_d=ad, T=9, m=m, **dims))
+                pack.append(dict(src=c.pf, dst_f=c.uf, amax_f=af, T=1, sets=x, **dims))
+                if dg:
+                    pack.append(dict(src=c.pd, dst_d=c.ud, amax_f=ad, T=1, sets=x, **dims))
+        self.prep, self.pack = ops.WeightJobTable(prep, 0, dev), ops.WeightJobTable(pack, 1, dev)
 
 
 class BatchNorm2dP(nn.Module):

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from . import hip_ops as ops
 from .engine import Var
-from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, bn_eval, conv_bn_act,
+from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, WeightBatch, bn_eval, conv_bn_act,
                      conv_forward)
 from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
 
@@ -381,8 +381,14 @@ class EncoderDecoder(nn.Module):
         return [m for m in self.modules() if isinstance(m, Conv2dP)]
 
     def repack_weights(self, need_dgrad=True):
+        batch = None
+        if WeightBatch.enabled:
+            batch = self.__dict__.setdefault('_weight_batch', WeightBatch())
+            batch.begin()
         for m in self.convs():
-            m.repack(need_dgrad)
+            m.repack(need_dgrad, batch)
+        if batch is not None:
+            batch.flush()
 
     def extract_feat(self, img, tape=None, grad_ready=None):
         x = img if isinstance(img, Var) else Var(img, False)

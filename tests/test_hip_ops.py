@@ -793,3 +793,59 @@ def test_src_perc_selection_counts(ops):
         torch.cuda.synchronize()
         for o in (0, 3):
             assert abs(float(stats[o]) - int(float(full[o]) * perc)) < 1e-3, (perc, o, float(stats[o]), float(full[o]))
+
+
+@pytest.mark.parametrize('need_dgrad', [True, False])
+def test_batched_weight_preparation_matches_the_per_layer_launches(ops, need_dgrad):
+    """layers.WeightBatch (three launches per network: zero the slots, pfst_weight_prep_batched, pfst_conv_pack_weight_f16x2_batched) writes
+    byte for byte the images and the maxima of the per-layer path (pfst_absmax / pfst_wino_filter_plain / pfst_conv_pack_weight_f16x2),
+    for every convolution of the DeepLabV3+ segmentor, and follows the weights when they change."""
+    from helpers import model_cfg
+    from pfst_amd import layers
+    from pfst_amd.registry import SEGMENTORS
+    from pfst_amd.synthetic import fill_state_dict
+    old_math, old_enabled = layers.CONV_MATH, layers.WeightBatch.enabled
+    layers.CONV_MATH = 'f16x3'
+    try:
+        model = SEGMENTORS.build(model_cfg())
+        fill_state_dict(model.state_dict(), 3)
+        model.to(DEV)
+        images = ('w4f', 'w4d', 'uf', 'ud', 'wf', 'wd', 'w6f', 'w6d')
+        maxima = ('w_amax', 'uf_amax', 'ud_amax')
+
+        def snapshot():
+            out = {}
+            for name, c in model.named_modules():
+                if not isinstance(c, layers.Conv2dP):
+                    continue
+                for a in images:
+                    if getattr(c, a) is not None:
+                        out[name, a] = getattr(c, a).clone()
+                for a in maxima:
+                    if getattr(c, a) is not None:
+                        out[name, a] = getattr(c, a).view(-1, ops.AMAX_SUB).max(dim=1).values.clone()
+                out[name, 'modes'] = (c.wino, c.wino_f16, c.f16_f, c.f16_d, c.split_f, c.split_d)
+            return out
+        for round_ in range(2):
+            layers.WeightBatch.enabled = True
+            model.repack_weights(need_dgrad)
+            got = snapshot()
+            layers.WeightBatch.enabled = False
+            for c in model.convs():          # forget the batch's buffers: the per-layer path allocates its own maxima
+                c.w_amax = c.uf_amax = c.ud_amax = None
+            model.repack_weights(need_dgrad)
+            want = snapshot()
+            assert got.keys() == want.keys()
+            n_f16 = 0
+            for k in want:
+                if k[1] == 'modes':
+                    assert got[k] == want[k], k
+                    n_f16 += want[k][1] or want[k][2] or want[k][3]
+                else:
+                    assert torch.equal(got[k], want[k]), k
+            assert n_f16 > 40               # the batch really covered the network
+            with torch.no_grad():           # next round: other weights, same tables
+                for p in model.parameters():
+                    p.mul_(1.7).add_(0.01)
+    finally:
+        layers.CONV_MATH, layers.WeightBatch.enabled = old_math, old_enabled
