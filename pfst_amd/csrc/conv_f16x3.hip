@@ -210,12 +210,14 @@ __global__ __launch_bounds__(256) void pack_weight_f16x2_batched_kernel(const pf
 // issue slots, accumulators already in the 32x32 layout of conv_epilogue -- no re-layout through LDS)
 // BNB != 0 (SHAPE 32 only): the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h)
 // BPACK: the activation operand is stored pre-split (Winograd-domain V written by pfst_wino_input in packed mode)
-template <int SHAPE, int BNB = 0, bool BPACK = false>
+// ONE: a 1x1 convolution with stride 1 and no padding (and the Winograd-domain GEMMs): output pixel = input pixel, no tap arithmetic --
+// the form the tile chain exists for (fewer live scalars: the chain's two-sided tile state must not push the loop's SGPRs out)
+template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride, const PfstBnbArgs& bnb) {
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb) {
   static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
   static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
   constexpr int BM = 128, WAVES_N = 2;
@@ -231,52 +233,68 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wid / WAVES_N) * 64, wn0 = (wid % WAVES_N) * 64;
   const int P = Ho * Wo, HiWi = Hi * Wi;
-  int bx, by;
-  {
-    const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
-    const int lin = blockIdx.x;
+  const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM, X = gx * gy;
+  const int total = X * Y * Z, G = gridDim.x;
+  // tile number -> (pixel tile, row tile, filter set y, image z): x fastest, the order a (X, Y, Z) grid is dispatched in
+  auto decode = [&](int lin, int& bx, int& by, int& y, int& n) {
+    const int zy = lin / X, x = lin - zy * X;
+    const int z = zy / Y;
+    y = zy - z * Y;
+    n = y * Z + z;
     if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      const int grp = x / (8 * gy), r = x - grp * 8 * gy;
       by = r >> 3;
       bx = grp * 8 + (r & 7);
     } else {
-      by = lin / gx;
-      bx = lin - by * gx;
+      by = x / gx;
+      bx = x - by * gx;
     }
-  }
-  const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
+  };
   const int spt = C / 32;                                // K=32 steps per filter tap
-  const int KP = spt * ks * ks;                          // steps in all
-  const int KT16 = (C / 16) * ks * ks;
-  in += (i64)n * in_bs;
-  out += (i64)n * out_bs;
-
-  const int ea = amax_exponent(amax_read(w_amax + (i64)blockIdx.y * PFST_AMAX_SUB));
-  const int eb = amax_exponent(amax_read(in_amax + (i64)blockIdx.y * in_amax_stride * PFST_AMAX_SUB));
-  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));    // an SGPR
+  const int ntaps = ONE ? 1 : ks * ks;
+  const int KP = spt * ntaps;                            // steps in all
+  const int KT16 = (C / 16) * ntaps;
+  // CHAIN: the tiles of a workgroup form ONE software pipeline -- the loads that run two pairs ahead move on to the workgroup's next tile
+  // when a tile's pairs are used up, so the next tile's first pair is split and stored, and its second loaded, inside the last two steps
+  // of the current one: after the first tile there is no prologue and no memory latency in front of a tile's first MFMA.  (K <= 512
+  // launches spent 4-6 K-steps' worth of time per tile outside the loop: tools/gemm_k_sweep.py.)  Needs an even number of steps (the
+  // LDS buffer / register set of a pair is its parity) and the 32x32 loop; otherwise every tile runs its own prologue.
+  const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && chain != 0;
 
   const int pix = tid & (BN - 1), kh = tid >> 7;
-  const int p = p0 + pix;
-  const bool pvalid = p < P;
-  const int oy = pvalid ? p / Wo : 0;
-  const int ox = pvalid ? p - oy * Wo : 0;
-
+  const int a_seg = tid / BM, a_row = tid - a_seg * BM;  // chunk c = tid + 256 i of a tile -> segment seg + 2 i, same row
   constexpr unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk4) + (i64)blockIdx.y * KT16 * 2 * NP * M, 0,
-                                                                         KT16 * 2 * NP * M * 16, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in), 0, C * HiWi * 4, 0x00020000);
-  unsigned a_voff;
-  {
-    const int seg = tid / BM, row = tid - seg * BM;        // chunk c = tid + 256 i of a tile -> segment seg + 2 i, same row
-    a_voff = (m0 + row < M) ? 16u * ((unsigned)seg * (unsigned)M + (unsigned)(m0 + row)) : OOB;
-  }
   const int a_chunk = 2 * M * 16, a_tile = 2 * NP * M * 16, b_chan = HiWi * 4;
   const int chan_step = 32 * HiWi * 4;
+
+  // ---- the load side: tile ld_lin, its buffer resources and this thread's pixel / weight row
+  int ld_lin = blockIdx.x;
+  __amdgpu_buffer_rsrc_t a_rsrc, b_rsrc;
+  unsigned a_voff;
+  int ld_oy, ld_ox;
+  bool ld_pvalid;
+  auto set_load_side = [&](int lin) {
+    int bx, by, y, n;
+    decode(lin, bx, by, y, n);
+    const int p = bx * BN + pix, m0 = by * BM;
+    ld_pvalid = p < P;
+    if constexpr (ONE) {
+      ld_oy = p;                                         // the pixel itself
+      ld_ox = 0;
+    } else {
+      ld_oy = ld_pvalid ? p / Wo : 0;
+      ld_ox = ld_pvalid ? p - ld_oy * Wo : 0;
+    }
+    a_voff = (m0 + a_row < M) ? 16u * ((unsigned)a_seg * (unsigned)M + (unsigned)(m0 + a_row)) : OOB;
+    a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wk4) + (i64)y * KT16 * 2 * NP * M, 0, KT16 * 2 * NP * M * 16, 0x00020000);
+    b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (i64)n * in_bs, 0, C * HiWi * 4, 0x00020000);
+  };
   // activation voffset of the pixel for filter tap `tap` (0 .. ks*ks-1): constant while the tap does not change
   auto tap_voff = [&](int tap) -> unsigned {
+    if constexpr (ONE) return ld_pvalid ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)ld_oy) : OOB;
     const int ty = tap / ks, tx = tap - ty * ks;
     int sy, sx;
-    const bool ok = pvalid & src_coord(oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ox, tx, ca, cb, cc, cdivv, Wi, sx);
+    const bool ok = ld_pvalid & src_coord(ld_oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ld_ox, tx, ca, cb, cc, cdivv, Wi, sx);
     return ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
   };
 
@@ -306,22 +324,38 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   };
   // pairs are numbered (tap, channel block); the address of pair k+2 advances by one channel block per step, the pixel offset is
   // recomputed only when the tap changes (never for a 1x1 convolution): no integer divisions in the loop
-  const int ntaps = ks * ks;
   int tap2 = 0, sidx2 = 0;                               // (tap, channel block) of the pair whose activations are loaded next
-  unsigned voff2 = tap_voff(0);
+  unsigned voff2 = OOB;
   auto advance = [&]() {
     if (++sidx2 == spt) {
       sidx2 = 0;
       ++tap2;
-      voff2 = tap2 < ntaps ? tap_voff(tap2) : OOB;
+      if (tap2 < ntaps) {
+        voff2 = tap_voff(tap2);
+      } else if (CHAIN && tap2 == ntaps && ld_lin + G < total) {       // on to the workgroup's next tile
+        ld_lin += G;
+        set_load_side(ld_lin);
+        tap2 = 0;
+        voff2 = tap_voff(0);
+      } else {
+        voff2 = OOB;                                     // past the last pair: zeros (the weight offset leaves its buffer's range)
+      }
     }
   };
 
-  // ---- prologue: pair 0 through the plain split into LDS, pair 1 into register set 1 (+ its weights into areg)
-  {
+  const int eb = amax_exponent(amax_read(in_amax));
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));    // an SGPR
+  int ea = 0, ea_y = -1;                                 // the weight exponent of filter set ea_y
+
+  // pair 0 through the plain split into LDS buffer 0, pair 1 into register set 1 (+ its weights into areg)
+  auto prologue = [&](int lin) {
+    ld_lin = lin;
+    set_load_side(lin);
+    tap2 = sidx2 = 0;
+    voff2 = tap_voff(0);
     static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
-    advance();
     static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 0>(), 0); });
+    advance();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       uint4 ph, pl;
@@ -333,11 +367,14 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
     }
     // pair 1 (past the end of a one-step contraction the offset is out of range: zeros)
-    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, sidx2 * chan_step); });
-    static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), 2 * a_tile); });
+    {
+      const int soff = sidx2 * chan_step, a_soff = (tap2 * spt + sidx2) * 2 * a_tile;
+      static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, soff); });
+      static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), a_soff); });
+    }
     advance();
-  }
-  __syncthreads();
+    __syncthreads();
+  };
 
   const int l15 = lane & 15, lq = lane >> 4;
   const int a_frag = (lq >> 1) * TILE_A + (lq & 1) * BM + wm0 + l15;
@@ -360,7 +397,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       else rd_a(r - 12, 0);
     };
     const int soff2 = sidx2 * chan_step;
-    const int a_soff2 = (k + 2) * 2 * a_tile;
+    const int a_soff2 = (tap2 * spt + sidx2) * 2 * a_tile;
     static_for<5>([&](auto rc) { read_frag(rc); });
     __builtin_amdgcn_sched_barrier(0);
     constexpr int PA[3] = {1, 0, 0};
@@ -415,7 +452,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       else rd_a(t, 1, pa);
     };
     const int soff2 = sidx2 * chan_step;
-    const int a_soff2 = (k + 2) * 2 * a_tile;
+    const int a_soff2 = (tap2 * spt + sidx2) * 2 * a_tile;
     static_for<4>([&](auto rc) { read_frag(rc); });
     __builtin_amdgcn_sched_barrier(0);
     SplitF16 s0, s1;
@@ -456,71 +493,99 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     advance();
     __syncthreads();
   };
-  for (int k = 0; k < KP; k += 2) {
-    if constexpr (SHAPE == 32) {
-      step32(std::integral_constant<int, 1>(), k);
-      if (k + 1 < KP) step32(std::integral_constant<int, 0>(), k + 1);
-    } else {
-      step(std::integral_constant<int, 1>(), k);
-      if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
-    }
-  }
-
   // un-scale (an exact power of two, in two factors so that neither over- nor underflows) and hand over to the common epilogue
-  const float ua = unscale_of(ea), ub = unscale_of(eb);
-  if constexpr (SHAPE == 32) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc32[i][j][r] = acc32[i][j][r] * ua * ub;
-    if constexpr (BNB != 0) {
-      __syncthreads();                                   // the reduction scratch overlaps the tiles other waves may still be reading
-      static_assert(sizeof(smem) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into the tiles");
-      conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
-                                                  reinterpret_cast<float*>(smem));
-    } else {
-      conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+  auto epilogue = [&](int lin) {
+    int bx, by, y, n;
+    decode(lin, bx, by, y, n);
+    if (y != ea_y) {
+      ea = amax_exponent(amax_read(w_amax + (i64)y * PFST_AMAX_SUB));
+      ea_y = y;
     }
-    return;
+    const int p0 = bx * BN, m0 = by * BM;
+    float* const outn = out + (i64)n * out_bs;
+    const float ua = unscale_of(ea), ub = unscale_of(eb);
+    if constexpr (SHAPE == 32) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc32[i][j][r] = acc32[i][j][r] * ua * ub;
+      if constexpr (BNB != 0) {
+        // the reduction scratch is LDS buffer 1: the last step (odd, or the only one) read it and ended with a barrier; buffer 0 may
+        // already hold the next tile's first pair
+        static_assert(PAIR_CHUNKS * sizeof(uint4) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into one pair buffer");
+        conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
+                                                    reinterpret_cast<float*>(smem + PAIR_CHUNKS));
+        __syncthreads();                                 // before the next tile's first step stores into that buffer
+      } else {
+        conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    } else {
+      float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r] * ua * ub;
+        wave_lds_phase_fence();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
+        wave_lds_phase_fence();
+      }
+      conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      __syncthreads();                                   // the re-layout scratch is the tile buffer the next prologue writes
+    }
+  };
+
+  // ---- the workgroup's tiles: blockIdx.x, + gridDim.x, ...  (every tile index below `total`; gridDim.x <= total)
+  for (int lin = blockIdx.x; lin < total; lin += G) {
+    if (!CHAIN || lin == (int)blockIdx.x) prologue(lin);
+    for (int k = 0; k < KP; k += 2) {
+      if constexpr (SHAPE == 32) {
+        step32(std::integral_constant<int, 1>(), k);
+        if (k + 1 < KP) step32(std::integral_constant<int, 0>(), k + 1);
+      } else {
+        step(std::integral_constant<int, 1>(), k);
+        if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
+      }
+    }
+    epilogue(lin);
   }
-  float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
-#pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r] * ua * ub;
-    wave_lds_phase_fence();
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
-    wave_lds_phase_fence();
-  }
-  conv_epilogue<2, 2, WAVES_N, BN>(acc32, out, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
 }
 
-template <int SHAPE, bool BPACK = false>
+template <int SHAPE, bool BPACK = false, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride) {
-  conv_igemm_f16x3_body<SHAPE, 0, BPACK>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                               w_amax, in_amax, in_amax_stride, PfstBnbArgs());
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain) {
+  conv_igemm_f16x3_body<SHAPE, 0, BPACK, ONE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                               w_amax, in_amax, Y, Z, chain, PfstBnbArgs());
 }
-template <int BNB>
+template <int BNB, bool ONE = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_bnb_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int in_amax_stride, PfstBnbArgs bnb) {
-  conv_igemm_f16x3_body<32, BNB>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                                 w_amax, in_amax, in_amax_stride, bnb);
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, PfstBnbArgs bnb) {
+  conv_igemm_f16x3_body<32, BNB, false, ONE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+                                 w_amax, in_amax, Y, Z, chain, bnb);
 }
 
 
@@ -689,6 +754,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
   }
 }
 
+// grid of the tile-chain GEMM.  A workgroup walks tiles blockIdx.x, + gridDim.x, ... as one software pipeline; how many tiles it gets is a
+// balance: long chains amortise the one prologue (4-6 K-steps' worth, tools/gemm_k_sweep.py), but the hardware can only even out the
+// CUs' speeds by handing out whole workgroups, and a last round of workgroups that fills a fraction of the slots wastes the rest.
+// -> of the grids total / t (t = 1..8) and one-workgroup-per-slot, the one whose rounds waste the least (ties: the longer chains).
+// PFST_F16X3_CHAIN=0: one workgroup per tile (the launch shape before the chain, for A/B runs).
+int f16x3_chain() {
+  static const int v = getenv("PFST_F16X3_CHAIN") ? atoi(getenv("PFST_F16X3_CHAIN")) : 1;
+  return v != 0;
+}
+unsigned f16x3_grid(i64 total, bool chainable) {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = 2 * cus;                                      // __launch_bounds__(256, 2): two workgroups per CU
+  }
+  if (!chainable || !f16x3_chain() || total <= slots) return (unsigned)total;
+  i64 best_g = total;
+  double best_waste = 1e30;
+  for (int t = 0; t <= 8; ++t) {                          // t = 0: one workgroup per slot
+    const i64 g = t == 0 ? slots : (total + t - 1) / t;
+    if (g < slots) continue;
+    const i64 per_wg = (total + g - 1) / g, rounds = (g + slots - 1) / slots;
+    if (per_wg > 8) continue;                             // measured: 4-8 tiles per workgroup beat both 1 and 32 at every K
+    const double waste = (double)(rounds * per_wg * slots) / (double)total;
+    if (waste < best_waste - 1e-9 || (waste < best_waste + 1e-9 && g < best_g)) { best_waste = waste; best_g = g; }
+  }
+  return (unsigned)best_g;
+}
+
 int f16x3_shape() {
   static const int v = getenv("PFST_F16X3_SHAPE") ? atoi(getenv("PFST_F16X3_SHAPE")) : 32;
   return v == 16 ? 16 : 32;
@@ -765,26 +860,39 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
-  dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, 128), 1, N);
+  const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, 128) * N;
+  PFST_CHECK_ARG(total < (1ll << 31));
+  const bool one = ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
+  const dim3 grid(f16x3_grid(total, one && (C / 32) % 2 == 0));
+  const int chain = f16x3_chain();
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
     PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);
-#define PFST_LAUNCH_F16_BNB(MODE_)                                                                                                          \
-    hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
-                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0, *bnb)
-    if (!bnb->relu) PFST_LAUNCH_F16_BNB(3);
-    else if (bnb->y) PFST_LAUNCH_F16_BNB(2);
-    else PFST_LAUNCH_F16_BNB(1);
+#define PFST_LAUNCH_F16_BNB(MODE_, ONE_)                                                                                                    \
+    hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_, ONE_>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
+                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb)
+    if (one) {
+      if (!bnb->relu) PFST_LAUNCH_F16_BNB(3, true);
+      else if (bnb->y) PFST_LAUNCH_F16_BNB(2, true);
+      else PFST_LAUNCH_F16_BNB(1, true);
+    } else {
+      if (!bnb->relu) PFST_LAUNCH_F16_BNB(3, false);
+      else if (bnb->y) PFST_LAUNCH_F16_BNB(2, false);
+      else PFST_LAUNCH_F16_BNB(1, false);
+    }
 #undef PFST_LAUNCH_F16_BNB
     PFST_CHECK_LAUNCH();
     return PFST_OK;
   }
-  if (f16x3_shape() == 32)
+  if (one)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+  else if (f16x3_shape() == 32)
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
   else
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 0);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -797,17 +905,20 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
   const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
-  dim3 grid(cdiv((i64)T, BN) * cdiv(M, 128), nx, N);
+  const i64 total = (i64)cdiv((i64)T, BN) * cdiv(M, 128) * nx * N;
+  PFST_CHECK_ARG(total < (1ll << 31));
+  const dim3 grid(f16x3_grid(total, f16x3_shape() == 32 && (K / 32) % 2 == 0));
+  const int chain = f16x3_chain();
   // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
   if (v_packed)
-    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
-                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
   else if (f16x3_shape() == 32)
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
   else
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, 0);
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
