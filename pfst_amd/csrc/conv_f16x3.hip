@@ -754,6 +754,180 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
   }
 }
 
+// The same weight gradient with K = 32 per step (a PAIR of K=16 tiles per LDS buffer, the implicit GEMM's step32 shape): 24 MFMAs per
+// barrier instead of 12, so the fragment-read latency in front of a step's first MFMA and the barrier are paid half as often.
+// 64 KB of LDS (two pair buffers of both operands), two workgroups per CU as before.  Per step and thread: 8 wide loads (pair k+2),
+// 96 split instructions (pair k+1; 32 permutes when PACK), 8 LDS stores to the other buffer, 16 fragment reads.
+template <bool PACK>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
+    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
+  constexpr int BM = 128, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
+  constexpr int TILE = 2 * NP * BM;                         // chunks of one K=16 tile of one operand (BM == BJ)
+  constexpr unsigned OOB = 0x80000000u;
+  __shared__ uint4 As[2][2 * TILE];                       // [buffer][tile][piece][k-half][row]
+  __shared__ uint4 Bs[2][2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  int bx, by, bz;
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * BJ, m0 = by * BM;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
+  const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
+  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
+
+  const int srow = tid >> 1, half = tid & 1;        // staging role: 8 consecutive pixels of one row per operand and tile
+  const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
+  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
+
+  float la[2][2][8], lb[2][2][8];                   // [register set][tile of the pair][8 pixels]
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // load q = 0..7 of the pair starting at pixel pk0: operand q / 4 (dy, x), tile (q / 2) % 2, quad q % 2.  P % 4 == 0 and
+  // chunk_len % 16 == 0: a quad is entirely in or out (out: zeros -- an odd tile count leaves the pair's second tile empty)
+  auto load_quad = [&](auto qc, auto setc, int pk0) {
+    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value, opb = q >> 2, t = (q >> 1) & 1, quad = q & 1;
+    const int p = pk0 + 16 * t + 8 * half + 4 * quad;
+    const bool v = p < pend;
+    const float4 w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(opb ? b_rsrc : a_rsrc, v ? (opb ? b_voff : a_voff) : OOB,
+                                                                                      pk0 * 4 + 64 * t + 16 * quad, 0));
+    float (&dst)[8] = opb ? lb[SET][t] : la[SET][t];
+    dst[4 * quad + 0] = w.x; dst[4 * quad + 1] = w.y; dst[4 * quad + 2] = w.z; dst[4 * quad + 3] = w.w;
+  };
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // prologue: pair 0 through the plain split into buffer 0, pair 1 into register set 1
+  static_for<8>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    uint4 ph, pl;
+    if constexpr (PACK) unpack8_f16(la[0][t], ph, pl);
+    else split8_f16(la[0][t], sa, ph, pl);
+    As[0][t * TILE + (0 * 2 + half) * BM + srow] = ph; As[0][t * TILE + (1 * 2 + half) * BM + srow] = pl;
+    if constexpr (PACK) unpack8_f16(lb[0][t], ph, pl);
+    else split8_f16(lb[0][t], sb, ph, pl);
+    Bs[0][t * TILE + (0 * 2 + half) * BJ + srow] = ph; Bs[0][t * TILE + (1 * 2 + half) * BJ + srow] = pl;
+  }
+  static_for<8>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 32); });
+  __syncthreads();
+
+  // one step on LDS buffer CUR = k & 1 (register set NXT holds pair k+1; pair k+2 is loaded into set CUR, whose values were split during
+  // the previous step).  24 MFMAs product-major, tile-minor (al bh | ah bl | ah bh); slots 0-11 one fragment read, 0-7 one wide load,
+  // 0-23 four split instructions (dy tile 0: 0-5, dy tile 1: 6-11, x tile 0: 12-17, x tile 1: 18-23), the LDS stores behind the MFMAs of
+  // slots 6 / 12 / 18 / 23.
+  auto step = [&](auto curc, int kp) {
+    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+    f16x8 af[2][TM][NP], bf[2][TN][NP];
+    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR][t * TILE + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
+    auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR][t * TILE + (pl * 2 + lh) * BJ + wn0 + j * 32 + l31]); };
+    // r = 0..15: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 a1, the MFMAs' order
+    auto read_frag = [&](auto rc) {
+      constexpr int r = decltype(rc)::value, grp = r >> 2, e = r & 3, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
+      if constexpr (e == 0) rd_a(t, 0, pa);
+      else if constexpr (e == 1) rd_b(t, 0, pb);
+      else if constexpr (e == 2) rd_b(t, 1, pb);
+      else rd_a(t, 1, pa);
+    };
+    static_for<4>([&](auto rc) { read_frag(rc); });
+    __builtin_amdgcn_sched_barrier(0);
+    SplitF16 s0, s1;
+    const int pk2 = pbeg + (kp + 2) * 32;
+    static_for<24>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int prod = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
+      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc[i][j], 0, 0, 0);
+      if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
+      if constexpr (m < 8) load_quad(mc, curc, pk2);
+      static_for<4>([&](auto kc) {
+        constexpr int k = (m % 6) * 4 + decltype(kc)::value;          // 0..23 within the 8-value group of slot group m / 6
+        constexpr int g = m / 6;                                      // 0: dy tile 0, 1: dy tile 1, 2: x tile 0, 3: x tile 1
+        if constexpr (PACK) {
+          if constexpr (k < 8) {
+            if constexpr (g == 0) unpack_op_f16<k>(la[NXT][0], s0);
+            else if constexpr (g == 1) unpack_op_f16<k>(la[NXT][1], s1);
+            else if constexpr (g == 2) unpack_op_f16<k>(lb[NXT][0], s0);
+            else unpack_op_f16<k>(lb[NXT][1], s1);
+          }
+        } else {
+          if constexpr (g == 0) split_op_f16<k>(la[NXT][0], sa, s0);
+          else if constexpr (g == 1) split_op_f16<k>(la[NXT][1], sa, s1);
+          else if constexpr (g == 2) split_op_f16<k>(lb[NXT][0], sb, s0);
+          else split_op_f16<k>(lb[NXT][1], sb, s1);
+        }
+      });
+      if constexpr (m == 6) {
+        As[NXT][(0 * 2 + half) * BM + srow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+        As[NXT][(1 * 2 + half) * BM + srow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      }
+      if constexpr (m == 12) {
+        As[NXT][TILE + (0 * 2 + half) * BM + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+        As[NXT][TILE + (1 * 2 + half) * BM + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      }
+      if constexpr (m == 18) {
+        Bs[NXT][(0 * 2 + half) * BJ + srow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+        Bs[NXT][(1 * 2 + half) * BJ + srow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      }
+      if constexpr (m == 23) {
+        Bs[NXT][TILE + (0 * 2 + half) * BJ + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+        Bs[NXT][TILE + (1 * 2 + half) * BJ + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  const int KPAIRS = (pend - pbeg + 31) / 32;
+  for (int kp = 0; kp < KPAIRS; kp += 2) {
+    step(std::integral_constant<int, 0>(), kp);
+    if (kp + 1 < KPAIRS) step(std::integral_constant<int, 1>(), kp + 1);
+  }
+  const float ua = unscale_of(ea), ub = unscale_of(eb);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r] * ua * ub);
+      }
+    }
+  }
+}
+
 // grid of the tile-chain GEMM.  A workgroup walks tiles blockIdx.x, + gridDim.x, ... as one software pipeline; how many tiles it gets is a
 // balance: long chains amortise the one prologue (4-6 K-steps' worth, tools/gemm_k_sweep.py), but the hardware can only even out the
 // CUs' speeds by handing out whole workgroups, and a last round of workgroups that fills a fraction of the slots wastes the rest.
@@ -941,7 +1115,14 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, 128), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  if (packed)
+  static const int pair = getenv("PFST_F16X3_WGRAD_PAIR") ? atoi(getenv("PFST_F16X3_WGRAD_PAIR")) : 1;     // 0: the K=16-step kernel (A/B runs)
+  if (pair && packed)
+    hipLaunchKernelGGL(conv_wgrad_f16x3_pair_kernel<true>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
+                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+  else if (pair)
+    hipLaunchKernelGGL(conv_wgrad_f16x3_pair_kernel<false>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
+                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+  else if (packed)
     hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<true>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
                        x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
   else
