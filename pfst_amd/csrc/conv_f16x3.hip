@@ -225,8 +225,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
   // stores of pair k+1 go to the other buffer whenever their data is ready.  SHAPE 16: one buffer, barrier A in the MFMA stream.
   constexpr int PAIR_CHUNKS = 2 * TILE_A + 2 * TILE_B;
-  constexpr int SMEM_CHUNKS = SHAPE == 32 ? 2 * PAIR_CHUNKS : (PAIR_CHUNKS > (4 * 32 * 68 / 4) ? PAIR_CHUNKS : (4 * 32 * 68 / 4));
-  __shared__ uint4 smem[SMEM_CHUNKS];                           // SHAPE 16: the tiles (32 KB); the epilogue's re-layout scratch needs 34 KB
+  constexpr int SMEM_CHUNKS = 2 * PAIR_CHUNKS;
+  static_assert(SMEM_CHUNKS * 16 >= 4 * 32 * 68 * 4, "SHAPE 16: the epilogue's re-layout scratch (34 KB) lives in the tile buffers");
+  __shared__ uint4 smem[SMEM_CHUNKS];
   uint4* const As = smem;
   uint4* const Bs = smem + 2 * TILE_A;
 
@@ -383,9 +384,10 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // one step on pair k: SETN = (k + 1) & 1 holds pair k+1 (split and stored here), pair k+2 is loaded into set k & 1
   auto step = [&](auto setn_c, int k) {
     constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
+    constexpr int CUR = SETL * PAIR_CHUNKS, NXT = SETN * PAIR_CHUNKS;       // as step32: pair k in LDS buffer k & 1, pair k+1 goes to the other
     f16x8 af[4][NP], bf[4][NP];
-    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(f16x8, As[a_frag + pl * 2 * BM + i * 16]); };
-    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(f16x8, Bs[b_frag + pl * 2 * BN + j * 16]); };
+    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(f16x8, As[CUR + a_frag + pl * 2 * BM + i * 16]); };
+    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(f16x8, Bs[CUR + b_frag + pl * 2 * BN + j * 16]); };
     // fragment reads in the order the terms (al bh) (ah bl) (ah bh) need them; r = 0..15, the first five before the first MFMA
     auto read_frag = [&](auto rc) {
       constexpr int r = decltype(rc)::value;
@@ -403,8 +405,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     constexpr int PA[3] = {1, 0, 0};
     constexpr int PB[3] = {0, 1, 0};
     SplitF16 s0, s1;
-    // slots: 0-10 the remaining fragment reads; 0-3 the weight chunks of pair k+1; 4-19 the activations of pair k+2; 11-34 two split
-    // instructions each (pair k+1); 16 barrier A; 40-47 the eight LDS stores; barrier B after the last MFMA
+    // slots: 0-10 the remaining fragment reads; 4-19 the activations of pair k+2; 11-34 two split instructions each (pair k+1); 36-39 /
+    // 44-47 the eight LDS stores (to the other buffer); 40-43 the weight chunks of pair k+2; one barrier after the last MFMA
     static_for<48>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       constexpr int t = m >> 4, i = (m >> 2) & 3, j = m & 3;
@@ -412,21 +414,17 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       if constexpr (m < 11) read_frag(std::integral_constant<int, 5 + m>());
       // (past the last pair the offsets are out of the buffers' ranges: the loads return zeros, no branches in the stream)
       if constexpr (m >= 4 && m < 20) load_b(std::integral_constant<int, m - 4>(), std::integral_constant<int, SETL>(), voff2, soff2);
-      if constexpr (m == 16) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads have landed
-        __builtin_amdgcn_s_barrier();
-      }
       if constexpr (m >= 11 && m < 35) {
         constexpr int kk = (m - 11) * 2;
         if constexpr (kk < 24) { split_op_f16<kk>(breg[SETN][0], sb, s0); split_op_f16<kk + 1>(breg[SETN][0], sb, s0); }
         else { split_op_f16<kk - 24>(breg[SETN][1], sb, s1); split_op_f16<kk - 23>(breg[SETN][1], sb, s1); }
       }
-      if constexpr (m >= 36 && m < 40) As[((m - 36) / 2) * TILE_A + tid + 256 * ((m - 36) % 2)] = areg[SETN][m - 36];
+      if constexpr (m >= 36 && m < 40) As[NXT + ((m - 36) / 2) * TILE_A + tid + 256 * ((m - 36) % 2)] = areg[SETN][m - 36];
       if constexpr (m >= 40 && m < 44) load_a(std::integral_constant<int, m - 40>(), std::integral_constant<int, SETL>(), a_soff2);
-      if constexpr (m == 44) Bs[(0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
-      if constexpr (m == 45) Bs[(1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
-      if constexpr (m == 46) Bs[TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-      if constexpr (m == 47) Bs[TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      if constexpr (m == 44) Bs[NXT + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+      if constexpr (m == 45) Bs[NXT + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      if constexpr (m == 46) Bs[NXT + TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+      if constexpr (m == 47) Bs[NXT + TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
       __builtin_amdgcn_sched_barrier(0);
     });
     advance();
