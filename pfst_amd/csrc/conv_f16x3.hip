@@ -251,7 +251,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       bx = x - by * gx;
     }
   };
-  const int spt = C / 32;                                // K=32 steps per filter tap
+  const int spt = (C + 31) / 32;                         // K=32 steps per filter tap (1x1: the last one may be half empty)
   const int ntaps = ONE ? 1 : ks * ks;
   const int KP = spt * ntaps;                            // steps in all
   const int KT16 = (C / 16) * ntaps;
@@ -1010,7 +1010,7 @@ extern "C" int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs
   return PFST_OK;
 }
 
-// fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 and M > 64.
+// fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 (1x1: C % 16 == 0) and M > 64.
 extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                                      int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
@@ -1019,8 +1019,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
-  if (C % 32 != 0 || M <= 64) {
-    pfst_set_error(__FILE__, __LINE__, "f16x3 kernel needs C % 32 == 0 and more than 64 output channels (use pfst_conv_igemm_split)");
+  // a 1x1 convolution may end in half a channel block: the loads of the 16 missing channels (activations and weight chunks alike) lie
+  // outside their buffers' ranges and return zeros (the range check of gfx950 includes the scalar offset: tools/probes/soffset_range_probe.hip)
+  if ((C % 32 != 0 && !(ksize == 1 && C % 16 == 0)) || M <= 64) {
+    pfst_set_error(__FILE__, __LINE__, "f16x3 kernel needs C % 32 == 0 (1x1: C % 16 == 0) and more than 64 output channels (use pfst_conv_igemm_split)");
     return PFST_ERR_UNSUPPORTED;
   }
   const int span = (ksize - 1) * dil;
@@ -1035,7 +1037,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const bool one = ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
-  const dim3 grid(f16x3_grid(total, one && (C / 32) % 2 == 0));
+  const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0));
   const int chain = f16x3_chain();
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics

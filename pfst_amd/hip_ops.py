@@ -226,9 +226,11 @@ def absmax(x, planes=1, out=None):
     return out
 
 
-def f16x3_eligible(cin, cout):
-    """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks and more than 64 output rows"""
-    return cin % 32 == 0 and cout > 64
+def f16x3_eligible(cin, cout, ksize=3):
+    """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks -- a 1x1 convolution also a last half block: the loads of
+    the missing 16 channels fall outside their buffers' ranges and return zeros (the range check includes the scalar offset on gfx950:
+    tools/probes/soffset_range_probe.hip) -- and more than 64 output rows"""
+    return (cin % 32 == 0 or (ksize == 1 and cin % 16 == 0)) and cout > 64
 
 
 def pack_weight_f16x2(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, amax=None, sets=1):
@@ -280,7 +282,7 @@ class WeightJobTable:
 def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
     n, c, hi, wi = x.shape
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
-    assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout)
+    assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout, ksize)
     if out is None:
         out = torch.empty(n, cout, ho, wo, device=x.device)
     slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
@@ -304,7 +306,7 @@ def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, di
     """bnb: as conv_dgrad (returns (out, partials, slots) then)"""
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
-    assert wk4_d.numel() == 4 * ksize * ksize * co * cin and f16x3_eligible(co, cin)
+    assert wk4_d.numel() == 4 * ksize * ksize * co * cin and f16x3_eligible(co, cin, ksize)
     if out is None:
         assert not accumulate
         out = torch.empty(n, cin, hi, wi, device=dy.device)

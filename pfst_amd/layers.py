@@ -219,8 +219,8 @@ class Conv2dP(nn.Module):
                 pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
             if self.bias is None:
                 return                    # the direct-convolution packings are not needed
-        self.f16_f = f16 and ops.f16x3_eligible(self.cin, self.cout)
-        self.f16_d = f16 and need_dgrad and ops.f16x3_eligible(self.cout, self.cin)
+        self.f16_f = f16 and ops.f16x3_eligible(self.cin, self.cout, self.k)
+        self.f16_d = f16 and need_dgrad and ops.f16x3_eligible(self.cout, self.cin, self.k)
         # the fp32 K-major images only for the directions that run on the fp32-input MFMA kernels (every layer under 'f32'; the stems
         # and the classifiers' data gradient otherwise): 106 small launches per step less in the split modes
         fp32_f = not (self.f16_f or (_split_mode() and self.cin % 16 == 0))

@@ -235,7 +235,9 @@ def test_winograd_on_the_bf16x6_gemm(ops, case, m):
     assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d, m=m), dx_ref, WINO_TOL[m], 'winograd/bf16x6 dgrad')
 
 
-F16_CASES = [c for c in CONV_CASES if c[1] % 32 == 0 and c[2] > 64]
+F16_CASES = [c for c in CONV_CASES if c[1] % 32 == 0 and c[2] > 64] + [
+    # 1x1 contractions that end in half a channel block (the decoder's 560 -> 512 pointwise convolution; 48: a single, half-empty pair)
+    (2, 560, 512, 16, 24, 1, 1, 1, 0), (1, 48, 96, 12, 12, 1, 1, 1, 0), (2, 80, 160, 9, 14, 1, 2, 1, 0)]
 
 
 @pytest.mark.parametrize('spread', [0.0, 2.5])
@@ -252,7 +254,7 @@ def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
         w = w * 1e-3 * torch.exp(0.5 * spread * torch.randn(w.shape, generator=g(8)))
     ref = F.conv2d(x.double(), w.double(), None, s, p, d)
     xd, wd = x.to(DEV), w.to(DEV)
-    w4f, w4d, wa = ops.pack_weight_f16x2(wd, True, co % 32 == 0 and ci > 64)
+    w4f, w4d, wa = ops.pack_weight_f16x2(wd, True, ops.f16x3_eligible(co, ci, k))
     xa = ops.absmax(xd)
     assert float(xa.max()) == float(x.abs().max()) and float(wa.max()) == float(w.abs().max())       # the slot group holds the exact maximum
     y = ops.conv_fprop_f16x3(xd, w4f, wa, xa, co, k, s, d, p)
@@ -283,11 +285,12 @@ def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
 def test_f16x3_refuses_shapes_it_does_not_cover(ops):
     from pfst_amd._lib import PfstHipError
     x = torch.randn(1, 48, 8, 8, device=DEV)
-    w = torch.randn(128, 48, 1, 1, device=DEV)
+    w = torch.randn(128, 48, 3, 3, device=DEV)           # a 3x3 contraction over 1.5 channel blocks per tap
     w4f, _, wa = ops.pack_weight_f16x2(w, True, False)
     assert not ops.f16x3_eligible(48, 128) and not ops.f16x3_eligible(64, 64) and ops.f16x3_eligible(64, 96)
+    assert ops.f16x3_eligible(48, 128, 1) and not ops.f16x3_eligible(40, 128, 1)
     with pytest.raises((PfstHipError, AssertionError)):
-        ops.conv_fprop_f16x3(x, w4f, wa, ops.absmax(x), 128, 1)
+        ops.conv_fprop_f16x3(x, w4f, wa, ops.absmax(x), 128, 3, pad=1)
 
 
 def test_absmax_slot_groups(ops):
