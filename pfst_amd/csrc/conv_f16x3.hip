@@ -935,13 +935,15 @@ int f16x3_chain() {
   static const int v = getenv("PFST_F16X3_CHAIN") ? atoi(getenv("PFST_F16X3_CHAIN")) : 1;
   return v != 0;
 }
+int f16x3_slots_override = 0;                             // pfst_f16x3_set_slots
 unsigned f16x3_grid(i64 total, bool chainable) {
-  static int slots = 0;
-  if (slots == 0) {
+  static int dev_slots = 0;
+  if (dev_slots == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    slots = 2 * cus;                                      // __launch_bounds__(256, 2): two workgroups per CU
+    dev_slots = 2 * cus;                                  // __launch_bounds__(256, 2): two workgroups per CU
   }
+  const int slots = f16x3_slots_override > 0 ? f16x3_slots_override : dev_slots;
   if (!chainable || !f16x3_chain() || total <= slots) return (unsigned)total;
   i64 best_g = total;
   double best_waste = 1e30;
@@ -962,6 +964,14 @@ int f16x3_shape() {
 }
 
 }  // namespace
+
+// number of resident workgroup slots the tile-chain grid is sized for (0: two per CU of the current device).  A test hook: with a few
+// slots small problems run as chains of up to 8 tiles per workgroup, the shape the b = 8 x 1024^2 launches have.
+extern "C" int pfst_f16x3_set_slots(int slots) {
+  PFST_CHECK_ARG(slots >= 0);
+  f16x3_slots_override = slots;
+  return PFST_OK;
+}
 
 // max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the
 // groups must have been zeroed (or hold an earlier maximum to extend).  pfst_absmax is the stand-alone form; producers of GEMM operands write their slots themselves.

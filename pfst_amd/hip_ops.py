@@ -226,6 +226,11 @@ def absmax(x, planes=1, out=None):
     return out
 
 
+def set_f16x3_slots(slots):
+    """resident workgroup slots the f16x3 GEMMs size their tile-chain grid for (0: the device's two per CU) -- a test hook"""
+    call('pfst_f16x3_set_slots', int(slots))
+
+
 def f16x3_eligible(cin, cout, ksize=3):
     """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks -- a 1x1 convolution also a last half block: the loads of
     the missing 16 channels fall outside their buffers' ranges and return zeros (the range check includes the scalar offset on gfx950:

@@ -852,3 +852,58 @@ def test_batched_weight_preparation_matches_the_per_layer_launches(ops, need_dgr
                     p.mul_(1.7).add_(0.01)
     finally:
         layers.CONV_MATH, layers.WeightBatch.enabled = old_math, old_enabled
+
+
+@pytest.mark.parametrize('slots', [2, 5])
+def test_f16x3_tile_chain_is_the_same_arithmetic(ops, slots):
+    """The f16x3 GEMMs walk up to 8 tiles per workgroup as one software pipeline (the next tile's first pairs are loaded, split and stored
+    inside the current tile's last steps).  With the grid sized for a handful of slots (pfst_f16x3_set_slots) small problems take that
+    path -- chains of 2 ... 8 tiles, tiles of several images / filter sets in one chain, ragged last tiles, the fused statistics and the
+    fused BatchNorm-backward sums, accumulation -- and must reproduce the one-tile-per-workgroup launch bit for bit."""
+    torch.manual_seed(5)
+
+    def run():
+        out = {}
+        # 1x1 fprop with statistics: K = 64 (2 steps: the load side runs two tiles ahead), 128, 560 (a half-empty last block), ragged rows / pixels
+        for ci, co, hw in ((64, 256, 24), (128, 96, 20), (560, 128, 16), (192, 130, 33)):
+            x = torch.randn(3, ci, hw, hw, generator=g(ci)).to(DEV) * 3.0
+            w = (torch.randn(co, ci, 1, 1, generator=g(co)) * 0.1).to(DEV)
+            w4f, w4d, wa = ops.pack_weight_f16x2(w, True, ops.f16x3_eligible(co, ci, 1))
+            y, st, sl = ops.conv_fprop_f16x3(x, w4f, wa, ops.absmax(x), co, 1, want_stats=True)
+            out['y', ci, co] = y.clone()
+            out['stats', ci, co] = st[:2 * co * sl].clone()
+            if w4d is not None:
+                dy = torch.randn(3, co, hw, hw, generator=g(1)).to(DEV) * 1e-3
+                dx = ops.conv_dgrad_f16x3(dy, w4d, wa, ops.absmax(dy), ci, (hw, hw), 1)
+                out['dx', ci, co] = dx.clone()
+                out['dx2', ci, co] = ops.conv_dgrad_f16x3(dy, w4d, wa, ops.absmax(dy), ci, (hw, hw), 1, out=dx, accumulate=True).clone()
+        # data gradient with the fused BatchNorm-backward sums (whole 128-row tiles), with and without the residual form
+        n, co, ci, hw = 2, 96, 256, 32
+        w = (torch.randn(co, ci, 1, 1, generator=g(3)) * 0.1).to(DEV)
+        _, w4d, wa = ops.pack_weight_f16x2(w, False, True)
+        dy = torch.randn(n, co, hw, hw, generator=g(4)).to(DEV)
+        pre = torch.randn(n, ci, hw, hw, generator=g(5)).to(DEV)
+        gamma, beta = torch.rand(ci, generator=g(6)).to(DEV) + 0.5, (torch.randn(ci, generator=g(7)) * 0.1).to(DEV)
+        _, _, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+        yres = torch.relu(torch.randn(n, ci, hw, hw, generator=g(8))).to(DEV)
+        for name, bnb in (('relu', (pre, None, coef, True)), ('residual', (pre, yres, coef, True)), ('plain', (pre, None, coef, False))):
+            dx, part, sl = ops.conv_dgrad_f16x3(dy, w4d, wa, ops.absmax(dy), ci, (hw, hw), 1, bnb=bnb)
+            out['bnb', name] = dx.clone()
+            out['bnb_part', name] = part[:2 * ci * sl].clone()
+        # the 36 transform-domain GEMMs of a Winograd layer (tiles of different filter sets in one chain) and their data gradient
+        x = torch.randn(2, 128, 24, 24, generator=g(9)).to(DEV)
+        w3 = (torch.randn(160, 128, 3, 3, generator=g(10)) * 0.1).to(DEV)
+        uf, ud, af, ad = ops.wino_pack_weight_f16(w3)
+        out['wino'] = ops.wino_conv(x, uf, 160, 2, u_amax=af).clone()
+        out['wino_d'] = ops.wino_conv(out['wino'], ud, 128, 2, u_amax=ad).clone()
+        return out
+    try:
+        ops.set_f16x3_slots(slots)
+        chained = run()
+        ops.set_f16x3_slots(1 << 20)          # more slots than tiles: one workgroup per tile
+        single = run()
+    finally:
+        ops.set_f16x3_slots(0)
+    assert chained.keys() == single.keys()
+    for k in single:
+        assert torch.equal(chained[k], single[k]), k
