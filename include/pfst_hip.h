@@ -154,6 +154,7 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
 /* The f16x3 GEMMs walk their tiles in chains of up to 8 per workgroup, the grid sized for the resident workgroup slots of the device
  * (2 per CU).  pfst_f16x3_set_slots overrides that number (0 = the device's): a test hook that makes small problems chain. */
 int pfst_f16x3_set_slots(int slots);
+int pfst_f16x3_chain_grid(long long total_tiles, int chainable);   /* the workgroup count such a launch uses */
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                          int M, int T, int m, int v_packed, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,

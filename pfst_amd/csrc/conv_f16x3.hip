@@ -973,6 +973,13 @@ extern "C" int pfst_f16x3_set_slots(int slots) {
   return PFST_OK;
 }
 
+// the grid pfst_conv_igemm_f16x3 / pfst_wino_gemm_f16x3 launch for `total_tiles` 128 x 128 tiles (chainable: a 1x1 / Winograd-domain
+// contraction with an even number of K = 32 steps): total_tiles itself, or fewer workgroups that each walk up to 8 tiles
+extern "C" int pfst_f16x3_chain_grid(long long total_tiles, int chainable) {
+  if (total_tiles <= 0 || total_tiles >= (1ll << 31)) return 0;
+  return (int)f16x3_grid(total_tiles, chainable != 0);
+}
+
 // max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the
 // groups must have been zeroed (or hold an earlier maximum to extend).  pfst_absmax is the stand-alone form; producers of GEMM operands write their slots themselves.
 extern "C" int pfst_absmax(const float* x, long long n, int planes, long long plane_stride, int slot_stride, float* slots,
