@@ -13,6 +13,9 @@ import os
 SLICE_ELEMS = 16 * 1024 * 1024      # 64 MB per collective
 # bucketed all-reduce overlapped with the backward sweep (GradReducer); PFST_DDP_OVERLAP=0: one reduction after the sweep
 OVERLAP_ALLREDUCE = os.environ.get('PFST_DDP_OVERLAP', '1') == '1'
+# smallest bucket the overlapped reducer sends on its own: xGMI is point-to-point (ring all-reduce: per-link bound, ~20-50 us of latency per
+# collective on 8 ranks), so a 174 MB gradient travels as ~10 collectives of >= 16 MB rather than one per layer
+BUCKET_ELEMS = int(float(os.environ.get('PFST_DDP_BUCKET_MB', '16')) * (1 << 20) / 4)
 
 
 def is_distributed():
@@ -114,13 +117,13 @@ class GradReducer:
     continues; `finish()` reduces what is left and makes the current stream wait for all of it.  Mean over ranks (AVG on RCCL, SUM
     and a scale on gloo)."""
 
-    def __init__(self, flat, group=None, min_bucket=1 << 20):
+    def __init__(self, flat, group=None, min_bucket=None):
         assert flat.dim() == 1 and flat.is_contiguous()
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group)
         self.avg = dist.get_backend(group) == 'nccl'
         self.hi = flat.numel()               # everything at or above `hi` is already on its way
-        self.min_bucket = min_bucket
+        self.min_bucket = BUCKET_ELEMS if min_bucket is None else min_bucket
         self.pending = []
 
     def _launch(self, lo, hi):
