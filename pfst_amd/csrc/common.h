@@ -31,6 +31,32 @@ typedef long long i64;
 
 static inline int cdiv(i64 a, i64 b) { return (int)((a + b - 1) / b); }
 
+// Tile order of the implicit-GEMM kernels: workgroup `lin` of an image's gx x gy tiles -> (pixel tile bx, row tile by).  Workgroups are
+// dealt round-robin over the 8 XCDs (each with its own L2), so for gx % 8 == 0
+//  - the row tiles that share a pixel tile (= one activation tile) get ids 8 apart: same XCD, back to back, L2 hits for all but one;
+//  - band != 0 (3x3 kernels): every XCD walks its OWN contiguous eighth of the pixel tiles, so that the tiles of adjacent image rows,
+//    which re-read each other's rows through the taps, meet in one L2.  Dealt round-robin, vertical neighbours sit Wo / 128 ids apart,
+//    i.e. on different XCDs: 2.6x the activation bytes came from beyond L2 on the 32-channel stem layers (HBM-bound at 4.7 TB/s).
+#ifdef __HIPCC__
+__device__ __forceinline__ void pfst_tile_order(int lin, int gx, int gy, int band, int& bx, int& by) {
+  if ((gx & 7) == 0) {
+    if (band) {
+      const int j = lin >> 3;
+      const int idx = j / gy;
+      by = j - idx * gy;
+      bx = (lin & 7) * (gx >> 3) + idx;
+    } else {
+      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
+      by = r >> 3;
+      bx = grp * 8 + (r & 7);
+    }
+  } else {
+    by = lin / gx;
+    bx = lin - by * gx;
+  }
+}
+#endif
+
 // grid size for a grid-stride elementwise kernel: cap at 256 CUs x 8 blocks
 static inline int ew_grid(i64 n, int block = 256) {
   i64 g = (n + block - 1) / block;

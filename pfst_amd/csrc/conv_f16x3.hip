@@ -242,14 +242,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const int z = zy / Y;
     y = zy - z * Y;
     n = y * Z + z;
-    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
-      const int grp = x / (8 * gy), r = x - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = x / gx;
-      bx = x - by * gx;
-    }
+    pfst_tile_order(x, gx, gy, !ONE && ks == 3, bx, by);   // XCD-aware (common.h)
   };
   const int spt = (C + 31) / 32;                         // K=32 steps per filter tap (1x1: the last one may be half empty)
   const int ntaps = ONE ? 1 : ks * ks;

@@ -98,14 +98,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void c
     t_n = blockIdx.y * N + blockIdx.z;              // image index straight from SGPRs: the buffer descriptors stay scalar
     const int lin = tile;
     int by;
-    if ((gx & 7) == 0) {
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      t_bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      t_bx = lin - by * gx;
-    }
+    pfst_tile_order(lin, gx, gy, ks == 3, t_bx, by);
     t_p0 = t_bx * BN;
     t_m0 = by * BM;
     in = in_all + (i64)t_n * in_bs;

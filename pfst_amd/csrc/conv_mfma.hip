@@ -65,14 +65,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   {
     const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int lin = blockIdx.x;
-    if ((gx & 7) == 0) {
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      bx = lin - by * gx;
-    }
+    pfst_tile_order(lin, gx, gy, ks == 3, bx, by);
   }
   const int p0 = bx * BN, m0 = by * BM, n = blockIdx.z;
   const int K = C * ks * ks;

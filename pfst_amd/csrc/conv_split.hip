@@ -81,14 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_split_kernel(
   {
     const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int lin = blockIdx.x;
-    if ((gx & 7) == 0) {
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      bx = lin - by * gx;
-    }
+    pfst_tile_order(lin, gx, gy, ks == 3, bx, by);
   }
   const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;   // gridDim.y > 1: batched GEMMs (Winograd), group = blockIdx.y
   const int K = C * ks * ks;
@@ -353,14 +346,7 @@ __device__ __forceinline__ void conv_igemm_split_pipe_body(
   {
     const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int lin = blockIdx.x;
-    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD (see above)
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      bx = lin - by * gx;
-    }
+    pfst_tile_order(lin, gx, gy, ks == 3, bx, by);
   }
   const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
   const int spt = C / 16;                                // K-steps per filter tap
@@ -558,14 +544,7 @@ __device__ __forceinline__ void conv_igemm_split_pair_body(
   {
     const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM;
     const int lin = blockIdx.x;
-    if ((gx & 7) == 0) {                                 // the m-tiles of one pixel tile run back to back on one XCD
-      const int grp = lin / (8 * gy), r = lin - grp * 8 * gy;
-      by = r >> 3;
-      bx = grp * 8 + (r & 7);
-    } else {
-      by = lin / gx;
-      bx = lin - by * gx;
-    }
+    pfst_tile_order(lin, gx, gy, ks == 3, bx, by);
   }
   const int p0 = bx * BN, m0 = by * BM, n = blockIdx.y * gridDim.z + blockIdx.z;
   const int spt = C / 32;                                // K=32 steps per filter tap
