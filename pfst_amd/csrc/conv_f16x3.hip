@@ -212,7 +212,11 @@ __global__ __launch_bounds__(256) void pack_weight_f16x2_batched_kernel(const pf
 // BPACK: the activation operand is stored pre-split (Winograd-domain V written by pfst_wino_input in packed mode)
 // ONE: a 1x1 convolution with stride 1 and no padding (and the Winograd-domain GEMMs): output pixel = input pixel, no tap arithmetic --
 // the form the tile chain exists for (fewer live scalars: the chain's two-sided tile state must not push the loop's SGPRs out)
-template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false>
+// BMT: rows of the workgroup tile.  256 (512 threads, eight waves of 64 x 64, one workgroup per CU; 1x1 / Winograd-domain launches with
+// M % 256 == 0): every thread stages ONE K=16 tile of a pair instead of both, i.e. half the split instructions, activation loads and
+// activation LDS stores per MFMA, and an activation tile is fetched once for 256 output rows.  (Diagnostic: the 128-row loop with the
+// second tile's loads and split removed -- wrong results, timing only -- runs 10-11 % faster at every K.)
+template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false, int BMT = 128>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
@@ -220,7 +224,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb) {
   static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
   static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
-  constexpr int BM = 128, WAVES_N = 2;
+  static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE), "the 256-row tile exists for the pixel-to-pixel 32x32 loop");
+  constexpr int BM = BMT, WAVES_N = 2, NT = 2 * BM;             // NT threads: BM / 64 x 2 waves
+  constexpr int TPT = BM == 128 ? 2 : 1;                        // K=16 activation tiles of a pair one thread stages
   constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
   // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
   // stores of pair k+1 go to the other buffer whenever their data is ready.  SHAPE 16: one buffer, barrier A in the MFMA stream.
@@ -255,8 +261,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // LDS buffer / register set of a pair is its parity) and the 32x32 loop; otherwise every tile runs its own prologue.
   const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && chain != 0;
 
-  const int pix = tid & (BN - 1), kh = tid >> 7;
-  const int a_seg = tid / BM, a_row = tid - a_seg * BM;  // chunk c = tid + 256 i of a tile -> segment seg + 2 i, same row
+  const int pix = tid & (BN - 1), kh = (tid >> 7) & 1;   // activation staging: pixel, k-half ...
+  const int bt = BM == 128 ? 0 : tid >> 8;               // ... and (256-row tile) which K=16 tile of the pair
+  const int a_seg = tid / BM, a_row = tid - a_seg * BM;  // chunk c = tid + NT i of a tile -> segment seg + 2 i, same row
   constexpr unsigned OOB = 0x80000000u;
   const int a_chunk = 2 * M * 16, a_tile = 2 * NP * M * 16, b_chan = HiWi * 4;
   const int chan_step = 32 * HiWi * 4;
@@ -285,7 +292,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   };
   // activation voffset of the pixel for filter tap `tap` (0 .. ks*ks-1): constant while the tap does not change
   auto tap_voff = [&](int tap) -> unsigned {
-    if constexpr (ONE) return ld_pvalid ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)ld_oy) : OOB;
+    if constexpr (ONE) return ld_pvalid ? 4u * ((unsigned)(bt * 16 + kh * 8) * (unsigned)HiWi + (unsigned)ld_oy) : OOB;
     const int ty = tap / ks, tx = tap - ty * ks;
     int sy, sx;
     const bool ok = ld_pvalid & src_coord(ld_oy, ty, ca, cb, cc, cdivv, Hi, sy) & src_coord(ld_ox, tx, ca, cb, cc, cdivv, Wi, sx);
@@ -293,7 +300,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   };
 
   uint4 areg[2][4];                                      // [register set][tile 2][piece 2]: like the activations, two pairs ahead
-  float breg[2][2][8];                                   // [register set][tile][channel kh * 8 + i of the tile's 16]
+  float breg[2][TPT][8];                                 // [register set][tile][channel kh * 8 + i of the tile's 16]
   f32x4 acc[4][4];                                       // SHAPE 16
   pfst_f32x16 acc32[2][2];                               // SHAPE 32 (and the epilogue's layout)
 #pragma unroll
@@ -309,7 +316,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
 
   // loads of pair q: activations into register set SET (v = 0..15), weights into areg (v = 16..19)
   auto load_b = [&](auto vc, auto setc, unsigned voff, int soff) {
-    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;
+    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;                // v = 0 .. 8 TPT - 1 (256-row tile: the thread's one tile sits in voff)
     breg[SET][v >> 3][v & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, soff + ((v >> 3) * 16 + (v & 7)) * b_chan, 0));
   };
   auto load_a = [&](auto vc, auto setc, int a_soff) {
@@ -347,23 +354,26 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     set_load_side(lin);
     tap2 = sidx2 = 0;
     voff2 = tap_voff(0);
-    static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
+    static_for<8 * TPT>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
     static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 0>(), 0); });
     advance();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      As[t * TILE_A + tid] = areg[0][t * 2 + 0];
+      As[t * TILE_A + tid + NT] = areg[0][t * 2 + 1];
+    }
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) {
       uint4 ph, pl;
       if constexpr (BPACK) unpack8_f16(breg[0][t], ph, pl);
       else split8_f16(breg[0][t], sb, ph, pl);
-      As[t * TILE_A + tid] = areg[0][t * 2 + 0];
-      As[t * TILE_A + tid + 256] = areg[0][t * 2 + 1];
-      Bs[t * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
-      Bs[t * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
+      Bs[(t + bt) * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
+      Bs[(t + bt) * TILE_B + (1 * 2 + kh) * BN + pix] = pl;
     }
     // pair 1 (past the end of a one-step contraction the offset is out of range: zeros)
     {
       const int soff = sidx2 * chan_step, a_soff = (tap2 * spt + sidx2) * 2 * a_tile;
-      static_for<16>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, soff); });
+      static_for<8 * TPT>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, soff); });
       static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), a_soff); });
     }
     advance();
@@ -453,31 +463,40 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
       acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc32[i][j], 0, 0, 0);
       if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
-      if constexpr (m < 8) {
-        load_b(std::integral_constant<int, 2 * m>(), std::integral_constant<int, SETL>(), voff2, soff2);
-        load_b(std::integral_constant<int, 2 * m + 1>(), std::integral_constant<int, SETL>(), voff2, soff2);
+      if constexpr (m < 8) {                                        // (256-row tile: one load per slot)
+        if constexpr (TPT == 2) {
+          load_b(std::integral_constant<int, 2 * m>(), std::integral_constant<int, SETL>(), voff2, soff2);
+          load_b(std::integral_constant<int, 2 * m + 1>(), std::integral_constant<int, SETL>(), voff2, soff2);
+        } else {
+          load_b(std::integral_constant<int, m>(), std::integral_constant<int, SETL>(), voff2, soff2);
+        }
       }
-      if constexpr (m >= 8 && m < 12) As[NXT + ((m - 8) / 2) * TILE_A + tid + 256 * ((m - 8) % 2)] = areg[SETN][m - 8];
+      if constexpr (m >= 8 && m < 12) As[NXT + ((m - 8) / 2) * TILE_A + tid + NT * ((m - 8) % 2)] = areg[SETN][m - 8];
       if constexpr (m >= 12) {
-        static_for<4>([&](auto kc) {
-          constexpr int kk = (m - 12) * 4 + decltype(kc)::value;
-          if constexpr (BPACK) {                                  // 16 permutes (slots 12-15) instead of 48 split instructions
+        constexpr int SPS = 2 * TPT;                                // split instructions per slot: 48 (24: one tile) over slots 12-23
+        static_for<SPS>([&](auto kc) {
+          constexpr int kk = (m - 12) * SPS + decltype(kc)::value;
+          if constexpr (BPACK) {                                  // 16 (8) permutes instead of 48 (24) split instructions
             if constexpr (kk < 8) unpack_op_f16<kk>(breg[SETN][0], s0);
-            else if constexpr (kk < 16) unpack_op_f16<kk - 8>(breg[SETN][1], s1);
+            else if constexpr (kk < 16 && TPT == 2) unpack_op_f16<kk - 8>(breg[SETN][TPT - 1], s1);
           } else {
             if constexpr (kk < 24) split_op_f16<kk>(breg[SETN][0], sb, s0);
-            else split_op_f16<kk - 24>(breg[SETN][1], sb, s1);
+            else split_op_f16<kk - 24>(breg[SETN][TPT - 1], sb, s1);
           }
         });
       }
       if constexpr (m >= 12 && m < 16) load_a(std::integral_constant<int, m - 12>(), std::integral_constant<int, SETL>(), a_soff2);
-      if constexpr (m == 18) {
+      if constexpr (m == 18 && TPT == 2) {
         Bs[NXT + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
         Bs[NXT + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
       }
-      if constexpr (m == 23) {
+      if constexpr (m == 23 && TPT == 2) {
         Bs[NXT + TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
         Bs[NXT + TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      }
+      if constexpr (m == 23 && TPT == 1) {                          // the thread's one tile
+        Bs[NXT + bt * TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+        Bs[NXT + bt * TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -505,7 +524,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       if constexpr (BNB != 0) {
         // the reduction scratch is LDS buffer 1: the last step (odd, or the only one) read it and ended with a barrier; buffer 0 may
         // already hold the next tile's first pair
-        static_assert(PAIR_CHUNKS * sizeof(uint4) >= 4 * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into one pair buffer");
+        static_assert(PAIR_CHUNKS * sizeof(uint4) >= (NT / 64) * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into one pair buffer");
         conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
                                                     reinterpret_cast<float*>(smem + PAIR_CHUNKS));
         __syncthreads();                                 // before the next tile's first step stores into that buffer
@@ -560,22 +579,22 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   }
 }
 
-template <int SHAPE, bool BPACK = false, bool ONE = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_kernel(
+template <int SHAPE, bool BPACK = false, bool ONE = false, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain) {
-  conv_igemm_f16x3_body<SHAPE, 0, BPACK, ONE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+  conv_igemm_f16x3_body<SHAPE, 0, BPACK, ONE, BMT>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                w_amax, in_amax, Y, Z, chain, PfstBnbArgs());
 }
-template <int BNB, bool ONE = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_bnb_kernel(
+template <int BNB, bool ONE = false, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_bnb_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, PfstBnbArgs bnb) {
-  conv_igemm_f16x3_body<32, BNB, false, ONE>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
+  conv_igemm_f16x3_body<32, BNB, false, ONE, BMT>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                  w_amax, in_amax, Y, Z, chain, bnb);
 }
 
@@ -929,14 +948,19 @@ int f16x3_chain() {
   return v != 0;
 }
 int f16x3_slots_override = 0;                             // pfst_f16x3_set_slots
-unsigned f16x3_grid(i64 total, bool chainable) {
-  static int dev_slots = 0;
-  if (dev_slots == 0) {
-    int dev = 0, cus = 0;
+int f16x3_bm256() {                                       // PFST_F16X3_BM256=0: the 128-row tile everywhere (A/B runs)
+  static const int v = getenv("PFST_F16X3_BM256") ? atoi(getenv("PFST_F16X3_BM256")) : 1;
+  return v != 0;
+}
+unsigned f16x3_grid(i64 total, bool chainable, int wg_per_cu = 2) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    dev_slots = 2 * cus;                                  // __launch_bounds__(256, 2): two workgroups per CU
   }
-  const int slots = f16x3_slots_override > 0 ? f16x3_slots_override : dev_slots;
+  // resident workgroups: two 256-thread workgroups per CU, one of the 512-thread 256-row tile (the override counts 256-thread slots)
+  int slots = (f16x3_slots_override > 0 ? f16x3_slots_override : 2 * cus) * wg_per_cu / 2;
+  if (slots < 1) slots = 1;
   if (!chainable || !f16x3_chain() || total <= slots) return (unsigned)total;
   i64 best_g = total;
   double best_waste = 1e30;
@@ -1044,10 +1068,11 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
-  const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, 128) * N;
-  PFST_CHECK_ARG(total < (1ll << 31));
   const bool one = ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
-  const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0));
+  const bool big = one && M % 256 == 0 && f16x3_bm256();                              // 256-row tiles, 512 threads, one workgroup per CU
+  const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : 128) * N;
+  PFST_CHECK_ARG(total < (1ll << 31));
+  const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
   const int chain = f16x3_chain();
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
@@ -1055,7 +1080,14 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
 #define PFST_LAUNCH_F16_BNB(MODE_, ONE_)                                                                                                    \
     hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_, ONE_>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
                        out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb)
-    if (one) {
+#define PFST_LAUNCH_F16_BNB_BIG(MODE_)                                                                                                      \
+    hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
+                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb)
+    if (big) {
+      if (!bnb->relu) PFST_LAUNCH_F16_BNB_BIG(3);
+      else if (bnb->y) PFST_LAUNCH_F16_BNB_BIG(2);
+      else PFST_LAUNCH_F16_BNB_BIG(1);
+    } else if (one) {
       if (!bnb->relu) PFST_LAUNCH_F16_BNB(3, true);
       else if (bnb->y) PFST_LAUNCH_F16_BNB(2, true);
       else PFST_LAUNCH_F16_BNB(1, true);
@@ -1065,10 +1097,14 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
       else PFST_LAUNCH_F16_BNB(1, false);
     }
 #undef PFST_LAUNCH_F16_BNB
+#undef PFST_LAUNCH_F16_BNB_BIG
     PFST_CHECK_LAUNCH();
     return PFST_OK;
   }
-  if (one)
+  if (big)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+  else if (one)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
   else if (f16x3_shape() == 32)
@@ -1089,12 +1125,19 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
   const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
-  const i64 total = (i64)cdiv((i64)T, BN) * cdiv(M, 128) * nx * N;
+  const bool big = M % 256 == 0 && f16x3_bm256() && (v_packed || f16x3_shape() == 32);
+  const i64 total = (i64)cdiv((i64)T, BN) * cdiv(M, big ? 256 : 128) * nx * N;
   PFST_CHECK_ARG(total < (1ll << 31));
-  const dim3 grid(f16x3_grid(total, f16x3_shape() == 32 && (K / 32) % 2 == 0));
+  const dim3 grid(f16x3_grid(total, (v_packed || f16x3_shape() == 32) && (K / 32) % 2 == 0, big ? 1 : 2));
   const int chain = f16x3_chain();
   // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
-  if (v_packed)
+  if (big && v_packed)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+  else if (big)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+  else if (v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
                        (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
   else if (f16x3_shape() == 32)

@@ -896,6 +896,17 @@ def test_f16x3_tile_chain_is_the_same_arithmetic(ops, slots):
         uf, ud, af, ad = ops.wino_pack_weight_f16(w3)
         out['wino'] = ops.wino_conv(x, uf, 160, 2, u_amax=af).clone()
         out['wino_d'] = ops.wino_conv(out['wino'], ud, 128, 2, u_amax=ad).clone()
+        # ... and with 256 output rows: the 256-row workgroup tile (512 threads), packed and plain activations
+        w4 = (torch.randn(256, 128, 3, 3, generator=g(11)) * 0.1).to(DEV)
+        uf4, _, af4, _ = ops.wino_pack_weight_f16(w4, True, False)
+        out['wino256'] = ops.wino_conv(x, uf4, 256, 1, u_amax=af4).clone()
+        for ci, co, hw in ((128, 512, 20), (192, 256, 33)):
+            xx = torch.randn(2, ci, hw, hw, generator=g(ci + 1)).to(DEV)
+            ww = (torch.randn(co, ci, 1, 1, generator=g(co + 1)) * 0.1).to(DEV)
+            w4f, _, wa = ops.pack_weight_f16x2(ww, True, False)
+            y, st, sl = ops.conv_fprop_f16x3(xx, w4f, wa, ops.absmax(xx), co, 1, want_stats=True)
+            out['y256', ci, co] = y.clone()
+            out['stats256', ci, co] = st[:2 * co * sl].clone()
         return out
     try:
         ops.set_f16x3_slots(slots)
