@@ -768,15 +768,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
 // barrier instead of 12, so the fragment-read latency in front of a step's first MFMA and the barrier are paid half as often.
 // 64 KB of LDS (two pair buffers of both operands), two workgroups per CU as before.  Per step and thread: 8 wide loads (pair k+2),
 // 96 split instructions (pair k+1; 32 permutes when PACK), 8 LDS stores to the other buffer, 16 fragment reads.
-template <bool PACK>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
+// BMT = 256: 256 rows of dY per workgroup (512 threads, one workgroup per CU): a thread stages both tiles of its dY row but ONE tile of
+// its X row -- 24 values per step instead of 32, and an X tile is fetched once for 256 rows of dY.
+template <bool PACK, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_pair_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
     int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
     const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
-  constexpr int BM = 128, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
-  constexpr int TILE = 2 * NP * BM;                         // chunks of one K=16 tile of one operand (BM == BJ)
+  constexpr int BM = BMT, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
+  constexpr int TILE_A = 2 * NP * BM, TILE = 2 * NP * BJ;   // chunks of one K=16 tile of dY / of X
+  constexpr int TPTB = BM == 128 ? 2 : 1;                   // X tiles of a pair one thread stages
   constexpr unsigned OOB = 0x80000000u;
-  __shared__ uint4 As[2][2 * TILE];                       // [buffer][tile][piece][k-half][row]
+  __shared__ uint4 As[2][2 * TILE_A];                     // [buffer][tile][piece][k-half][row]
   __shared__ uint4 Bs[2][2 * TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -812,11 +815,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
 
-  const int srow = tid >> 1, half = tid & 1;        // staging role: 8 consecutive pixels of one row per operand and tile
+  // staging role: 8 consecutive pixels of one row per operand and tile (256-row tile: row tid / 2 of dY, both tiles; row (tid / 2) % 128
+  // of X, tile tid / 256)
+  const int srow = tid >> 1, half = tid & 1;
+  const int brow = BM == 128 ? srow : srow & 127, bt = BM == 128 ? 0 : tid >> 8;
   const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
-  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
+  const unsigned b_voff = (j0 + brow < J) ? 4u * ((unsigned)(j0 + brow) * (unsigned)P + 8u * half + 16u * bt) : OOB;
 
-  float la[2][2][8], lb[2][2][8];                   // [register set][tile of the pair][8 pixels]
+  float la[2][2][8], lb[2][TPTB][8];                // [register set][tile of the pair][8 pixels]
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -827,9 +833,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
 
   // load q = 0..7 of the pair starting at pixel pk0: operand q / 4 (dy, x), tile (q / 2) % 2, quad q % 2.  P % 4 == 0 and
   // chunk_len % 16 == 0: a quad is entirely in or out (out: zeros -- an odd tile count leaves the pair's second tile empty)
+  // (256-row tile: q = 4, 5 are the two quads of the thread's ONE X tile, whose 16-pixel offset sits in b_voff)
   auto load_quad = [&](auto qc, auto setc, int pk0) {
-    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value, opb = q >> 2, t = (q >> 1) & 1, quad = q & 1;
-    const int p = pk0 + 16 * t + 8 * half + 4 * quad;
+    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value, opb = q >> 2, t = (TPTB == 1 && opb) ? 0 : (q >> 1) & 1, quad = q & 1;
+    const int p = pk0 + 16 * (opb ? t + bt : t) + 8 * half + 4 * quad;
     const bool v = p < pend;
     const float4 w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(opb ? b_rsrc : a_rsrc, v ? (opb ? b_voff : a_voff) : OOB,
                                                                                       pk0 * 4 + 64 * t + 16 * quad, 0));
@@ -839,18 +846,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
   const int l31 = lane & 31, lh = lane >> 5;
 
   // prologue: pair 0 through the plain split into buffer 0, pair 1 into register set 1
-  static_for<8>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
+  static_for<4 + 2 * TPTB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     uint4 ph, pl;
     if constexpr (PACK) unpack8_f16(la[0][t], ph, pl);
     else split8_f16(la[0][t], sa, ph, pl);
-    As[0][t * TILE + (0 * 2 + half) * BM + srow] = ph; As[0][t * TILE + (1 * 2 + half) * BM + srow] = pl;
+    As[0][t * TILE_A + (0 * 2 + half) * BM + srow] = ph; As[0][t * TILE_A + (1 * 2 + half) * BM + srow] = pl;
+  }
+#pragma unroll
+  for (int t = 0; t < TPTB; ++t) {
+    uint4 ph, pl;
     if constexpr (PACK) unpack8_f16(lb[0][t], ph, pl);
     else split8_f16(lb[0][t], sb, ph, pl);
-    Bs[0][t * TILE + (0 * 2 + half) * BJ + srow] = ph; Bs[0][t * TILE + (1 * 2 + half) * BJ + srow] = pl;
+    Bs[0][(t + bt) * TILE + (0 * 2 + half) * BJ + brow] = ph; Bs[0][(t + bt) * TILE + (1 * 2 + half) * BJ + brow] = pl;
   }
-  static_for<8>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 32); });
+  static_for<4 + 2 * TPTB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 32); });
   __syncthreads();
 
   // one step on LDS buffer CUR = k & 1 (register set NXT holds pair k+1; pair k+2 is loaded into set CUR, whose values were split during
@@ -860,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
   auto step = [&](auto curc, int kp) {
     constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
     f16x8 af[2][TM][NP], bf[2][TN][NP];
-    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR][t * TILE + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
+    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR][t * TILE_A + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
     auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR][t * TILE + (pl * 2 + lh) * BJ + wn0 + j * 32 + l31]); };
     // r = 0..15: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 a1, the MFMAs' order
     auto read_frag = [&](auto rc) {
@@ -880,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
       constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc[i][j], 0, 0, 0);
       if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
-      if constexpr (m < 8) load_quad(mc, curc, pk2);
+      if constexpr (m < 4 + 2 * TPTB) load_quad(mc, curc, pk2);
       static_for<4>([&](auto kc) {
         constexpr int k = (m % 6) * 4 + decltype(kc)::value;          // 0..23 within the 8-value group of slot group m / 6
         constexpr int g = m / 6;                                      // 0: dy tile 0, 1: dy tile 1, 2: x tile 0, 3: x tile 1
@@ -889,13 +900,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
             if constexpr (g == 0) unpack_op_f16<k>(la[NXT][0], s0);
             else if constexpr (g == 1) unpack_op_f16<k>(la[NXT][1], s1);
             else if constexpr (g == 2) unpack_op_f16<k>(lb[NXT][0], s0);
-            else unpack_op_f16<k>(lb[NXT][1], s1);
+            else if constexpr (TPTB == 2) unpack_op_f16<k>(lb[NXT][TPTB - 1], s1);
           }
         } else {
           if constexpr (g == 0) split_op_f16<k>(la[NXT][0], sa, s0);
           else if constexpr (g == 1) split_op_f16<k>(la[NXT][1], sa, s1);
           else if constexpr (g == 2) split_op_f16<k>(lb[NXT][0], sb, s0);
-          else split_op_f16<k>(lb[NXT][1], sb, s1);
+          else if constexpr (TPTB == 2) split_op_f16<k>(lb[NXT][TPTB - 1], sb, s1);
         }
       });
       if constexpr (m == 6) {
@@ -903,16 +914,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_pair_kernel(
         As[NXT][(1 * 2 + half) * BM + srow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
       }
       if constexpr (m == 12) {
-        As[NXT][TILE + (0 * 2 + half) * BM + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-        As[NXT][TILE + (1 * 2 + half) * BM + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+        As[NXT][TILE_A + (0 * 2 + half) * BM + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+        As[NXT][TILE_A + (1 * 2 + half) * BM + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
       }
-      if constexpr (m == 18) {
-        Bs[NXT][(0 * 2 + half) * BJ + srow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
-        Bs[NXT][(1 * 2 + half) * BJ + srow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      if constexpr (m == 18) {                                      // (256-row tile: the thread's one X tile)
+        Bs[NXT][bt * TILE + (0 * 2 + half) * BJ + brow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
+        Bs[NXT][bt * TILE + (1 * 2 + half) * BJ + brow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
       }
-      if constexpr (m == 23) {
-        Bs[NXT][TILE + (0 * 2 + half) * BJ + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-        Bs[NXT][TILE + (1 * 2 + half) * BJ + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
+      if constexpr (m == 23 && TPTB == 2) {
+        Bs[NXT][TILE + (0 * 2 + half) * BJ + brow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
+        Bs[NXT][TILE + (1 * 2 + half) * BJ + brow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -1153,9 +1164,12 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                             i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
-  const int tiles = cdiv(J, 128) * cdiv(M, 128) * groups;
-  // split-K chunking: whole rounds of resident workgroups (2 per CU)
-  const double slots = 256.0 * 2;
+  static const int pair = getenv("PFST_F16X3_WGRAD_PAIR") ? atoi(getenv("PFST_F16X3_WGRAD_PAIR")) : 1;     // 0: the K=16-step kernel (A/B runs)
+  const bool big = pair && M % 256 == 0 && f16x3_bm256();       // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
+  const int bm = big ? 256 : 128;
+  const int tiles = cdiv(J, 128) * cdiv(M, bm) * groups;
+  // split-K chunking: whole rounds of resident workgroups (2 per CU; the 256-row tile: 1)
+  const double slots = big ? 256.0 : 256.0 * 2;
   int chunks = 1;
   double best = -1.0;
   for (int c = 1; c <= 64 && (c == 1 || P / c >= 512); ++c) {
@@ -1166,21 +1180,18 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
   }
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
-  const int gx = cdiv(J, 128), gy = cdiv(M, 128), gz = N * groups * chunks;
+  const int gx = cdiv(J, 128), gy = cdiv(M, bm), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  static const int pair = getenv("PFST_F16X3_WGRAD_PAIR") ? atoi(getenv("PFST_F16X3_WGRAD_PAIR")) : 1;     // 0: the K=16-step kernel (A/B runs)
-  if (pair && packed)
-    hipLaunchKernelGGL(conv_wgrad_f16x3_pair_kernel<true>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
-                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
-  else if (pair)
-    hipLaunchKernelGGL(conv_wgrad_f16x3_pair_kernel<false>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
-                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
-  else if (packed)
-    hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<true>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
-                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
-  else
-    hipLaunchKernelGGL(conv_wgrad_f16x3_kernel<false>, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N,
-                       x_gs, dy_gs, dw_gs, gx, gy, gz, x_amax, dy_amax);
+#define PFST_LAUNCH_WGRAD(KERNEL_, THREADS_)                                                                                               \
+  hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, \
+                     gx, gy, gz, x_amax, dy_amax)
+  if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true, 256>), 512);
+  else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false, 256>), 512);
+  else if (pair && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true>), 256);
+  else if (pair) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false>), 256);
+  else if (packed) PFST_LAUNCH_WGRAD(conv_wgrad_f16x3_kernel<true>, 256);
+  else PFST_LAUNCH_WGRAD(conv_wgrad_f16x3_kernel<false>, 256);
+#undef PFST_LAUNCH_WGRAD
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
