@@ -949,6 +949,204 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
   }
 }
 
+// The pair kernel with WHOLE-LINE loads.  There a thread loaded 8 consecutive pixels of a row (two lanes per row): one load instruction
+// touched 32 rows x 32 bytes, a quarter of each 128-byte line, and the other three quarters came from three more instructions -- the vector
+// L1 had to hold every line across four instructions; timing with fully coalesced (wrong) addresses: 51.8 -> 44.1 ms per step.  Here a
+// row's 32 pixels of a pair (128 bytes) are ONE line read by 8 adjacent lanes, a load instruction covers 8 whole lines: thread
+// (row slot r = tid / 8, segment s = tid % 8) loads pixels 4 s .. 4 s + 3 of rows r, r + RPP, ... (RPP = threads / 8 rows per pass), i.e.
+// half a 16-byte LDS chunk of tile s / 4, k-half (s / 2) % 2, and stores its two 8-byte piece halves with ds_write_b64.  The planes are
+// padded (+2 chunks per (piece, half) plane, +4 per tile) so that the 16 lanes of a ds_write_b64 group -- two rows x eight segments --
+// fall into 16 different bank pairs; the fragment reads stay 16 consecutive chunks per group.
+struct Split4 {
+  unsigned h[2], l[2];
+  float t0[2], t1[2];
+};
+template <int K>
+__device__ __forceinline__ void split4_op_f16(const float (&v)[4], float s, Split4& st) {        // K = 0..11: split_op_f16 on two pairs
+  constexpr int q = K / 6, op = K % 6;
+  if constexpr (op == 0) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(st.t0[q]) : "s"(s), "v"(v[2 * q]));
+  else if constexpr (op == 1) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(st.t1[q]) : "s"(s), "v"(v[2 * q + 1]));
+  else if constexpr (op == 2) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.h[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
+  else if constexpr (op == 3)
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(st.t0[q]) : "v"(v[2 * q]), "s"(s), "v"(st.h[q]));
+  else if constexpr (op == 4)
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(st.t1[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
+  else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.l[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
+}
+template <int K>
+__device__ __forceinline__ void unpack4_op_f16(const float (&v)[4], Split4& st) {                 // K = 0..3: the permutes of a pre-split quad
+  constexpr int q = K & 1;
+  if constexpr (K < 2) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(st.h[q]) : "v"(v[2 * q + 1]), "v"(v[2 * q]), "s"(0x05040100u));
+  else asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(st.l[q]) : "v"(v[2 * q + 1]), "v"(v[2 * q]), "s"(0x07060302u));
+}
+
+template <bool PACK, int BMT = 128>
+__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_line_kernel(
+    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
+    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
+    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
+  constexpr int BM = BMT, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2, NT = 2 * BM;
+  constexpr int RPP = NT / 8;                               // rows per load pass
+  constexpr int PA = BM / RPP, PB = BJ / RPP;               // passes (= loads per thread and pair) over the dY / X rows: 4 + 4, or 4 + 2
+  constexpr int ROWS_A = BM + 2, ROWS_B = BJ + 2;           // padded (piece, half) planes, in 16-byte chunks
+  constexpr int TILE_A = 4 * ROWS_A + 4, TILE_B = 4 * ROWS_B + 4;
+  __shared__ uint4 As[2][2 * TILE_A];                     // [buffer][tile][piece][k-half][row]
+  __shared__ uint4 Bs[2][2 * TILE_B];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
+  int bx, by, bz;
+  {
+    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
+    if (lin < tiles * z8) {
+      const int xcd = lin & 7, idx = lin >> 3;
+      const int sl = idx / tiles, t = idx - sl * tiles;
+      bz = sl * 8 + xcd;
+      by = t / gx;
+      bx = t - by * gx;
+    } else {
+      bz = lin / tiles;
+      const int t = lin - bz * tiles;
+      by = t / gx;
+      bx = t - by * gx;
+    }
+  }
+  const int j0 = bx * BJ, m0 = by * BM;
+  const int ng = bz / chunks, chunk = bz - ng * chunks;
+  const int grp = ng / N, n = ng - grp * N;
+  const int pbeg = chunk * chunk_len;
+  const int pend = min(P, pbeg + chunk_len);
+  if (pbeg >= pend) return;
+  x += (i64)grp * x_gs + (i64)n * x_bs;
+  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
+  dw += (i64)grp * dw_gs;
+  const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
+  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
+  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
+  // rows past M / J lie outside the buffers' ranges and read zeros (the range check includes the scalar offset)
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
+
+  const int rslot = tid >> 3, seg = tid & 7;               // staging role: row slot, 16-byte segment of the pair's 128-byte line
+  constexpr unsigned OOB = 0x80000000u;
+  const unsigned a_voff = 4u * ((unsigned)(m0 + rslot) * (unsigned)P) + 16u * seg;
+  const unsigned b_voff = 4u * ((unsigned)(j0 + rslot) * (unsigned)P) + 16u * seg;
+  const int row_step = RPP * P * 4;                        // bytes between the rows of two passes (scalar offset)
+  // this thread's half chunk: tile seg / 4, k-half (seg / 2) % 2, 8-byte half seg % 2 of the chunk of row `rslot` (+ RPP per pass)
+  const int a_half = 2 * ((seg >> 2) * TILE_A + ((seg >> 1) & 1) * ROWS_A + rslot) + (seg & 1);     // in 8-byte units
+  const int b_half = 2 * ((seg >> 2) * TILE_B + ((seg >> 1) & 1) * ROWS_B + rslot) + (seg & 1);
+
+  float la[2][PA][4], lb[2][PB][4];                 // [register set][pass][4 pixels]
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // load q = 0 .. PA + PB - 1 of the pair starting at pixel pk0: dY passes first.  P % 4 == 0 and chunk_len % 16 == 0: a quad is entirely
+  // in or out of the chunk (out: zeros)
+  auto load_quad = [&](auto qc, auto setc, int pk0) {
+    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value, opb = q >= PA, pass = opb ? q - PA : q;
+    const bool v = pk0 + 4 * seg < pend;
+    const float4 w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(opb ? b_rsrc : a_rsrc, v ? (opb ? b_voff : a_voff) : OOB,
+                                                                                      pk0 * 4 + pass * row_step, 0));
+    float (&dst)[4] = opb ? lb[SET][pass] : la[SET][pass];
+    dst[0] = w.x; dst[1] = w.y; dst[2] = w.z; dst[3] = w.w;
+  };
+  // the two 8-byte stores of half chunk q (pieces h, l: planes 2 apart)
+  auto store_half = [&](auto qc, int buf, const Split4& st) {
+    constexpr int q = decltype(qc)::value, opb = q >= PA, pass = opb ? q - PA : q;
+    if constexpr (opb) {
+      uint2* b2 = reinterpret_cast<uint2*>(&Bs[buf][0]);
+      b2[b_half + 2 * pass * RPP] = make_uint2(st.h[0], st.h[1]);
+      b2[b_half + 2 * (pass * RPP + 2 * ROWS_B)] = make_uint2(st.l[0], st.l[1]);
+    } else {
+      uint2* a2 = reinterpret_cast<uint2*>(&As[buf][0]);
+      a2[a_half + 2 * pass * RPP] = make_uint2(st.h[0], st.h[1]);
+      a2[a_half + 2 * (pass * RPP + 2 * ROWS_A)] = make_uint2(st.l[0], st.l[1]);
+    }
+  };
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  // prologue: pair 0 through the plain split into buffer 0, pair 1 into register set 1
+  static_for<PA + PB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
+  static_for<PA + PB>([&](auto qc) {
+    constexpr int q = decltype(qc)::value, opb = q >= PA, pass = opb ? q - PA : q;
+    Split4 st;
+    static_for<PACK ? 4 : 12>([&](auto kc) {
+      if constexpr (PACK) unpack4_op_f16<decltype(kc)::value>(opb ? lb[0][pass] : la[0][pass], st);
+      else split4_op_f16<decltype(kc)::value>(opb ? lb[0][pass] : la[0][pass], opb ? sb : sa, st);
+    });
+    store_half(qc, 0, st);
+  });
+  static_for<PA + PB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 32); });
+  __syncthreads();
+
+  // one step on LDS buffer CUR = k & 1 (register set NXT holds pair k+1; pair k+2 is loaded into set CUR).  24 MFMAs product-major,
+  // tile-minor; slots 0-11 one fragment read, 0 .. PA+PB-1 one load, three slots of four split instructions per half chunk (its two
+  // stores behind the MFMA of the third slot).
+  auto step = [&](auto curc, int kp) {
+    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
+    f16x8 af[2][TM][NP], bf[2][TN][NP];
+    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR][t * TILE_A + (pl * 2 + lh) * ROWS_A + wm0 + i * 32 + l31]); };
+    auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR][t * TILE_B + (pl * 2 + lh) * ROWS_B + wn0 + j * 32 + l31]); };
+    auto read_frag = [&](auto rc) {
+      constexpr int r = decltype(rc)::value, grp = r >> 2, e = r & 3, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
+      if constexpr (e == 0) rd_a(t, 0, pa);
+      else if constexpr (e == 1) rd_b(t, 0, pb);
+      else if constexpr (e == 2) rd_b(t, 1, pb);
+      else rd_a(t, 1, pa);
+    };
+    static_for<4>([&](auto rc) { read_frag(rc); });
+    __builtin_amdgcn_sched_barrier(0);
+    Split4 st[2];
+    const int pk2 = pbeg + (kp + 2) * 32;
+    static_for<24>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int prod = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
+      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc[i][j], 0, 0, 0);
+      if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
+      if constexpr (m < PA + PB) load_quad(mc, curc, pk2);
+      constexpr int q = m / 3, part = m % 3;                          // half chunk q = 0 .. 7 in slots 3 q .. 3 q + 2
+      if constexpr (q < PA + PB) {
+        constexpr int opb = q >= PA, pass = opb ? q - PA : q;
+        static_for<4>([&](auto kc) {
+          constexpr int k = part * 4 + decltype(kc)::value;
+          if constexpr (PACK) {
+            if constexpr (k < 4) unpack4_op_f16<k>(opb ? lb[NXT][pass] : la[NXT][pass], st[q & 1]);
+          } else {
+            split4_op_f16<k>(opb ? lb[NXT][pass] : la[NXT][pass], opb ? sb : sa, st[q & 1]);
+          }
+        });
+        if constexpr (part == 2) store_half(std::integral_constant<int, q>(), NXT, st[q & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __syncthreads();
+  };
+  const int KPAIRS = (pend - pbeg + 31) / 32;
+  for (int kp = 0; kp < KPAIRS; kp += 2) {
+    step(std::integral_constant<int, 0>(), kp);
+    if (kp + 1 < KPAIRS) step(std::integral_constant<int, 1>(), kp + 1);
+  }
+  const float ua = unscale_of(ea), ub = unscale_of(eb);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int jj = j0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r] * ua * ub);
+      }
+    }
+  }
+}
+
 // grid of the tile-chain GEMM.  A workgroup walks tiles blockIdx.x, + gridDim.x, ... as one software pipeline; how many tiles it gets is a
 // balance: long chains amortise the one prologue (4-6 K-steps' worth, tools/gemm_k_sweep.py), but the hardware can only even out the
 // CUs' speeds by handing out whole workgroups, and a last round of workgroups that fills a fraction of the slots wastes the rest.
@@ -1185,7 +1383,12 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
 #define PFST_LAUNCH_WGRAD(KERNEL_, THREADS_)                                                                                               \
   hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, \
                      gx, gy, gz, x_amax, dy_amax)
-  if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true, 256>), 512);
+  static const int line = getenv("PFST_F16X3_WGRAD_LINE") ? atoi(getenv("PFST_F16X3_WGRAD_LINE")) : 1;     // 0: the pair kernel's 32-byte row pieces
+  if (line && pair && big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
+  else if (line && pair && big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256>), 512);
+  else if (line && pair && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true>), 256);
+  else if (line && pair) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false>), 256);
+  else if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true, 256>), 512);
   else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false, 256>), 512);
   else if (pair && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true>), 256);
   else if (pair) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false>), 256);
