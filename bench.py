@@ -177,8 +177,8 @@ def pmc_traffic(kernel):
               'conv_wgrad_split_q_kernel': ('conv_wgrad_split_q_pipe_kernel',)}.get(base, ()) if want == ['128'] else ()
     if base == 'conv_igemm_f16x3_kernel':          # + the variants with the fused BatchNorm-backward epilogue
         family = ('conv_igemm_f16x3_bnb_kernel',)
-    if base == 'conv_wgrad_f16x3_kernel':          # the K=32-per-step kernel the entry point launches by default
-        family = ('conv_wgrad_f16x3_pair_kernel',)
+    if base == 'conv_wgrad_f16x3_kernel':          # the K=32-per-step kernels the entry point launches by default (whole-line loads)
+        family = ('conv_wgrad_f16x3_pair_kernel', 'conv_wgrad_f16x3_line_kernel')
     tot, calls = 0.0, 0
     for k, v in rec.items():          # all instantiations whose leading template arguments match (e.g. the fused-epilogue variants
         if not isinstance(v, dict):   # <128, 0..3> of conv_igemm_q_kernel<128>), weighted by their launch counts
