@@ -242,11 +242,14 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const int P = Ho * Wo, HiWi = Hi * Wi;
   const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM, X = gx * gy;
   const int total = X * Y * Z, G = gridDim.x;
-  // tile number -> (pixel tile, row tile, filter set y, image z): x fastest, the order a (X, Y, Z) grid is dispatched in
+  // tile number -> (pixel tile, row tile, filter set y, image z): the tiles of one GEMM fastest, then the IMAGES of one filter set, then
+  // the sets -- a set's weights (1 MB at 512 x 512) are then reused by the 8 images that follow each other on an XCD; with the sets
+  // inside the images (the order of an (X, Y, Z) grid) every image re-read all 36 sets: 2.9 GB of L2 misses per launch against 0.6 GB of
+  // activations, 5.3 TB/s of fabric traffic under a kernel meant to be matrix-bound
   auto decode = [&](int lin, int& bx, int& by, int& y, int& n) {
     const int zy = lin / X, x = lin - zy * X;
-    const int z = zy / Y;
-    y = zy - z * Y;
+    y = zy / Z;
+    const int z = zy - y * Z;
     n = y * Z + z;
     pfst_tile_order(x, gx, gy, !ONE && ks == 3, bx, by);   // XCD-aware (common.h)
   };
