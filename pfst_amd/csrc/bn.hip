@@ -219,20 +219,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int end = min(beg + chunk, HW);
   double s = 0.0, sx = 0.0;
   if (VEC) {
-    for (int i4 = (beg >> 2) + threadIdx.x; i4 < (end >> 2); i4 += blockDim.x) {
-      float4 g = reinterpret_cast<const float4*>(gp)[i4];
-      const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
-      if (relu) {
-        bool on[4];
-        relu_on4(mp, yp, i4, xv, sc, sh, on);
-        if (!on[0]) g.x = 0.f;
-        if (!on[1]) g.y = 0.f;
-        if (!on[2]) g.z = 0.f;
-        if (!on[3]) g.w = 0.f;
+    // four 16-byte loads per operand in flight per thread (as in the apply passes); the sums keep the order of the plain loop
+    constexpr int U = 4;
+    const int e4 = end >> 2;
+    for (int i0 = (beg >> 2) + threadIdx.x; i0 < e4; i0 += U * blockDim.x) {
+      float4 gq[U], xq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i4 = i0 + u * blockDim.x;
+        if (i4 < e4) {
+          gq[u] = reinterpret_cast<const float4*>(gp)[i4];
+          xq[u] = reinterpret_cast<const float4*>(xp)[i4];
+        }
       }
-      s += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
-      sx += ((double)g.x * (double)((xv.x - mu) * is) + (double)g.y * (double)((xv.y - mu) * is)) +
-            ((double)g.z * (double)((xv.z - mu) * is) + (double)g.w * (double)((xv.w - mu) * is));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i4 = i0 + u * blockDim.x;
+        if (i4 >= e4) break;
+        float4 g = gq[u];
+        const float4 xv = xq[u];
+        if (relu) {
+          bool on[4];
+          relu_on4(mp, yp, i4, xv, sc, sh, on);
+          if (!on[0]) g.x = 0.f;
+          if (!on[1]) g.y = 0.f;
+          if (!on[2]) g.z = 0.f;
+          if (!on[3]) g.w = 0.f;
+        }
+        s += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+        sx += ((double)g.x * (double)((xv.x - mu) * is) + (double)g.y * (double)((xv.y - mu) * is)) +
+              ((double)g.z * (double)((xv.z - mu) * is) + (double)g.w * (double)((xv.w - mu) * is));
+      }
     }
   } else {
     for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
