@@ -1176,11 +1176,12 @@ unsigned f16x3_grid(i64 total, bool chainable, int wg_per_cu = 2) {
   if (!chainable || !f16x3_chain() || total <= slots) return (unsigned)total;
   i64 best_g = total;
   double best_waste = 1e30;
-  for (int t = 0; t <= 8; ++t) {                          // t = 0: one workgroup per slot
+  for (int t = 0; t <= 32; ++t) {                         // t = 0: one workgroup per slot
     const i64 g = t == 0 ? slots : (total + t - 1) / t;
     if (g < slots) continue;
     const i64 per_wg = (total + g - 1) / g, rounds = (g + slots - 1) / slots;
-    if (per_wg > 8) continue;                             // measured: 4-8 tiles per workgroup beat both 1 and 32 at every K
+    static const int cap = getenv("PFST_F16X3_CHAIN_CAP") ? atoi(getenv("PFST_F16X3_CHAIN_CAP")) : 8;
+    if (per_wg > cap) continue;                           // measured: 4-8 tiles per workgroup beat both 1 and 32 at every K
     const double waste = (double)(rounds * per_wg * slots) / (double)total;
     if (waste < best_waste - 1e-9 || (waste < best_waste + 1e-9 && g < best_g)) { best_waste = waste; best_g = g; }
   }
