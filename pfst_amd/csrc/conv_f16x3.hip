@@ -1266,6 +1266,9 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
+  // 32-bit buffer ranges and offsets (the out-of-range marker 0x80000000 is ADDED to them): one image of either operand and the weight
+  // image must stay below 2 GB, as in pfst_wino_gemm_f16x3 / pfst_conv_wgrad_f16x3
+  PFST_CHECK_ARG((i64)C * Hi * Wi * 4 < (1ll << 31) && (i64)M * Ho * Wo * 4 < (1ll << 31) && (i64)ksize * ksize * C * M * 4 < (1ll << 31));
   // a 1x1 convolution may end in half a channel block: the loads of the 16 missing channels (activations and weight chunks alike) lie
   // outside their buffers' ranges and return zeros (the range check of gfx950 includes the scalar offset: tools/probes/soffset_range_probe.hip)
   if ((C % 32 != 0 && !(ksize == 1 && C % 16 == 0)) || M <= 64) {

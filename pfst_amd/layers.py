@@ -443,8 +443,12 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     f16 = split and CONV_MATH == 'f16x3' and conv.cout > 64
     v, v_amax = saved_v if saved_v is not None else (None, None)
     if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
-        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16 else split, v_amax=v_amax, x_amax=x_amax,
-                        dy_amax=dy_amax)
+        # the f16x3 Winograd-domain weight gradient pairs with the f16x3 forward pass: only a `wino_f16` layer keeps a PACKED V with
+        # the slot group of its scale bound.  A Winograd layer outside the f16x3 GEMM's shapes (3x3 64 -> 256, 48 -> 512: Cin not a
+        # multiple of 32, or a data gradient the kernel does not cover) kept a plain fp32 V and takes the bf16x6 product
+        f16w = f16 and conv.wino_f16
+        ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16w else split, v_amax=v_amax if f16w else None,
+                        x_amax=x_amax if f16w else None, dy_amax=dy_amax if f16w else None)
     elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
         ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                               dy_amax if dy_amax is not None else ops.absmax(dy))

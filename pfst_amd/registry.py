@@ -20,6 +20,7 @@ class Registry:
         return deco(module) if module is not None else deco
 
     def get(self, key):
+        _register_builtin_types()
         return self._modules.get(key)
 
     def build(self, cfg, default_args=None):
@@ -34,6 +35,20 @@ class Registry:
         if cls is None:
             raise KeyError(f'{t} is not in the {self.name} registry (pfst_amd covers the PFST hot path only)')
         return cls(**args)
+
+
+_REGISTERED = False
+
+
+def _register_builtin_types():
+    """import the modules whose decorators register the reference's type names (PFGST, PFGSTLoss, EncoderDecoder, ResNetV1c, the
+    heads, CrossEntropyLoss), on the first lookup: `import pfst_amd` stays cheap for processes that never build a model -- the data
+    loader's worker processes un-pickle pfst_amd.data / pfst_amd.pipeline objects and need neither the kernels' front end nor the
+    model code"""
+    global _REGISTERED
+    if not _REGISTERED:
+        _REGISTERED = True
+        from . import models, uda  # noqa: F401
 
 
 MODELS = Registry('models')

@@ -61,6 +61,7 @@ class IterBasedRunner:
         self.model, self.optimizer, self.cfg, self.work_dir, self.eval_fn, self.log = model, optimizer, cfg, work_dir, eval_fn, log
         self.max_iters = cfg.runner.max_iters
         self.iter = 0
+        self.epoch = 0
         self.base_lr = [g['lr'] for g in optimizer.param_groups]
         lr_cfg = cfg.get('lr_config') or {}
         if lr_cfg.get('policy', 'poly') != 'poly' or lr_cfg.get('warmup', 'linear') not in (None, 'linear'):
@@ -81,7 +82,7 @@ class IterBasedRunner:
             return None
         path = os.path.join(self.work_dir, f'iter_{self.iter}.pth')
         # meta as mmcv's runner writes / reads it back on resume (epoch + iter) plus what tools/train.py:228-236 adds (CLASSES, PALETTE)
-        meta = dict(iter=self.iter, epoch=getattr(self, 'epoch', 0), time=time.asctime(), CLASSES=getattr(self.model, 'CLASSES', None),
+        meta = dict(iter=self.iter, epoch=self.epoch, time=time.asctime(), CLASSES=getattr(self.model, 'CLASSES', None),
                     PALETTE=getattr(self.model, 'PALETTE', None))
         torch.save(dict(meta=meta,
                         state_dict=OrderedDict((k, v.cpu() if torch.is_tensor(v) else v) for k, v in self.model.state_dict().items()),
@@ -98,6 +99,7 @@ class IterBasedRunner:
         if 'optimizer' in ckpt:
             self.optimizer.load_state_dict(ckpt['optimizer'])
         self.iter = ckpt.get('meta', {}).get('iter', 0)
+        self.epoch = ckpt.get('meta', {}).get('epoch', 0)         # build_loader(start_epoch=runner.epoch) continues the data order
         self.log(f'resumed from {path} at iter {self.iter}')
 
     def load_checkpoint(self, path, revise_keys=(('module.', ''),)):
@@ -118,7 +120,7 @@ class IterBasedRunner:
             t0 = time.time()
             batch = next(data_iter)
             data_time = time.time() - t0
-            self.epoch = getattr(data_iter, 'epoch', 0)          # meta['epoch'] of the checkpoints (mmcv writes the data epoch)
+            self.epoch = getattr(data_iter, 'epoch', self.epoch)          # meta['epoch'] of the checkpoints: the epoch of the CONSUMED data
             for g, lr in zip(self.optimizer.param_groups, self.current_lr()):
                 g['lr'] = lr
             out = self.model.train_step(batch, self.optimizer)

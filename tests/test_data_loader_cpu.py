@@ -118,3 +118,62 @@ def test_reference_worker_seeding_option_and_rank_sharding(tmp_path):
     assert set(r0).isdisjoint(r1) and sorted(r0 + r1) == list(range(len(ds)))
     with pytest.raises(ValueError):
         build_loader(ds, 2, device='cpu', seeding='nope')
+
+
+def test_workers_closed_mid_batch_exit_cleanly(tmp_path):
+    """a spawned worker that is still handing over a batch when the loader is closed must leave with status 0.
+    Before the fix (data._join_queue_feeders) its daemon QueueFeederThread was cut off inside torch's shared-memory reduction at
+    interpreter finalisation -> std::terminate -> SIGABRT (exit code -6, 'terminate called without an active exception'); an
+    `atexit.register(os._exit, 0)` had masked it.  Closing right after the first batches leaves every worker busy prefetching."""
+    import inspect
+    from pfst_amd import data
+    from pfst_amd.data import build_loader, build_uda_dataset
+    assert 'os._exit' not in inspect.getsource(data._worker_init)             # the mask is gone
+    ds = build_uda_dataset(_folders(tmp_path, size=1024))                      # full-size tiles: ~50 ms per sample, so workers are mid-item
+    loader = build_loader(ds, 2, device='cpu', seed=3, workers=2)
+    next(loader), next(loader)
+    procs = list(loader._it._workers)
+    loader.close()                      # torch raises here if a worker is killed by a signal
+    for p in procs:
+        p.join(30)
+    assert [p.exitcode for p in procs] == [0, 0]
+
+
+def test_inline_worker_seeding_leaves_the_training_process_alone(tmp_path):
+    """build_loader(workers=0, seeding='worker') seeds the streams only -- it must not pin torch to one thread nor install an
+    exit hook in the training process (the worker_init_fn is for worker processes)."""
+    import atexit
+    from unittest import mock
+    from pfst_amd.data import build_loader, build_uda_dataset
+    ds = build_uda_dataset(_folders(tmp_path))
+    threads = torch.get_num_threads()
+    saved = np.random.get_state(), random.getstate()
+    try:
+        with mock.patch.object(atexit, 'register') as reg:
+            loader = build_loader(ds, 2, device='cpu', seed=5, workers=0, seeding='worker')
+        assert not reg.called
+        assert torch.get_num_threads() == threads
+        assert np.random.get_state()[1][0] == np.random.RandomState(5).get_state()[1][0]
+        loader.close()
+    finally:
+        np.random.set_state(saved[0]); random.setstate(saved[1])
+
+
+def test_loader_reports_the_epoch_of_the_consumed_batch(tmp_path):
+    """the checkpoint's meta['epoch'] is the epoch of the data the training loop CONSUMED (mmcv IterLoader), not the one the
+    sampler -- running ahead by workers * prefetch batches -- is drawing from; start_epoch continues a resumed run."""
+    from pfst_amd.data import build_loader, build_uda_dataset, epoch_indices
+    ds = build_uda_dataset(_folders(tmp_path))
+    per_epoch = len(epoch_indices(len(ds), 1, 0, 0, 7)) // 2
+    loader = build_loader(ds, 2, device='cpu', seed=7, workers=2, prefetch=2)
+    seen = []
+    for _ in range(per_epoch + 2):
+        next(loader)
+        seen.append(loader.epoch)
+    assert loader._loader.batch_sampler.epoch >= 1                    # the sampler is already ahead ...
+    loader.close()
+    assert seen == [0] * per_epoch + [1, 1]                           # ... the reported epoch is the delivered batch's
+    resumed = build_loader(ds, 2, device='cpu', seed=7, workers=0, start_epoch=3)
+    next(resumed)
+    assert resumed.epoch == 3
+    resumed.close()

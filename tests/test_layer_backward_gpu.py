@@ -295,3 +295,47 @@ def test_pfgst_loss_link_as_wired(opts, prefill):
     for name, worst, nrm, scale in rows:
         print(f'   {worst:8.3f} {nrm:9.2e}  max|ref| {scale:.2e}  pfgst_loss:{name}  (prefill={prefill}, target region {state["mask_frac"]:.2f})')
         assert scale > 0 and worst <= (1.0 if not prefill else 1.5), (name, worst, nrm)
+
+
+@pytest.mark.parametrize('math', ['f16x3', 'bf16x6'])
+@pytest.mark.parametrize('chan', [(64, 256), (48, 512), (128, 80), (96, 160)])
+def test_winograd_layers_outside_the_f16x3_shapes_train(chan, math):
+    """a Winograd-eligible 3x3 layer with more than 64 output channels that the f16x3 GEMM does NOT cover (Cin not a multiple
+    of 32: 48 -> 512; a data gradient over <= 64 rows: 64 -> 256) keeps a plain fp32 V in forward; its weight gradient must then take
+    the bf16x6 product instead of asserting on the missing scale group.  (128 -> 80 stays direct, 96 -> 160 is the covered case.)
+    conv -> BN(train) -> ReLU forward + backward as wired (layers.conv_bn_act) against fp64 autograd, element-wise bound."""
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape, Var
+    cin, cout = chan
+    prev = layers.CONV_MATH
+    layers.CONV_MATH = math
+    try:
+        torch.manual_seed(cin + cout)
+        mod = layers.ConvModule(cin, cout, 3, padding=2, dilation=2).cuda()
+        ParamArena(list(mod.named_parameters()), torch.device('cuda'), with_grad=True)
+        mod.conv.repack(need_dgrad=True)
+        expect_wino = cin * cout >= layers.WINO_MIN_CC
+        assert mod.conv.wino == expect_wino
+        if math == 'f16x3' and chan in ((64, 256), (48, 512)):
+            assert mod.conv.wino and not mod.conv.wino_f16                       # the case under test
+        x = torch.randn(2, cin, 32, 32, generator=torch.Generator().manual_seed(1))
+        dy = torch.randn(2, cout, 32, 32, generator=torch.Generator().manual_seed(2))
+        tape = Tape()
+        xv = Var(x.cuda(), True)
+        yv = mod(xv, tape)
+        buf, _ = yv.grad_target()
+        buf.copy_(dy.cuda())
+        tape.backward()
+        torch.cuda.synchronize()
+        x64 = x.double().requires_grad_()
+        w64 = mod.conv.weight.detach().cpu().double().requires_grad_()
+        g64 = mod.bn.weight.detach().cpu().double().requires_grad_()
+        b64 = mod.bn.bias.detach().cpu().double().requires_grad_()
+        ref = F.relu(F.batch_norm(F.conv2d(x64, w64, None, 1, 2, 2), None, None, g64, b64, True, 0.1, 1e-5))
+        ref.backward(dy.double())
+        for name, got, want in (('y', yv.data, ref), ('dx', xv.grad, x64.grad), ('dW', mod.conv.weight.grad, w64.grad),
+                                ('dgamma', mod.bn.weight.grad, g64.grad), ('dbeta', mod.bn.bias.grad, b64.grad)):
+            worst, nrm = mixed_err(got, want)
+            assert worst <= 1.0, (chan, math, name, worst, nrm)
+    finally:
+        layers.CONV_MATH = prev

@@ -142,7 +142,8 @@ def main(argv=None):
         # the RESOLVED seed (--seed / cfg.seed / the broadcast random one) drives the sampler's shuffle (apis/train.py:74-89 passes
         # cfg.seed to build_dataloader) and the per-sample streams; the data side never touches the training thread's NumPy stream
         workers = args.workers if args.workers is not None else int(data_cfg.get('workers_per_gpu', 0))
-        loader = build_loader(dataset, bs, dev, seed=seed, rank=rank, world=world, workers=workers, seeding=args.seeding)
+        loader = build_loader(dataset, bs, dev, seed=seed, rank=rank, world=world, workers=workers, seeding=args.seeding,
+                              start_epoch=runner.epoch)          # a resumed run continues with the checkpoint's data epoch
     runner.run(iter(loader))
     runner.save_checkpoint()
     if hasattr(loader, 'close'):
