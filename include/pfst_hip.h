@@ -155,6 +155,10 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
  * (2 per CU).  pfst_f16x3_set_slots overrides that number (0 = the device's): a test hook that makes small problems chain. */
 int pfst_f16x3_set_slots(int slots);
 int pfst_f16x3_chain_grid(long long total_tiles, int chainable);   /* the workgroup count such a launch uses */
+/* Test hook: the two-piece split of n values (n % 8 == 0), scale from the slot group `amax`, as the GEMM loops issue it (8-value and
+ * 4-value pinned instruction sequences) and as the prologues / packing kernels compute it; each output element = h | l << 16. */
+int pfst_f16x3_split_probe(const float* x, long long n, const float* amax, unsigned* pieces_loop, unsigned* pieces_loop4,
+                           unsigned* pieces_plain, pfst_stream_t stream);
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                          int M, int T, int m, int v_packed, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,

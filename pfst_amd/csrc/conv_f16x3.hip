@@ -95,13 +95,19 @@ __device__ __forceinline__ void unpack8_f16(const float (&v)[8], uint4& ph, uint
 struct SplitF16;
 template <int K> __device__ __forceinline__ void unpack_op_f16(const float (&v)[8], SplitF16& st);
 
-// The same split as 24 single VALU instructions pinned in place (volatile asm, like split_op of conv_split.hip), K = 0..23 on the
-// eight values: per pair q six instructions -- two scale multiplies, v_cvt_pk_f16_f32 (h), two v_fma_mix_f32 computing
-// x s - h in one exact step straight from the packed halves, v_cvt_pk_f16_f32 (l).  The scale sits in an SGPR.
+// The same split as single VALU instructions pinned in place (volatile asm, like split_op of conv_split.hip), K = 0..23 on the eight
+// values, six slots per pair q of which FOUR carry an instruction (round 4; PFST_F16X3_SPLIT6: the six-instruction form of round 3 --
+// two scale multiplies, v_cvt_pk_f16_f32, two v_fma_mix_f32, v_cvt_pk_f16_f32).  v_fma_mixlo_f16 / v_fma_mixhi_f16 compute
+// fma(x, s, c) in fp32 and round ONCE to fp16 into the low / high half of the destination:
+//     h.lo = f16(x0 s)   h.hi = f16(x1 s)            x s is exact (a power of two), so this is the round-to-nearest-even of x s
+//     l.lo = f16(x0 s - h.lo)   l.hi = f16(x1 s - h.hi)    the remainder is exact in fp32 (|x s - h| <= ulp_f16 / 2), rounded once
+// -- the same two pieces bit for bit (tests/test_f16x3_elementwise_gpu.py::test_split_instructions_against_the_definition), 16
+// instead of 24 vector instructions per 8 values on loops that are bound by what they issue beside the MFMAs.  The scale sits in an SGPR.
 struct SplitF16 {
   unsigned h[4], l[4];
   float t0[4], t1[4];
 };
+#ifdef PFST_F16X3_SPLIT6
 template <int K>
 __device__ __forceinline__ void split_op_f16(const float (&v)[8], float s, SplitF16& st) {
   constexpr int q = K / 6, op = K % 6;
@@ -114,6 +120,18 @@ __device__ __forceinline__ void split_op_f16(const float (&v)[8], float s, Split
     asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(st.t1[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
   else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.l[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
 }
+#else
+template <int K>
+__device__ __forceinline__ void split_op_f16(const float (&v)[8], float s, SplitF16& st) {
+  constexpr int q = K / 6, op = K % 6;               // slots 0, 1 of a pair are empty: the issue schedules of the loops keep their shape
+  if constexpr (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(st.h[q]) : "v"(v[2 * q]), "s"(s));
+  else if constexpr (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(st.h[q]) : "v"(v[2 * q + 1]), "s"(s));
+  else if constexpr (op == 4)
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(st.l[q]) : "v"(v[2 * q]), "s"(s), "v"(st.h[q]));
+  else if constexpr (op == 5)
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(st.l[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
+}
+#endif
 
 // K = 0..7: permute number K of unpack8_f16 as one pinned instruction (h pairs first)
 template <int K>
@@ -964,6 +982,7 @@ struct Split4 {
   unsigned h[2], l[2];
   float t0[2], t1[2];
 };
+#ifdef PFST_F16X3_SPLIT6
 template <int K>
 __device__ __forceinline__ void split4_op_f16(const float (&v)[4], float s, Split4& st) {        // K = 0..11: split_op_f16 on two pairs
   constexpr int q = K / 6, op = K % 6;
@@ -976,6 +995,18 @@ __device__ __forceinline__ void split4_op_f16(const float (&v)[4], float s, Spli
     asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(st.t1[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
   else asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(st.l[q]) : "v"(st.t0[q]), "v"(st.t1[q]));
 }
+#else
+template <int K>
+__device__ __forceinline__ void split4_op_f16(const float (&v)[4], float s, Split4& st) {        // K = 0..11: split_op_f16 on two pairs
+  constexpr int q = K / 6, op = K % 6;
+  if constexpr (op == 2) asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(st.h[q]) : "v"(v[2 * q]), "s"(s));
+  else if constexpr (op == 3) asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(st.h[q]) : "v"(v[2 * q + 1]), "s"(s));
+  else if constexpr (op == 4)
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(st.l[q]) : "v"(v[2 * q]), "s"(s), "v"(st.h[q]));
+  else if constexpr (op == 5)
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(st.l[q]) : "v"(v[2 * q + 1]), "s"(s), "v"(st.h[q]));
+}
+#endif
 template <int K>
 __device__ __forceinline__ void unpack4_op_f16(const float (&v)[4], Split4& st) {                 // K = 0..3: the permutes of a pre-split quad
   constexpr int q = K & 1;
@@ -1208,6 +1239,54 @@ extern "C" int pfst_f16x3_set_slots(int slots) {
 extern "C" int pfst_f16x3_chain_grid(long long total_tiles, int chainable) {
   if (total_tiles <= 0 || total_tiles >= (1ll << 31)) return 0;
   return (int)f16x3_grid(total_tiles, chainable != 0);
+}
+
+// Test hook: the split exactly as the GEMM loops issue it (split_op_f16 / split4_op_f16, the pinned instruction sequences) and as the
+// prologues and packing kernels do it (split8_f16, plain code), on n values (n % 8 == 0) scaled from the slot group `amax`:
+// pieces_loop[i], pieces_loop4[i], pieces_plain[i] = (h | l << 16) of x[i].
+namespace {
+__global__ __launch_bounds__(256) void f16x3_split_probe_kernel(const float* __restrict__ x, i64 n8, const float* __restrict__ amax,
+                                                                unsigned* __restrict__ pieces_loop, unsigned* __restrict__ pieces_loop4,
+                                                                unsigned* __restrict__ pieces_plain) {
+  const float s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(amax_exponent(amax_read(amax))))));
+  for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += (i64)gridDim.x * blockDim.x) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = x[g * 8 + j];
+    SplitF16 st;
+    static_for<24>([&](auto kc) { split_op_f16<decltype(kc)::value>(v, s, st); });
+    uint4 ph, pl;
+    split8_f16(v, s, ph, pl);
+    const unsigned hp[4] = {ph.x, ph.y, ph.z, ph.w}, lp[4] = {pl.x, pl.y, pl.z, pl.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      pieces_loop[g * 8 + 2 * q] = (st.h[q] & 0xffffu) | (st.l[q] << 16);
+      pieces_loop[g * 8 + 2 * q + 1] = (st.h[q] >> 16) | (st.l[q] & 0xffff0000u);
+      pieces_plain[g * 8 + 2 * q] = (hp[q] & 0xffffu) | (lp[q] << 16);
+      pieces_plain[g * 8 + 2 * q + 1] = (hp[q] >> 16) | (lp[q] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const float v4[4] = {v[4 * half], v[4 * half + 1], v[4 * half + 2], v[4 * half + 3]};
+      Split4 s4;
+      static_for<12>([&](auto kc) { split4_op_f16<decltype(kc)::value>(v4, s, s4); });
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        pieces_loop4[g * 8 + 4 * half + 2 * q] = (s4.h[q] & 0xffffu) | (s4.l[q] << 16);
+        pieces_loop4[g * 8 + 4 * half + 2 * q + 1] = (s4.h[q] >> 16) | (s4.l[q] & 0xffff0000u);
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int pfst_f16x3_split_probe(const float* x, long long n, const float* amax, unsigned* pieces_loop, unsigned* pieces_loop4,
+                                      unsigned* pieces_plain, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && amax && pieces_loop && pieces_loop4 && pieces_plain && n > 0 && n % 8 == 0);
+  hipLaunchKernelGGL(f16x3_split_probe_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (i64)(n / 8), amax, pieces_loop,
+                     pieces_loop4, pieces_plain);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
 }
 
 // max |x| of `planes` planes of `n` floats (plane_stride apart) into the slot GROUP (1024 floats, amax.h) number plane * slot_stride; the

@@ -18,8 +18,13 @@ OVERLAP_ALLREDUCE = os.environ.get('PFST_DDP_OVERLAP', '1') == '1'
 BUCKET_ELEMS = int(float(os.environ.get('PFST_DDP_BUCKET_MB', '16')) * (1 << 20) / 4)
 
 
+# PFST_DDP_FORCE=1: run the exchange (reducer, packed log vector, key check) in an initialised process group of ONE rank too -- the only
+# way to put RCCL's asynchronous collectives behind a real train step on a single-GPU box (tests/test_ddp_gpu.py)
+FORCE_EXCHANGE = os.environ.get('PFST_DDP_FORCE', '0') == '1'
+
+
 def is_distributed():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_EXCHANGE)
 
 
 def allreduce_mean_(flat, group=None, slice_elems=SLICE_ELEMS):

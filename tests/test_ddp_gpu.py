@@ -37,8 +37,17 @@ def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pfst_amd import dist as pdist
+    snaps, launch = [], pdist.GradReducer._launch
+
+    def recording_launch(self, lo, hi):                       # this rank's values of a bucket at the moment its marker fires
+        if hi > lo:
+            snaps.append((lo, hi, self.flat[lo:hi].clone()))
+        return launch(self, lo, hi)
+    pdist.GradReducer._launch = recording_launch
     out, grad, weights, teacher = _one_step(rank)
-    torch.save(dict(log=out['log_vars'], grad=grad, weights=weights, teacher=teacher), os.path.join(outdir, f'r{rank}.pt'))
+    torch.save(dict(log=out['log_vars'], grad=grad, weights=weights, teacher=teacher, snaps=[(lo, hi, t.cpu()) for lo, hi, t in snaps]),
+               os.path.join(outdir, f'r{rank}.pt'))
     dist.destroy_process_group()
 
 
@@ -55,6 +64,12 @@ def test_two_rank_data_parallel_step(tmp_path, overlap):
     assert torch.equal(r0['grad'], r1['grad']), 'all ranks must hold the same reduced gradient'
     assert torch.equal(r0['weights'], r1['weights']), 'all ranks must end the step with identical student weights'
     assert r0['log'] == r1['log'], 'log_vars are averaged over ranks'
+    # every ready(offset) marker fired after the last writer of its range in BOTH student graphs: what each rank handed to a bucket's
+    # collective is all that ever reaches that range -- the reduced arena is exactly the mean of the two ranks' values at launch
+    assert len(r0['snaps']) == len(r1['snaps']) and (len(r0['snaps']) >= 3) == (overlap == '1')      # heads / layer4 / layer3 markers + finish()
+    for (lo, hi, a), (lo1, hi1, b) in zip(r0['snaps'], r1['snaps']):
+        assert (lo, hi) == (lo1, hi1)
+        assert torch.equal((a + b) * 0.5, r0['grad'][lo:hi]), f'arena range [{lo}, {hi}) was written after its marker'
     # single-process references for the two shards
     (o0, g0, _, _), (o1, g1, _, _) = _one_step(0), _one_step(1)
     mean = 0.5 * (g0 + g1)
@@ -96,3 +111,58 @@ def test_rccl_backend_ops_used_by_the_exchange(tmp_path):
     port = 29700 + (os.getpid() % 1000)
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert open(tmp_path / 'nccl_ok').read() == 'True'
+
+
+def _rccl_step_worker(rank, world, port, outdir, overlap):
+    """one whole train step in a single-rank RCCL group with the exchange forced on (PFST_DDP_FORCE=1)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      PFST_DDP_FORCE='1', PFST_DDP_OVERLAP=overlap, PFST_DDP_BUCKET_MB='8')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+    from pfst_amd import dist as pdist
+    assert pdist.is_distributed() and pdist.OVERLAP_ALLREDUCE == (overlap == '1')
+    snaps = []
+    launch = pdist.GradReducer._launch
+
+    def recording_launch(self, lo, hi):
+        if hi > lo:
+            # the values the collective is handed, in stream order: a clone queued right before it
+            snaps.append((lo, hi, self.flat[lo:hi].clone()))
+        return launch(self, lo, hi)
+    pdist.GradReducer._launch = recording_launch
+    out, grad, weights, _ = _one_step(0)
+    ok, cover = True, []
+    arena_numel = grad.numel()
+    for lo, hi, snap in snaps:
+        # world = 1: AVG is the identity, so the final arena must still hold exactly what was final when the bucket left.  A writer
+        # (either student graph's weight gradient, a BatchNorm gradient, a bias) running AFTER its range's marker would show here.
+        ok = ok and bool(torch.equal(snap.cpu(), grad[lo:hi]))
+        cover.append((lo, hi))
+    cover.sort()
+    contiguous = bool(cover) and cover[0][0] == 0 and cover[-1][1] == arena_numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    torch.save(dict(ok=ok, buckets=len(snaps), contiguous=contiguous, grad=grad, log=out['log_vars'],
+                    sizes=[hi - lo for lo, hi, _ in snaps]), os.path.join(outdir, f'rccl_{overlap}.pt'))
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_over_rccl_inside_a_whole_step(tmp_path):
+    """VERDICT r3 next #8.  The bucketed reducer issues `all_reduce(async_op=True)` on the finished TAIL of the gradient arena while the
+    backward sweep keeps writing lower offsets; that is correct only if every `ready(offset)` marker really follows the last writer of
+    everything at or above `offset` in BOTH student graphs.  Run over RCCL (one rank: the collectives are real, asynchronous, on RCCL's
+    own stream) inside a whole train step: every bucket's content at launch must be bit-identical to the arena after the step, the
+    buckets tile the arena exactly once, and the step agrees with the PFST_DDP_OVERLAP=0 schedule to the noise of the weight
+    gradients' fp32 atomics (two runs of one schedule differ by as much: no bit-for-bit claim between runs)."""
+    res = {}
+    for i, overlap in enumerate(('1', '0')):
+        port = 29800 + (os.getpid() % 1000) + 11 * i
+        mp.spawn(_rccl_step_worker, args=(1, port, str(tmp_path), overlap), nprocs=1, join=True)
+        res[overlap] = torch.load(tmp_path / f'rccl_{overlap}.pt', weights_only=False)
+    on, off = res['1'], res['0']
+    print('overlapped buckets (elements):', on['sizes'])
+    assert on['buckets'] >= 3 and on['contiguous'], (on['buckets'], on['contiguous'])     # 174 MB in >= 8 MB buckets from the markers + finish()
+    assert on['ok'], 'a gradient range was written after the marker that declared it final'
+    assert off['buckets'] == 0                                       # the single reduction after the sweep goes through allreduce_mean_
+    err = float((on['grad'].double() - off['grad'].double()).norm() / off['grad'].double().norm())
+    assert err < 1e-4, err
+    for k in on['log']:
+        assert abs(on['log'][k] - off['log'][k]) <= 1e-5 * max(abs(off['log'][k]), 1e-2), (k, on['log'][k], off['log'][k])

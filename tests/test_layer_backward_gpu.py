@@ -210,7 +210,9 @@ def test_every_backward_link_as_wired(wino, math):
         print(f'   {worst:8.3f} {nrm:9.2e}  fwd {fe:8.1e}  chain-dy {de:8.1e}  {name}:{k} [{op}]')
     print(f'   {n_fused[0]} BatchNorm layers had received fused backward sums from the launch completing their gradient')
     if layers.FUSE_BN_BWD and layers.FUSE_BN_BWD_MIN_K <= 512:                     # the defaults (not PFST_FUSE_BN_BWD=0 / a higher threshold)
-        assert n_fused[0] >= (20 if math == 'f32' else 0)  # layers.FUSE_BN_BWD_MIN_K = 512: the MFMA-bound fp32 data-gradient launches only
+        # conv3 of layer2-4 (13), conv1 of layer4 (3), the three ASPP pointwise convs + the 1x1 branch, sep_bottleneck.1: the K >= 512
+        # data gradients that complete a conv -> BN layer's gradient, under EVERY arithmetic (f16x3: conv_igemm_f16x3_bnb_kernel)
+        assert n_fused[0] >= 15, (math, n_fused[0])
     checked_ops = {r[0] for r in rows}
     assert {'conv_bn_act', 'conv', 'maxpool', 'resize', 'gap', 'broadcast', 'ce'} <= checked_ops, checked_ops
     n_bn = sum(1 for m in model.modules() if isinstance(m, layers.BatchNorm2dP))

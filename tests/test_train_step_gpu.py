@@ -186,6 +186,104 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
             assert e < (TOL if 'conv_seg' in k else 2e-2 if 'sep_bottleneck.1' in k else 0.1), (k, e)
 
 
+class count_fused_dgrad_launches:
+    """`with count_fused_dgrad_launches() as n:` -- n['f16x3'] / n['bf16x6'] / n['f32'] = data-gradient launches of the step that
+    carried the fused BatchNorm-backward epilogue (a `bnb` argument: conv_igemm_f16x3_bnb_kernel and its siblings), n['all'] = every
+    data-gradient launch of those entry points"""
+
+    NAMES = dict(f16x3='conv_dgrad_f16x3', bf16x6='conv_dgrad_split', f32='conv_dgrad')
+
+    def __enter__(self):
+        from pfst_amd import hip_ops
+        self.ops, self.orig, self.n = hip_ops, {}, dict(f16x3=0, bf16x6=0, f32=0, all=0)
+        for key, fn in self.NAMES.items():
+            self.orig[fn] = getattr(hip_ops, fn)
+
+            def wrapped(*a, _key=key, _fn=self.orig[fn], **kw):
+                self.n['all'] += 1
+                self.n[_key] += kw.get('bnb') is not None
+                return _fn(*a, **kw)
+            setattr(hip_ops, fn, wrapped)
+        return self.n
+
+    def __exit__(self, *exc):
+        for fn, f in self.orig.items():
+            setattr(self.ops, fn, f)
+
+
+def test_train_step_at_512_matches_oracle():
+    """One whole step at b = 2 x 512^2 (BASELINE config #1's tile size) under the DEFAULT arithmetic against the oracle.
+    At S = 128 a 1/8-grid GEMM has two pixel tiles per image; here it has 32, so the f16x3 machinery of round 3 sits inside an
+    end-to-end comparison: workgroups walk tile CHAINS (1024 tiles of layer4.conv3 on 512 resident slots), grids run several rounds,
+    the 3x3 kernels use the band tile order per XCD, the whole-line weight gradients split K over pixel chunks, the Winograd-domain
+    GEMMs run image-after-image per filter set, and the K >= 512 data gradients carry the fused BatchNorm-backward sums.
+    Same checks as the S = 128 test: 14 log values, mixed-label map exact, logits element-wise, gradients against fp64."""
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops, layers
+    from pfst_amd._lib import lib
+    from pfst_amd.hostinfo import usable_cpus
+    from pfst_amd.synthetic import synth_batch
+    assert layers.CONV_MATH == os.environ.get('PFST_CONV_MATH', 'f16x3')
+    b, S = 2, 512
+    # the machinery engages at this size: more tiles than workgroups for the large 1x1 GEMMs -> chains
+    tiles = (S // 8) * (S // 8) // 128 * (2048 // 128) * b            # layer4.conv3 in 128 x 128 tiles (the unit pfst_f16x3_chain_grid counts slots in)
+    if layers.CONV_MATH == 'f16x3':
+        assert lib().pfst_f16x3_chain_grid(tiles, 1) < tiles, 'layer4.conv3 would run one tile per workgroup: no chain in this test'
+    model, opt, student, teacher = _build(0.30)
+    oracle = O.OraclePFGST(student, pseudo_threshold=0.30, teacher_sd=teacher)
+    torch.set_num_threads(usable_cpus())
+    batch = synth_batch(b, S, 6, seed=4242)
+    random.seed(101); np.random.seed(101)
+    olog, ex = oracle.train_step(batch, return_extras=True)
+    random.seed(101); np.random.seed(101)
+    model.debug = {}
+    model.injected_pseudo = (ex['pseudo_label'].to(torch.uint8).cuda(), torch.tensor([ex['n_conf']], dtype=torch.int64).cuda())
+    with count_fused_dgrad_launches() as launches:
+        out = model.train_step(to_dev(batch, 'cuda'), opt)
+    dbg, lv = model.debug, out['log_vars']
+    print(f'data-gradient launches {launches}')
+    if layers.FUSE_BN_BWD and layers.CONV_MATH == 'f16x3' and layers.FUSE_BN_BWD_MIN_K_SPLIT <= 512:
+        assert launches['f16x3'] >= 30, launches          # per student graph: conv3 of layer2-4, conv1 of layer4, ASPP pointwise + 1x1, sep_bottleneck.1
+    assert list(lv.keys()) == list(olog.keys()) and out['num_samples'] == b
+    mism = 1.0 - (dbg['own_pseudo_label'].cpu() == ex['pseudo_label']).float().mean().item()
+    print(f'end-to-end pseudo-label mismatch rate {mism:.2e}')
+    assert mism < 2e-3, mism
+    l64, _, _ = hip_ops.pseudo_label(ex['ema_logits_low'].cuda(), (S, S), 0.30)
+    assert torch.equal(l64.cpu(), ex['pseudo_label']), 'pseudo-label kernel must be bit exact on identical logits'
+    assert torch.equal(dbg['mix_masks'].cpu().long(), ex['masks']), 'class-mix masks'
+    assert bool((dbg['mixed_lbl'].cpu() == ex['mixed_lbl']).all()), 'mixed label map'
+    assert abs(int(dbg['own_conf_count'].item()) - ex['n_conf']) <= 16
+    for name, key in (('source logits', 'src_logits'), ('mixed-pass logits', 'mix_logits'), ('teacher decoded features', 'ema_dec')):
+        assert rel(dbg[key], ex[key]) < TOL, (name, rel(dbg[key], ex[key]))
+        assert_elementwise(dbg[key], ex[key], name)
+    assert_elementwise(dbg['ema_logits'], ex['ema_logits_low'], 'teacher logits')
+    assert rel(dbg['mixed_w'], ex['mixed_w']) < 1e-5
+    for k in olog:
+        assert abs(lv[k] - olog[k]) <= TOL * max(abs(olog[k]), 1e-2), (k, lv[k], olog[k])
+    assert_live_target_side(olog, ex)
+    assert_live_target_side(lv)
+    # gradients: as close to fp64 as the oracle's own fp32 path (x5), 1e-3 next to the loss -- the criterion of the S = 128 test
+    arena = model.student_arena
+    dd = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    o64 = O.OraclePFGST(dd(student), pseudo_threshold=0.30, teacher_sd=dd(teacher))
+    b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    random.seed(101); np.random.seed(101)
+    _, ex64 = o64.train_step(b64, masks=ex['masks'], return_extras=True, pseudo_override=(ex['pseudo_label'], ex['n_conf']))
+    rows = [(name, rel(arena.view(arena.grad, name), g64), rel(ex['grads'][name], g64)) for name, g64 in ex64['grads'].items()]
+    print('grad rel err vs fp64:  HIP / oracle-fp32 (worst ten by ratio)')
+    for name, a, r in sorted(rows, key=lambda t: -t[1] / max(t[2], 1e-12))[:10]:
+        print(f'   {a:.2e} {r:.2e} {name}')
+    for name, a, r in rows:
+        assert a <= max(TOL, 5.0 * r), (name, a, r)
+    for name in ('decode_head.conv_seg.bias', 'auxiliary_head.conv_seg.weight', 'auxiliary_head.conv_seg.bias'):
+        assert rel(arena.view(arena.grad, name), ex['grads'][name]) < TOL, name
+    flat_64 = torch.cat([g.flatten() for g in ex64['grads'].values()])
+    flat_o = torch.cat([g.flatten() for g in ex['grads'].values()])
+    flat_m = torch.cat([arena.view(arena.grad, n).flatten() for n in ex['grads']])
+    print('flat gradient rel err vs fp64: HIP %.3e  oracle-fp32 %.3e' % (rel(flat_m, flat_64), rel(flat_o, flat_64)))
+    assert rel(flat_m, flat_64) <= max(TOL, 2.0 * rel(flat_o, flat_64))
+
+
 def test_pfgst_loss_downscale1_matches_oracle():
     """SeasonNet setting (configs/pfst/pfst_season_net_sp2fa_*.py: downscale=1): 1/8 features resized to the 1/4 grid."""
     import pfst_amd  # noqa: F401
@@ -419,13 +517,22 @@ def test_fused_bn_backward_does_not_change_the_step():
         try:
             model, opt, _, _ = _build(0.30)
             random.seed(106); np.random.seed(106)      # a class draw that leaves a live target region (helpers.assert_live_target_side)
-            log0 = model.train_step(batch, opt)['log_vars']
+            with count_fused_dgrad_launches() as launches:
+                log0 = model.train_step(batch, opt)['log_vars']
             grad0 = model.student_arena.grad.clone().cpu()
             random.seed(101); np.random.seed(101)
             log1 = model.train_step(batch, opt)['log_vars']
         finally:
             layers.FUSE_BN_BWD = prev
         runs.append((log0, grad0, log1))
+        # the comparison is only worth something if the fused epilogue really ran in the `fuse` run, under the arithmetic in use
+        # (default f16x3: conv_igemm_f16x3_bnb_kernel), and not at all in the other
+        print(f'FUSE_BN_BWD={fuse}: data-gradient launches {launches}')
+        if fuse:
+            # per student graph: conv3 of layer2-4 (13), conv1 of layer4 (3), the three ASPP pointwise convs + the 1x1 branch, sep_bottleneck.1
+            assert launches[layers.CONV_MATH] >= 30, launches
+        else:
+            assert launches['f16x3'] + launches['bf16x6'] + launches['f32'] == 0, launches
     (a0, g0, a1), (b0, g1, b1) = runs
     assert_live_target_side(a0)           # the whole loss graph is alive: the target-side PFGSTLoss gradient runs through the fused sums too
     for k in a0:
