@@ -223,6 +223,18 @@ int pfst_upsample_nearest(const float* x, float* y, int NC, int h, int w, int fa
 int pfst_upsample_nearest_bwd(const float* dy, float* dx, int NC, int h, int w, int factor, pfst_stream_t stream);
 /* nn.Dropout2d (decode_head.py:103-107): y = x * mask[n][c] */
 int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream);
+/* ---- test-time inference beyond the whole-image arg-max (rsiseg/models/segmentors/encoder_decoder.py): sliding windows, flips, averaging */
+/* F.softmax(seg_logit, dim=1) (:311) with torch's arithmetic: y[n][c][p] = exp(x - max_c) / sum_c exp(x - max_c) */
+int pfst_softmax_nchw(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int HW, pfst_stream_t stream);
+/* slide_inference (:220-263): preds[:, :, y1:y1+Hc, x1:x1+Wc] += crop (F.pad + add, :246-248), count[:, y1:.., x1:..] += 1 (:250) */
+int pfst_window_accumulate(const float* crop, float* preds, float* count, int N, int C, int Hc, int Wc, int H, int W, int y1, int x1,
+                           pfst_stream_t stream);
+int pfst_window_normalize(float* preds, const float* count, int N, int C, int HW, pfst_stream_t stream);      /* preds / count_mat (:256) */
+/* seg_logit.argmax(dim=1) (:332, :368): first maximal class per pixel, uint8 */
+int pfst_argmax_nchw(const float* x, long long x_bs, unsigned char* label_u8, int N, int C, int HW, pfst_stream_t stream);
+/* output.flip(dims=(3,)) / (2,) (:316-325) on `planes` H x W maps, out of place */
+int pfst_flip_planes(const float* x, float* y, int planes, int H, int W, int horizontal, int vertical, pfst_stream_t stream);
+int pfst_div_scalar(float* x, long long n, float divisor, pfst_stream_t stream);                              /* seg_logit /= len(imgs) (:367) */
 
 /* ---- fused bilinear-upsample + softmax cross-entropy + accuracy (decode_head.py:249-283,
  * cross_entropy_loss.py:45-65, accuracy.py:6-61).  logits are [N][C][h][w]; labels/weights [N][H][W].

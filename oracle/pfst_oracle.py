@@ -248,6 +248,70 @@ def encode_decode(sd, img, pre='', return_feats=False):
     return out + (feats,) if return_feats else out
 
 
+# ---------------------------------------------------------------------------
+# test time beyond the whole-image arg-max (encoder_decoder.py:220-372), model.eval(): BN on running statistics
+# ---------------------------------------------------------------------------
+def eval_encode_decode(sd, img, pre=''):
+    """EncoderDecoder.encode_decode under model.eval() (encoder_decoder.py:72-84): logits bilinear to the input size"""
+    feats = backbone_forward(sd, img, False, pre)
+    logits, _ = decode_head_forward(sd, feats, False, None, pre)
+    return F.interpolate(logits, size=img.shape[2:], mode='bilinear', align_corners=False)
+
+
+def slide_inference(sd, img, img_meta, test_cfg, rescale, num_classes):
+    """encoder_decoder.py:220-263, line by line"""
+    h_stride, w_stride = test_cfg['stride']
+    h_crop, w_crop = test_cfg['crop_size']
+    batch_size, _, h_img, w_img = img.size()
+    h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+    w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+    preds = img.new_zeros((batch_size, num_classes, h_img, w_img))
+    count_mat = img.new_zeros((batch_size, 1, h_img, w_img))
+    for h_idx in range(h_grids):
+        for w_idx in range(w_grids):
+            y1 = h_idx * h_stride
+            x1 = w_idx * w_stride
+            y2 = min(y1 + h_crop, h_img)
+            x2 = min(x1 + w_crop, w_img)
+            y1 = max(y2 - h_crop, 0)
+            x1 = max(x2 - w_crop, 0)
+            crop_seg_logit = eval_encode_decode(sd, img[:, :, y1:y2, x1:x2])
+            preds += F.pad(crop_seg_logit, (int(x1), int(preds.shape[3] - x2), int(y1), int(preds.shape[2] - y2)))
+            count_mat[:, :, y1:y2, x1:x2] += 1
+    assert (count_mat == 0).sum() == 0
+    preds = preds / count_mat
+    if rescale:
+        preds = F.interpolate(preds, size=img_meta[0]['ori_shape'][:2], mode='bilinear', align_corners=False)
+    return preds
+
+
+def inference_probs(sd, img, img_meta, test_cfg, rescale=True, num_classes=6):
+    """EncoderDecoder.inference (encoder_decoder.py:284-327): slide / whole -> softmax -> un-flip"""
+    assert test_cfg['mode'] in ['slide', 'whole']
+    if test_cfg['mode'] == 'slide':
+        seg_logit = slide_inference(sd, img, img_meta, test_cfg, rescale, num_classes)
+    else:
+        seg_logit = eval_encode_decode(sd, img)
+        if rescale:
+            seg_logit = F.interpolate(seg_logit, size=img_meta[0]['ori_shape'][:2], mode='bilinear', align_corners=False)
+    output = F.softmax(seg_logit, dim=1)
+    if img_meta[0]['flip']:
+        direction = img_meta[0]['flip_direction']
+        for d in (direction if isinstance(direction, list) else [direction]):
+            assert d in ['horizontal', 'vertical']
+            output = output.flip(dims=(3,)) if d == 'horizontal' else output.flip(dims=(2,))
+    return output
+
+
+def aug_test(sd, imgs, img_metas, test_cfg, num_classes=6):
+    """EncoderDecoder.aug_test (encoder_decoder.py:355-372): mean of the views' probabilities, arg-max"""
+    seg_logit = inference_probs(sd, imgs[0], img_metas[0], test_cfg, True, num_classes)
+    for i in range(1, len(imgs)):
+        seg_logit += inference_probs(sd, imgs[i], img_metas[i], test_cfg, True, num_classes)
+    seg_logit /= len(imgs)
+    return seg_logit.argmax(dim=1), seg_logit
+
+
 def parse_losses(losses):
     """BaseSegmentor._parse_losses (base.py:177-222), single process."""
     log_vars = OrderedDict((k, v.mean()) for k, v in losses.items())

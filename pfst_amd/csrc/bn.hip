@@ -70,6 +70,37 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int C, double 
   }
 }
 
+// this thread's share of the T (sum, sum') slots of one channel, in fp64.  The slots of the high-resolution layers are many (T = 8192 at
+// 1/4, 32768 at 1/2 resolution: 64-256 KB per channel) and one workgroup per channel walks them: eight slots per thread in flight (four
+// independent 16-byte loads) instead of one -- the 1-slot loop spent 20-100 us per launch on the stem / layer1 channels, latency-bound.
+__device__ __forceinline__ void sum_partial_slots(const float2* __restrict__ p, int T, double& s, double& ss) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  int done = 0;
+  if (((uintptr_t)p & 15) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const int T2 = T >> 1, bd = blockDim.x;
+    for (int i = threadIdx.x; i < T2; i += 4 * bd) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 v0 = p4[i];
+      const float4 v1 = i + bd < T2 ? p4[i + bd] : z;
+      const float4 v2 = i + 2 * bd < T2 ? p4[i + 2 * bd] : z;
+      const float4 v3 = i + 3 * bd < T2 ? p4[i + 3 * bd] : z;
+      a0 += (double)v0.x + (double)v0.z; b0 += (double)v0.y + (double)v0.w;
+      a1 += (double)v1.x + (double)v1.z; b1 += (double)v1.y + (double)v1.w;
+      a2 += (double)v2.x + (double)v2.z; b2 += (double)v2.y + (double)v2.w;
+      a3 += (double)v3.x + (double)v3.z; b3 += (double)v3.y + (double)v3.w;
+    }
+    done = T2 * 2;
+  }
+  for (int i = done + threadIdx.x; i < T; i += blockDim.x) {
+    const float2 v = p[i];
+    a0 += (double)v.x;
+    b0 += (double)v.y;
+  }
+  s = (a0 + a1) + (a2 + a3);
+  ss = (b0 + b1) + (b2 + b3);
+}
+
 // statistics from the conv epilogue's partials: part[c][T][2] (sum, sum of squares per slot)   grid: C blocks
 __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ part, int T, double count,
                                                                     float* __restrict__ mean, float* __restrict__ invstd,
@@ -78,13 +109,8 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
                                                                     const float* __restrict__ beta, float4* __restrict__ coef) {
   __shared__ double sm[32];
   const int c = blockIdx.x;
-  const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
-  double s = 0.0, ss = 0.0;
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
-    const float2 v = p[i];
-    s += (double)v.x;
-    ss += (double)v.y;
-  }
+  double s, ss;
+  sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, ss);
   block_sum2_d(s, ss, sm);
   if (threadIdx.x == 0) {
     const double m = s / count;
@@ -274,13 +300,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __res
                                                               const float* __restrict__ invstd, double* __restrict__ ws) {
   __shared__ double sm[32];
   const int c = blockIdx.x;
-  const float2* p = reinterpret_cast<const float2*>(part) + (i64)c * T;
-  double s = 0.0, sx = 0.0;
-  for (int i = threadIdx.x; i < T; i += blockDim.x) {
-    const float2 v = p[i];
-    s += (double)v.x;
-    sx += (double)v.y;
-  }
+  double s, sx;
+  sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, sx);
   block_sum2_d(s, sx, sm);
   if (threadIdx.x == 0) {
     ws[2 * c] = s;

@@ -207,6 +207,61 @@ __global__ void channel_scale_kernel(const float* __restrict__ x, const float* _
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) y[base + i] = x[base + i] * m;
 }
 
+// ---- test-time inference beyond the whole-image argmax (encoder_decoder.py:220-263 slide_inference, :284-327 inference, :355-372 aug_test):
+// class probabilities, the sliding-window sum of crop logits with its count map, flips of probability maps, arg-max of averaged maps
+// y[n][c][p] = softmax over c of x[n][:][p] with torch's arithmetic (max, sequential fp32 sum of expf(z - max), IEEE division)
+__global__ void softmax_nchw_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ y, i64 y_bs, int C, int HW) {
+  const int n = blockIdx.y;
+  const float* xp = x + (i64)n * x_bs;
+  float* yp = y + (i64)n * y_bs;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, xp[(i64)c * HW + p]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(xp[(i64)c * HW + p] - mx);
+    for (int c = 0; c < C; ++c) yp[(i64)c * HW + p] = __fdiv_rn(expf(xp[(i64)c * HW + p] - mx), se);
+  }
+}
+// preds[n][c][y1 + i][x1 + j] += crop[n][c][i][j] (F.pad + add, :246-248); count[n][y1 + i][x1 + j] += 1 (:250)       grid: (blocks, C + 1, N)
+__global__ void window_accumulate_kernel(const float* __restrict__ crop, float* __restrict__ preds, float* __restrict__ count, int C, int Hc,
+                                         int Wc, int H, int W, int y1, int x1) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hc * Wc; i += gridDim.x * blockDim.x) {
+    const int iy = i / Wc, ix = i - iy * Wc;
+    const i64 dst = (i64)(y1 + iy) * W + (x1 + ix);
+    if (c < C) preds[((i64)n * C + c) * H * W + dst] += crop[((i64)n * C + c) * Hc * Wc + i];
+    else count[(i64)n * H * W + dst] += 1.f;
+  }
+}
+__global__ void window_normalize_kernel(float* __restrict__ preds, const float* __restrict__ count, int C, int HW) {      // preds / count_mat (:256)
+  const int c = blockIdx.y, n = blockIdx.z;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x)
+    preds[((i64)n * C + c) * HW + i] = __fdiv_rn(preds[((i64)n * C + c) * HW + i], count[(i64)n * HW + i]);
+}
+__global__ void argmax_nchw_kernel(const float* __restrict__ x, i64 x_bs, unsigned char* __restrict__ lab, int C, int HW) {  // first maximal class
+  const int n = blockIdx.y;
+  const float* xp = x + (i64)n * x_bs;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+    float best = xp[p];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = xp[(i64)c * HW + p];
+      if (v > best) { best = v; arg = c; }
+    }
+    lab[(i64)n * HW + p] = (unsigned char)arg;
+  }
+}
+__global__ void flip_planes_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int hflip, int vflip) {   // output.flip (:316-325)
+  const i64 base = (i64)blockIdx.y * H * W;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < H * W; o += gridDim.x * blockDim.x) {
+    const int oy = o / W, ox = o - oy * W;
+    y[base + o] = x[base + (i64)(vflip ? H - 1 - oy : oy) * W + (hflip ? W - 1 - ox : ox)];
+  }
+}
+__global__ void div_scalar_kernel(float* __restrict__ x, i64 n, float d) {                                               // seg_logit /= len(imgs) (:367)
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) x[i] = __fdiv_rn(x[i], d);
+}
+
 // ---- integer-factor nearest up-sampling of small maps and its adjoint (F.interpolate(mode='nearest'),
 // pfgst_loss.py:57-58 when downscale == 1: features at 1/8 are resized to the 1/4 logits grid)
 __global__ void upsample_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w, int u) {
@@ -323,6 +378,46 @@ extern "C" int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N
 extern "C" int pfst_channel_scale(const float* x, const float* mask, float* y, int N, int C, int HW, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && mask && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
   hipLaunchKernelGGL(channel_scale_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, x, mask, y, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_softmax_nchw(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && N > 0 && N <= 65535 && C > 0 && HW > 0 && x_bs >= (i64)C * HW && y_bs >= (i64)C * HW);
+  hipLaunchKernelGGL(softmax_nchw_kernel, dim3(hw_blocks(HW), N), dim3(256), 0, (hipStream_t)stream, x, (i64)x_bs, y, (i64)y_bs, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_window_accumulate(const float* crop, float* preds, float* count, int N, int C, int Hc, int Wc, int H, int W, int y1, int x1,
+                                      pfst_stream_t stream) {
+  PFST_CHECK_ARG(crop && preds && count && N > 0 && N <= 65535 && C > 0 && C < 65535 && Hc > 0 && Wc > 0);
+  PFST_CHECK_ARG(y1 >= 0 && x1 >= 0 && y1 + Hc <= H && x1 + Wc <= W);          // the window lies inside the image: nothing is written outside preds
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(hw_blocks(Hc * Wc), C + 1, N), dim3(256), 0, (hipStream_t)stream, crop, preds, count, C, Hc,
+                     Wc, H, W, y1, x1);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_window_normalize(float* preds, const float* count, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(preds && count && N > 0 && N <= 65535 && C > 0 && C <= 65535 && HW > 0);
+  hipLaunchKernelGGL(window_normalize_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, preds, count, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_argmax_nchw(const float* x, long long x_bs, unsigned char* label_u8, int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && label_u8 && N > 0 && N <= 65535 && C > 0 && C <= 255 && HW > 0 && x_bs >= (i64)C * HW);
+  hipLaunchKernelGGL(argmax_nchw_kernel, dim3(hw_blocks(HW), N), dim3(256), 0, (hipStream_t)stream, x, (i64)x_bs, label_u8, C, HW);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_flip_planes(const float* x, float* y, int planes, int H, int W, int horizontal, int vertical, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && y && x != y && planes > 0 && planes <= 65535 && H > 0 && W > 0);
+  hipLaunchKernelGGL(flip_planes_kernel, dim3(hw_blocks(H * W), planes), dim3(256), 0, (hipStream_t)stream, x, y, H, W, horizontal, vertical);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+extern "C" int pfst_div_scalar(float* x, long long n, float divisor, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && n > 0 && divisor != 0.f);
+  hipLaunchKernelGGL(div_scalar_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (i64)n, divisor);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

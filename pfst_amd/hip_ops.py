@@ -691,6 +691,55 @@ def channel_scale(x, mask):
     return y
 
 
+# ---------------------------------------------------------------- test-time inference (sliding windows, flips, averaging)
+def softmax_nchw(x, out=None):
+    """F.softmax(x, dim=1) of an NCHW tensor (dense planes)"""
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty(n, c, h, w, device=x.device)
+    call('pfst_softmax_nchw', x.data_ptr(), _bs(x), out.data_ptr(), _bs(out), n, c, h * w, _stream())
+    return out
+
+
+def window_accumulate_(preds, count, crop, y1, x1):
+    """preds[:, :, y1:y1+hc, x1:x1+wc] += crop; count[:, :, y1:.., x1:..] += 1 (encoder_decoder.py:246-250)"""
+    _dense(preds), _dense(count), _dense(crop)
+    n, c, h, w = preds.shape
+    hc, wc = crop.shape[-2:]
+    assert crop.shape[:2] == (n, c) and count.numel() == n * h * w
+    call('pfst_window_accumulate', crop.data_ptr(), preds.data_ptr(), count.data_ptr(), n, c, hc, wc, h, w, int(y1), int(x1), _stream())
+
+
+def window_normalize_(preds, count):
+    _dense(preds), _dense(count)
+    n, c, h, w = preds.shape
+    call('pfst_window_normalize', preds.data_ptr(), count.data_ptr(), n, c, h * w, _stream())
+    return preds
+
+
+def argmax_nchw(x):
+    """x.argmax(dim=1) as uint8 [N, H, W] (first maximal class)"""
+    n, c, h, w = x.shape
+    lab = torch.empty(n, h, w, dtype=U8, device=x.device)
+    call('pfst_argmax_nchw', x.data_ptr(), _bs(x), lab.data_ptr(), n, c, h * w, _stream())
+    return lab
+
+
+def flip_planes(x, horizontal=False, vertical=False):
+    """x.flip(dims=(3,)) / (2,) of a dense NCHW tensor, out of place"""
+    _dense(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x)
+    call('pfst_flip_planes', x.data_ptr(), y.data_ptr(), n * c, h, w, int(horizontal), int(vertical), _stream())
+    return y
+
+
+def div_scalar_(x, d):
+    _dense(x)
+    call('pfst_div_scalar', x.data_ptr(), x.numel(), float(d), _stream())
+    return x
+
+
 # ---------------------------------------------------------------- losses
 def ce_upsample_fwd(logits, label_u8, pix_weight=None, class_weight=None, ignore_index=255):
     """-> (lse [N,H,W], acc float64[4] = (weighted nll sum, #correct, #valid, #labels outside [0,C) that are not ignore_index))"""

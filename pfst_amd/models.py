@@ -6,6 +6,7 @@ Reference behaviour followed (file:line under /root/reference/rsiseg/models):
   decode_heads/decode_head.py:55-108,188-283  aspp_head.py:53-126  sep_aspp_head.py:29-111  fcn_head.py:24-98
   segmentors/encoder_decoder.py:65-217  losses/cross_entropy_loss.py:198-298
 Only what the PFST hot path uses is implemented; unsupported options raise instead of silently differing."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -402,15 +403,77 @@ class EncoderDecoder(nn.Module):
         states.update({'feats': x, 'seg_logits': logits})
         return logits, states
 
-    # ------------------------------------------------------------------ test time (encoder_decoder.py:265-353)
+    # ------------------------------------------------------------------ test time (encoder_decoder.py:220-372)
+    def _eval_encode_decode(self, img):
+        """encode_decode as the test loop runs it (model.eval(): BatchNorm on running statistics, dropout off): the logits resized to the
+        INPUT size (encoder_decoder.py:72-84) -> (full-size logits tensor, backbone features, low-resolution logits)"""
+        with bn_eval():
+            x = self.extract_feat(img.contiguous(), None)
+            logits = self.decode_head(x, return_features=False, tape=None, training=False)
+        return ops.resize_bilinear(logits.data, tuple(img.shape[2:])), x, logits
+
+    def slide_inference(self, img, img_meta, rescale):
+        """Inference by sliding window with overlap (encoder_decoder.py:220-263): crops of test_cfg.crop_size every test_cfg.stride pixels,
+        the last window of a row / column shifted back inside the image, crop logits summed into place and divided by the cover count.
+        An image smaller than the crop is decoded whole, without padding."""
+        h_stride, w_stride = self.test_cfg['stride']
+        h_crop, w_crop = self.test_cfg['crop_size']
+        n, _, h_img, w_img = img.shape
+        num_classes = self.decode_head.num_classes
+        h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+        w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+        preds = torch.zeros(n, num_classes, h_img, w_img, device=img.device)
+        count = torch.zeros(n, 1, h_img, w_img, device=img.device)
+        covered = np.zeros((h_img, w_img), bool)                     # the reference's `assert (count_mat == 0).sum() == 0`, without a device read
+        for h_idx in range(h_grids):
+            for w_idx in range(w_grids):
+                y1, x1 = h_idx * h_stride, w_idx * w_stride
+                y2, x2 = min(y1 + h_crop, h_img), min(x1 + w_crop, w_img)
+                y1, x1 = max(y2 - h_crop, 0), max(x2 - w_crop, 0)
+                crop_logit, _, _ = self._eval_encode_decode(img[:, :, y1:y2, x1:x2])
+                ops.window_accumulate_(preds, count, crop_logit, y1, x1)
+                covered[y1:y2, x1:x2] = True
+        assert covered.all()
+        ops.window_normalize_(preds, count)
+        if rescale:
+            preds = ops.resize_bilinear(preds, tuple(img_meta[0]['ori_shape'][:2]))
+        return preds
+
+    def inference_probs(self, img, img_meta=None, rescale=True):
+        """`inference` of the reference (encoder_decoder.py:284-327): slide / whole logits -> softmax over the classes -> flipped inputs
+        flipped back; -> (probabilities [N, C, H, W], states)"""
+        mode = (self.test_cfg or {}).get('mode', 'whole')
+        assert mode in ('slide', 'whole')
+        if img_meta is not None and 'ori_shape' in img_meta[0]:
+            assert all(tuple(m['ori_shape']) == tuple(img_meta[0]['ori_shape']) for m in img_meta)
+        rescale = bool(rescale and img_meta is not None and 'ori_shape' in img_meta[0])
+        self.repack_weights(need_dgrad=False)
+        if mode == 'slide':
+            seg_logit, states = self.slide_inference(img, img_meta, rescale), {}
+        else:
+            seg_logit, x, low = self._eval_encode_decode(img)
+            size = tuple(img_meta[0]['ori_shape'][:2]) if rescale else tuple(img.shape[2:])
+            if size != tuple(img.shape[2:]):
+                seg_logit = ops.resize_bilinear(seg_logit, size)          # whole_inference (:269-280): a second resize from the input size
+            states = dict(feats=[v.data for v in x], seg_logits=low.data)
+        output = ops.softmax_nchw(seg_logit)
+        if img_meta is not None and img_meta[0].get('flip'):
+            direction = img_meta[0]['flip_direction']
+            for d in (direction if isinstance(direction, list) else [direction]):
+                assert d in ('horizontal', 'vertical')
+                output = ops.flip_planes(output, horizontal=d == 'horizontal', vertical=d == 'vertical')
+        return output, states
+
     def inference(self, img, img_meta=None, rescale=True):
-        """whole-image inference in eval mode -> (argmax label map uint8 [N,H,W], low-res logits).  The softmax of the
+        """-> (argmax label map uint8 [N,H,W], low-res logits or None).  Whole-image mode (all shipped configs): the softmax of the
         reference (`F.softmax(seg_logit)` then `argmax`) is what the fused upsample+softmax+argmax kernel evaluates (its tie rule: §7).
         As in the reference the logits are first resized to the INPUT size (encode_decode, encoder_decoder.py:77-81) and, when `rescale`
         asks for another `ori_shape`, resized a second time from there (whole_inference :269-280); flipped inputs are flipped back
-        (:314-325)."""
+        (:314-325).  Slide mode: the arg-max of `inference_probs`."""
         if self.test_cfg is not None and self.test_cfg.get('mode', 'whole') != 'whole':
-            raise NotImplementedError('slide inference is outside the PFST configs (test_cfg.mode="whole")')
+            probs, _ = self.inference_probs(img, img_meta, rescale)
+            self._last_states = None                              # the reference returns no states in slide mode (:306-307)
+            return ops.argmax_nchw(probs), None
         self.repack_weights(need_dgrad=False)
         with bn_eval():
             x = self.extract_feat(img.contiguous(), None)
@@ -434,17 +497,32 @@ class EncoderDecoder(nn.Module):
     def simple_test(self, img, img_meta=None, rescale=True):
         """-> (list of per-image label maps, list of per-image state dicts), the fork's contract (encoder_decoder.py:329-353; consumed as
         `result, state = model(return_loss=False, **data)` by apis/test.py:97).  The states hold the backbone features and the low-res
-        logits of each image (device tensors; the reference copies them to the host)."""
+        logits of each image (device tensors; the reference copies them to the host); empty dicts in slide mode."""
         lab8, _ = self.inference(img, img_meta, rescale)
         st = self._last_states
-        states = [dict(feats=[f[i] for f in st['feats']], seg_logits=st['seg_logits'][i]) for i in range(lab8.shape[0])]
+        if st is None:
+            states = [dict() for _ in range(lab8.shape[0])]
+        else:
+            states = [dict(feats=[f[i] for f in st['feats']], seg_logits=st['seg_logits'][i]) for i in range(lab8.shape[0])]
         self._last_states = None
         return list(lab8.cpu().numpy()), states
 
+    def aug_test(self, imgs, img_metas, rescale=True):
+        """Test with augmentations (encoder_decoder.py:355-372): the class probabilities of every augmented view, each mapped back to
+        `ori_shape` and un-flipped, are averaged; the arg-max of the average is the prediction.  Only rescale=True, like the reference."""
+        assert rescale
+        seg_logit, _ = self.inference_probs(imgs[0], img_metas[0], rescale)
+        for i in range(1, len(imgs)):
+            cur, _ = self.inference_probs(imgs[i], img_metas[i], rescale)
+            ops.axpy_(seg_logit, cur)
+        ops.div_scalar_(seg_logit, len(imgs))
+        return list(ops.argmax_nchw(seg_logit).cpu().numpy()), {}
+
     def forward_test(self, imgs, img_metas=None, **kwargs):
+        """base.py:74-99: one view -> simple_test, several -> aug_test"""
         if isinstance(imgs, (list, tuple)):
             if len(imgs) != 1:
-                raise NotImplementedError('aug_test (multi-scale / flip) is outside the PFST configs')
+                return self.aug_test(list(imgs), list(img_metas), **kwargs)
             imgs, img_metas = imgs[0], (img_metas[0] if img_metas else None)
         return self.simple_test(imgs, img_metas, **kwargs)
 

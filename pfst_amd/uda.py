@@ -174,7 +174,7 @@ class UDADecorator(nn.Module):
         return self.get_model().simple_test(img, img_meta, rescale)
 
     def aug_test(self, imgs, img_metas, rescale=True):
-        raise NotImplementedError('aug_test is outside the PFST configs')
+        return self.get_model().aug_test(imgs, img_metas, rescale)
 
 
 @UDA.register_module()

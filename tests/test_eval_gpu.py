@@ -170,3 +170,92 @@ def test_inference_rescale_and_flip_follow_the_reference():
     assert torch.equal(lab_f, lab.flip(dims=(2,)).flip(dims=(1,)))
     lab_n, _ = model.get_model().inference(batch['img'].cuda(), metas, rescale=False)
     assert tuple(lab_n.shape) == (2, 128, 128)
+
+
+def _eval_model_and_state(test_cfg=None):
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd.registry import UDA
+    cfg = uda_cfg()
+    if test_cfg is not None:
+        cfg['model']['test_cfg'] = test_cfg
+    model = UDA.build(cfg)
+    both, _, _ = seeded_pfgst_state(O, 9)
+    g = torch.Generator().manual_seed(1)
+    for k, v in both.items():                      # non-trivial running statistics
+        if k.endswith('running_mean'):
+            v.copy_(0.05 * torch.randn(v.shape, generator=g))
+        elif k.endswith('running_var'):
+            v.copy_(0.8 + 0.4 * torch.rand(v.shape, generator=g))
+    student = {k[6:]: v for k, v in both.items() if k.startswith('model.')}
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    return model, student, O
+
+
+@pytest.mark.parametrize('shape', [(160, 224), (96, 112)])
+def test_slide_inference_follows_the_reference(shape):
+    """test_cfg.mode='slide' (encoder_decoder.py:220-263): overlapping windows with the last one shifted back inside the image, crop logits
+    summed and divided by the cover count, rescaled to ori_shape; an image smaller than the crop (second shape: one axis) is decoded
+    without padding.  Probabilities against the oracle's line-by-line restatement, predictions through the registry API."""
+    H, W = shape
+    test_cfg = dict(mode='slide', crop_size=(128, 128), stride=(85, 85))
+    model, student, O = _eval_model_and_state(test_cfg)
+    img = torch.randn(2, 3, H, W, generator=torch.Generator().manual_seed(3))
+    metas = [dict(ori_shape=(H + 16, W + 8, 3), flip=False)] * 2
+    with torch.no_grad():
+        ref = O.inference_probs(student, img, metas, test_cfg, True)
+    seg = model.get_model()
+    probs, states = seg.inference_probs(img.cuda(), metas, True)
+    assert states == {} and tuple(probs.shape) == (2, 6, H + 16, W + 8)
+    assert float((probs.cpu() - ref).abs().max()) < 1e-3 * float(ref.max())
+    out, st = model(img.cuda(), metas, return_loss=False)
+    assert st == [{}, {}]
+    pred = torch.from_numpy(np.stack(out)).long()
+    assert (pred != ref.argmax(1)).float().mean() < 2e-3
+    # the window kernels themselves are exact: same sums as F.pad + add on identical crops
+    from pfst_amd import hip_ops as ops
+    a, b = torch.randn(2, 6, 40, 56, generator=torch.Generator().manual_seed(5)), torch.randn(2, 6, 40, 56, generator=torch.Generator().manual_seed(6))
+    preds, count = torch.zeros(2, 6, 64, 80, device='cuda'), torch.zeros(2, 1, 64, 80, device='cuda')
+    ops.window_accumulate_(preds, count, a.cuda(), 0, 0)
+    ops.window_accumulate_(preds, count, b.cuda(), 24, 24)
+    ops.window_accumulate_(preds, count, a.cuda(), 24, 0)
+    want = F.pad(a, (0, 24, 0, 24)) + F.pad(b, (24, 0, 24, 0)) + F.pad(a, (0, 24, 24, 0))
+    cnt = F.pad(torch.ones(2, 1, 40, 56), (0, 24, 0, 24)) + F.pad(torch.ones(2, 1, 40, 56), (24, 0, 24, 0)) + F.pad(torch.ones(2, 1, 40, 56), (0, 24, 24, 0))
+    assert torch.equal(preds.cpu(), want) and torch.equal(count.cpu(), cnt)
+
+
+@pytest.mark.parametrize('mode', ['whole', 'slide'])
+def test_aug_test_averages_the_views_like_the_reference(mode):
+    """aug_test (encoder_decoder.py:355-372; base.py:74-99 dispatches a list of views to it): three views -- plain, horizontally flipped,
+    a larger scale flipped vertically -- each mapped back to ori_shape and un-flipped, probabilities averaged, arg-max."""
+    test_cfg = dict(mode='whole') if mode == 'whole' else dict(mode='slide', crop_size=(96, 96), stride=(64, 64))
+    model, student, O = _eval_model_and_state(test_cfg)
+    g = torch.Generator().manual_seed(11)
+    base = torch.randn(2, 3, 128, 128, generator=g)
+    big = F.interpolate(base, size=(160, 160), mode='bilinear', align_corners=False)
+    imgs = [base, base.flip(3), big.flip(2)]
+    metas = [[dict(ori_shape=(128, 128, 3), flip=False)] * 2,
+             [dict(ori_shape=(128, 128, 3), flip=True, flip_direction='horizontal')] * 2,
+             [dict(ori_shape=(128, 128, 3), flip=True, flip_direction='vertical')] * 2]
+    with torch.no_grad():
+        ref_pred, ref_prob = O.aug_test(student, [i.clone() for i in imgs], metas, test_cfg)
+    out, st = model([i.cuda() for i in imgs], metas, return_loss=False)
+    assert st == {} and len(out) == 2 and out[0].shape == (128, 128)
+    pred = torch.from_numpy(np.stack(out)).long()
+    assert (pred != ref_pred).float().mean() < 2e-3
+    seg = model.get_model()
+    p0, _ = seg.inference_probs(imgs[1].cuda(), metas[1], True)
+    with torch.no_grad():
+        r0 = O.inference_probs(student, imgs[1], metas[1], test_cfg, True)
+    assert float((p0.cpu() - r0).abs().max()) < 1e-3 * float(r0.max())
+    # softmax / arg-max / flip kernels against torch on identical inputs: probabilities to 2 ulp, labels and flips exact
+    from pfst_amd import hip_ops as ops
+    z = torch.randn(2, 6, 33, 47, generator=g) * 3
+    sm = ops.softmax_nchw(z.cuda()).cpu()
+    assert float((sm - z.softmax(1)).abs().max()) < 3e-7
+    assert torch.equal(ops.argmax_nchw(sm.cuda()).cpu().long(), sm.argmax(1))
+    tie = torch.zeros(1, 6, 4, 4); tie[:, 2] = 1.0; tie[:, 4] = 1.0
+    assert int(ops.argmax_nchw(tie.cuda()).max()) == 2 and int(ops.argmax_nchw(tie.cuda()).min()) == 2          # first maximal class
+    assert torch.equal(ops.flip_planes(z.cuda(), horizontal=True).cpu(), z.flip(3)) and torch.equal(ops.flip_planes(z.cuda(), vertical=True).cpu(), z.flip(2))
+    assert torch.equal(ops.div_scalar_(z.clone().cuda(), 3).cpu(), z / 3)
