@@ -191,8 +191,10 @@ int pfst_bn_finalize_partials(const float* partials, int T, int C, double count,
  * 1 bit per element instead of the fp32 output y in both of its passes. */
 int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, pfst_stream_t stream);
-/* y_amax: NULL, or the slot group (1024 floats, zeroed) that receives max |y|: the scale of an f16x3 GEMM reading y */
+                  int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, const float* post_scale, pfst_stream_t stream);
+/* y_amax: NULL, or the slot group (1024 floats, zeroed) that receives max |y|: the scale of an f16x3 GEMM reading y.
+ * post_scale: NULL, or [N][C] factors y is multiplied by after the ReLU -- nn.Dropout2d's keep / (1 - p) mask of the layer feeding conv_seg
+ * (decode_head.py:103-107,242-247) folded into this pass (no residual then) */
 /* backward of the above: dz = dy * (y > 0 if relu); dres (+)= dz; dgamma += sum dz*xhat; dbeta += sum dz;
  * dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)).  ws: >= 2*C doubles.  The ReLU gate comes from relu_mask (as written by
  * pfst_bn_apply), else from the saved output y; if both are NULL and beta != NULL (layer without residual) it is recomputed from
@@ -201,7 +203,9 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
                      const float* mean, const float* invstd, const float* gamma, const float* beta,
                      float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                      float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                     double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, pfst_stream_t stream);
+                     double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, const float* post_scale, pfst_stream_t stream);
+/* post_scale: the factors pfst_bn_apply folded into y: dy is the gradient of the SCALED output, dz = dy * post_scale[n][c] * gate (no dres, no
+ * bwd_partials then) */
 /* bwd_partials != NULL: (sum dz, sum dz*x) were already produced by the launch that wrote dy (pfst_bnb_fuse_t, [C][bwd_slots][2]); the
  * reduction pass over dy and x is skipped and only the partials are summed (fp64). */
 

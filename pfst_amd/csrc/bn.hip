@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int C, int HW, int relu, unsigned long long* __restrict__ mask, int rev,
-                                                       float* __restrict__ amax) {
+                                                       float* __restrict__ amax, const float* __restrict__ post) {
+  // post != NULL: y is multiplied by post[n][c] after the ReLU -- nn.Dropout2d's keep / (1 - p) factor of the layer that feeds conv_seg
+  // (decode_head.py:103-107,242-247) folded into this pass: the same product the separate scaling pass formed, one tensor round trip less
   // rev: walk the tensor from its end (planes, images and blocks in descending order) -- see pfst_bn_order()
   // amax != NULL: max |y| of what this launch writes goes to that slot group (amax.h): the scale of the next f16x3 GEMM's operand
   float am = 0.f;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   float sc, sh;
   bn_affine(mean[c], invstd[c], gamma[c], beta[c], sc, sh);
+  const float pm = post ? post[n * C + c] : 1.f;
   const float* xp = x + (i64)n * x_bs + (i64)c * HW;
   const float* rp = res ? res + (i64)n * res_bs + (i64)c * HW : nullptr;
   float* yp = y + (i64)n * y_bs + (i64)c * HW;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
           if (l < 4) mask[((i64)n * C + c) * (HW >> 6) + (i64)(i >> 6) * 4 + l] = l == 0 ? b0 : (l == 1 ? b1 : (l == 2 ? b2 : b3));
         }
         if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+        if (post) { w.x *= pm; w.y *= pm; w.z *= pm; w.w *= pm; }
         if (i < n4) am = fmaxf(fmaxf(am, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), yr, off[u], 0, 0);
       }
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       float v = __fmaf_rn(xp[i], sc, sh);
       if (rp) v += rp[i];
       if (relu) v = fmaxf(v, 0.f);
+      if (post) v *= pm;
       am = fmaxf(am, fabsf(v));
       yp[i] = v;
     }
@@ -228,11 +233,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int HW, int chunk, int relu, const unsigned long long* __restrict__ mask,
-                                                            double* __restrict__ ws, int rev) {
+                                                            double* __restrict__ ws, int rev, const float* __restrict__ post) {
+  // post != NULL: the incoming gradient is the gradient of y * post[n][c] (bn_apply's folded Dropout2d factor): dz = dy * post * gate
   __shared__ double sm[32];
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   const float mu = mean[c], is = invstd[c];
+  const float pm = post ? post[n * gridDim.y + c] : 1.f;
   // ReLU mask: from the saved output y, or (no residual) recomputed bit-identically to bn_apply from x -- saves the y read
   float sc, sh;
   bn_affine(mu, is, gamma[c], beta ? beta[c] : 0.f, sc, sh);
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         if (i4 >= e4) break;
         float4 g = gq[u];
         const float4 xv = xq[u];
+        if (post) { g.x *= pm; g.y *= pm; g.z *= pm; g.w *= pm; }
         if (relu) {
           bool on[4];
           relu_on4(mp, yp, i4, xv, sc, sh, on);
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int i = beg + threadIdx.x; i < end; i += blockDim.x) {
       float dz = gp[i];
       const float xv = xp[i];
+      if (post) dz *= pm;
       if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
       const float xh = (xv - mu) * is;
       s += (double)dz;
@@ -320,11 +329,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int C, int HW, double inv_count, int relu,
                                                            const unsigned long long* __restrict__ mask, const double* __restrict__ ws, int rev,
-                                                           float* __restrict__ amax) {
+                                                           float* __restrict__ amax, const float* __restrict__ post) {
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
   const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
   float am = 0.f;                                      // max |dx| written here -> slot group `amax` (f16x3 scale of the gradient operand)
   const float mu = mean[c], is = invstd[c];
+  const float pm = post ? post[n * C + c] : 1.f;       // folded Dropout2d factor (see bn_bwd_reduce_kernel)
   // the two projections are subtracted in fp64: dz - mean(dz) cancels heavily when dz has a large common mode
   const double m1 = ws[2 * c] * inv_count, m2 = ws[2 * c + 1] * inv_count;
   const double gs = (double)gamma[c] * (double)is;
@@ -346,6 +356,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int i4 = bxi * blockDim.x + threadIdx.x; i4 < (HW >> 2); i4 += stride) {
       float4 g = reinterpret_cast<const float4*>(gp)[i4];
       const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
+      if (post) { g.x *= pm; g.y *= pm; g.z *= pm; g.w *= pm; }
       if (relu) {
         bool on[4];
         relu_on4(mp, yp, i4, xv, sc, sh, on);
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (int i = bxi * blockDim.x + threadIdx.x; i < HW; i += stride) {
       float dz = gp[i];
       const float xv = xp[i];
+      if (post) dz *= pm;
       if (relu && !relu_on(mp, yp, i, xv, sc, sh)) dz = 0.f;
       const double xh = ((double)xv - (double)mu) * (double)is;
       const float o = (float)(gs * ((double)dz - m1 - xh * m2));
@@ -436,15 +448,17 @@ static int pfst_bn_order() {
 
 extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                             int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, pfst_stream_t stream) {
+                             int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, const float* post_scale,
+                             pfst_stream_t stream) {
   PFST_CHECK_ARG(x && y && mean && invstd && gamma && beta && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!post_scale || !residual);          // the folded Dropout2d factor belongs to a plain conv -> BN -> ReLU layer
   // the bitmask comes out of the float4 path only: whole 256-element groups per wave, 16-byte aligned planes
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0 && ((x_bs | y_bs | (residual ? res_bs : 0)) & 3) == 0 &&
                                 (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0));
   int gx = cdiv(HW, 256 * 4 * 4);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, residual, res_bs, y, y_bs, mean,
-                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1, y_amax);
+                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1, y_amax, post_scale);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -453,8 +467,10 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
                                 const float* mean, const float* invstd, const float* gamma, const float* beta,
                                 float* dx, long long dx_bs, float* dres, long long dres_bs, int dres_accumulate,
                                 float* dgamma, float* dbeta, int N, int C, int HW, int relu, const unsigned long long* relu_mask,
-                                double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, pfst_stream_t stream) {
+                                double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, const float* post_scale,
+                                pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && mean && invstd && gamma && dx && ws && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!post_scale || (!dres && !bwd_partials));     // no residual branch, no fused sums (they were formed without the factor)
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0));
   PFST_CHECK_ARG(!relu || relu_mask || y || beta);   // ReLU mask from y, or recomputed from x with beta (no residual)
   PFST_CHECK_ARG(!bwd_partials || bwd_slots > 0);
@@ -472,15 +488,15 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   if (vec) {
     if (!fused)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1);
+                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
-                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax);
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   } else {
     if (!fused)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1);
+                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
-                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax);
+                       dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   }
   PFST_CHECK_LAUNCH();
   return PFST_OK;

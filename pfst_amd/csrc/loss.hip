@@ -5,6 +5,7 @@
 // Reference: rsiseg/models/decode_heads/decode_head.py:249-283 (resize + CE + accuracy),
 // losses/cross_entropy_loss.py:45-65, losses/utils.py:60-69, losses/accuracy.py:6-61,
 // uda/pfgst.py:259-300 (pseudo labels, class mix), utils/dacs_transforms.py:110-144.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/pfst_hip.h"
 
@@ -40,13 +41,28 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
     const int lab = label[(i64)n * H * W + p];
     float mx = -INFINITY, zl = 0.f;
     int arg = 0;
-    for (int c = 0; c < C; ++c) {
-      const float z = interp(lp + (i64)c * hw, w, b);
-      if (z > mx) { mx = z; arg = c; }
-      if (c == lab) zl = z;
-    }
     float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
+    if (C <= 8) {
+      // up to eight classes (the ISPRS / INRIA configs: 6 / 2): the interpolated logits stay in registers between the max and the sum pass
+      // (same values, same order of operations: bit-identical to the two-pass form below)
+      float zc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        zc[c] = c < C ? interp(lp + (i64)c * hw, w, b) : -INFINITY;
+        if (c < C && zc[c] > mx) { mx = zc[c]; arg = c; }
+        if (c == lab) zl = zc[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) se += expf(zc[c] - mx);
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const float z = interp(lp + (i64)c * hw, w, b);
+        if (z > mx) { mx = z; arg = c; }
+        if (c == lab) zl = z;
+      }
+      for (int c = 0; c < C; ++c) se += expf(interp(lp + (i64)c * hw, w, b) - mx);
+    }
     const float l = mx + logf(se);
     lse[(i64)n * H * W + p] = l;
     if (lab != ignore && lab < C) {
@@ -112,6 +128,66 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     }
     acc *= scale;
     dp[i] = accumulate ? dp[i] + acc : acc;
+  }
+}
+
+// The same gather with ONE thread per low-resolution cell for all classes (C <= 8): the per-pixel work that does not depend on the class --
+// source coordinates and weights, label, log-sum-exp, pixel weight -- is done once instead of C times, the C accumulators live in
+// registers.  Per class the terms and their order are those of ce_bwd_kernel: bit-identical gradients.       grid: (blocks over h*w, 1, N)
+__global__ __launch_bounds__(256) void ce_bwd_cells_kernel(const float* __restrict__ logits, int C, int h, int w,
+                                                           const unsigned char* __restrict__ label, const float* __restrict__ pw,
+                                                           const float* __restrict__ cw, int H, int W, int ignore, float sh, float sw,
+                                                           const float* __restrict__ lse, float scale, float* __restrict__ dlogits,
+                                                           int accumulate) {
+  const int n = blockIdx.z;
+  const int hw = h * w;
+  const float* lp = logits + (i64)n * C * hw;
+  const unsigned char* lab = label + (i64)n * H * W;
+  const float* ls = lse + (i64)n * H * W;
+  const float* pwp = pw ? pw + (i64)n * H * W : nullptr;
+  float* dp = dlogits + (i64)n * C * hw;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+    const int iy = i / w, ix = i - iy * w;
+    int oy_lo = (int)floorf(((float)iy - 0.5f) / sh - 0.5f) - 1, oy_hi = (int)ceilf(((float)iy + 1.5f) / sh - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 0.5f) / sw - 0.5f) - 1, ox_hi = (int)ceilf(((float)ix + 1.5f) / sw - 0.5f) + 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, H - 1);
+    ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, W - 1);
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly0, ly1;
+      bilin_src(oy, sh, h, y0, y1, ly0, ly1);
+      const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        Bilin b;
+        b.y0 = y0; b.y1 = y1; b.ly0 = ly0; b.ly1 = ly1;
+        bilin_src(ox, sw, w, b.x0, b.x1, b.lx0, b.lx1);
+        const float wx = (b.x0 == ix ? b.lx0 : 0.f) + (b.x1 == ix ? b.lx1 : 0.f);
+        if (wx == 0.f) continue;
+        const int p = oy * W + ox;
+        const int l = lab[p];
+        if (l == ignore || l >= C) continue;
+        float g = pwp ? pwp[p] : 1.f;
+        if (cw) g *= cw[l];
+        const float wg = wy * wx * g, lsp = ls[p];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (c < C) {
+            const float prob = expf(interp(lp + (i64)c * hw, w, b) - lsp);
+            acc[c] = fmaf(wg, prob - (l == c ? 1.f : 0.f), acc[c]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c < C) {
+        const float a = acc[c] * scale;
+        dp[(i64)c * hw + i] = accumulate ? dp[(i64)c * hw + i] + a : a;
+      }
+    }
   }
 }
 
@@ -249,8 +325,13 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
                                     float* dlogits, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && label && lse && dlogits && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   int gx = cdiv((i64)h * w, 256);
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
-                     class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
+  static const bool cells = !(getenv("PFST_CE_CELLS") && atoi(getenv("PFST_CE_CELLS")) == 0);      // PFST_CE_CELLS=0: the per-(cell, class) kernel (A/B)
+  if (C <= 8 && cells)
+    hipLaunchKernelGGL(ce_bwd_cells_kernel, dim3(gx, 1, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
+                       class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
+  else
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
+                       class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -575,10 +575,12 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gam
     return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False, amax=None):
+def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False, amax=None, post=None):
     """want_mask: also return the ReLU gate as a bitmask (int64 words) for bn_backward, or None where the kernel cannot
-    produce it (plane size not a multiple of 256, unaligned slices) -- the caller then keeps using y."""
+    produce it (plane size not a multiple of 256, unaligned slices) -- the caller then keeps using y.
+    post: [N, C] factors applied after the ReLU (the Dropout2d mask of the layer feeding conv_seg, folded into this pass)"""
     n, c, h, w = x.shape
+    assert post is None or (residual is None and post.numel() == n * c)
     if out is None:
         out = torch.empty(n, c, h, w, device=x.device)
     assert out.shape == x.shape
@@ -588,12 +590,12 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, w
         mask = torch.empty(n * c * h * w // 64, dtype=torch.int64, device=x.device)
     call('pfst_bn_apply', x.data_ptr(), _bs(x), _p(residual), 0 if residual is None else _bs(residual), out.data_ptr(), _bs(out),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _p(mask),
-         _p(amax), _stream())
+         _p(amax), _p(None if post is None else _dense(post)), _stream())
     return (out, mask) if want_mask else out
 
 
 def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=None, dres_accumulate=False, dx=None, beta=None,
-                mask=None, partials=None, slots=0, amax=None):
+                mask=None, partials=None, slots=0, amax=None, post=None):
     """mask: the bitmask bn_apply(..., want_mask=True) returned; replaces y as the source of the ReLU gate.
     partials / slots: the (sum dz, sum dz*x) partials the launch that wrote dy emitted (conv_dgrad(bnb=...)): no reduction pass"""
     n, c, h, w = x.shape
@@ -604,7 +606,7 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
     call('pfst_bn_backward', dy.data_ptr(), _bs(dy), _p(y), 0 if y is None else _bs(y), x.data_ptr(), _bs(x),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _p(beta), dx.data_ptr(), _bs(dx),
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
-         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _p(amax), _stream())
+         n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _p(amax), _p(None if post is None else _dense(post)), _stream())
     return dx
 
 

@@ -350,8 +350,8 @@ class ConvModule(nn.Module):
         self.conv = Conv2dP(cin, cout, k, stride, padding, dilation, groups, bias=False)
         self.bn = BatchNorm2dP(cout)
 
-    def forward(self, x, tape, relu=True, residual=None, out=None):
-        return conv_bn_act(x, self.conv, self.bn, tape, relu, residual, out)
+    def forward(self, x, tape, relu=True, residual=None, out=None, post_scale=None):
+        return conv_bn_act(x, self.conv, self.bn, tape, relu, residual, out, post_scale)
 
 
 class DepthwiseSeparableConvModule(nn.Module):
@@ -360,8 +360,8 @@ class DepthwiseSeparableConvModule(nn.Module):
         self.depthwise_conv = ConvModule(cin, cin, k, 1, padding, dilation, groups=cin)
         self.pointwise_conv = ConvModule(cin, cout, 1)
 
-    def forward(self, x, tape, out=None):
-        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out)
+    def forward(self, x, tape, out=None, post_scale=None):
+        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale)
 
 
 def conv_forward(x, conv, tape, out=None):
@@ -498,9 +498,12 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
             _dgrad_into(x, conv, dy, final, dy_amax)
 
 
-def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
+def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scale=None):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
-    (then the returned Var is expected to be obtained from the concat Var's .slice())."""
+    (then the returned Var is expected to be obtained from the concat Var's .slice()).
+    post_scale: [N, C] factors applied to y after the ReLU -- the Dropout2d mask of the layer feeding conv_seg, folded into the
+    normalisation pass and, in backward, into the BatchNorm-backward passes (one tensor round trip less each way)"""
+    assert post_scale is None or residual is None
     xd = x.data
     # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
     # cancellation: var = E[x^2] - mean^2 from the epilogue's fp32 partial sums of squares loses what torch's two-pass variance keeps
@@ -544,7 +547,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     # f16x3: the normalisation pass publishes max |y| for the GEMMs that will read y (no separate pass over the tensor)
     yv = out_var if out_var is not None else Var(None, tape is not None)
     y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
-                     None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device))
+                     None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device),
+                     post=post_scale)
     gate = None
     if want_mask:
         y, gate = y
@@ -555,7 +559,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
     final = x.claim_first_use()
     if residual is not None:
         residual.claim_first_use()
-    if coef is not None and out_var is None:
+    if coef is not None and out_var is None and post_scale is None:
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
         yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)
@@ -572,7 +576,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None):
                                                                     or conv.wino_f16)
         dpre_amax = ops.amax_slots(pre.device) if need_amax else None
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax)
+                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax,
+                               post=post_scale)
         conv_backward(x, conv, dpre, saved_v, final, dy_amax=dpre_amax)
         if yv.parent is None:
             yv.free_grad()

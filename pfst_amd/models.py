@@ -6,6 +6,8 @@ Reference behaviour followed (file:line under /root/reference/rsiseg/models):
   decode_heads/decode_head.py:55-108,188-283  aspp_head.py:53-126  sep_aspp_head.py:29-111  fcn_head.py:24-98
   segmentors/encoder_decoder.py:65-217  losses/cross_entropy_loss.py:198-298
 Only what the PFST hot path uses is implemented; unsupported options raise instead of silently differing."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -15,6 +17,10 @@ from .engine import Var
 from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, WeightBatch, bn_eval, conv_bn_act,
                      conv_forward)
 from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
+
+
+# PFST_FOLD_DROPOUT=0: the decode head's Dropout2d as a scaling pass of its own (A/B runs); default: folded into sep_bottleneck[1]'s normalisation
+FOLD_DROPOUT = os.environ.get('PFST_FOLD_DROPOUT', '1') == '1'
 
 
 def _check_norm(norm_cfg):
@@ -231,23 +237,34 @@ class BaseDecodeHead(nn.Module):
         self.dropout_enabled = True            # the teacher switches this off (pfgst.py:247-251)
         self.injected_dropout_mask = None      # parity tests inject the (n, C) keep/scale mask
 
-    def cls_seg(self, feat, tape, training):
+    def dropout_mask(self, n, training):
+        """the (n, C) keep / (1 - p) factors of nn.Dropout2d (decode_head.py:103-107), or None when dropout is off (evaluation, the
+        teacher, p = 0); the parity tests inject theirs.  Drawn by the head right before its last conv -> BN -> ReLU layer, which
+        applies it in its normalisation pass (layers.conv_bn_act(post_scale=...)): the torch generator sees the same draws in the
+        same order as when the mask was drawn after that layer (nothing in between draws from it)"""
         p = self.dropout_ratio
-        if self.injected_dropout_mask is not None or (training and self.dropout_enabled and p > 0):
-            n, c = feat.data.shape[:2]
-            mask = self.injected_dropout_mask
-            if mask is None:
-                mask = (torch.rand(n, c, device=feat.data.device) >= p).float() / (1.0 - p)
+        if self.injected_dropout_mask is not None:
+            return self.injected_dropout_mask
+        if training and self.dropout_enabled and p > 0:
+            dev = self.conv_seg.weight.device
+            return (torch.rand(n, self.channels, device=dev) >= p).float() / (1.0 - p)
+        return None
+
+    def cls_seg(self, feat, tape, training, dropped=False):
+        """dropout + conv_seg (decode_head.py:242-247).  dropped: `feat` already carries the Dropout2d factors (folded into the layer that
+        produced it); otherwise they are applied here as a pass of their own"""
+        mask = None if dropped else self.dropout_mask(feat.data.shape[0], training)
+        if mask is not None:
             src = feat
             y = ops.channel_scale(src.data, mask)
             feat = Var(y, tape is not None)
             if tape is not None:
-                dropped = feat
+                dropped_v = feat
 
                 def bwd():
-                    src._grad = ops.channel_scale(dropped.grad, mask)
-                    dropped.free_grad()
-                tape.record(bwd, dict(op='channel_scale', x=src, out=dropped, mask=mask))
+                    src._grad = ops.channel_scale(dropped_v.grad, mask)
+                    dropped_v.free_grad()
+                tape.record(bwd, dict(op='channel_scale', x=src, out=dropped_v, mask=mask))
         return conv_forward(feat, self.conv_seg, tape)
 
     def losses(self, seg_logit, seg_label_u8, seg_weight, tape, grad_scale=1.0):
@@ -326,8 +343,10 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
             tape.record(bwd_up, dict(op='resize', name='decode_head.up', x=feats, out=cat2.slice(0, ch)))
         self.c1_bottleneck(c1, tape, out=cat2.slice(ch, ch + self.c1_channels))
         o = self.sep_bottleneck[0](cat2, tape)
-        o = self.sep_bottleneck[1](o, tape)
-        logits = self.cls_seg(o, tape, training)
+        fold = FOLD_DROPOUT
+        mask = self.dropout_mask(n, training) if fold else None
+        o = self.sep_bottleneck[1](o, tape, post_scale=mask)          # Dropout2d folded into this layer's normalisation pass
+        logits = self.cls_seg(o, tape, training, dropped=fold)
         return (logits, feats) if return_features else logits
 
     @staticmethod
@@ -349,6 +368,8 @@ class FCNHead(BaseDecodeHead):
         self.convs = nn.Sequential(ConvModule(self.in_channels, self.channels, 3, padding=dilation, dilation=dilation))
 
     def forward(self, inputs, return_features=False, tape=None, training=True):
+        # (the features this head returns are the PRE-dropout ones, fcn_head.py:92-98, so its Dropout2d stays a pass of its own -- an eighth
+        # of the decode head's tensor; the decode head returns the ASPP bottleneck output and folds its dropout, see above)
         feats = self.convs[0](inputs[self.in_index], tape)
         logits = self.cls_seg(feats, tape, training)
         return (logits, feats) if return_features else logits

@@ -664,6 +664,38 @@ def gen_train_step(ref):
     np.savez_compressed(os.path.join(OUT, 'train_step.npz'), **out)
 
 
+def gen_train_step_512(ref):
+    """One full PFGST.train_step of the reference at b = 2 x 512^2 (BASELINE config #1's tile size), the input of
+    tests/test_train_step_gpu.py::test_train_step_at_512_matches_oracle (same seeds): pins the mid-size whole-step comparison -- where
+    the HIP path's tile chains, multi-round grids and split-K engage -- to the EXECUTED reference, not only to the oracle."""
+    torch.manual_seed(0)
+    C, S, b = 6, 512, 2
+    cfg = uda_cfg(C, dropout=0.0)
+    model = ref.builder.UDA.build(cfg)
+    sd = model.state_dict()
+    fill_state_dict(sd, 9)
+    model.load_state_dict(sd)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    random.seed(101)
+    np.random.seed(101)
+    batch = synth_batch(b, S, C, seed=4242)
+    model.pseudo_threshold = 0.30
+    res = model.train_step(batch, opt)
+    lv, st = res['log_vars'], res['states']
+    out = dict(log_keys=np.array(list(lv.keys())), log_vals=np.array([float(v) for v in lv.values()], dtype=np.float64),
+               mixed_lbl=st['vis|seg_mask_mix'][1].numpy().astype(np.uint8), mix_pred=st['vis|seg_mask_mix'][2].numpy().astype(np.uint8),
+               ignore_mask_trg=st['vis|density_sim_feat'][2].numpy(), np_state_after=np.random.get_state()[1][:8].copy())
+    _assert_live_target_side(lv, st, 'train_step_512')
+    g = {n: p.grad for n, p in model.model.named_parameters()}
+    out['grad_names'] = np.array(list(g.keys()))
+    out['grad_norms'] = np.array([float(v.norm()) for v in g.values()])
+    for n in GRAD_SAMPLES + ['decode_head.conv_seg.weight', 'auxiliary_head.conv_seg.weight']:
+        out['grad|' + n] = g[n].numpy().reshape(g[n].shape[0], -1)[:32, :64].copy()
+    np.savez_compressed(os.path.join(OUT, 'train_step_512.npz'), **out)
+    print('train_step_512.npz', lv)
+
+
 GRAD_SAMPLES = ['decode_head.conv_seg.bias', 'decode_head.sep_bottleneck.1.pointwise_conv.conv.weight',
                 'decode_head.sep_bottleneck.1.pointwise_conv.bn.weight', 'decode_head.sep_bottleneck.0.depthwise_conv.conv.weight',
                 'decode_head.bottleneck.bn.bias', 'backbone.layer4.2.bn3.weight']
@@ -728,7 +760,7 @@ def gen_train_step_variants(ref, only=None):
 if __name__ == '__main__':
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step', 'variants']
+    which = sys.argv[1:] or ['small', 'options', 'options2', 'dataset', 'dataset2', 'pipeline', 'seg', 'step', 'variants', 'step512']
     if 'options2' in which:
         gen_pfgst_options2(ref)
     if 'small' in which:
@@ -747,3 +779,5 @@ if __name__ == '__main__':
         gen_train_step(ref)
     if 'variants' in which:
         gen_train_step_variants(ref)
+    if 'step512' in which:
+        gen_train_step_512(ref)

@@ -341,3 +341,91 @@ def test_winograd_layers_outside_the_f16x3_shapes_train(chan, math):
             assert worst <= 1.0, (chan, math, name, worst, nrm)
     finally:
         layers.CONV_MATH = prev
+
+
+@pytest.mark.parametrize('math', ['f16x3', 'f32'])
+def test_dropout2d_folded_into_the_normalisation_pass(math):
+    """nn.Dropout2d before conv_seg (decode_head.py:103-107,242-247).  The decode head applies its keep / (1 - p) factors inside the
+    normalisation pass of sep_bottleneck[1]'s pointwise layer (bn_apply post_scale) and, in backward, inside that layer's
+    BatchNorm-backward passes; the auxiliary head keeps the separate scaling pass (its returned features are the pre-dropout ones).  One
+    segmentor forward + backward with INJECTED masks against the oracle: losses, logits, and the gradients on both sides of the dropout."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=4321)
+    img, gt = batch['img'], batch['gt_semantic_seg']
+    g = torch.Generator().manual_seed(17)
+    p = 0.3                                            # a third of the planes dropped: every code path sees zeros and scaled planes
+    m_dec = ((torch.rand(b, 512, generator=g) >= p).float() / (1 - p))
+    m_aux = ((torch.rand(b, 256, generator=g) >= p).float() / (1 - p))
+    sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and 'running' not in k else
+              (v.clone().double() if v.is_floating_point() else v.clone())) for k, v in student.items()}
+    losses, _, logits, _, aux_logits = O.segmentor_forward_train(sd, img.double(), gt, None,
+                                                                  drop_masks=(m_dec.double().view(b, 512, 1, 1), m_aux.double().view(b, 256, 1, 1)))
+    sum(v for k, v in losses.items() if 'loss' in k).backward()
+    prev = layers.CONV_MATH
+    layers.CONV_MATH = math
+    try:
+        model = build_segmentor(model_cfg(C, 3, dropout=0.1))
+        model.load_state_dict(student, strict=True)
+        model.cuda()
+        arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+        model.repack_weights(need_dgrad=True)
+        model.decode_head.injected_dropout_mask, model.auxiliary_head.injected_dropout_mask = m_dec.cuda(), m_aux.cuda()
+        calls = []
+        orig = ops.channel_scale
+        ops.channel_scale = lambda x, m: (calls.append(tuple(x.shape)), orig(x, m))[1]
+        try:
+            tape = Tape()
+            out = model.forward_train(img.cuda(), batch['img_metas'], ops.to_u8(gt.cuda()), None, return_logits=True, tape=tape)
+            tape.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.channel_scale = orig
+    finally:
+        layers.CONV_MATH = prev
+    # the decode head's dropout ran inside bn_apply / bn_backward: the only separate scaling passes are the auxiliary head's (fwd + bwd)
+    assert calls == [(b, 256, S // 8, S // 8)] * 2, calls
+    for k in ('decode.loss_ce', 'aux.loss_ce', 'decode.acc_seg', 'aux.acc_seg'):
+        assert abs(float(out[k]) - float(losses[k])) <= 1e-3 * max(abs(float(losses[k])), 1e-2), (k, float(out[k]), float(losses[k]))
+    worst, nrm = mixed_err(out['logits'].data, logits, )
+    assert nrm < 1e-3, nrm
+    # gradients above the dropout (conv_seg: 1e-3), of the layer it is folded into (one train-mode BatchNorm below the loss: the fp32
+    # conditioning regime of tests/test_train_step_gpu.py's golden samples, 2e-2) and one layer further down (0.1).  A wrong or missing
+    # factor would show as O(0.3): a third of the planes are zeroed, the rest scaled by 1.43.
+    for name, tol in (('decode_head.conv_seg.weight', 1e-3), ('decode_head.conv_seg.bias', 1e-3),
+                      ('decode_head.sep_bottleneck.1.pointwise_conv.conv.weight', 2e-2),
+                      ('decode_head.sep_bottleneck.1.pointwise_conv.bn.weight', 2e-2), ('decode_head.sep_bottleneck.1.pointwise_conv.bn.bias', 2e-2),
+                      ('decode_head.sep_bottleneck.1.depthwise_conv.conv.weight', 0.1), ('auxiliary_head.conv_seg.weight', 1e-3),
+                      ('auxiliary_head.convs.0.bn.weight', 2e-2), ('auxiliary_head.convs.0.conv.weight', 2e-2)):
+        _, e = mixed_err(arena.view(arena.grad, name), sd[name].grad)
+        print(f'   {name}: rel err vs fp64 {e:.2e} (bound {tol})')
+        assert e < tol, (name, e)
+    # and the fold is the SAME arithmetic as the separate scaling pass (one product per element, in the same place of both chains): the
+    # logits are bit-identical, the gradients agree to the weight gradients' atomic summation order
+    from pfst_amd import models
+    grad_fold, logits_fold = arena.grad.clone(), out['logits'].data.clone()
+    prev_fold, models.FOLD_DROPOUT = models.FOLD_DROPOUT, False
+    layers.CONV_MATH = math
+    try:
+        arena.zero_grad()
+        model.repack_weights(need_dgrad=True)
+        for m in model.modules():                                  # same BatchNorm running buffers as the first pass started from
+            if isinstance(m, layers.BatchNorm2dP):
+                m.running_mean.zero_(); m.running_var.fill_(1.0)
+        tape = Tape()
+        out2 = model.forward_train(img.cuda(), batch['img_metas'], ops.to_u8(gt.cuda()), None, return_logits=True, tape=tape)
+        tape.backward()
+        torch.cuda.synchronize()
+    finally:
+        models.FOLD_DROPOUT, layers.CONV_MATH = prev_fold, prev
+    assert torch.equal(out2['logits'].data, logits_fold), 'folded and separate Dropout2d must give bit-identical logits'
+    _, e = mixed_err(arena.grad, grad_fold)
+    assert e < 1e-4, e

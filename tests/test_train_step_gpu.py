@@ -282,6 +282,21 @@ def test_train_step_at_512_matches_oracle():
     flat_m = torch.cat([arena.view(arena.grad, n).flatten() for n in ex['grads']])
     print('flat gradient rel err vs fp64: HIP %.3e  oracle-fp32 %.3e' % (rel(flat_m, flat_64), rel(flat_o, flat_64)))
     assert rel(flat_m, flat_64) <= max(TOL, 2.0 * rel(flat_o, flat_64))
+    # ... and against the EXECUTED reference at this size (tests/golden/train_step_512.npz, make_golden.py:gen_train_step_512, same seeds;
+    # tests/test_oracle_golden.py::test_train_step_512_golden pins the oracle to the same fixture): log values, the mixed label map as the
+    # reference stores it (255 where the pixel weight is zero), gradients next to the loss
+    gold = np.load(os.path.join(G, 'train_step_512.npz'))
+    assert list(lv.keys()) == [str(k) for k in gold['log_keys']]
+    for k, v in zip(lv, gold['log_vals']):
+        assert abs(lv[k] - v) <= 2 * TOL * max(abs(v), 1e-2), (k, lv[k], v)
+    ml = dbg['mixed_lbl'].cpu()
+    ml = torch.where(dbg['mixed_w'].cpu().unsqueeze(1) > 0, ml, torch.full_like(ml, 255))
+    assert (ml.numpy().astype(np.uint8) != gold['mixed_lbl']).mean() < 1e-9          # the step ran on the oracle's (= the reference's) pseudo labels
+    for name in ('decode_head.conv_seg.bias', 'decode_head.conv_seg.weight', 'auxiliary_head.conv_seg.weight'):
+        gg = arena.view(arena.grad, name)
+        e = rel(gg.reshape(gg.shape[0], -1)[:32, :64], torch.from_numpy(gold['grad|' + name]))
+        print(f'   golden gradient sample {name}: rel err {e:.2e}')
+        assert e < 5 * TOL, (name, e)
 
 
 def test_pfgst_loss_downscale1_matches_oracle():
