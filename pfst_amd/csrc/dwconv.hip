@@ -78,19 +78,46 @@ __device__ __forceinline__ void row_taps_d1(const float* __restrict__ row, int c
   vr = make_float4(vc.y, vc.z, vc.w, rx);
 }
 
+// nine per-thread partial sums -> nine atomics per workgroup (wave shuffles, then one value per wave through `scratch`: >= 8 x 9 floats;
+// every thread of the workgroup calls it; the scratch may be reused after the call)
+__device__ __forceinline__ void block_add9(const float (&acc)[9], float* __restrict__ dst, float* __restrict__ scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();                                 // the scratch may still be read by a previous reduction
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const float v = wave_sum(acc[t]);
+    if (lane == 0) scratch[wid * 9 + t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    float v = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += scratch[k * 9 + threadIdx.x];
+    atomicAdd(&dst[threadIdx.x], v);
+  }
+}
+
 // MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation;
 // MODE 3: float4 outputs, dilation 1 (row_taps_d1)
-template <int MODE>
+// WG (backward only, flip = 1: x = dY, y = dX): the same pass also forms the WEIGHT gradient.  With v_t = dY[p + off(t)] the nine
+// neighbours the data gradient reads for output position p,  dW[8 - t] = sum_p X[p] v_t(p)  (substitute p = q + off in
+// dW[t'] = sum_q dY[q] X[q + off(t')]): one more 16-byte load (the layer's forward input X at p) and 9 x 4 fused multiply-adds per
+// output quad instead of a second kernel that stages X and re-reads dY -- 3 N of traffic for the two gradients instead of 4 N.
+template <int MODE, bool WG = false>
 __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
-                                                        int flip, int accumulate, float* __restrict__ stats) {
+                                                        int flip, int accumulate, float* __restrict__ stats,
+                                                        const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr) {
   extern __shared__ float tile[];
-  __shared__ double red[32];
+  __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of this block's outputs (stats != NULL)
   const int c = blockIdx.y, n = blockIdx.z;
   const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
   float* yp = y + (i64)n * y_bs + (i64)c * H * W;
+  const float* fxp = WG ? fx + (i64)n * fx_bs + (i64)c * H * W : nullptr;
+  float accw[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) accw[t] = 0.f;
   float wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
@@ -103,6 +130,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       const int r = i / W4, c4 = i - r * W4;
       const int yy = s.y0 + r;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (WG) xq = *(reinterpret_cast<const float4*>(fxp + (i64)yy * W) + c4);
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
         const int sy = yy + (ty - 1) * dil;
@@ -115,6 +144,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
           const float4 v = MODE == 3 ? tv[tx] : row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
           const float k = wt[ty * 3 + tx];
           acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
+          if (WG) accw[8 - (ty * 3 + tx)] += (xq.x * v.x + xq.y * v.y) + (xq.z * v.z + xq.w * v.w);
         }
       }
       float4* out = reinterpret_cast<float4*>(yp + (i64)yy * W) + c4;
@@ -137,7 +167,10 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
           const int sx = col + (tx - 1) * dil;
-          if (sx >= 0 && sx < W) acc = fmaf(wt[ty * 3 + tx], row[sx], acc);
+          if (sx >= 0 && sx < W) {
+            acc = fmaf(wt[ty * 3 + tx], row[sx], acc);
+            if (WG) accw[8 - (ty * 3 + tx)] = fmaf(fxp[(i64)yy * W + col], row[sx], accw[8 - (ty * 3 + tx)]);
+          }
         }
       }
       const i64 o = (i64)yy * W + col;
@@ -158,18 +191,20 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       *dst = make_float2((float)bs, (float)bq);
     }
   }
+  if (WG) block_add9(accw, dw + c * 9, reinterpret_cast<float*>(red));
 }
 
 // Whole-plane variant (the plane fits the LDS budget: the 128x128 ASPP planes): a workgroup walks `cpb` consecutive channels of one image
 // and fetches the NEXT plane into registers (8 x 16 bytes per thread, issued right after the barrier) while it computes the current one
 // from LDS -- the load latency of a plane is hidden behind the stencil of the previous one instead of being exposed once per plane.
 // grid: (1, ceil(C / cpb), N), 512 threads, float4 outputs (MODE 1: dilation % 4 == 0, MODE 2: any dilation).
-template <int MODE>
+template <int MODE, bool WG = false>
 __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                               float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int cpb,
-                                                              int flip, int accumulate, float* __restrict__ stats) {
+                                                              int flip, int accumulate, float* __restrict__ stats,
+                                                              const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr) {
   extern __shared__ float tile[];
-  __shared__ double red[32];
+  __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
   const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
   float4 r[8];                                     // host: n4 <= 8 * 512
@@ -192,7 +227,20 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
     for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
     float* yp = y + (i64)n * y_bs + (i64)c * HW;
     float st_s = 0.f, st_q = 0.f;
-    for (int i = tid; i < n4; i += 512) {
+    float accw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) accw[t] = 0.f;
+    float4 xr[8];                                  // WG: the forward input's quads this thread's outputs pair with, all in flight at once
+    if (WG) {
+      const __amdgpu_buffer_rsrc_t xs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fx + (i64)n * fx_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xr[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * 512), 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * 512;
+      if (i >= n4) break;
       const int yy = i / W4, c4 = i - yy * W4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -207,6 +255,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
           const float4 v = MODE == 3 ? tv[tx] : row4<MODE == 1>(row, c4 * 4 + (tx - 1) * dil, W);
           const float k = wt[ty * 3 + tx];
           acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
+          if (WG) accw[8 - (ty * 3 + tx)] += (xr[u].x * v.x + xr[u].y * v.y) + (xr[u].z * v.z + xr[u].w * v.w);
         }
       }
       float4* out = reinterpret_cast<float4*>(yp) + i;
@@ -220,6 +269,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
       block_sum2_d<true>(bs, bq, red);
       if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
     }
+    if (WG) block_add9(accw, dw + c * 9, reinterpret_cast<float*>(red));
     __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
   }
 }
@@ -325,6 +375,152 @@ __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __res
   }
 }
 
+// ---- the three atrous depthwise branches of the ASPP head in one pass (sep_aspp_head.py:63-77: dilations 12 / 24 / 36 on the SAME 2048-channel
+// map).  Separately each branch stages the input plane again (forward: 3 x (N + N) of traffic) and, in backward, reads and re-writes the
+// shared input gradient (3 x (dy + x + old dx + dx)).  Here a plane is staged ONCE for all NS branches (forward: N + NS N), and the backward
+// stages the NS output gradients of a channel one after the other while the input-gradient quads and the forward input's quads stay in
+// registers: x once, every dy once, dx written once (x + NS dy + [old dx] + dx).  Whole planes of at most 8 x 512 quads, dilations % 4 == 0.
+struct DwSets {
+  const float* w[3];        // [C][9] filters
+  float* y[3];              // forward: outputs; backward: unused
+  const float* dy[3];       // backward: output gradients
+  float* dw[3];             // backward: weight gradients (+=)
+  float* stats[3];          // forward: BatchNorm partials [C][N][2] or NULL
+  long long bs[3];          // batch strides of y / dy
+  int dil[3];
+};
+
+template <int NS>
+__global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, int C, int H, int W, int cpb) {
+  extern __shared__ float tile[];
+  __shared__ double red[40];
+  const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
+  const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
+  float4 r[8];
+  auto fetch = [&](int c) {
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (i64)n * x_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * 512), 0, 0));
+  };
+  fetch(c0);
+  for (int c = c0; c < c1; ++c) {
+    float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+    __syncthreads();
+    if (c + 1 < c1) fetch(c + 1);
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {
+      const int dil = S.dil[si];
+      float wt[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t] = S.w[si][c * 9 + t];
+      float* yp = S.y[si] + (i64)n * S.bs[si] + (i64)c * HW;
+      float st_s = 0.f, st_q = 0.f;
+      for (int i = tid; i < n4; i += 512) {
+        const int yy = i / W4, c4 = i - yy * W4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int sy = yy + (ty - 1) * dil;
+          if (sy < 0 || sy >= H) continue;
+          const float* row = tile + sy * W;
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const float4 v = row4<true>(row, c4 * 4 + (tx - 1) * dil, W);
+            const float k = wt[ty * 3 + tx];
+            acc.x = fmaf(k, v.x, acc.x); acc.y = fmaf(k, v.y, acc.y); acc.z = fmaf(k, v.z, acc.z); acc.w = fmaf(k, v.w, acc.w);
+          }
+        }
+        reinterpret_cast<float4*>(yp)[i] = acc;
+        st_s += (acc.x + acc.y) + (acc.z + acc.w);
+        st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
+      }
+      if (S.stats[si]) {                           // same partial layout as dwconv3x3_plane_kernel: stats[c][n][2]
+        double bs = (double)st_s, bq = (double)st_q;
+        block_sum2_d<true>(bs, bq, red);
+        if (tid == 0) reinterpret_cast<float2*>(S.stats[si])[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
+      }
+    }
+    __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
+  }
+}
+
+template <int NS>
+__global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, float* __restrict__ dx,
+                                                                  i64 dx_bs, int accumulate, int C, int H, int W, int cpb) {
+  extern __shared__ float tile[];
+  __shared__ double red[40];
+  const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
+  const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
+  float4 r[8];
+  auto fetch = [&](int c, int si) {                // the gradient plane of branch si, channel c -> registers
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.dy[si] + (i64)n * S.bs[si] + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * 512), 0, 0));
+  };
+  fetch(c0, 0);
+  for (int c = c0; c < c1; ++c) {
+    float4 xr[8], dxa[8];
+    {
+      const __amdgpu_buffer_rsrc_t xs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (i64)n * x_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        xr[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * 512), 0, 0));
+        dxa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll 1
+    for (int si = 0; si < NS; ++si) {              // (a run-time loop: unrolled, the 8 x 9 x NS tap bodies spill)
+      float4* t4 = reinterpret_cast<float4*>(tile);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+      __syncthreads();
+      if (si + 1 < NS) fetch(c, si + 1);
+      else if (c + 1 < c1) fetch(c + 1, 0);
+      const int dil = S.dil[si];
+      float wt[9], accw[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { wt[t] = S.w[si][c * 9 + 8 - t]; accw[t] = 0.f; }       // mirrored taps: the data gradient
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = tid + u * 512;
+        if (i >= n4) break;
+        const int yy = i / W4, c4 = i - yy * W4;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+          const int sy = yy + (ty - 1) * dil;
+          if (sy < 0 || sy >= H) continue;
+          const float* row = tile + sy * W;
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const float4 v = row4<true>(row, c4 * 4 + (tx - 1) * dil, W);
+            const float k = wt[ty * 3 + tx];
+            dxa[u].x = fmaf(k, v.x, dxa[u].x); dxa[u].y = fmaf(k, v.y, dxa[u].y); dxa[u].z = fmaf(k, v.z, dxa[u].z); dxa[u].w = fmaf(k, v.w, dxa[u].w);
+            accw[8 - (ty * 3 + tx)] += (xr[u].x * v.x + xr[u].y * v.y) + (xr[u].z * v.z + xr[u].w * v.w);
+          }
+        }
+      }
+      block_add9(accw, S.dw[si] + c * 9, reinterpret_cast<float*>(red));
+      __syncthreads();                             // every tap of this gradient plane has been read: the tile may be overwritten
+    }
+    float4* out = reinterpret_cast<float4*>(dx + (i64)n * dx_bs + (i64)c * HW);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + u * 512;
+      if (i >= n4) break;
+      float4 a = dxa[u];
+      if (accumulate) { const float4 o = out[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+      out[i] = a;
+    }
+  }
+}
+
 // rows per strip so that (R + 2*dil) * W floats fit the LDS budget; whole plane when it fits
 inline int strip_rows(int H, int W, int dil) {
   if ((i64)H * W * 4 <= DW_LDS_BYTES) return H;
@@ -393,6 +589,134 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
     hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
   else
     hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// Backward of the depthwise convolution in ONE pass: dx (+)= the stencil of dy with mirrored taps, dw += the weight gradient, from one
+// staging of dy and one read of the forward input x (see the WG note above dwconv3x3_kernel): 3 N of traffic instead of 2 N + 2 N.
+extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,
+                                  float* dw, int N, int C, int H, int W, int dil, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && x && w && dx && dw && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  PFST_CHECK_ARG(dy_bs >= (i64)C * H * W && x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
+  const int R = strip_rows(H, W, dil);
+  const size_t lds = strip_lds(R, H, W, dil);
+  PFST_CHECK_ARG(lds <= 150 * 1024);
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    set = true;
+  }
+  const bool vec = (W % 4 == 0) && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)x) % 16 == 0) && (dy_bs % 4 == 0) && (dx_bs % 4 == 0) &&
+                   (x_bs % 4 == 0) && (((i64)H * W) % 4 == 0);
+  const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
+  dim3 grid(cdiv(H, R), C, N);
+  hipStream_t st = (hipStream_t)stream;
+  static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;
+  float* const none = nullptr;
+  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0) {
+    dim3 gp(1, cdiv(C, cpb), N);
+    if (mode == 1)
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<1, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
+    else if (mode == 3)
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<3, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
+    else
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<2, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
+  if (mode == 1)
+    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+  else if (mode == 2)
+    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+  else if (mode == 3)
+    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+  else
+    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+// The NS <= 3 depthwise branches that share one input (the ASPP head's atrous branches): forward in one pass over x, backward in one pass over
+// x with every branch's output gradient read once and the input gradient written once.  Whole planes (H * W <= 16384, W % 4 == 0),
+// dilations % 4 == 0, 16-byte aligned dense planes: pfst_dwconv3x3_multi_ok says whether a shape qualifies.
+extern "C" int pfst_dwconv3x3_multi_ok(int H, int W, int ns, const int* dils) {
+  if (ns < 1 || ns > 3 || H <= 0 || W <= 0 || W % 4 != 0 || (i64)H * W > 8 * 512 * 4 || (i64)H * W * 4 > DW_LDS_BYTES) return 0;
+  for (int i = 0; i < ns; ++i)
+    if (dils[i] < 4 || dils[i] % 4 != 0) return 0;
+  return 1;
+}
+
+static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const* y, const float* const* dy, float* const* dw, float* const* stats,
+                         const long long* bs, const int* dils, i64 plane_elems) {
+  for (int i = 0; i < 3; ++i) {
+    const int k = i < ns ? i : 0;
+    S.w[i] = w[k];
+    S.y[i] = y ? y[k] : nullptr;
+    S.dy[i] = dy ? dy[k] : nullptr;
+    S.dw[i] = dw ? dw[k] : nullptr;
+    S.stats[i] = stats ? stats[k] : nullptr;
+    S.bs[i] = bs[k];
+    S.dil[i] = dils[k];
+    if (!S.w[i] || S.bs[i] < plane_elems || (S.bs[i] & 3)) return 0;
+    if (((uintptr_t)S.y[i] | (uintptr_t)S.dy[i]) & 15) return 0;
+  }
+  return 1;
+}
+
+extern "C" int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float* const* w, float* const* y, const long long* y_bs,
+                                        float* const* stats, const int* dils, int N, int C, int H, int W, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && w && y && y_bs && dils && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
+  PFST_CHECK_ARG(x_bs >= (i64)C * H * W && (x_bs & 3) == 0 && ((uintptr_t)x & 15) == 0);
+  DwSets S;
+  PFST_CHECK_ARG(dw_multi_sets(S, ns, w, y, nullptr, nullptr, stats, y_bs, dils, (i64)C * H * W));
+  for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(y[i] != nullptr);
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_fwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    set = true;
+  }
+  const int cpb = 4;
+  const size_t lds = (size_t)H * W * sizeof(float);
+  dim3 gp(1, cdiv(C, cpb), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ns == 1) hipLaunchKernelGGL(dwconv3x3_multi_fwd_kernel<1>, gp, dim3(512), lds, st, x, (i64)x_bs, S, C, H, W, cpb);
+  else if (ns == 2) hipLaunchKernelGGL(dwconv3x3_multi_fwd_kernel<2>, gp, dim3(512), lds, st, x, (i64)x_bs, S, C, H, W, cpb);
+  else hipLaunchKernelGGL(dwconv3x3_multi_fwd_kernel<3>, gp, dim3(512), lds, st, x, (i64)x_bs, S, C, H, W, cpb);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
+                                        const long long* dy_bs, float* const* dw, const int* dils, float* dx, long long dx_bs, int accumulate,
+                                        int N, int C, int H, int W, pfst_stream_t stream) {
+  PFST_CHECK_ARG(x && w && dy && dy_bs && dw && dils && dx && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
+  PFST_CHECK_ARG(x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && ((x_bs | dx_bs) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0);
+  DwSets S;
+  PFST_CHECK_ARG(dw_multi_sets(S, ns, w, nullptr, dy, dw, nullptr, dy_bs, dils, (i64)C * H * W));
+  for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(dy[i] != nullptr && dw[i] != nullptr);
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    set = true;
+  }
+  const int cpb = 4;
+  const size_t lds = (size_t)H * W * sizeof(float);
+  dim3 gp(1, cdiv(C, cpb), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (ns == 1) hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<1>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
+  else if (ns == 2) hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<2>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
+  else hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<3>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

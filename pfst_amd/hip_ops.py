@@ -107,6 +107,16 @@ def _stats_ws(dev, nfloat):
     return t
 
 
+def _stats_ws_multi(dev, nfloat, i):
+    """as _stats_ws, one scratch per branch of a multi-branch launch (all of them are alive until their statistics are finalised)"""
+    key = (dev, torch.cuda.current_stream().cuda_stream, 'multi', i)
+    t = _stats_cache.get(key)
+    if t is None or t.numel() < nfloat:
+        t = torch.empty(max(nfloat, 1 << 16), dtype=F32, device=dev)
+        _stats_cache[key] = t
+    return t
+
+
 def conv_stats_slots(n, cout, ho, wo):
     return n * lib().pfst_conv_stats_slots(cout, ho, wo)
 
@@ -550,6 +560,52 @@ def dwconv_wgrad_(dw, x, dy, dil):
     assert dy.shape == x.shape and dw.numel() == c * 9
     call('pfst_dwconv3x3_wgrad', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, c, h, w, dil, _stream())
     return dw
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def dwconv_multi_ok(x, dils):
+    """the fused multi-branch depthwise kernels cover this input (whole planes <= 16384 elements, W % 4 == 0, dilations % 4 == 0, dense
+    16-byte aligned planes)"""
+    n, c, h, w = x.shape
+    if not (x.stride(3) == 1 and x.stride(2) == w and x.stride(1) == h * w):
+        return False
+    return (1 <= len(dils) <= 3 and _bs(x) % 4 == 0 and x.data_ptr() % 16 == 0
+            and bool(lib().pfst_dwconv3x3_multi_ok(h, w, len(dils), (ctypes.c_int * len(dils))(*dils))))
+
+
+def dwconv_multi(x, ws, dils, want_stats=False):
+    """y_i = depthwise 3x3 conv of x with filters ws[i] at dilation dils[i], every input plane staged ONCE for all branches
+    -> [(y_i, stats_i, slots_i)] (stats as dwconv(want_stats=True): per-channel BN partials, one slot per image)"""
+    n, c, h, w = x.shape
+    k = len(ws)
+    ys = [torch.empty(n, c, h, w, device=x.device) for _ in range(k)]
+    sts = [(_stats_ws_multi(x.device, 2 * c * n, i) if want_stats else None) for i in range(k)]
+    call('pfst_dwconv3x3_multi_fwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(ys),
+         (ctypes.c_longlong * k)(*[_bs(y) for y in ys]), _ptr_array(sts), (ctypes.c_int * k)(*dils), n, c, h, w, _stream())
+    return [(ys[i], sts[i], n if want_stats else 0) for i in range(k)]
+
+
+def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False):
+    """dws[i] += weight gradients, dx (+)= sum_i mirrored stencil of dys[i]: x read once, every dy once, dx written once"""
+    n, c, h, w = x.shape
+    k = len(ws)
+    assert all(tuple(d.shape) == tuple(x.shape) and _bs(d) % 4 == 0 and d.data_ptr() % 16 == 0 for d in dys) and tuple(dx.shape) == tuple(x.shape)
+    call('pfst_dwconv3x3_multi_bwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(dys),
+         (ctypes.c_longlong * k)(*[_bs(d) for d in dys]), _ptr_array([_dense(t) for t in dws]), (ctypes.c_int * k)(*dils),
+         dx.data_ptr(), _bs(dx), int(accumulate), n, c, h, w, _stream())
+    return dx
+
+
+def dwconv_bwd_(dw, x, dy, w, dil, dx, accumulate=False):
+    """both gradients of the depthwise convolution in one pass: dx (+)= the mirrored stencil of dy, dw += the weight gradient"""
+    n, c, h, wd = x.shape
+    assert dy.shape == x.shape and tuple(dx.shape) == tuple(x.shape) and dw.numel() == c * 9 and w.numel() == c * 9
+    call('pfst_dwconv3x3_bwd', dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), _dense(w).data_ptr(), dx.data_ptr(), _bs(dx),
+         _dense(dw).data_ptr(), n, c, h, wd, dil, int(accumulate), _stream())
+    return dx
 
 
 # ---------------------------------------------------------------- batch norm

@@ -55,6 +55,8 @@ def _amax_target(yv, dev):
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
 WGRAD_SPLIT_ALL = os.environ.get('PFST_WGRAD_SPLIT_ALL', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
+# depthwise layers: weight and data gradient in one pass (csrc/dwconv.hip, pfst_dwconv3x3_bwd); PFST_FUSE_DW_BWD=0: the two kernels
+FUSE_DW_BWD = os.environ.get('PFST_FUSE_DW_BWD', '1') == '1'
 # Winograd F(m x m,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 4x (m = 4, default) or 2.25x
 # (PFST_WINO_TILE=2) fewer MACs.
 # Threshold on Cin*Cout from tools/wino_microbench.py / bench.py: Winograd wins for fprop, dgrad and (with the transformed input
@@ -364,6 +366,70 @@ class DepthwiseSeparableConvModule(nn.Module):
         return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale)
 
 
+# the atrous depthwise branches of the ASPP head as ONE launch each way (csrc/dwconv.hip, pfst_dwconv3x3_multi_*); PFST_FUSE_ASPP_DW=0: per branch
+FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
+
+
+def dwsep_branches(x, mods, tape, outs):
+    """DepthwiseSeparableConvModules `mods` applied to the SAME input x (the ASPP head's atrous branches, sep_aspp_head.py:63-77), results
+    into the concat slices `outs`.  Where the fused kernels cover the shape the depthwise stages run as one launch -- every plane of x is
+    staged once for all branches -- and their backward as one launch after the branches' BatchNorm-backward passes: x read once, every
+    branch's gradient once, dL/dx written once (per branch: 3 x (dy + x + old dx + dx)).  Each branch keeps its own BatchNorm (statistics
+    from the launch's per-branch partials), its pointwise layer is the ordinary ConvModule.  Same results as the per-branch path: the
+    forward bit for bit, the input gradient in a different summation order (branch sum in registers instead of through memory)."""
+    convs = [m.depthwise_conv.conv for m in mods]
+    dils = [c.dilation for c in convs]
+    fused = (FUSE_ASPP_DW and len(mods) > 1 and x.parent is None and all(c.depthwise and c.k == 3 and c.stride == 1 and c.padding == c.dilation
+                                                                          for c in convs) and ops.dwconv_multi_ok(x.data, dils))
+    if not fused:
+        return [m(x, tape, out=o) for m, o in zip(mods, outs)]
+    xd = x.data
+    want_stats = FUSE_BN_STATS and not _BN_EVAL
+    res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats)
+    dpres = [None] * len(mods)
+    if tape is not None:
+        x.claim_first_use()
+
+        def bwd_dw():                                # recorded FIRST: runs after the branches' BatchNorm-backward closures below
+            buf, acc = x.grad_target()
+            ops.dwconv_multi_bwd_([c.weight.grad for c in convs], xd, dpres, [c.weight.data for c in convs], dils, buf, accumulate=acc)
+            for i in range(len(dpres)):
+                dpres[i] = None
+        tape.record(bwd_dw, dict(op='dwconv_multi', x=x, convs=convs))
+    ys = []
+    for i, m in enumerate(mods):
+        bn = m.depthwise_conv.bn
+        pre, st, slots = res[i]
+        if _BN_EVAL:
+            assert tape is None, 'eval-mode BN is inference only'
+            mean, invstd, coef = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS), None
+        else:
+            want_coef = tape is not None and FUSE_BN_BWD
+            gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
+            n, c, h, w = pre.shape
+            if want_stats:
+                out3 = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
+            else:
+                out3 = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
+            mean, invstd = out3[:2]
+            coef = out3[2] if want_coef else None
+            bn._pending_batches += 1
+        yv = Var(None, tape is not None)
+        yv.data = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, True, None, amax=_amax_target(yv, pre.device))
+        if tape is not None:
+            if coef is not None:
+                yv.bn = BnBackwardCtx(pre, None, coef, True)       # the pointwise layer's data gradient may emit this layer's sums
+
+            def bwd_bn(i=i, bn=bn, yv=yv, pre=pre, mean=mean, invstd=invstd):
+                part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
+                dpres[i] = ops.bn_backward(yv.grad, None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad, True, None, False,
+                                           beta=bn.bias.data, partials=part, slots=nslots)
+                yv.free_grad()
+            tape.record(bwd_bn, dict(op='dw_bn_act', bn=bn, conv=convs[i], x=x, out=yv))
+        ys.append(m.pointwise_conv(yv, tape, out=outs[i]))
+    return ys
+
+
 def conv_forward(x, conv, tape, out=None):
     """bare convolution (used by conv_seg); returns Var"""
     xd = x.data
@@ -486,10 +552,14 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
             _dgrad_into(x, conv, dy, final, dy_amax)
         return
     if conv.depthwise:
-        ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
-        if x.requires_grad:
-            buf, acc = x.grad_target()
-            ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
+        if x.requires_grad and FUSE_DW_BWD:
+            buf, acc = x.grad_target()         # both gradients from one staging of dy and one read of x (3 N of traffic instead of 4 N)
+            ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc)
+        else:
+            ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
+            if x.requires_grad:
+                buf, acc = x.grad_target()
+                ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
         _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
         if conv.bias is not None:

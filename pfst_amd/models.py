@@ -15,7 +15,7 @@ import torch.nn as nn
 from . import hip_ops as ops
 from .engine import Var
 from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, WeightBatch, bn_eval, conv_bn_act,
-                     conv_forward)
+                     conv_forward, dwsep_branches)
 from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
 
 
@@ -309,8 +309,8 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         # depend on the order): in backward the pool branch's broadcast then lands in dL/dx BEFORE the 1x1 branch's data gradient,
         # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
         self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
-        for i in range(1, len(self.dilations)):
-            self.aspp_modules[i](x, tape, out=cat.slice((i + 1) * ch, (i + 2) * ch))
+        nd = len(self.dilations)
+        dwsep_branches(x, [self.aspp_modules[i] for i in range(1, nd)], tape, [cat.slice((i + 1) * ch, (i + 2) * ch) for i in range(1, nd)])
         # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)
         pooled = Var(ops.global_avgpool(x.data), tape is not None)
         pa = self.image_pool[1](pooled, tape)

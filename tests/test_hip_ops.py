@@ -370,6 +370,43 @@ def test_depthwise(ops, dil, H, W):
     dw = torch.zeros_like(wd)
     ops.dwconv_wgrad_(dw, xd, dyd, dil)
     assert_close(dw, w.grad, 1e-4, 'dw wgrad')
+    # both gradients in one pass (pfst_dwconv3x3_bwd: the layers' backward since round 4): same dx as the data-gradient kernel bit for bit,
+    # the weight gradient within fp32 summation order of the stand-alone kernel; accumulate variants of both outputs
+    dx1, dw1 = torch.empty_like(xd), torch.zeros_like(wd)
+    ops.dwconv_bwd_(dw1, xd, dyd, wd, dil, dx1)
+    assert torch.equal(dx1, ops.dwconv(dyd, wd, dil, flip=True)), 'fused dw backward: dx'
+    assert_close(dw1, w.grad, 1e-4, 'fused dw backward: dw')
+    dx2 = xd.clone()
+    ops.dwconv_bwd_(dw1, xd, dyd, wd, dil, dx2, accumulate=True)
+    assert_close(dx2, x.grad + x.detach(), 1e-5, 'fused dw backward: dx accumulate')
+    assert_close(dw1, 2 * w.grad, 1e-4, 'fused dw backward: dw accumulates')
+
+
+@pytest.mark.parametrize('H,W,dils', [(32, 32, (12, 24, 36)), (128, 128, (12, 24, 36)), (24, 40, (4, 8)), (16, 16, (36,))])
+def test_depthwise_branches_in_one_pass(ops, H, W, dils):
+    """pfst_dwconv3x3_multi_fwd / _bwd (the ASPP head's atrous branches): every branch's output and BatchNorm partials bit-identical to
+    its own pfst_dwconv3x3 launch; the backward's input gradient = the sum of the branches' data gradients, its weight gradients those of
+    pfst_dwconv3x3_wgrad, both to fp32 summation order; accumulate into an existing input gradient."""
+    n, c = 2, 20
+    x = torch.randn(n, c, H, W, generator=g(1))
+    ws = [torch.randn(c, 1, 3, 3, generator=g(2 + i)) for i in range(len(dils))]
+    dys = [torch.randn(n, c, H, W, generator=g(7 + i)) for i in range(len(dils))]
+    xd, wd, dyd = x.to(DEV), [w.to(DEV) for w in ws], [d.to(DEV) for d in dys]
+    assert ops.dwconv_multi_ok(xd, list(dils)) and not ops.dwconv_multi_ok(xd, [3]) and not ops.dwconv_multi_ok(xd[:, :, :, 1:], list(dils))
+    res = ops.dwconv_multi(xd, wd, list(dils), want_stats=True)
+    for i, d in enumerate(dils):
+        y1, st1, sl1 = ops.dwconv(xd, wd[i], d, want_stats=True)
+        assert torch.equal(res[i][0], y1) and res[i][2] == sl1 and torch.equal(res[i][1][:2 * c * sl1], st1[:2 * c * sl1]), (i, d)
+    dx_ref = sum(torch.nn.grad.conv2d_input(x.shape, ws[i].double(), dys[i].double(), 1, d, d, c) for i, d in enumerate(dils))
+    dws, dx = [torch.zeros_like(w) for w in wd], torch.empty_like(xd)
+    ops.dwconv_multi_bwd_(dws, xd, dyd, wd, list(dils), dx)
+    assert_close(dx, dx_ref, 1e-5, 'multi-branch dw backward: dx')
+    for i, d in enumerate(dils):
+        dw_ref = torch.nn.grad.conv2d_weight(x.double(), ws[i].shape, dys[i].double(), 1, d, d, c)
+        assert_close(dws[i], dw_ref, 1e-4, f'multi-branch dw backward: dw[{i}]')
+    dx2 = xd.clone()
+    ops.dwconv_multi_bwd_(dws, xd, dyd, wd, list(dils), dx2, accumulate=True)
+    assert_close(dx2, dx_ref + x.double(), 1e-5, 'multi-branch dw backward: dx accumulate')
 
 
 @pytest.mark.parametrize('shape,relu,res', [((4, 32, 16, 16), True, False), ((2, 48, 9, 13), True, True),

@@ -70,8 +70,11 @@ def test_every_backward_link_as_wired(wino, math):
     dys = {k: t.grad for k, t in cap.items() if t.grad is not None}
 
     # ---- HIP model, wired exactly as in the product
-    prev, prev_math = layers.WINOGRAD, layers.CONV_MATH
+    prev, prev_math, prev_dw = layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW
     layers.WINOGRAD, layers.CONV_MATH = wino, math      # both arithmetics of the dense convolutions: fp32-input MFMA and the bf16x6 split
+    # one closure per conv -> BN link here: the ASPP head's fused three-branch depthwise launch (one closure for three layers' data and weight
+    # gradients) is checked against this per-branch wiring in test_aspp_depthwise_branches_fused_equals_per_branch below
+    layers.FUSE_ASPP_DW = False
     try:
         model = build_segmentor(model_cfg(C, 3, dropout=0.0))
         model.load_state_dict(student, strict=True)
@@ -203,7 +206,7 @@ def test_every_backward_link_as_wired(wino, math):
         tape.backward()
         torch.cuda.synchronize()
     finally:
-        layers.WINOGRAD, layers.CONV_MATH = prev, prev_math
+        layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW = prev, prev_math, prev_dw
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
     for op, name, k, worst, nrm, fe, de, _, _ in sorted(rows, key=lambda r: -r[3])[:25]:
@@ -429,3 +432,57 @@ def test_dropout2d_folded_into_the_normalisation_pass(math):
     assert torch.equal(out2['logits'].data, logits_fold), 'folded and separate Dropout2d must give bit-identical logits'
     _, e = mixed_err(arena.grad, grad_fold)
     assert e < 1e-4, e
+
+
+def test_aspp_depthwise_branches_fused_equals_per_branch():
+    """layers.dwsep_branches: the ASPP head's three atrous depthwise stages as one launch each way (pfst_dwconv3x3_multi_fwd / _bwd).  One
+    segmentor forward + backward with the fusion on and off: the forward is bit-identical (same stencil arithmetic per element, same
+    BatchNorm partial layout), every parameter gradient agrees to the summation order of the fp32 atomics / the branch sum (1e-5 norm-wise
+    on the whole arena, 1e-4 on the three depthwise filters' own gradients)."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    C, b, S = 6, 2, 256                     # 32 x 32 planes at 1/8: dilations 12 / 24 / 36 reach well inside the plane
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=99)
+    runs, launches = {}, {}
+    prev = layers.FUSE_ASPP_DW
+    try:
+        for fuse in (True, False):
+            layers.FUSE_ASPP_DW = fuse
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            n_multi = [0]
+            orig = ops.dwconv_multi_bwd_
+            ops.dwconv_multi_bwd_ = lambda *a, **k: (n_multi.__setitem__(0, n_multi[0] + 1), orig(*a, **k))[1]
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.dwconv_multi_bwd_ = orig
+            runs[fuse] = (out['logits'].data.clone(), arena.grad.clone(), {n: arena.view(arena.grad, n).clone() for n in arena.names
+                                                                          if 'aspp_modules' in n and 'depthwise_conv.conv' in n},
+                          float(out['decode.loss_ce']))
+            launches[fuse] = n_multi[0]
+    finally:
+        layers.FUSE_ASPP_DW = prev
+    assert launches == {True: 1, False: 0}, launches
+    (l1, g1, d1, c1), (l0, g0, d0, c0) = runs[True], runs[False]
+    assert torch.equal(l1, l0) and c1 == c0, 'the fused forward must be bit-identical to the per-branch one'
+    _, e = mixed_err(g1, g0)
+    assert e < 1e-5, e
+    assert len(d1) == 3
+    for n in d1:
+        _, e = mixed_err(d1[n], d0[n])
+        assert e < 1e-4, (n, e)
