@@ -176,13 +176,16 @@ int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long l
 /* ns <= 3 depthwise branches that read the SAME input (the ASPP head's atrous branches, sep_aspp_head.py:63-77: dilations 12 / 24 / 36 on one
  * 2048-channel map), whole planes (H * W <= 16384, W % 4 == 0), dilations % 4 == 0, 16-byte aligned dense planes.
  *   fwd: y[i] = dwconv(x, w[i], dils[i]) (+ BatchNorm partials stats[i][C][N][2] or NULL) with every input plane staged once;
- *   bwd: dw[i] += weight gradients, dx (+)= sum_i conv(dy[i], mirrored w[i]): x read once, every dy[i] once, dx written once. */
+ *        plane_mean != NULL: also [N][C] means of x's planes = nn.AdaptiveAvgPool2d(1) of the image-pool branch (aspp_head.py:69-77),
+ *        as pfst_global_avgpool forms them (fp64 sum);
+ *   bwd: dw[i] += weight gradients, dx (+)= sum_i conv(dy[i], mirrored w[i]) [+ plane_mean_grad[n][c] / (H W), the pool's adjoint]:
+ *        x read once, every dy[i] once, dx written once. */
 int pfst_dwconv3x3_multi_ok(int H, int W, int ns, const int* dils);
 int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float* const* w, float* const* y, const long long* y_bs,
-                             float* const* stats, const int* dils, int N, int C, int H, int W, pfst_stream_t stream);
+                             float* const* stats, const int* dils, float* plane_mean, int N, int C, int H, int W, pfst_stream_t stream);
 int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
-                             const long long* dy_bs, float* const* dw, const int* dils, float* dx, long long dx_bs, int accumulate,
-                             int N, int C, int H, int W, pfst_stream_t stream);
+                             const long long* dy_bs, float* const* dw, const int* dils, const float* plane_mean_grad, float* dx,
+                             long long dx_bs, int accumulate, int N, int C, int H, int W, pfst_stream_t stream);
 /* both gradients of the depthwise convolution in one pass over dy and the forward input x (autograd of the same F.conv2d(groups = C)):
  * dx (+)= conv(dy, mirrored w), dw += sum dy * shifted x -- 3 N of HBM traffic instead of the two kernels' 4 N */
 int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,

@@ -388,6 +388,9 @@ struct DwSets {
   float* stats[3];          // forward: BatchNorm partials [C][N][2] or NULL
   long long bs[3];          // batch strides of y / dy
   int dil[3];
+  float* pool;              // forward: NULL, or [N][C] plane means of x (nn.AdaptiveAvgPool2d(1) of the image-pool branch, aspp_head.py:69-77)
+  const float* pool_grad;   // backward: NULL, or [N][C] gradients of those means: dx += pool_grad[n][c] * pool_scale
+  float pool_scale;         // 1 / (H W)
 };
 
 template <int NS>
@@ -409,6 +412,14 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+    if (S.pool) {                                  // the plane's mean, in fp64 like pfst_global_avgpool (one pass over x less for the image-pool branch)
+      double ps = 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (tid + u * 512 < n4) ps += ((double)r[u].x + (double)r[u].y) + ((double)r[u].z + (double)r[u].w);
+      ps = block_sum_d(ps, red);
+      if (tid == 0) S.pool[n * C + c] = (float)(ps * (double)S.pool_scale);
+    }
     __syncthreads();
     if (c + 1 < c1) fetch(c + 1);
 #pragma unroll 1
@@ -510,11 +521,13 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
       __syncthreads();                             // every tap of this gradient plane has been read: the tile may be overwritten
     }
     float4* out = reinterpret_cast<float4*>(dx + (i64)n * dx_bs + (i64)c * HW);
+    const float pg = S.pool_grad ? S.pool_grad[n * C + c] * S.pool_scale : 0.f;     // adjoint of the plane mean: the same value to every element
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = tid + u * 512;
       if (i >= n4) break;
       float4 a = dxa[u];
+      if (S.pool_grad) { a.x += pg; a.y += pg; a.z += pg; a.w += pg; }
       if (accumulate) { const float4 o = out[i]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
       out[i] = a;
     }
@@ -655,6 +668,9 @@ extern "C" int pfst_dwconv3x3_multi_ok(int H, int W, int ns, const int* dils) {
 
 static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const* y, const float* const* dy, float* const* dw, float* const* stats,
                          const long long* bs, const int* dils, i64 plane_elems) {
+  S.pool = nullptr;
+  S.pool_grad = nullptr;
+  S.pool_scale = 0.f;
   for (int i = 0; i < 3; ++i) {
     const int k = i < ns ? i : 0;
     S.w[i] = w[k];
@@ -671,12 +687,14 @@ static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const*
 }
 
 extern "C" int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float* const* w, float* const* y, const long long* y_bs,
-                                        float* const* stats, const int* dils, int N, int C, int H, int W, pfst_stream_t stream) {
+                                        float* const* stats, const int* dils, float* plane_mean, int N, int C, int H, int W, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && y_bs && dils && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && (x_bs & 3) == 0 && ((uintptr_t)x & 15) == 0);
   DwSets S;
   PFST_CHECK_ARG(dw_multi_sets(S, ns, w, y, nullptr, nullptr, stats, y_bs, dils, (i64)C * H * W));
   for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(y[i] != nullptr);
+  S.pool = plane_mean;
+  S.pool_scale = 1.0f / (float)(H * W);
   static bool set = false;
   if (!set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -696,13 +714,15 @@ extern "C" int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, 
 }
 
 extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
-                                        const long long* dy_bs, float* const* dw, const int* dils, float* dx, long long dx_bs, int accumulate,
-                                        int N, int C, int H, int W, pfst_stream_t stream) {
+                                        const long long* dy_bs, float* const* dw, const int* dils, const float* plane_mean_grad, float* dx,
+                                        long long dx_bs, int accumulate, int N, int C, int H, int W, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && dy && dy_bs && dw && dils && dx && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && ((x_bs | dx_bs) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0);
   DwSets S;
   PFST_CHECK_ARG(dw_multi_sets(S, ns, w, nullptr, dy, dw, nullptr, dy_bs, dils, (i64)C * H * W));
   for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(dy[i] != nullptr && dw[i] != nullptr);
+  S.pool_grad = plane_mean_grad;
+  S.pool_scale = 1.0f / (float)(H * W);
   static bool set = false;
   if (!set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -576,26 +576,30 @@ def dwconv_multi_ok(x, dils):
             and bool(lib().pfst_dwconv3x3_multi_ok(h, w, len(dils), (ctypes.c_int * len(dils))(*dils))))
 
 
-def dwconv_multi(x, ws, dils, want_stats=False):
+def dwconv_multi(x, ws, dils, want_stats=False, want_mean=False):
     """y_i = depthwise 3x3 conv of x with filters ws[i] at dilation dils[i], every input plane staged ONCE for all branches
-    -> [(y_i, stats_i, slots_i)] (stats as dwconv(want_stats=True): per-channel BN partials, one slot per image)"""
+    -> [(y_i, stats_i, slots_i)] (stats as dwconv(want_stats=True): per-channel BN partials, one slot per image);
+    want_mean: -> (that list, [N, C, 1, 1] plane means of x = global_avgpool(x)) from the same pass"""
     n, c, h, w = x.shape
     k = len(ws)
     ys = [torch.empty(n, c, h, w, device=x.device) for _ in range(k)]
     sts = [(_stats_ws_multi(x.device, 2 * c * n, i) if want_stats else None) for i in range(k)]
+    mean = torch.empty(n, c, 1, 1, device=x.device) if want_mean else None
     call('pfst_dwconv3x3_multi_fwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(ys),
-         (ctypes.c_longlong * k)(*[_bs(y) for y in ys]), _ptr_array(sts), (ctypes.c_int * k)(*dils), n, c, h, w, _stream())
-    return [(ys[i], sts[i], n if want_stats else 0) for i in range(k)]
+         (ctypes.c_longlong * k)(*[_bs(y) for y in ys]), _ptr_array(sts), (ctypes.c_int * k)(*dils), _p(mean), n, c, h, w, _stream())
+    res = [(ys[i], sts[i], n if want_stats else 0) for i in range(k)]
+    return (res, mean) if want_mean else res
 
 
-def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False):
-    """dws[i] += weight gradients, dx (+)= sum_i mirrored stencil of dys[i]: x read once, every dy once, dx written once"""
+def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False, mean_grad=None):
+    """dws[i] += weight gradients, dx (+)= sum_i mirrored stencil of dys[i]: x read once, every dy once, dx written once;
+    mean_grad: [N, C] gradient of the plane means dwconv_multi(want_mean=True) returned: dx += mean_grad / (H W)"""
     n, c, h, w = x.shape
     k = len(ws)
     assert all(tuple(d.shape) == tuple(x.shape) and _bs(d) % 4 == 0 and d.data_ptr() % 16 == 0 for d in dys) and tuple(dx.shape) == tuple(x.shape)
     call('pfst_dwconv3x3_multi_bwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(dys),
          (ctypes.c_longlong * k)(*[_bs(d) for d in dys]), _ptr_array([_dense(t) for t in dws]), (ctypes.c_int * k)(*dils),
-         dx.data_ptr(), _bs(dx), int(accumulate), n, c, h, w, _stream())
+         _p(None if mean_grad is None else _dense(mean_grad)), dx.data_ptr(), _bs(dx), int(accumulate), n, c, h, w, _stream())
     return dx
 
 

@@ -370,13 +370,16 @@ class DepthwiseSeparableConvModule(nn.Module):
 FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
 
 
-def dwsep_branches(x, mods, tape, outs):
+def dwsep_branches(x, mods, tape, outs, pool=None):
     """DepthwiseSeparableConvModules `mods` applied to the SAME input x (the ASPP head's atrous branches, sep_aspp_head.py:63-77), results
     into the concat slices `outs`.  Where the fused kernels cover the shape the depthwise stages run as one launch -- every plane of x is
     staged once for all branches -- and their backward as one launch after the branches' BatchNorm-backward passes: x read once, every
     branch's gradient once, dL/dx written once (per branch: 3 x (dy + x + old dx + dx)).  Each branch keeps its own BatchNorm (statistics
     from the launch's per-branch partials), its pointwise layer is the ordinary ConvModule.  Same results as the per-branch path: the
-    forward bit for bit, the input gradient in a different summation order (branch sum in registers instead of through memory)."""
+    forward bit for bit, the input gradient in a different summation order (branch sum in registers instead of through memory).
+    pool: a dict the image-pool branch shares with this call -- on the fused path pool['mean'] receives the plane means of x (the
+    AdaptiveAvgPool2d(1) of that branch, from the same pass over x) and the fused backward adds pool['grad'] (set by that branch's backward,
+    which runs earlier) / (H W) to dL/dx; left untouched on the per-branch path (the caller then pools and broadcasts itself)."""
     convs = [m.depthwise_conv.conv for m in mods]
     dils = [c.dilation for c in convs]
     fused = (FUSE_ASPP_DW and len(mods) > 1 and x.parent is None and all(c.depthwise and c.k == 3 and c.stride == 1 and c.padding == c.dilation
@@ -385,14 +388,18 @@ def dwsep_branches(x, mods, tape, outs):
         return [m(x, tape, out=o) for m, o in zip(mods, outs)]
     xd = x.data
     want_stats = FUSE_BN_STATS and not _BN_EVAL
-    res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats)
+    if pool is not None:
+        res, pool['mean'] = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats, want_mean=True)
+    else:
+        res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats)
     dpres = [None] * len(mods)
     if tape is not None:
         x.claim_first_use()
 
         def bwd_dw():                                # recorded FIRST: runs after the branches' BatchNorm-backward closures below
             buf, acc = x.grad_target()
-            ops.dwconv_multi_bwd_([c.weight.grad for c in convs], xd, dpres, [c.weight.data for c in convs], dils, buf, accumulate=acc)
+            ops.dwconv_multi_bwd_([c.weight.grad for c in convs], xd, dpres, [c.weight.data for c in convs], dils, buf, accumulate=acc,
+                                  mean_grad=None if pool is None else pool.pop('grad', None))
             for i in range(len(dpres)):
                 dpres[i] = None
         tape.record(bwd_dw, dict(op='dwconv_multi', x=x, convs=convs))

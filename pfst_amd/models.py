@@ -21,6 +21,7 @@ from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_ba
 
 # PFST_FOLD_DROPOUT=0: the decode head's Dropout2d as a scaling pass of its own (A/B runs); default: folded into sep_bottleneck[1]'s normalisation
 FOLD_DROPOUT = os.environ.get('PFST_FOLD_DROPOUT', '1') == '1'
+FUSE_ASPP_POOL = os.environ.get('PFST_FUSE_ASPP_POOL', '1') == '1'
 
 
 def _check_norm(norm_cfg):
@@ -310,9 +311,13 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
         self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
         nd = len(self.dilations)
-        dwsep_branches(x, [self.aspp_modules[i] for i in range(1, nd)], tape, [cat.slice((i + 1) * ch, (i + 2) * ch) for i in range(1, nd)])
+        # on the fused path the atrous branches' launch also forms the plane means of x, its backward their adjoint (PFST_FUSE_ASPP_POOL=0: not)
+        pool = {} if FUSE_ASPP_POOL else None
+        dwsep_branches(x, [self.aspp_modules[i] for i in range(1, nd)], tape, [cat.slice((i + 1) * ch, (i + 2) * ch) for i in range(1, nd)],
+                       pool=pool)
         # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)
-        pooled = Var(ops.global_avgpool(x.data), tape is not None)
+        fused_pool = pool is not None and 'mean' in pool
+        pooled = Var(pool['mean'] if fused_pool else ops.global_avgpool(x.data), tape is not None)
         pa = self.image_pool[1](pooled, tape)
         ops.broadcast_hw(pa.data, cat.data[:, 0:ch])
         if tape is not None:
@@ -323,6 +328,10 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
                 pa._grad = ops.reduce_hw(g[:, 0:ch])
 
             def bwd_gap():
+                if fused_pool:                     # handed to the atrous branches' fused backward, which runs later and writes dL/dx once
+                    pool['grad'] = pooled.grad
+                    pooled.free_grad()
+                    return
                 buf, acc = x.grad_target()
                 if not acc:
                     ops.fill_(buf, 0.0)

@@ -407,6 +407,15 @@ def test_depthwise_branches_in_one_pass(ops, H, W, dils):
     dx2 = xd.clone()
     ops.dwconv_multi_bwd_(dws, xd, dyd, wd, list(dils), dx2, accumulate=True)
     assert_close(dx2, dx_ref + x.double(), 1e-5, 'multi-branch dw backward: dx accumulate')
+    # the image-pool branch's plane means from the same forward pass, their adjoint in the same backward pass
+    res2, mean = ops.dwconv_multi(xd, wd, list(dils), want_stats=False, want_mean=True)
+    assert torch.equal(res2[0][0], res[0][0])
+    gap = ops.global_avgpool(xd)
+    assert tuple(mean.shape) == (n, c, 1, 1) and float((mean - gap).abs().max()) <= 1e-7 * float(gap.abs().max())
+    mg = torch.randn(n, c, generator=g(20))
+    dx3 = torch.empty_like(xd)
+    ops.dwconv_multi_bwd_([torch.zeros_like(w) for w in wd], xd, dyd, wd, list(dils), dx3, mean_grad=mg.to(DEV))
+    assert_close(dx3, dx_ref + (mg.double() / (H * W)).view(n, c, 1, 1), 1e-5, 'multi-branch dw backward: + adjoint of the plane mean')
 
 
 @pytest.mark.parametrize('shape,relu,res', [((4, 32, 16, 16), True, False), ((2, 48, 9, 13), True, True),
