@@ -167,7 +167,10 @@ int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long 
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
 int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                   int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, pfst_stream_t stream);
+                   int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, const float* bn_on_load_coef,
+                   pfst_stream_t stream);
+/* bn_on_load_coef: NULL, or coef[C][4] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer that feeds this depthwise layer: x is then that
+ * layer's PRE-normalisation output, normalised + rectified while it is staged (forward only; the normalised tensor is never written) */
 /* stats != NULL: per-channel partial (sum, sum of squares) of the outputs, stats[C][N * pfst_dwconv_stats_slots(H, W, dil)][2],
  * for pfst_bn_finalize_partials (as the `stats` argument of pfst_conv_igemm) */
 int pfst_dwconv_stats_slots(int H, int W, int dil);
@@ -189,7 +192,8 @@ int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float
 /* both gradients of the depthwise convolution in one pass over dy and the forward input x (autograd of the same F.conv2d(groups = C)):
  * dx (+)= conv(dy, mirrored w), dw += sum dy * shifted x -- 3 N of HBM traffic instead of the two kernels' 4 N */
 int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,
-                       float* dw, int N, int C, int H, int W, int dil, int accumulate, pfst_stream_t stream);
+                       float* dw, int N, int C, int H, int W, int dil, int accumulate, const float* bn_on_load_coef, pfst_stream_t stream);
+/* (bn_on_load_coef as in pfst_dwconv3x3: x holds the pre-normalisation tensor, its quads are normalised as they are loaded) */
 
 /* ---- BatchNorm2d, training mode (nn.BatchNorm2d inside mmcv ConvModule; eps 1e-5, momentum .1) */
 /* batch mean / 1/sqrt(biased var + eps) per channel; updates running stats (unbiased var) when
@@ -228,7 +232,11 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
 
 /* ---- pooling / resize ---------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:638); idx holds the winning tap 0..8 */
-int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream);
+int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, const float* bn_on_load_coef, int C,
+                      pfst_stream_t stream);
+/* bn_on_load_coef: NULL, or coef[C][4] = (mean, invstd, sc, sh) (pfst_bn_finalize_partials / pfst_bn_stats) of the conv -> BN -> ReLU layer
+ * in front of the pool: x is then that layer's PRE-normalisation output (NC = N * C planes) and y = maxpool(relu(x * sc + sh)) -- the
+ * normalised tensor is never written (its only consumer is the pool) */
 int pfst_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, float* dx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream);
 /* F.interpolate(mode='bilinear', align_corners=False) (ops/wrappers.py:27) and its adjoint */
 int pfst_resize_bilinear(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, pfst_stream_t stream);

@@ -29,8 +29,16 @@ __device__ __forceinline__ Strip make_strip(int strip_idx, int R, int H, int dil
   return s;
 }
 
-// contiguous copy of rows [lo,hi) of one plane into LDS
-__device__ __forceinline__ void stage_rows(const float* __restrict__ plane, float* __restrict__ tile, int lo, int hi, int W) {
+// y = relu(x * sc + sh): the producing conv -> BN -> ReLU layer's normalisation applied on load (bnl), with bn_apply's pinned roundings
+__device__ __forceinline__ float bn_on_load(float v, float sc, float sh) { return fmaxf(__fmaf_rn(v, sc, sh), 0.f); }
+__device__ __forceinline__ float4 bn_on_load4(float4 v, float sc, float sh) {
+  return make_float4(bn_on_load(v.x, sc, sh), bn_on_load(v.y, sc, sh), bn_on_load(v.z, sc, sh), bn_on_load(v.w, sc, sh));
+}
+
+// contiguous copy of rows [lo,hi) of one plane into LDS; bnl: the rows hold the PRE-normalisation tensor of the layer that feeds this
+// convolution and are normalised + rectified while they are staged (the normalised tensor itself is never written)
+__device__ __forceinline__ void stage_rows(const float* __restrict__ plane, float* __restrict__ tile, int lo, int hi, int W, bool bnl = false,
+                                           float sc = 1.f, float sh = 0.f) {
   const int n = (hi - lo) * W;
   const float* src = plane + (i64)lo * W;
   if ((W & 3) == 0 && (((uintptr_t)src) & 15) == 0) {
@@ -47,10 +55,10 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ plane, floa
       for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (i0 + u * bd), 0, 0));
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i0 + u * bd < n4) t4[i0 + u * bd] = r[u];
+        if (i0 + u * bd < n4) t4[i0 + u * bd] = bnl ? bn_on_load4(r[u], sc, sh) : r[u];
     }
   } else {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = src[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = bnl ? bn_on_load(src[i], sc, sh) : src[i];
   }
 }
 
@@ -106,7 +114,11 @@ template <int MODE, bool WG = false>
 __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
                                                         int flip, int accumulate, float* __restrict__ stats,
-                                                        const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr) {
+                                                        const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
+                                                        const float4* __restrict__ bnl = nullptr) {
+  // bnl != NULL: coef[C] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer whose PRE-normalisation output is this convolution's
+  // forward input: forward (WG = false) x is that tensor and is normalised while staged; backward (WG) fx is, and its quads are
+  // normalised as they are loaded.  The normalised tensor is never materialised (its only consumer is this depthwise layer).
   extern __shared__ float tile[];
   __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of this block's outputs (stats != NULL)
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
   float wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
-  stage_rows(xp, tile, s.lo, s.hi, W);
+  const float bsc = bnl ? bnl[c].z : 1.f, bsh = bnl ? bnl[c].w : 0.f;
+  stage_rows(xp, tile, s.lo, s.hi, W, bnl != nullptr && !WG, bsc, bsh);
   __syncthreads();
   if (MODE != 0) {
     const int W4 = W >> 2;
@@ -131,7 +144,10 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       const int yy = s.y0 + r;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (WG) xq = *(reinterpret_cast<const float4*>(fxp + (i64)yy * W) + c4);
+      if (WG) {
+        xq = *(reinterpret_cast<const float4*>(fxp + (i64)yy * W) + c4);
+        if (bnl) xq = bn_on_load4(xq, bsc, bsh);
+      }
 #pragma unroll
       for (int ty = 0; ty < 3; ++ty) {
         const int sy = yy + (ty - 1) * dil;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
           const int sx = col + (tx - 1) * dil;
           if (sx >= 0 && sx < W) {
             acc = fmaf(wt[ty * 3 + tx], row[sx], acc);
-            if (WG) accw[8 - (ty * 3 + tx)] = fmaf(fxp[(i64)yy * W + col], row[sx], accw[8 - (ty * 3 + tx)]);
+            if (WG) accw[8 - (ty * 3 + tx)] = fmaf(bnl ? bn_on_load(fxp[(i64)yy * W + col], bsc, bsh) : fxp[(i64)yy * W + col], row[sx], accw[8 - (ty * 3 + tx)]);
           }
         }
       }
@@ -556,8 +572,11 @@ extern "C" int pfst_dwconv_stats_slots(int H, int W, int dil) {
 }
 
 extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                              int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, pfst_stream_t stream) {
+                              int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, const float* bn_on_load_coef,
+                              pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  PFST_CHECK_ARG(!bn_on_load_coef || !flip);         // the forward input is normalised on load; a data gradient has nothing to normalise
+  const float4* bnl = reinterpret_cast<const float4*>(bn_on_load_coef);
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && y_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
   const int R = strip_rows(H, W, dil);
   const size_t lds = strip_lds(R, H, W, dil);
@@ -576,7 +595,7 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
   static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;   // channels per workgroup of the plane kernel, 0 = off
-  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0) {
+  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl) {      // (the strip kernel carries the normalise-on-load variant)
     static bool set2 = false;
     if (!set2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_plane_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
@@ -595,13 +614,13 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
     return PFST_OK;
   }
   if (mode == 1)
-    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
   else if (mode == 2)
-    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
   else if (mode == 3)
-    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats);
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -609,8 +628,10 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
 // Backward of the depthwise convolution in ONE pass: dx (+)= the stencil of dy with mirrored taps, dw += the weight gradient, from one
 // staging of dy and one read of the forward input x (see the WG note above dwconv3x3_kernel): 3 N of traffic instead of 2 N + 2 N.
 extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,
-                                  float* dw, int N, int C, int H, int W, int dil, int accumulate, pfst_stream_t stream) {
+                                  float* dw, int N, int C, int H, int W, int dil, int accumulate, const float* bn_on_load_coef,
+                                  pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && w && dx && dw && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  const float4* bnl = reinterpret_cast<const float4*>(bn_on_load_coef);
   PFST_CHECK_ARG(dy_bs >= (i64)C * H * W && x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
   const int R = strip_rows(H, W, dil);
   const size_t lds = strip_lds(R, H, W, dil);
@@ -633,7 +654,7 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
   hipStream_t st = (hipStream_t)stream;
   static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;
   float* const none = nullptr;
-  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0) {
+  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl) {
     dim3 gp(1, cdiv(C, cpb), N);
     if (mode == 1)
       hipLaunchKernelGGL((dwconv3x3_plane_kernel<1, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
@@ -645,13 +666,13 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
     return PFST_OK;
   }
   if (mode == 1)
-    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
   else if (mode == 2)
-    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
   else if (mode == 3)
-    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
   else
-    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw);
+    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -34,10 +34,13 @@ __global__ void u8_to_i64_kernel(const unsigned char* __restrict__ s, long long*
 }
 
 // ---- max pool 3x3 stride 2 pad 1; first maximum in row-major scan order wins (torch CPU/GPU semantics)
+// bnl != NULL: x is the PRE-normalisation output of the conv -> BN -> ReLU layer in front of the pool (stem.6); coef[c] = (mean, invstd, sc, sh)
+// of that layer, applied to every tap as it is read (bn_apply's pinned arithmetic) -- the normalised tensor is never written
 __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int H, int W,
-                               int Ho, int Wo) {
+                               int Ho, int Wo, const float4* __restrict__ bnl, int C) {
   const int nc = blockIdx.y;
   const float* xp = x + (i64)nc * H * W;
+  const float bsc = bnl ? bnl[nc % C].z : 1.f, bsh = bnl ? bnl[nc % C].w : 0.f;
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < Ho * Wo; o += gridDim.x * blockDim.x) {
     const int oy = o / Wo, ox = o - oy * Wo;
     float best = -INFINITY;
@@ -51,7 +54,8 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
       for (int tx = 0; tx < 3; ++tx) {
         const int sx = ox * 2 - 1 + tx;
         if (sx < 0 || sx >= W) continue;
-        const float v = xp[(i64)sy * W + sx];
+        float v = xp[(i64)sy * W + sx];
+        if (bnl) v = fmaxf(__fmaf_rn(v, bsc, bsh), 0.f);
         if (first || v > best || v != v) { best = v; bt = ty * 3 + tx; first = false; }
       }
     }
@@ -316,10 +320,13 @@ extern "C" int pfst_u8_to_i64(const unsigned char* src, long long* dst, long lon
   return PFST_OK;
 }
 
-extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, pfst_stream_t stream) {
+extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo,
+                                 const float* bn_on_load_coef, int C, pfst_stream_t stream) {
+  PFST_CHECK_ARG(!bn_on_load_coef || (C > 0 && NC % C == 0));
   PFST_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 * 16 && H > 0 && W > 0);
   PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1 && NC <= 65535);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo,
+                     reinterpret_cast<const float4*>(bn_on_load_coef), C > 0 ? C : 1);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

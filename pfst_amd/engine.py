@@ -18,7 +18,7 @@ class Var:
     runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax')
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -27,6 +27,9 @@ class Var:
         self.parent, self.c0, self.c1 = parent, c0, c1
         self.bn = None
         self._claimed = self._sealed = False
+        # (pre, coef): a conv -> BN -> ReLU output that is never materialised -- data is None, the ONE consumer (a depthwise layer, the stem's
+        # max-pool) normalises the pre-BN tensor `pre` with coef[c] = (mean, invstd, sc, sh) as it loads it (layers.conv_bn_act(defer=True))
+        self.lazy = None
         self.amax = None          # device slot with max |data| (scale of the two-piece fp16 split, layers.CONV_MATH == 'f16x3'), set on first use
 
     def claim_first_use(self):
@@ -53,7 +56,8 @@ class Var:
             buf, acc = self.parent.grad_target_full()
             return buf[:, self.c0:self.c1], acc
         if self._grad is None:
-            self._grad = torch.empty(self.data.shape, dtype=self.data.dtype, device=self.data.device)
+            like = self.data if self.lazy is None else self.lazy[0]
+            self._grad = torch.empty(like.shape, dtype=like.dtype, device=like.device)
             return self._grad, False
         return self._grad, True
 

@@ -539,8 +539,9 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None, x_amax
 
 
 # ---------------------------------------------------------------- depthwise
-def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False):
-    """want_stats: also return (stats_ws, slots), per-channel BN partial sums of the output (as conv_fprop)"""
+def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False, bnl=None):
+    """want_stats: also return (stats_ws, slots), per-channel BN partial sums of the output (as conv_fprop);
+    bnl: coef [C, 4] of the conv -> BN -> ReLU layer feeding this one: x is that layer's PRE-normalisation output, normalised on load"""
     n, c, h, wd = x.shape
     assert w.numel() == c * 9
     if out is None:
@@ -551,7 +552,7 @@ def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False):
         slots = n * lib().pfst_dwconv_stats_slots(h, wd, dil)
         st = _stats_ws(x.device, 2 * c * slots)
     call('pfst_dwconv3x3', x.data_ptr(), _bs(x), _dense(w).data_ptr(), out.data_ptr(), _bs(out), n, c, h, wd, dil,
-         int(flip), int(accumulate), _p(st), _stream())
+         int(flip), int(accumulate), _p(st), _p(bnl), _stream())
     return (out, st, slots) if want_stats else out
 
 
@@ -603,12 +604,12 @@ def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False, mean_grad=Non
     return dx
 
 
-def dwconv_bwd_(dw, x, dy, w, dil, dx, accumulate=False):
+def dwconv_bwd_(dw, x, dy, w, dil, dx, accumulate=False, bnl=None):
     """both gradients of the depthwise convolution in one pass: dx (+)= the mirrored stencil of dy, dw += the weight gradient"""
     n, c, h, wd = x.shape
     assert dy.shape == x.shape and tuple(dx.shape) == tuple(x.shape) and dw.numel() == c * 9 and w.numel() == c * 9
     call('pfst_dwconv3x3_bwd', dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), _dense(w).data_ptr(), dx.data_ptr(), _bs(dx),
-         _dense(dw).data_ptr(), n, c, h, wd, dil, int(accumulate), _stream())
+         _dense(dw).data_ptr(), n, c, h, wd, dil, int(accumulate), _p(bnl), _stream())
     return dx
 
 
@@ -671,13 +672,13 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
 
 
 # ---------------------------------------------------------------- pooling / resize
-def maxpool(x):
+def maxpool(x, bnl=None):
     _dense(x)
     n, c, h, w = x.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty(n, c, ho, wo, device=x.device)
     idx = torch.empty(n, c, ho, wo, dtype=U8, device=x.device)
-    call('pfst_maxpool3x3s2', x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, h, w, ho, wo, _stream())
+    call('pfst_maxpool3x3s2', x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, h, w, ho, wo, _p(bnl), c, _stream())
     return y, idx
 
 

@@ -352,8 +352,8 @@ class ConvModule(nn.Module):
         self.conv = Conv2dP(cin, cout, k, stride, padding, dilation, groups, bias=False)
         self.bn = BatchNorm2dP(cout)
 
-    def forward(self, x, tape, relu=True, residual=None, out=None, post_scale=None):
-        return conv_bn_act(x, self.conv, self.bn, tape, relu, residual, out, post_scale)
+    def forward(self, x, tape, relu=True, residual=None, out=None, post_scale=None, defer=False):
+        return conv_bn_act(x, self.conv, self.bn, tape, relu, residual, out, post_scale, defer)
 
 
 class DepthwiseSeparableConvModule(nn.Module):
@@ -362,12 +362,15 @@ class DepthwiseSeparableConvModule(nn.Module):
         self.depthwise_conv = ConvModule(cin, cin, k, 1, padding, dilation, groups=cin)
         self.pointwise_conv = ConvModule(cin, cout, 1)
 
-    def forward(self, x, tape, out=None, post_scale=None):
-        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale)
+    def forward(self, x, tape, out=None, post_scale=None, defer=False):
+        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale, defer=defer)
 
 
 # the atrous depthwise branches of the ASPP head as ONE launch each way (csrc/dwconv.hip, pfst_dwconv3x3_multi_*); PFST_FUSE_ASPP_DW=0: per branch
 FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
+# a conv -> BN -> ReLU output whose ONLY consumer can normalise on load (a depthwise layer: sep_bottleneck[0] -> [1]; the stem's max-pool) is
+# never written: the consumer reads the pre-BN tensor.  PFST_DEFER_BN_APPLY=0: every normalised tensor is materialised (A/B, per-link test)
+DEFER_BN_APPLY = os.environ.get('PFST_DEFER_BN_APPLY', '1') == '1'
 
 
 def dwsep_branches(x, mods, tape, outs, pool=None):
@@ -543,7 +546,8 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
     """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward;
     final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use);
     dy_amax: the slot group the kernel that produced dy published max |dy| to (f16x3)"""
-    xd = x.data
+    xd = x.data if x.lazy is None else x.lazy[0]
+    x_bnl = None if x.lazy is None else x.lazy[1]          # the depthwise layer's input is normalised on load (conv_bn_act(defer=True))
     f16w = CONV_MATH == 'f16x3' and not conv.depthwise and conv.cout > 64 and conv.k == 1 and conv.stride == 1
     wino16 = CONV_MATH == 'f16x3' and not conv.depthwise and conv.wino_f16
     x_amax = amax_of(x) if (f16w or (wino16 and saved_v is None)) else None
@@ -559,10 +563,11 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
             _dgrad_into(x, conv, dy, final, dy_amax)
         return
     if conv.depthwise:
-        if x.requires_grad and FUSE_DW_BWD:
+        if x.requires_grad and (FUSE_DW_BWD or x_bnl is not None):
             buf, acc = x.grad_target()         # both gradients from one staging of dy and one read of x (3 N of traffic instead of 4 N)
-            ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc)
+            ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc, bnl=x_bnl)
         else:
+            assert x_bnl is None
             ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
             if x.requires_grad:
                 buf, acc = x.grad_target()
@@ -575,13 +580,18 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
             _dgrad_into(x, conv, dy, final, dy_amax)
 
 
-def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scale=None):
+def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scale=None, defer=False):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
     (then the returned Var is expected to be obtained from the concat Var's .slice()).
     post_scale: [N, C] factors applied to y after the ReLU -- the Dropout2d mask of the layer feeding conv_seg, folded into the
     normalisation pass and, in backward, into the BatchNorm-backward passes (one tensor round trip less each way)"""
     assert post_scale is None or residual is None
-    xd = x.data
+    # defer: the caller guarantees that the ONLY consumer of the result normalises on load (a depthwise layer or the stem's max-pool): the
+    # normalisation pass is skipped, the returned Var carries (pre, coef) in .lazy and no data.  x.lazy: this layer IS such a consumer.
+    xd = x.data if x.lazy is None else x.lazy[0]
+    x_bnl = None if x.lazy is None else x.lazy[1]
+    assert x_bnl is None or conv.depthwise, 'only a depthwise layer (or the max-pool) reads a deferred normalisation'
+    defer = bool(defer and DEFER_BN_APPLY and not _BN_EVAL and relu and residual is None and out is None and post_scale is None)
     # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
     # cancellation: var = E[x^2] - mean^2 from the epilogue's fp32 partial sums of squares loses what torch's two-pass variance keeps
     # (per-link test: 1.3e-3 on that layer's backward against 6e-5 for torch-fp32).  Those tiny layers take the stand-alone statistics
@@ -590,9 +600,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
     if conv.depthwise:
         if fused_stats:                            # batch statistics come out of the producing kernel in every case
-            pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True)
+            pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True, bnl=x_bnl)
         else:
-            pre = ops.dwconv(xd, conv.weight.data, conv.dilation)
+            pre = ops.dwconv(xd, conv.weight.data, conv.dilation, bnl=x_bnl)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
         pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
     else:
@@ -606,7 +616,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
             # torch.nn.functional.batch_norm's own check: the image-pool BatchNorm of the ASPP head sees N x C x 1 x 1, so a per-GPU batch of
             # one cannot train; same exception type and text as the reference raises
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {torch.Size(pre.shape)}')
-        want_coef = tape is not None and FUSE_BN_BWD
+        want_coef = (tape is not None and FUSE_BN_BWD) or defer
         gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
         if fused_stats:
             n, c, h, w = pre.shape
@@ -623,9 +633,12 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     want_mask = tape is not None and relu and residual is not None
     # f16x3: the normalisation pass publishes max |y| for the GEMMs that will read y (no separate pass over the tensor)
     yv = out_var if out_var is not None else Var(None, tape is not None)
-    y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
-                     None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device),
-                     post=post_scale)
+    if defer:
+        yv.lazy, y = (pre, coef), None               # no normalisation pass: the consumer applies (sc, sh) of `coef` and the ReLU as it loads `pre`
+    else:
+        y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
+                         None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device),
+                         post=post_scale)
     gate = None
     if want_mask:
         y, gate = y
@@ -636,7 +649,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     final = x.claim_first_use()
     if residual is not None:
         residual.claim_first_use()
-    if coef is not None and out_var is None and post_scale is None:
+    if coef is not None and out_var is None and post_scale is None and not defer:
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
         yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)

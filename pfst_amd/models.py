@@ -126,15 +126,19 @@ class ResNetV1c(nn.Module):
         s = self.stem
         x = conv_bn_act(x, s[0], s[1], tape)
         x = conv_bn_act(x, s[3], s[4], tape)
-        x = conv_bn_act(x, s[6], s[7], tape)
+        x = conv_bn_act(x, s[6], s[7], tape, defer=True)     # its only consumer, the max-pool, normalises on load: stem.6's output is never written
         xin = x
-        y, idx = ops.maxpool(xin.data)
+        if xin.lazy is not None:
+            y, idx = ops.maxpool(xin.lazy[0], bnl=xin.lazy[1])
+        else:
+            y, idx = ops.maxpool(xin.data)
+        in_hw = tuple((xin.data if xin.lazy is None else xin.lazy[0]).shape[-2:])
         x = Var(y, tape is not None)
         if tape is not None:
             pooled = x
 
             def bwd_pool():
-                xin._grad = ops.maxpool_bwd(pooled.grad, idx, xin.data.shape[-2:])
+                xin._grad = ops.maxpool_bwd(pooled.grad, idx, in_hw)
                 pooled.free_grad()
             tape.record(bwd_pool, dict(op='maxpool', name='backbone.maxpool', x=xin, out=pooled))
         outs = []
@@ -351,7 +355,7 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
                 ops.resize_bilinear_bwd(cat2.grad[:, 0:ch], (h, w), out=buf, accumulate=acc)
             tape.record(bwd_up, dict(op='resize', name='decode_head.up', x=feats, out=cat2.slice(0, ch)))
         self.c1_bottleneck(c1, tape, out=cat2.slice(ch, ch + self.c1_channels))
-        o = self.sep_bottleneck[0](cat2, tape)
+        o = self.sep_bottleneck[0](cat2, tape, defer=True)          # its only consumer, sep_bottleneck[1]'s depthwise layer, normalises on load
         fold = FOLD_DROPOUT
         mask = self.dropout_mask(n, training) if fold else None
         o = self.sep_bottleneck[1](o, tape, post_scale=mask)          # Dropout2d folded into this layer's normalisation pass

@@ -370,6 +370,23 @@ def test_depthwise(ops, dil, H, W):
     dw = torch.zeros_like(wd)
     ops.dwconv_wgrad_(dw, xd, dyd, dil)
     assert_close(dw, w.grad, 1e-4, 'dw wgrad')
+    # normalise-on-load (layers.conv_bn_act(defer=True)): the depthwise layer reads the PRE-BatchNorm tensor of the layer in front of it and
+    # applies scale, shift and ReLU while staging -- forward and the fused backward's weight-gradient operand bit-identical to the same
+    # kernels on the tensor bn_apply would have written
+    pre = torch.randn(n, c, H, W, generator=g(11)).to(DEV) * 2
+    gamma, beta = (torch.rand(c, generator=g(12)) + 0.5).to(DEV) * torch.where(torch.arange(c) % 5 == 0, -1.0, 1.0).to(DEV), torch.randn(c, generator=g(13)).to(DEV)
+    mean, invstd, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+    ymat = ops.bn_apply(pre, mean, invstd, gamma, beta, True)
+    assert torch.equal(ops.dwconv(pre, wd, dil, bnl=coef), ops.dwconv(ymat, wd, dil))
+    ya, sta, sla = ops.dwconv(pre, wd, dil, want_stats=True, bnl=coef)
+    yb, stb, slb = ops.dwconv(ymat, wd, dil, want_stats=True)
+    assert torch.equal(ya, yb) and sla == slb
+    dxa, dwa = torch.empty_like(xd), torch.zeros_like(wd)
+    dxb, dwb = torch.empty_like(xd), torch.zeros_like(wd)
+    ops.dwconv_bwd_(dwa, pre, dyd, wd, dil, dxa, bnl=coef)
+    ops.dwconv_bwd_(dwb, ymat, dyd, wd, dil, dxb)
+    assert torch.equal(dxa, dxb)
+    assert_close(dwa, dwb, 1e-5, 'normalise-on-load: fused dw backward weight gradient')
     # both gradients in one pass (pfst_dwconv3x3_bwd: the layers' backward since round 4): same dx as the data-gradient kernel bit for bit,
     # the weight gradient within fp32 summation order of the stand-alone kernel; accumulate variants of both outputs
     dx1, dw1 = torch.empty_like(xd), torch.zeros_like(wd)
@@ -501,6 +518,16 @@ def test_maxpool(ops, H, W):
     assert torch.equal(y.cpu(), y_ref.detach())
     dx = ops.maxpool_bwd(dy.to(DEV), idx, (H, W))
     assert_close(dx, x.grad, 1e-6)
+    # normalise-on-load (stem.6 -> max-pool): pooling the pre-BatchNorm tensor with (sc, sh, ReLU) applied per tap = pooling what bn_apply
+    # would have written, values and winning taps alike (negative scales included: the pool is not taken before the affine map)
+    pre = (torch.randn(2, 8, H, W, generator=g(3)) * 2).to(DEV)
+    gamma = (torch.tensor([1.0, -0.7, 0.3, 2.0, -1.5, 0.9, 1.1, -0.2])).to(DEV)
+    beta = torch.randn(8, generator=g(4)).to(DEV)
+    mean, invstd, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+    ymat = ops.bn_apply(pre, mean, invstd, gamma, beta, True)
+    y1, i1 = ops.maxpool(pre, bnl=coef)
+    y0, i0 = ops.maxpool(ymat)
+    assert torch.equal(y1, y0) and torch.equal(i1, i0)
 
 
 @pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128),

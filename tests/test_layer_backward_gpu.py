@@ -70,11 +70,15 @@ def test_every_backward_link_as_wired(wino, math):
     dys = {k: t.grad for k, t in cap.items() if t.grad is not None}
 
     # ---- HIP model, wired exactly as in the product
-    prev, prev_math, prev_dw = layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW
+    prev, prev_math, prev_dw, prev_defer = layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY
     layers.WINOGRAD, layers.CONV_MATH = wino, math      # both arithmetics of the dense convolutions: fp32-input MFMA and the bf16x6 split
     # one closure per conv -> BN link here: the ASPP head's fused three-branch depthwise launch (one closure for three layers' data and weight
     # gradients) is checked against this per-branch wiring in test_aspp_depthwise_branches_fused_equals_per_branch below
     layers.FUSE_ASPP_DW = False
+    # ... and every normalised tensor is materialised here (the observer reads each link's input and output): the two deferred
+    # normalisations of the product (stem.6 -> max-pool, sep_bottleneck[0] -> [1]) are checked against this wiring in
+    # test_deferred_normalisation_equals_the_materialised_one below
+    layers.DEFER_BN_APPLY = False
     try:
         model = build_segmentor(model_cfg(C, 3, dropout=0.0))
         model.load_state_dict(student, strict=True)
@@ -206,7 +210,7 @@ def test_every_backward_link_as_wired(wino, math):
         tape.backward()
         torch.cuda.synchronize()
     finally:
-        layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW = prev, prev_math, prev_dw
+        layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY = prev, prev_math, prev_dw, prev_defer
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
     for op, name, k, worst, nrm, fe, de, _, _ in sorted(rows, key=lambda r: -r[3])[:25]:
@@ -490,3 +494,51 @@ def test_aspp_depthwise_branches_fused_equals_per_branch():
     for n in d1:
         _, e = mixed_err(d1[n], d0[n])
         assert e < 1e-4, (n, e)
+
+
+def test_deferred_normalisation_equals_the_materialised_one():
+    """layers.conv_bn_act(defer=True): the outputs of stem.6 (consumer: the max-pool) and of sep_bottleneck[0] (consumer: sep_bottleneck[1]'s
+    depthwise layer) are never written -- the consumer reads the pre-BatchNorm tensor and applies scale, shift and ReLU as it loads, in
+    forward and (the depthwise layer's weight gradient) in backward.  Same arithmetic per element as bn_apply, so one segmentor forward +
+    backward with the deferral on and off gives bit-identical logits and gradients equal to the atomics' summation order; the two
+    normalisation launches are really gone."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=31)
+    runs, applies = {}, {}
+    prev = layers.DEFER_BN_APPLY
+    try:
+        for defer in (True, False):
+            layers.DEFER_BN_APPLY = defer
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            n_apply = [0]
+            orig = ops.bn_apply
+            ops.bn_apply = lambda *a, **k: (n_apply.__setitem__(0, n_apply[0] + 1), orig(*a, **k))[1]
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.bn_apply = orig
+            runs[defer] = (out['logits'].data.clone(), arena.grad.clone())
+            applies[defer] = n_apply[0]
+    finally:
+        layers.DEFER_BN_APPLY = prev
+    assert applies[False] == 70 and applies[True] == 68, applies
+    assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    assert e < 1e-4, e
