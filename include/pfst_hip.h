@@ -43,6 +43,14 @@ typedef struct pfst_bnb_fuse {
   int relu;
 } pfst_bnb_fuse_t;
 
+/* What a kernel needs to apply the SECOND pass of BatchNorm backward on the fly, per channel: dx = gs * (dz - m1 - xhat * m2) with
+ * dz = dy * [x * sc + sh > 0], xhat = (x - mu) * is, in the arithmetic of pfst_bn_backward's apply pass (fp64 projections).  Written by
+ * pfst_bn_backward_sums, read by pfst_dwconv3x3_bwd / pfst_dwconv3x3_multi_bwd (the depthwise layers' backward forms dL/dpre itself). */
+typedef struct pfst_bn_bwd_rec {
+  double m1, m2, gs;
+  float mu, is, sc, sh;
+} pfst_bn_bwd_rec_t;
+
 /* ---- dense convolution as implicit GEMM on fp32 MFMA (F.conv2d, groups=1) ---------------
  * resnet.py:169-209 (Bottleneck 1x1/3x3), resnet.py:593-624 (stem), aspp_head.py:32-42,85-92,
  * fcn_head.py:40-49, decode_head.py:242-247 (conv_seg), mmcv pointwise convs. */
@@ -188,12 +196,17 @@ int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float
                              float* const* stats, const int* dils, float* plane_mean, int N, int C, int H, int W, pfst_stream_t stream);
 int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
                              const long long* dy_bs, float* const* dw, const int* dils, const float* plane_mean_grad, float* dx,
-                             long long dx_bs, int accumulate, int N, int C, int H, int W, pfst_stream_t stream);
+                             long long dx_bs, int accumulate, const float* const* bn_pre, const pfst_bn_bwd_rec_t* const* bn_rec,
+                             int N, int C, int H, int W, pfst_stream_t stream);
+/* bn_pre / bn_rec != NULL (all branches or none): as in pfst_dwconv3x3_bwd, per branch (bn_pre[i] has dy[i]'s batch stride) */
 /* both gradients of the depthwise convolution in one pass over dy and the forward input x (autograd of the same F.conv2d(groups = C)):
  * dx (+)= conv(dy, mirrored w), dw += sum dy * shifted x -- 3 N of HBM traffic instead of the two kernels' 4 N */
 int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,
-                       float* dw, int N, int C, int H, int W, int dil, int accumulate, const float* bn_on_load_coef, pfst_stream_t stream);
-/* (bn_on_load_coef as in pfst_dwconv3x3: x holds the pre-normalisation tensor, its quads are normalised as they are loaded) */
+                       float* dw, int N, int C, int H, int W, int dil, int accumulate, const float* bn_on_load_coef,
+                       const float* bn_pre, long long bn_pre_bs, const pfst_bn_bwd_rec_t* bn_rec, pfst_stream_t stream);
+/* (bn_on_load_coef as in pfst_dwconv3x3: x holds the pre-normalisation tensor, its quads are normalised as they are loaded)
+ * bn_rec != NULL: dy is the gradient of the BatchNorm + ReLU OUTPUT of this depthwise layer, bn_pre the layer's pre-normalisation tensor
+ * (the depthwise convolution's own output): dL/dpre is formed while the rows are staged (pfst_bn_backward_sums ran before) */
 
 /* ---- BatchNorm2d, training mode (nn.BatchNorm2d inside mmcv ConvModule; eps 1e-5, momentum .1) */
 /* batch mean / 1/sqrt(biased var + eps) per channel; updates running stats (unbiased var) when
@@ -227,6 +240,12 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
                      double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, const float* post_scale, pfst_stream_t stream);
 /* post_scale: the factors pfst_bn_apply folded into y: dy is the gradient of the SCALED output, dz = dy * post_scale[n][c] * gate (no dres, no
  * bwd_partials then) */
+/* The FIRST half of pfst_bn_backward alone, for a conv -> BN -> ReLU layer without residual whose convolution is depthwise: the two sums
+ * (from bwd_partials, else by the reduction pass), dgamma += sum dz*xhat, dbeta += sum dz, and rec[C] for the consumer that applies the
+ * second half while it loads dy and x (no dx is written here: 3 N of traffic less per layer).  ws: >= 2*C doubles. */
+int pfst_bn_backward_sums(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, float* dgamma, float* dbeta, int N, int C, int HW,
+                          double* ws, const float* bwd_partials, int bwd_slots, pfst_bn_bwd_rec_t* rec, pfst_stream_t stream);
 /* bwd_partials != NULL: (sum dz, sum dz*x) were already produced by the launch that wrote dy (pfst_bnb_fuse_t, [C][bwd_slots][2]); the
  * reduction pass over dy and x is skipped and only the partials are summed (fp64). */
 

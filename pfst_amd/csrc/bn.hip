@@ -396,6 +396,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   if (amax) amax_publish(amax, am);
 }
 
+// after the two sums are in ws: parameter gradients + the per-channel record a consumer needs to apply the second pass itself
+__global__ void bn_bwd_rec_kernel(const double* __restrict__ ws, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma,
+                                  float* __restrict__ dbeta, int C, double inv_count, pfst_bn_bwd_rec_t* __restrict__ rec) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dgamma) dgamma[c] += (float)ws[2 * c + 1];
+  if (dbeta) dbeta[c] += (float)ws[2 * c];
+  pfst_bn_bwd_rec_t r;
+  r.m1 = ws[2 * c] * inv_count;
+  r.m2 = ws[2 * c + 1] * inv_count;
+  r.gs = (double)gamma[c] * (double)invstd[c];
+  r.mu = mean[c];
+  r.is = invstd[c];
+  bn_affine(mean[c], invstd[c], gamma[c], beta[c], r.sc, r.sh);
+  rec[c] = r;
+}
+
 // split one HW plane into `splits` chunks (multiples of 4) so the reduction launches ~BN_SPLIT_TARGET blocks
 inline void split_for(int HW, int C, int N, int& splits, int& chunk) {
   i64 planes = (i64)C * N;
@@ -498,6 +516,34 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   }
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_bn_backward_sums(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, float* dgamma, float* dbeta, int N, int C, int HW,
+                                     double* ws, const float* bwd_partials, int bwd_slots, pfst_bn_bwd_rec_t* rec, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && x && mean && invstd && gamma && beta && ws && rec && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!bwd_partials || bwd_slots > 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (bwd_partials) {
+    hipLaunchKernelGGL(bn_bwd_partials_kernel, dim3(C), dim3(256), 0, s, bwd_partials, bwd_slots, mean, invstd, ws);
+  } else {
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+    int splits, chunk;
+    split_for(HW, C, N, splits, chunk);
+    const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs) & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
+    const float* none = nullptr;
+    const unsigned long long* nomask = nullptr;
+    if (vec)
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, none, (i64)0, x, (i64)x_bs, mean, invstd, gamma,
+                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none);
+    else
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, none, (i64)0, x, (i64)x_bs, mean, invstd, gamma,
+                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none);
+  }
+  hipLaunchKernelGGL(bn_bwd_rec_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, mean, invstd, gamma, beta, dgamma, dbeta, C,
+                     1.0 / ((double)N * HW), rec);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -62,6 +62,44 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ plane, floa
   }
 }
 
+// the second pass of BatchNorm backward for one element, exactly as bn_bwd_apply_kernel evaluates it (ReLU gate recomputed from the
+// pre-normalisation value like bn_apply decided it, projections subtracted in fp64)
+__device__ __forceinline__ float bn_bwd_elem(float g, float xv, const pfst_bn_bwd_rec_t& r) {
+  const float dz = __fmaf_rn(xv, r.sc, r.sh) > 0.f ? g : 0.f;
+  return (float)(r.gs * ((double)dz - r.m1 - (((double)xv - (double)r.mu) * (double)r.is) * r.m2));
+}
+__device__ __forceinline__ float4 bn_bwd_elem4(float4 g, float4 xv, const pfst_bn_bwd_rec_t& r) {
+  return make_float4(bn_bwd_elem(g.x, xv.x, r), bn_bwd_elem(g.y, xv.y, r), bn_bwd_elem(g.z, xv.z, r), bn_bwd_elem(g.w, xv.w, r));
+}
+
+// rows [lo,hi) of dL/dpre = BatchNorm-backward(dy, pre) of one plane into LDS: the depthwise layer's backward stages the gradient of its own
+// convolution output without that tensor ever being written (pfst_bn_backward_sums left the per-channel record)
+__device__ __forceinline__ void stage_rows_bnbwd(const float* __restrict__ dyp, const float* __restrict__ prep, float* __restrict__ tile, int lo,
+                                                 int hi, int W, const pfst_bn_bwd_rec_t& rec) {
+  const int n = (hi - lo) * W;
+  const float* g = dyp + (i64)lo * W;
+  const float* x = prep + (i64)lo * W;
+  if ((W & 3) == 0 && ((((uintptr_t)g) | ((uintptr_t)x)) & 15) == 0) {
+    float4* t4 = reinterpret_cast<float4*>(tile);
+    const int n4 = n >> 2, bd = blockDim.x;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g), 0, n4 * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, n4 * 16, 0x00020000);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * bd) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, 16 * (i0 + u * bd), 0, 0));
+        b[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, 16 * (i0 + u * bd), 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * bd < n4) t4[i0 + u * bd] = bn_bwd_elem4(a[u], b[u], rec);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) tile[i] = bn_bwd_elem(g[i], x[i], rec);
+  }
+}
+
 // load 4 consecutive floats starting at column sx (any alignment, zero outside [0,W))
 template <bool ALIGNED>
 __device__ __forceinline__ float4 row4(const float* __restrict__ row, int sx, int W) {
@@ -115,7 +153,10 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
                                                         float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int R,
                                                         int flip, int accumulate, float* __restrict__ stats,
                                                         const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
-                                                        const float4* __restrict__ bnl = nullptr) {
+                                                        const float4* __restrict__ bnl = nullptr, const float* __restrict__ bnpre = nullptr,
+                                                        i64 bnpre_bs = 0, const pfst_bn_bwd_rec_t* __restrict__ bnrec = nullptr) {
+  // bnrec != NULL (WG): x = the gradient of this layer's BatchNorm + ReLU output, bnpre = the layer's own convolution output: the rows
+  // staged are dL/dpre = the second pass of BatchNorm backward, formed on the fly (stage_rows_bnbwd)
   // bnl != NULL: coef[C] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer whose PRE-normalisation output is this convolution's
   // forward input: forward (WG = false) x is that tensor and is normalised while staged; backward (WG) fx is, and its quads are
   // normalised as they are loaded.  The normalised tensor is never materialised (its only consumer is this depthwise layer).
@@ -134,7 +175,12 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
   const float bsc = bnl ? bnl[c].z : 1.f, bsh = bnl ? bnl[c].w : 0.f;
-  stage_rows(xp, tile, s.lo, s.hi, W, bnl != nullptr && !WG, bsc, bsh);
+  if (WG && bnrec) {
+    const pfst_bn_bwd_rec_t rec = bnrec[c];
+    stage_rows_bnbwd(xp, bnpre + (i64)n * bnpre_bs + (i64)c * H * W, tile, s.lo, s.hi, W, rec);
+  } else {
+    stage_rows(xp, tile, s.lo, s.hi, W, bnl != nullptr && !WG, bsc, bsh);
+  }
   __syncthreads();
   if (MODE != 0) {
     const int W4 = W >> 2;
@@ -404,6 +450,8 @@ struct DwSets {
   float* stats[3];          // forward: BatchNorm partials [C][N][2] or NULL
   long long bs[3];          // batch strides of y / dy
   int dil[3];
+  const float* pre[3];      // backward with rec: the branches' own convolution outputs (pre-normalisation), batch stride bs[i]
+  const pfst_bn_bwd_rec_t* rec[3];   // backward: NULL, or the records of pfst_bn_backward_sums: dy[i] is then the gradient of the BN + ReLU output
   float* pool;              // forward: NULL, or [N][C] plane means of x (nn.AdaptiveAvgPool2d(1) of the image-pool branch, aspp_head.py:69-77)
   const float* pool_grad;   // backward: NULL, or [N][C] gradients of those means: dx += pool_grad[n][c] * pool_scale
   float pool_scale;         // 1 / (H W)
@@ -475,38 +523,55 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
   }
 }
 
-template <int NS>
+template <int NS, bool BNB>
 __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, float* __restrict__ dx,
                                                                   i64 dx_bs, int accumulate, int C, int H, int W, int cpb) {
+  // LDS: [gradient plane | forward-input plane].  BNB: the gradient plane staged is dL/dpre = BatchNorm-backward(dy, pre), formed from the two
+  // planes fetched into registers one branch ahead (bn_bwd_elem4) -- the branches' dL/dpre tensors are never written.
   extern __shared__ float tile[];
   __shared__ double red[40];
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
   const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
-  float4 r[8];
-  auto fetch = [&](int c, int si) {                // the gradient plane of branch si, channel c -> registers
+  float4* const t4 = reinterpret_cast<float4*>(tile);
+  float4* const x4 = t4 + n4;
+  float4 r[8], p[8];
+  auto fetch = [&](int c, int si) {                // the gradient plane (BNB: and the pre-normalisation plane) of branch si, channel c -> registers
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.dy[si] + (i64)n * S.bs[si] + (i64)c * HW), 0, HW * 4, 0x00020000);
 #pragma unroll
     for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * 512), 0, 0));
+    if (BNB) {
+      const __amdgpu_buffer_rsrc_t ps =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.pre[si] + (i64)n * S.bs[si] + (i64)c * HW), 0, HW * 4, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ps, 16 * (tid + u * 512), 0, 0));
+    }
   };
   fetch(c0, 0);
   for (int c = c0; c < c1; ++c) {
-    float4 xr[8], dxa[8];
-    {
+    float4 dxa[8];
+    {                                              // the forward input's plane: each thread keeps its own quads in LDS (read back per branch)
       const __amdgpu_buffer_rsrc_t xs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (i64)n * x_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        xr[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * 512), 0, 0));
+        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * 512), 0, 0));
+        if (tid + u * 512 < n4) x4[tid + u * 512] = v;
         dxa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll 1
     for (int si = 0; si < NS; ++si) {              // (a run-time loop: unrolled, the 8 x 9 x NS tap bodies spill)
-      float4* t4 = reinterpret_cast<float4*>(tile);
+      if (BNB) {
+        const pfst_bn_bwd_rec_t rec = S.rec[si][c];
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+        for (int u = 0; u < 8; ++u)
+          if (tid + u * 512 < n4) t4[tid + u * 512] = bn_bwd_elem4(r[u], p[u], rec);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+      }
       __syncthreads();
       if (si + 1 < NS) fetch(c, si + 1);
       else if (c + 1 < c1) fetch(c + 1, 0);
@@ -519,6 +584,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
         const int i = tid + u * 512;
         if (i >= n4) break;
         const int yy = i / W4, c4 = i - yy * W4;
+        const float4 xq = x4[i];
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
           const int sy = yy + (ty - 1) * dil;
@@ -529,7 +595,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
             const float4 v = row4<true>(row, c4 * 4 + (tx - 1) * dil, W);
             const float k = wt[ty * 3 + tx];
             dxa[u].x = fmaf(k, v.x, dxa[u].x); dxa[u].y = fmaf(k, v.y, dxa[u].y); dxa[u].z = fmaf(k, v.z, dxa[u].z); dxa[u].w = fmaf(k, v.w, dxa[u].w);
-            accw[8 - (ty * 3 + tx)] += (xr[u].x * v.x + xr[u].y * v.y) + (xr[u].z * v.z + xr[u].w * v.w);
+            accw[8 - (ty * 3 + tx)] += (xq.x * v.x + xq.y * v.y) + (xq.z * v.z + xq.w * v.w);
           }
         }
       }
@@ -629,8 +695,9 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
 // staging of dy and one read of the forward input x (see the WG note above dwconv3x3_kernel): 3 N of traffic instead of 2 N + 2 N.
 extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* w, float* dx, long long dx_bs,
                                   float* dw, int N, int C, int H, int W, int dil, int accumulate, const float* bn_on_load_coef,
-                                  pfst_stream_t stream) {
+                                  const float* bn_pre, long long bn_pre_bs, const pfst_bn_bwd_rec_t* bn_rec, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && x && w && dx && dw && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  PFST_CHECK_ARG((bn_rec == nullptr) == (bn_pre == nullptr) && (!bn_rec || bn_pre_bs >= (i64)C * H * W));
   const float4* bnl = reinterpret_cast<const float4*>(bn_on_load_coef);
   PFST_CHECK_ARG(dy_bs >= (i64)C * H * W && x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
   const int R = strip_rows(H, W, dil);
@@ -648,13 +715,13 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
     set = true;
   }
   const bool vec = (W % 4 == 0) && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)x) % 16 == 0) && (dy_bs % 4 == 0) && (dx_bs % 4 == 0) &&
-                   (x_bs % 4 == 0) && (((i64)H * W) % 4 == 0);
+                   (x_bs % 4 == 0) && (((i64)H * W) % 4 == 0) && (!bn_pre || (((uintptr_t)bn_pre % 16 == 0) && bn_pre_bs % 4 == 0));
   const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
   static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;
   float* const none = nullptr;
-  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl) {
+  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl && !bn_rec) {
     dim3 gp(1, cdiv(C, cpb), N);
     if (mode == 1)
       hipLaunchKernelGGL((dwconv3x3_plane_kernel<1, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
@@ -666,13 +733,13 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
     return PFST_OK;
   }
   if (mode == 1)
-    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
+    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
   else if (mode == 2)
-    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
+    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
   else if (mode == 3)
-    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
+    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
   else
-    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl);
+    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -694,6 +761,8 @@ static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const*
   S.pool_scale = 0.f;
   for (int i = 0; i < 3; ++i) {
     const int k = i < ns ? i : 0;
+    S.pre[i] = nullptr;
+    S.rec[i] = nullptr;
     S.w[i] = w[k];
     S.y[i] = y ? y[k] : nullptr;
     S.dy[i] = dy ? dy[k] : nullptr;
@@ -736,7 +805,8 @@ extern "C" int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, 
 
 extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
                                         const long long* dy_bs, float* const* dw, const int* dils, const float* plane_mean_grad, float* dx,
-                                        long long dx_bs, int accumulate, int N, int C, int H, int W, pfst_stream_t stream) {
+                                        long long dx_bs, int accumulate, const float* const* bn_pre, const pfst_bn_bwd_rec_t* const* bn_rec,
+                                        int N, int C, int H, int W, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && dy && dy_bs && dw && dils && dx && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && dx_bs >= (i64)C * H * W && ((x_bs | dx_bs) & 3) == 0 && (((uintptr_t)x | (uintptr_t)dx) & 15) == 0);
   DwSets S;
@@ -744,20 +814,36 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(dy[i] != nullptr && dw[i] != nullptr);
   S.pool_grad = plane_mean_grad;
   S.pool_scale = 1.0f / (float)(H * W);
+  const bool bnb = bn_rec != nullptr;
+  PFST_CHECK_ARG(bnb == (bn_pre != nullptr));
+  if (bnb)
+    for (int i = 0; i < 3; ++i) {
+      const int k = i < ns ? i : 0;
+      PFST_CHECK_ARG(bn_pre[k] && bn_rec[k] && ((uintptr_t)bn_pre[k] & 15) == 0);
+      S.pre[i] = bn_pre[k];
+      S.rec[i] = bn_rec[k];
+    }
   static bool set = false;
   if (!set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+#define PFST_DW_MULTI_ATTR(NS_, B_) \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+    PFST_DW_MULTI_ATTR(1, false); PFST_DW_MULTI_ATTR(2, false); PFST_DW_MULTI_ATTR(3, false);
+    PFST_DW_MULTI_ATTR(1, true); PFST_DW_MULTI_ATTR(2, true); PFST_DW_MULTI_ATTR(3, true);
+#undef PFST_DW_MULTI_ATTR
     set = true;
   }
   const int cpb = 4;
-  const size_t lds = (size_t)H * W * sizeof(float);
+  const size_t lds = 2 * (size_t)H * W * sizeof(float);          // gradient plane + forward-input plane
   dim3 gp(1, cdiv(C, cpb), N);
   hipStream_t st = (hipStream_t)stream;
-  if (ns == 1) hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<1>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
-  else if (ns == 2) hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<2>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
-  else hipLaunchKernelGGL(dwconv3x3_multi_bwd_kernel<3>, gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb);
+#define PFST_DW_MULTI_LAUNCH(NS_, B_) \
+  hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_>), gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
+  if (bnb) {
+    if (ns == 1) PFST_DW_MULTI_LAUNCH(1, true); else if (ns == 2) PFST_DW_MULTI_LAUNCH(2, true); else PFST_DW_MULTI_LAUNCH(3, true);
+  } else {
+    if (ns == 1) PFST_DW_MULTI_LAUNCH(1, false); else if (ns == 2) PFST_DW_MULTI_LAUNCH(2, false); else PFST_DW_MULTI_LAUNCH(3, false);
+  }
+#undef PFST_DW_MULTI_LAUNCH
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -592,24 +592,31 @@ def dwconv_multi(x, ws, dils, want_stats=False, want_mean=False):
     return (res, mean) if want_mean else res
 
 
-def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False, mean_grad=None):
+def dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, accumulate=False, mean_grad=None, bnb=None):
     """dws[i] += weight gradients, dx (+)= sum_i mirrored stencil of dys[i]: x read once, every dy once, dx written once;
-    mean_grad: [N, C] gradient of the plane means dwconv_multi(want_mean=True) returned: dx += mean_grad / (H W)"""
+    mean_grad: [N, C] gradient of the plane means dwconv_multi(want_mean=True) returned: dx += mean_grad / (H W);
+    bnb = [(pre_i, rec_i)]: dys[i] are the gradients of the branches' BatchNorm + ReLU outputs (see dwconv_bwd_)"""
     n, c, h, w = x.shape
     k = len(ws)
     assert all(tuple(d.shape) == tuple(x.shape) and _bs(d) % 4 == 0 and d.data_ptr() % 16 == 0 for d in dys) and tuple(dx.shape) == tuple(x.shape)
+    assert bnb is None or all(_bs(b[0]) == _bs(d) and tuple(b[0].shape) == tuple(d.shape) for b, d in zip(bnb, dys))
     call('pfst_dwconv3x3_multi_bwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(dys),
          (ctypes.c_longlong * k)(*[_bs(d) for d in dys]), _ptr_array([_dense(t) for t in dws]), (ctypes.c_int * k)(*dils),
-         _p(None if mean_grad is None else _dense(mean_grad)), dx.data_ptr(), _bs(dx), int(accumulate), n, c, h, w, _stream())
+         _p(None if mean_grad is None else _dense(mean_grad)), dx.data_ptr(), _bs(dx), int(accumulate),
+         None if bnb is None else _ptr_array([b[0] for b in bnb]), None if bnb is None else _ptr_array([b[1] for b in bnb]),
+         n, c, h, w, _stream())
     return dx
 
 
-def dwconv_bwd_(dw, x, dy, w, dil, dx, accumulate=False, bnl=None):
-    """both gradients of the depthwise convolution in one pass: dx (+)= the mirrored stencil of dy, dw += the weight gradient"""
+def dwconv_bwd_(dw, x, dy, w, dil, dx, accumulate=False, bnl=None, bnb=None):
+    """both gradients of the depthwise convolution in one pass: dx (+)= the mirrored stencil of dy, dw += the weight gradient.
+    bnb = (pre, rec): dy is the gradient of the layer's BatchNorm + ReLU OUTPUT, pre the convolution's own output, rec from
+    bn_backward_sums: the gradient of the convolution output is formed while the rows are staged"""
     n, c, h, wd = x.shape
     assert dy.shape == x.shape and tuple(dx.shape) == tuple(x.shape) and dw.numel() == c * 9 and w.numel() == c * 9
     call('pfst_dwconv3x3_bwd', dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), _dense(w).data_ptr(), dx.data_ptr(), _bs(dx),
-         _dense(dw).data_ptr(), n, c, h, wd, dil, int(accumulate), _p(bnl), _stream())
+         _dense(dw).data_ptr(), n, c, h, wd, dil, int(accumulate), _p(bnl), _p(None if bnb is None else bnb[0]),
+         0 if bnb is None else _bs(bnb[0]), _p(None if bnb is None else bnb[1]), _stream())
     return dx
 
 
@@ -669,6 +676,23 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
          n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _p(amax), _p(None if post is None else _dense(post)), _stream())
     return dx
+
+
+BN_BWD_REC_BYTES = 40          # sizeof(pfst_bn_bwd_rec_t): three doubles + four floats
+
+
+def bn_backward_sums(dy, x, mean, invstd, gamma, beta, dgamma, dbeta, partials=None, slots=0):
+    """the first half of bn_backward for a depthwise conv -> BN -> ReLU layer: the two sums (from `partials` or by the reduction pass),
+    dgamma / dbeta += ..., and the per-channel record (uint8 [C * 40]) with which the layer's fused depthwise backward applies the second
+    half itself while it stages dy and x (dwconv_bwd_(bnb=...), dwconv_multi_bwd_(bnb=...)): dL/dpre is never written"""
+    n, c, h, w = x.shape
+    assert dy.shape == x.shape
+    rec = torch.empty(c * BN_BWD_REC_BYTES, dtype=U8, device=x.device)
+    ws = torch.empty(2 * c, dtype=torch.float64, device=x.device)        # its own scratch: the record is read later, by another launch
+    call('pfst_bn_backward_sums', dy.data_ptr(), _bs(dy), x.data_ptr(), _bs(x), mean.data_ptr(), invstd.data_ptr(),
+         _dense(gamma).data_ptr(), _dense(beta).data_ptr(), _p(dgamma), _p(dbeta), n, c, h * w, ws.data_ptr(), _p(partials), int(slots),
+         rec.data_ptr(), _stream())
+    return rec
 
 
 # ---------------------------------------------------------------- pooling / resize

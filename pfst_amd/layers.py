@@ -371,6 +371,9 @@ FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
 # a conv -> BN -> ReLU output whose ONLY consumer can normalise on load (a depthwise layer: sep_bottleneck[0] -> [1]; the stem's max-pool) is
 # never written: the consumer reads the pre-BN tensor.  PFST_DEFER_BN_APPLY=0: every normalised tensor is materialised (A/B, per-link test)
 DEFER_BN_APPLY = os.environ.get('PFST_DEFER_BN_APPLY', '1') == '1'
+# depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
+# operands (dL/dpre is never written); PFST_FUSE_DW_BNBWD=0: the two-pass BatchNorm backward writes it first
+FUSE_DW_BNBWD = os.environ.get('PFST_FUSE_DW_BNBWD', '1') == '1'
 
 
 def dwsep_branches(x, mods, tape, outs, pool=None):
@@ -395,16 +398,16 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
         res, pool['mean'] = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats, want_mean=True)
     else:
         res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats)
-    dpres = [None] * len(mods)
+    dpres, bnbs = [None] * len(mods), [None] * len(mods)
     if tape is not None:
         x.claim_first_use()
 
         def bwd_dw():                                # recorded FIRST: runs after the branches' BatchNorm-backward closures below
             buf, acc = x.grad_target()
             ops.dwconv_multi_bwd_([c.weight.grad for c in convs], xd, dpres, [c.weight.data for c in convs], dils, buf, accumulate=acc,
-                                  mean_grad=None if pool is None else pool.pop('grad', None))
+                                  mean_grad=None if pool is None else pool.pop('grad', None), bnb=bnbs if bnbs[0] is not None else None)
             for i in range(len(dpres)):
-                dpres[i] = None
+                dpres[i] = bnbs[i] = None
         tape.record(bwd_dw, dict(op='dwconv_multi', x=x, convs=convs))
     ys = []
     for i, m in enumerate(mods):
@@ -432,8 +435,14 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
 
             def bwd_bn(i=i, bn=bn, yv=yv, pre=pre, mean=mean, invstd=invstd):
                 part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
-                dpres[i] = ops.bn_backward(yv.grad, None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad, True, None, False,
-                                           beta=bn.bias.data, partials=part, slots=nslots)
+                if FUSE_DW_BNBWD:
+                    # only the sums here; the fused backward of the branches applies the second pass while it stages (dy, pre)
+                    rec = ops.bn_backward_sums(yv.grad, pre, mean, invstd, bn.weight.data, bn.bias.data, bn.weight.grad, bn.bias.grad,
+                                               partials=part, slots=nslots)
+                    dpres[i], bnbs[i] = yv.grad, (pre, rec)
+                else:
+                    dpres[i] = ops.bn_backward(yv.grad, None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad, True, None, False,
+                                               beta=bn.bias.data, partials=part, slots=nslots)
                 yv.free_grad()
             tape.record(bwd_bn, dict(op='dw_bn_act', bn=bn, conv=convs[i], x=x, out=yv))
         ys.append(m.pointwise_conv(yv, tape, out=outs[i]))
@@ -542,7 +551,7 @@ def _dgrad_into(x, conv, dy, final, dy_amax=None):
     conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax)
 
 
-def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
+def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=None):
     """accumulate weight/bias grads and propagate the data gradient into x; saved_v: Winograd-transformed x from forward;
     final: this conv was x's first consumer in forward = the last writer of x's gradient (Var.claim_first_use);
     dy_amax: the slot group the kernel that produced dy published max |dy| to (f16x3)"""
@@ -565,9 +574,9 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None):
     if conv.depthwise:
         if x.requires_grad and (FUSE_DW_BWD or x_bnl is not None):
             buf, acc = x.grad_target()         # both gradients from one staging of dy and one read of x (3 N of traffic instead of 4 N)
-            ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc, bnl=x_bnl)
+            ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc, bnl=x_bnl, bnb=dw_bnb)
         else:
-            assert x_bnl is None
+            assert x_bnl is None and dw_bnb is None
             ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
             if x.requires_grad:
                 buf, acc = x.grad_target()
@@ -665,6 +674,15 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
         need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
                                                                     or conv.wino_f16)
         dpre_amax = ops.amax_slots(pre.device) if need_amax else None
+        if (conv.depthwise and FUSE_DW_BNBWD and (FUSE_DW_BWD or x.lazy is not None) and relu and residual is None and gate is None
+                and post_scale is None and x.requires_grad):
+            # the depthwise backward forms dL/dpre itself from (dy, pre) and the record of the two sums: 3 N of traffic less
+            rec = ops.bn_backward_sums(dy, pre, mean, invstd, bn.weight.data, bn.bias.data, bn.weight.grad, bn.bias.grad, partials=part,
+                                       slots=nslots)
+            conv_backward(x, conv, dy, saved_v, final, dw_bnb=(pre, rec))
+            if yv.parent is None:
+                yv.free_grad()
+            return
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
                                relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax,
                                post=post_scale)

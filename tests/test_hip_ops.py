@@ -387,6 +387,23 @@ def test_depthwise(ops, dil, H, W):
     ops.dwconv_bwd_(dwb, ymat, dyd, wd, dil, dxb)
     assert torch.equal(dxa, dxb)
     assert_close(dwa, dwb, 1e-5, 'normalise-on-load: fused dw backward weight gradient')
+    # BatchNorm backward's second pass applied on the fly (layers.FUSE_DW_BNBWD): dy is the gradient of THIS layer's BN + ReLU output, the
+    # kernel stages dL/dpre = bn_backward(dy, pre) itself; against bn_backward writing dL/dpre first: dx bit-identical, parameter gradients equal
+    pre2 = ops.dwconv(xd, wd, dil)
+    g2, b2 = (torch.rand(c, generator=g(14)) + 0.5).to(DEV), torch.randn(c, generator=g(15)).to(DEV) * 0.3
+    m2, i2, _ = ops.bn_stats(pre2, gamma=g2, beta=b2)
+    dyo = torch.randn(n, c, H, W, generator=g(16)).to(DEV)
+    dg_a, db_a, dg_b, db_b = (torch.zeros(c, device=DEV) for _ in range(4))
+    dpre = ops.bn_backward(dyo, None, pre2, m2, i2, g2, dg_b, db_b, True, beta=b2)
+    dxb, dwb = torch.empty_like(xd), torch.zeros_like(wd)
+    ops.dwconv_bwd_(dwb, xd, dpre, wd, dil, dxb)
+    rec = ops.bn_backward_sums(dyo, pre2, m2, i2, g2, b2, dg_a, db_a)
+    dxa, dwa = torch.empty_like(xd), torch.zeros_like(wd)
+    ops.dwconv_bwd_(dwa, xd, dyo, wd, dil, dxa, bnb=(pre2, rec))
+    assert torch.equal(dxa, dxb), 'BN backward applied on the fly: dx'
+    assert_close(dwa, dwb, 1e-5, 'BN backward applied on the fly: dw')
+    assert_close(dg_a, dg_b, 1e-6, 'dgamma')
+    assert_close(db_a, db_b, 1e-6, 'dbeta')
     # both gradients in one pass (pfst_dwconv3x3_bwd: the layers' backward since round 4): same dx as the data-gradient kernel bit for bit,
     # the weight gradient within fp32 summation order of the stand-alone kernel; accumulate variants of both outputs
     dx1, dw1 = torch.empty_like(xd), torch.zeros_like(wd)
@@ -433,6 +450,22 @@ def test_depthwise_branches_in_one_pass(ops, H, W, dils):
     dx3 = torch.empty_like(xd)
     ops.dwconv_multi_bwd_([torch.zeros_like(w) for w in wd], xd, dyd, wd, list(dils), dx3, mean_grad=mg.to(DEV))
     assert_close(dx3, dx_ref + (mg.double() / (H * W)).view(n, c, 1, 1), 1e-5, 'multi-branch dw backward: + adjoint of the plane mean')
+    # ... and with every branch's BatchNorm backward applied on the fly: the same as writing the three dL/dpre tensors first
+    gam = [(torch.rand(c, generator=g(30 + i)) + 0.5).to(DEV) for i in range(len(dils))]
+    bet = [(torch.randn(c, generator=g(40 + i)) * 0.3).to(DEV) for i in range(len(dils))]
+    pres = [r_[0] for r_ in res]
+    stats = [ops.bn_stats(pres[i], gamma=gam[i], beta=bet[i]) for i in range(len(dils))]
+    dpres, recs = [], []
+    for i in range(len(dils)):
+        dpres.append(ops.bn_backward(dyd[i], None, pres[i], stats[i][0], stats[i][1], gam[i], None, None, True, beta=bet[i]))
+        recs.append(ops.bn_backward_sums(dyd[i], pres[i], stats[i][0], stats[i][1], gam[i], bet[i], None, None))
+    dws_a, dws_b = [torch.zeros_like(w) for w in wd], [torch.zeros_like(w) for w in wd]
+    dxa, dxb = torch.empty_like(xd), torch.empty_like(xd)
+    ops.dwconv_multi_bwd_(dws_b, xd, dpres, wd, list(dils), dxb)
+    ops.dwconv_multi_bwd_(dws_a, xd, dyd, wd, list(dils), dxa, bnb=[(pres[i], recs[i]) for i in range(len(dils))])
+    assert torch.equal(dxa, dxb), 'multi-branch dw backward with BN backward on the fly: dx'
+    for i in range(len(dils)):
+        assert_close(dws_a[i], dws_b[i], 1e-5, f'multi-branch dw backward with BN backward on the fly: dw[{i}]')
 
 
 @pytest.mark.parametrize('shape,relu,res', [((4, 32, 16, 16), True, False), ((2, 48, 9, 13), True, True),
