@@ -252,7 +252,7 @@ int pfst_bn_backward_sums(const float* dy, long long dy_bs, const float* x, long
 /* ---- pooling / resize ---------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, 2, 1) (resnet.py:638); idx holds the winning tap 0..8 */
 int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo, const float* bn_on_load_coef, int C,
-                      pfst_stream_t stream);
+                      float* y_amax, pfst_stream_t stream);
 /* bn_on_load_coef: NULL, or coef[C][4] = (mean, invstd, sc, sh) (pfst_bn_finalize_partials / pfst_bn_stats) of the conv -> BN -> ReLU layer
  * in front of the pool: x is then that layer's PRE-normalisation output (NC = N * C planes) and y = maxpool(relu(x * sc + sh)) -- the
  * normalised tensor is never written (its only consumer is the pool) */
@@ -263,7 +263,9 @@ int pfst_resize_bilinear_bwd(const float* dy, long long dy_bs, float* dx, long l
 /* nn.AdaptiveAvgPool2d(1) (aspp_head.py:69-77): y[n][c] = mean_hw x */
 int pfst_global_avgpool(const float* x, long long x_bs, float* y, int N, int C, int HW, pfst_stream_t stream);
 /* dx[n][c][hw] (+)= dy[n][c] * scale */
-int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, pfst_stream_t stream);
+int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, float* y_amax,
+                      pfst_stream_t stream);
+/* y_amax (both): NULL, or the slot group (1024 floats, zeroed) that receives max |y| of what the launch writes (f16x3 scale, csrc/amax.h) */
 /* v[n][c] = sum_hw dy[n][c][hw]  (adjoint of the 1x1 -> HxW bilinear broadcast) */
 int pfst_reduce_hw(const float* dy, long long dy_bs, float* v, int N, int C, int HW, pfst_stream_t stream);
 /* F.interpolate(mode='nearest') by an integer factor on [NC][h][w] maps and its adjoint (pfgst_loss.py:57-58) */

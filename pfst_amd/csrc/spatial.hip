@@ -3,6 +3,7 @@
 // align_corners=False) at sep_aspp_head.py:81-100; nn.AdaptiveAvgPool2d(1) aspp_head.py:69-77;
 // nn.Dropout2d decode_head.py:103-107,242-247.  All HBM-bound; one pass each.
 #include "common.h"
+#include "amax.h"
 #include "../../include/pfst_hip.h"
 
 namespace {
@@ -37,7 +38,9 @@ __global__ void u8_to_i64_kernel(const unsigned char* __restrict__ s, long long*
 // bnl != NULL: x is the PRE-normalisation output of the conv -> BN -> ReLU layer in front of the pool (stem.6); coef[c] = (mean, invstd, sc, sh)
 // of that layer, applied to every tap as it is read (bn_apply's pinned arithmetic) -- the normalised tensor is never written
 __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int H, int W,
-                               int Ho, int Wo, const float4* __restrict__ bnl, int C) {
+                               int Ho, int Wo, const float4* __restrict__ bnl, int C, float* __restrict__ amax) {
+  // amax != NULL: max |y| of this launch's outputs -> that slot group (amax.h): the f16x3 GEMMs of layer1 read the pooled map
+  float am = 0.f;
   const int nc = blockIdx.y;
   const float* xp = x + (i64)nc * H * W;
   const float bsc = bnl ? bnl[nc % C].z : 1.f, bsh = bnl ? bnl[nc % C].w : 0.f;
@@ -61,7 +64,9 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
     }
     y[(i64)nc * Ho * Wo + o] = best;
     idx[(i64)nc * Ho * Wo + o] = (unsigned char)bt;
+    am = fmaxf(am, fabsf(best));
   }
+  if (amax) amax_publish(amax, am);
 }
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
                                    int H, int W, int Ho, int Wo) {
@@ -198,9 +203,11 @@ __global__ void plane_sum_kernel(const float* __restrict__ x, i64 x_bs, float* _
   s = block_sum_d(s, sm);
   if (threadIdx.x == 0) v[n * C + c] = (float)(s * (double)scale);
 }
-__global__ void broadcast_hw_kernel(const float* __restrict__ v, float* __restrict__ y, i64 y_bs, int C, int HW, float scale, int accumulate) {
+__global__ void broadcast_hw_kernel(const float* __restrict__ v, float* __restrict__ y, i64 y_bs, int C, int HW, float scale, int accumulate,
+                                    float* __restrict__ amax) {
   const int c = blockIdx.y, n = blockIdx.z;
   const float val = v[n * C + c] * scale;
+  if (amax) amax_publish(amax, accumulate ? 0.f : fabsf(val));      // (plain writes only: the value every element of the plane receives)
   float* yp = y + (i64)n * y_bs + (i64)c * HW;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) yp[i] = accumulate ? yp[i] + val : val;
 }
@@ -321,12 +328,12 @@ extern "C" int pfst_u8_to_i64(const unsigned char* src, long long* dst, long lon
 }
 
 extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, int NC, int H, int W, int Ho, int Wo,
-                                 const float* bn_on_load_coef, int C, pfst_stream_t stream) {
+                                 const float* bn_on_load_coef, int C, float* y_amax, pfst_stream_t stream) {
   PFST_CHECK_ARG(!bn_on_load_coef || (C > 0 && NC % C == 0));
   PFST_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 * 16 && H > 0 && W > 0);
   PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1 && NC <= 65535);
   hipLaunchKernelGGL(maxpool_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo,
-                     reinterpret_cast<const float4*>(bn_on_load_coef), C > 0 ? C : 1);
+                     reinterpret_cast<const float4*>(bn_on_load_coef), C > 0 ? C : 1, y_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -376,9 +383,10 @@ extern "C" int pfst_reduce_hw(const float* dy, long long dy_bs, float* v, int N,
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
-extern "C" int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, pfst_stream_t stream) {
-  PFST_CHECK_ARG(v && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
-  hipLaunchKernelGGL(broadcast_hw_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, v, y, y_bs, C, HW, scale, accumulate);
+extern "C" int pfst_broadcast_hw(const float* v, float* y, long long y_bs, int N, int C, int HW, float scale, int accumulate, float* y_amax,
+                                 pfst_stream_t stream) {
+  PFST_CHECK_ARG(v && y && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535 && (!y_amax || !accumulate));
+  hipLaunchKernelGGL(broadcast_hw_kernel, dim3(hw_blocks(HW), C, N), dim3(256), 0, (hipStream_t)stream, v, y, y_bs, C, HW, scale, accumulate, y_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

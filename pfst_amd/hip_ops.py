@@ -696,13 +696,13 @@ def bn_backward_sums(dy, x, mean, invstd, gamma, beta, dgamma, dbeta, partials=N
 
 
 # ---------------------------------------------------------------- pooling / resize
-def maxpool(x, bnl=None):
+def maxpool(x, bnl=None, amax=None):
     _dense(x)
     n, c, h, w = x.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     y = torch.empty(n, c, ho, wo, device=x.device)
     idx = torch.empty(n, c, ho, wo, dtype=U8, device=x.device)
-    call('pfst_maxpool3x3s2', x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, h, w, ho, wo, _p(bnl), c, _stream())
+    call('pfst_maxpool3x3s2', x.data_ptr(), y.data_ptr(), idx.data_ptr(), n * c, h, w, ho, wo, _p(bnl), c, _p(amax), _stream())
     return y, idx
 
 
@@ -746,10 +746,10 @@ def reduce_hw(dy):
     return v
 
 
-def broadcast_hw(v, out, scale=1.0, accumulate=False):
+def broadcast_hw(v, out, scale=1.0, accumulate=False, amax=None):
     n, c, h, w = out.shape
     assert v.numel() == n * c
-    call('pfst_broadcast_hw', _dense(v).data_ptr(), out.data_ptr(), _bs(out), n, c, h * w, float(scale), int(accumulate), _stream())
+    call('pfst_broadcast_hw', _dense(v).data_ptr(), out.data_ptr(), _bs(out), n, c, h * w, float(scale), int(accumulate), _p(amax), _stream())
     return out
 
 

@@ -42,11 +42,15 @@ def amax_of(v):
 
 
 def _amax_target(yv, dev):
-    """where the kernel producing Var `yv` publishes max |y| in f16x3 mode: the Var's own slot group.  Channel slices of a concat
-    buffer get none: other kernels (resize, broadcast) write slices too, so a shared group would not cover the buffer; whoever reads
-    such a buffer through an f16x3 GEMM computes the maximum itself (amax_of)."""
-    if CONV_MATH != 'f16x3' or yv.parent is not None:
+    """where the kernel producing Var `yv` publishes max |y| in f16x3 mode: the Var's own slot group; for a channel slice of a concat
+    buffer the buffer's group if its owner set one up, else none (whoever reads such a buffer through an f16x3 GEMM then computes the
+    maximum itself, amax_of)."""
+    if CONV_MATH != 'f16x3':
         return None
+    if yv.parent is not None:
+        # a concat buffer's group exists only where its owner makes EVERY writer of the buffer publish into it (the ASPP head's 2560-channel
+        # concat: four normalisation passes + the image-pool broadcast): a slice writer then adds its maximum to the shared group
+        return yv.parent.amax
     if yv.amax is None:
         yv.amax = ops.amax_slots(dev)
     return yv.amax
@@ -55,6 +59,8 @@ def _amax_target(yv, dev):
 WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
 WGRAD_SPLIT_ALL = os.environ.get('PFST_WGRAD_SPLIT_ALL', '0') == '1'
 FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
+# f16x3: the max-pool and all five writers of the ASPP concat publish max |.| themselves; PFST_PUBLISH_AMAX=0: a pfst_absmax pass per tensor
+PUBLISH_AMAX = os.environ.get('PFST_PUBLISH_AMAX', '1') == '1'
 # depthwise layers: weight and data gradient in one pass (csrc/dwconv.hip, pfst_dwconv3x3_bwd); PFST_FUSE_DW_BWD=0: the two kernels
 FUSE_DW_BWD = os.environ.get('PFST_FUSE_DW_BWD', '1') == '1'
 # Winograd F(m x m,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 4x (m = 4, default) or 2.25x

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops as ops
+from . import layers as layers_mod
 from .engine import Var
 from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvModule, WeightBatch, bn_eval, conv_bn_act,
                      conv_forward, dwsep_branches)
@@ -22,6 +23,10 @@ from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_ba
 # PFST_FOLD_DROPOUT=0: the decode head's Dropout2d as a scaling pass of its own (A/B runs); default: folded into sep_bottleneck[1]'s normalisation
 FOLD_DROPOUT = os.environ.get('PFST_FOLD_DROPOUT', '1') == '1'
 FUSE_ASPP_POOL = os.environ.get('PFST_FUSE_ASPP_POOL', '1') == '1'
+
+
+def xin_dev(v):
+    return (v.data if v.lazy is None else v.lazy[0]).device
 
 
 def _check_norm(norm_cfg):
@@ -128,12 +133,14 @@ class ResNetV1c(nn.Module):
         x = conv_bn_act(x, s[3], s[4], tape)
         x = conv_bn_act(x, s[6], s[7], tape, defer=True)     # its only consumer, the max-pool, normalises on load: stem.6's output is never written
         xin = x
+        pool_amax = ops.amax_slots(xin_dev(xin)) if layers_mod.CONV_MATH == 'f16x3' and layers_mod.PUBLISH_AMAX else None     # layer1's f16x3 GEMMs read the pooled map
         if xin.lazy is not None:
-            y, idx = ops.maxpool(xin.lazy[0], bnl=xin.lazy[1])
+            y, idx = ops.maxpool(xin.lazy[0], bnl=xin.lazy[1], amax=pool_amax)
         else:
-            y, idx = ops.maxpool(xin.data)
+            y, idx = ops.maxpool(xin.data, amax=pool_amax)
         in_hw = tuple((xin.data if xin.lazy is None else xin.lazy[0]).shape[-2:])
         x = Var(y, tape is not None)
+        x.amax = pool_amax
         if tape is not None:
             pooled = x
 
@@ -310,6 +317,10 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         n, _, h, w = x.data.shape
         ch, nb = self.channels, len(self.dilations) + 1
         cat = Var(torch.empty(n, nb * ch, h, w, device=x.data.device), tape is not None)
+        if layers_mod.CONV_MATH == 'f16x3' and layers_mod.PUBLISH_AMAX:
+            # every writer of the concat publishes max |.| into ONE group (layers._amax_target for the four slices, the broadcast below): the
+            # bottleneck's f16x3 scale needs no pass of its own over the 2560-channel buffer
+            cat.amax = ops.amax_slots(x.data.device)
         # The ASPP branches first, the image-pool branch after them (they write disjoint slices, so the forward result does not
         # depend on the order): in backward the pool branch's broadcast then lands in dL/dx BEFORE the 1x1 branch's data gradient,
         # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
@@ -323,7 +334,7 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         fused_pool = pool is not None and 'mean' in pool
         pooled = Var(pool['mean'] if fused_pool else ops.global_avgpool(x.data), tape is not None)
         pa = self.image_pool[1](pooled, tape)
-        ops.broadcast_hw(pa.data, cat.data[:, 0:ch])
+        ops.broadcast_hw(pa.data, cat.data[:, 0:ch], amax=cat.amax)
         if tape is not None:
             hw = float(h * w)
 

@@ -561,6 +561,11 @@ def test_maxpool(ops, H, W):
     y1, i1 = ops.maxpool(pre, bnl=coef)
     y0, i0 = ops.maxpool(ymat)
     assert torch.equal(y1, y0) and torch.equal(i1, i0)
+    # max |y| published by the pooling launch itself (the f16x3 scale of layer1's GEMMs): the group's maximum is the tensor's, exactly
+    for kw in ({}, {'bnl': coef}):
+        slots = ops.amax_slots(pre.device)
+        yk, _ = ops.maxpool(pre, amax=slots, **kw)
+        assert slots.max().item() == yk.abs().max().item()
 
 
 @pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128),
@@ -587,6 +592,9 @@ def test_pool_broadcast_dropout(ops):
     out = torch.zeros(3, 7, 9, 11, device=DEV)
     ops.broadcast_hw(v.to(DEV), out, 0.5)
     assert_close(out, (0.5 * v).expand(3, 7, 9, 11), 1e-6)
+    slots = ops.amax_slots(out.device)
+    ops.broadcast_hw(v.to(DEV), out, 0.5, amax=slots)
+    assert slots.max().item() == out.abs().max().item()
     m = (torch.rand(3, 7, generator=g(3)) > 0.3).float() / 0.7
     assert_close(ops.channel_scale(xd, m.to(DEV)), x * m.view(3, 7, 1, 1), 1e-6)
     a, b = torch.randn(1000, generator=g(4)), torch.randn(1000, generator=g(5))

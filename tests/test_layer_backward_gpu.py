@@ -542,3 +542,59 @@ def test_deferred_normalisation_equals_the_materialised_one():
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
     assert e < 1e-4, e
+
+
+def test_published_maxima_cover_every_f16x3_operand():
+    """f16x3 mode: the scale of an activation operand comes from the slot group its producer(s) published max |.| into -- the normalisation
+    pass, the max-pool (layer1's input) and, for the ASPP head's concat, all five writers of the buffer into ONE group (four normalisation
+    passes + the image-pool broadcast).  One segmentor forward + backward: every group handed to a GEMM holds exactly the maximum of the
+    tensor it describes, and no separate pfst_absmax pass runs over the concat or the pooled map."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if layers.CONV_MATH != 'f16x3':
+        pytest.skip('maxima are only published in f16x3 mode')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=5)
+    model = build_segmentor(model_cfg(C, 3, dropout=0.1))
+    model.load_state_dict(student, strict=True)
+    model.cuda()
+    ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+    model.repack_weights(need_dgrad=True)
+    cat_ch = model.decode_head.channels * (len(model.decode_head.dilations) + 1)
+    seen, scanned = {}, []
+    orig_of, orig_absmax = layers.amax_of, ops.absmax
+
+    def checked(v):
+        had = v.amax is not None
+        slots = orig_of(v)
+        if had and id(v) not in seen:
+            seen[id(v)] = (tuple(v.data.shape), slots.max().item(), v.data.abs().max().item())
+        return slots
+
+    def counted(x, *a, **k):
+        scanned.append(tuple(x.shape))
+        return orig_absmax(x, *a, **k)
+
+    layers.amax_of, ops.absmax = checked, counted
+    try:
+        tape = Tape()
+        model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None, tape=tape)
+        n_fwd_scans = len(scanned)
+        tape.backward()
+        torch.cuda.synchronize()
+    finally:
+        layers.amax_of, ops.absmax = orig_of, orig_absmax
+    assert len(seen) > 20, len(seen)
+    bad = [s for s in seen.values() if s[1] != s[2]]
+    assert not bad, bad
+    shapes = [s[0] for s in seen.values()]
+    assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
+    assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'
+    assert not [s for s in scanned[:n_fwd_scans] if len(s) == 4 and s[1] in (cat_ch,)], scanned[:n_fwd_scans]
