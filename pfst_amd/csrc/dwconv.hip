@@ -523,40 +523,44 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
   }
 }
 
-template <int NS, bool BNB>
-__global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, float* __restrict__ dx,
+// NT threads (512 or 1024), QPT = 4096 / NT quads each: 1024 threads keep half the planes' quads per thread -- under 128 registers, so the one
+// workgroup a CU holds (two planes of LDS) is sixteen waves instead of eight (2.51 -> 2.33 ms per launch at the bench shape,
+// tools/dw_multi_microbench.py).  [Gradient planes two iterations ahead in two register sets: 65+ spilled registers at either size.]
+template <int NS, bool BNB, int NT>
+__global__ __launch_bounds__(NT) void dwconv3x3_multi_bwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, float* __restrict__ dx,
                                                                   i64 dx_bs, int accumulate, int C, int H, int W, int cpb) {
   // LDS: [gradient plane | forward-input plane].  BNB: the gradient plane staged is dL/dpre = BatchNorm-backward(dy, pre), formed from the two
   // planes fetched into registers one branch ahead (bn_bwd_elem4) -- the branches' dL/dpre tensors are never written.
   extern __shared__ float tile[];
-  __shared__ double red[40];
+  __shared__ double red[72];                        // block_add9: NT / 64 x 9 floats
+  constexpr int QPT = 8 * 512 / NT;
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
   const int HW = H * W, n4 = HW >> 2, W4 = W >> 2, tid = threadIdx.x;
   float4* const t4 = reinterpret_cast<float4*>(tile);
   float4* const x4 = t4 + n4;
-  float4 r[8], p[8];
+  float4 r[QPT], p[QPT];
   auto fetch = [&](int c, int si) {                // the gradient plane (BNB: and the pre-normalisation plane) of branch si, channel c -> registers
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.dy[si] + (i64)n * S.bs[si] + (i64)c * HW), 0, HW * 4, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * 512), 0, 0));
+    for (int u = 0; u < QPT; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, 16 * (tid + u * NT), 0, 0));
     if (BNB) {
       const __amdgpu_buffer_rsrc_t ps =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(S.pre[si] + (i64)n * S.bs[si] + (i64)c * HW), 0, HW * 4, 0x00020000);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ps, 16 * (tid + u * 512), 0, 0));
+      for (int u = 0; u < QPT; ++u) p[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ps, 16 * (tid + u * NT), 0, 0));
     }
   };
   fetch(c0, 0);
   for (int c = c0; c < c1; ++c) {
-    float4 dxa[8];
+    float4 dxa[QPT];
     {                                              // the forward input's plane: each thread keeps its own quads in LDS (read back per branch)
       const __amdgpu_buffer_rsrc_t xs =
           __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (i64)n * x_bs + (i64)c * HW), 0, HW * 4, 0x00020000);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * 512), 0, 0));
-        if (tid + u * 512 < n4) x4[tid + u * 512] = v;
+      for (int u = 0; u < QPT; ++u) {
+        const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xs, 16 * (tid + u * NT), 0, 0));
+        if (tid + u * NT < n4) x4[tid + u * NT] = v;
         dxa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -565,12 +569,12 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
       if (BNB) {
         const pfst_bn_bwd_rec_t rec = S.rec[si][c];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tid + u * 512 < n4) t4[tid + u * 512] = bn_bwd_elem4(r[u], p[u], rec);
+        for (int u = 0; u < QPT; ++u)
+          if (tid + u * NT < n4) t4[tid + u * NT] = bn_bwd_elem4(r[u], p[u], rec);
       } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (tid + u * 512 < n4) t4[tid + u * 512] = r[u];
+        for (int u = 0; u < QPT; ++u)
+          if (tid + u * NT < n4) t4[tid + u * NT] = r[u];
       }
       __syncthreads();
       if (si + 1 < NS) fetch(c, si + 1);
@@ -580,8 +584,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
 #pragma unroll
       for (int t = 0; t < 9; ++t) { wt[t] = S.w[si][c * 9 + 8 - t]; accw[t] = 0.f; }       // mirrored taps: the data gradient
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = tid + u * 512;
+      for (int u = 0; u < QPT; ++u) {
+        const int i = tid + u * NT;
         if (i >= n4) break;
         const int yy = i / W4, c4 = i - yy * W4;
         const float4 xq = x4[i];
@@ -605,8 +609,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_bwd_kernel(const float* _
     float4* out = reinterpret_cast<float4*>(dx + (i64)n * dx_bs + (i64)c * HW);
     const float pg = S.pool_grad ? S.pool_grad[n * C + c] * S.pool_scale : 0.f;     // adjoint of the plane mean: the same value to every element
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = tid + u * 512;
+    for (int u = 0; u < QPT; ++u) {
+      const int i = tid + u * NT;
       if (i >= n4) break;
       float4 a = dxa[u];
       if (S.pool_grad) { a.x += pg; a.y += pg; a.z += pg; a.w += pg; }
@@ -826,7 +830,8 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   static bool set = false;
   if (!set) {
 #define PFST_DW_MULTI_ATTR(NS_, B_) \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
     PFST_DW_MULTI_ATTR(1, false); PFST_DW_MULTI_ATTR(2, false); PFST_DW_MULTI_ATTR(3, false);
     PFST_DW_MULTI_ATTR(1, true); PFST_DW_MULTI_ATTR(2, true); PFST_DW_MULTI_ATTR(3, true);
 #undef PFST_DW_MULTI_ATTR
@@ -836,12 +841,14 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   const size_t lds = 2 * (size_t)H * W * sizeof(float);          // gradient plane + forward-input plane
   dim3 gp(1, cdiv(C, cpb), N);
   hipStream_t st = (hipStream_t)stream;
+  static const int nt = [] { const char* e = getenv("PFST_DW_MULTI_NT"); return e && atoi(e) == 512 ? 512 : 1024; }();     // (diagnostic knob)
 #define PFST_DW_MULTI_LAUNCH(NS_, B_) \
-  hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_>), gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
+  if (nt == 512) hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 512>), gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb); \
+  else hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), gp, dim3(1024), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
   if (bnb) {
-    if (ns == 1) PFST_DW_MULTI_LAUNCH(1, true); else if (ns == 2) PFST_DW_MULTI_LAUNCH(2, true); else PFST_DW_MULTI_LAUNCH(3, true);
+    if (ns == 1) { PFST_DW_MULTI_LAUNCH(1, true); } else if (ns == 2) { PFST_DW_MULTI_LAUNCH(2, true); } else { PFST_DW_MULTI_LAUNCH(3, true); }
   } else {
-    if (ns == 1) PFST_DW_MULTI_LAUNCH(1, false); else if (ns == 2) PFST_DW_MULTI_LAUNCH(2, false); else PFST_DW_MULTI_LAUNCH(3, false);
+    if (ns == 1) { PFST_DW_MULTI_LAUNCH(1, false); } else if (ns == 2) { PFST_DW_MULTI_LAUNCH(2, false); } else { PFST_DW_MULTI_LAUNCH(3, false); }
   }
 #undef PFST_DW_MULTI_LAUNCH
   PFST_CHECK_LAUNCH();
