@@ -158,7 +158,11 @@ int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs_host, cons
 int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                           const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
-                          pfst_stream_t stream);
+                          const float* gate_dy, long long gate_dy_bs, const unsigned long long* gate_mask, pfst_stream_t stream);
+/* gate_dy != NULL (mode 1, accumulate 0, M % 128 == 0, Ho * Wo % 256 == 0): out = data gradient + (bit ? gate_dy : 0), gate_mask = the ReLU
+ * bitmask pfst_bn_apply wrote for an [N][M][Ho * Wo] tensor -- the identity branch of a residual block (resnet.py:149-167, out = relu(bn3 +
+ * identity)): dL/d(block input) = conv1's data gradient + dL/d(block output) gated by that ReLU, formed in conv1's epilogue instead of
+ * being written by pfst_bn_backward (dres) and read back here */
 /* The f16x3 GEMMs walk their tiles in chains of up to 8 per workgroup, the grid sized for the resident workgroup slots of the device
  * (2 per CU).  pfst_f16x3_set_slots overrides that number (0 = the device's): a test hook that makes small problems chain. */
 int pfst_f16x3_set_slots(int slots);
@@ -243,6 +247,11 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
 /* The FIRST half of pfst_bn_backward alone, for a conv -> BN -> ReLU layer without residual whose convolution is depthwise: the two sums
  * (from bwd_partials, else by the reduction pass), dgamma += sum dz*xhat, dbeta += sum dz, and rec[C] for the consumer that applies the
  * second half while it loads dy and x (no dx is written here: 3 N of traffic less per layer).  ws: >= 2*C doubles. */
+/* out (+)= (bit ? g : 0) with the ReLU bitmask pfst_bn_apply wrote (HW % 256 == 0): the gated identity-branch gradient of a residual block
+ * written out by itself -- the product folds it into conv1's data-gradient epilogue (pfst_conv_igemm_f16x3 gate_dy); this is the fallback
+ * when another reader needs the gradient first */
+int pfst_relu_gate(const float* g, long long g_bs, const unsigned long long* relu_mask, float* out, long long out_bs, int N, int C, int HW,
+                   int accumulate, pfst_stream_t stream);
 int pfst_bn_backward_sums(const float* dy, long long dy_bs, const float* x, long long x_bs, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, float* dgamma, float* dbeta, int N, int C, int HW,
                           double* ws, const float* bwd_partials, int bwd_slots, pfst_bn_bwd_rec_t* rec, pfst_stream_t stream);

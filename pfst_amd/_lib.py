@@ -61,6 +61,11 @@ def lib():
 def call(name, *args):
     """Invoke an int-returning entry point; raise with the library's message on failure."""
     L = lib()
+    # ctypes accepts SURPLUS arguments on a cdecl function without a word (the declared ones are converted, the rest passed through): an edit
+    # that appends an argument to the wrong call site would shift e.g. the stream out of its slot -- refuse any count but the header's
+    want = len(_decls[name][1])
+    if len(args) != want:
+        raise TypeError(f'{name} takes {want} arguments (include/pfst_hip.h), got {len(args)}')
     rc = getattr(L, name)(*args)
     if rc != 0:
         raise PfstHipError(f'{name} failed ({rc}): {L.pfst_last_error().decode()}')

@@ -426,6 +426,19 @@ inline void split_for(int HW, int C, int N, int& splits, int& chunk) {
   splits = (HW + chunk - 1) / chunk;
 }
 
+// out (+)= g where the ReLU bitmask has the element's bit (the identity branch of a residual block written out after all: engine.Var._flush_pending)
+__global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict__ g, i64 g_bs, const unsigned long long* __restrict__ mask,
+                                                        float* __restrict__ out, i64 out_bs, int C, int HW, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float* gp = g + (i64)n * g_bs + (i64)c * HW;
+  float* op = out + (i64)n * out_bs + (i64)c * HW;
+  const unsigned long long* mp = mask + ((i64)n * C + c) * (HW >> 6);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const float v = relu_on(mp, nullptr, i, 0.f, 0.f, 0.f) ? gp[i] : 0.f;
+    op[i] = accumulate ? op[i] + v : v;
+  }
+}
+
 }  // namespace
 
 extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
@@ -544,6 +557,15 @@ extern "C" int pfst_bn_backward_sums(const float* dy, long long dy_bs, const flo
   }
   hipLaunchKernelGGL(bn_bwd_rec_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, mean, invstd, gamma, beta, dgamma, dbeta, C,
                      1.0 / ((double)N * HW), rec);
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_relu_gate(const float* g, long long g_bs, const unsigned long long* relu_mask, float* out, long long out_bs, int N, int C,
+                              int HW, int accumulate, pfst_stream_t stream) {
+  PFST_CHECK_ARG(g && relu_mask && out && N > 0 && C > 0 && HW > 0 && HW % 256 == 0 && C <= 65535 && N <= 65535);
+  hipLaunchKernelGGL(relu_gate_kernel, dim3(cdiv(HW, 1024), C, N), dim3(256), 0, (hipStream_t)stream, g, (i64)g_bs, relu_mask, out, (i64)out_bs, C, HW,
+                     accumulate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

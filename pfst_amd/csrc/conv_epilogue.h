@@ -91,7 +91,11 @@ template <int TM, int TN, int WAVES_N, int BN, int BNB = 0, bool LDSRED = false>
 __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
                                               int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs(),
-                                              float* __restrict__ lds = nullptr) {
+                                              float* __restrict__ lds = nullptr, const float* __restrict__ gsrc = nullptr,
+                                              const unsigned long long* __restrict__ gmask = nullptr) {
+  // gsrc / gmask (this image's planes; whole row tiles, P % 256 == 0, no bias, accumulate = 0: checked on the host): out = acc + (bit ? gsrc : 0)
+  // -- the identity branch of a residual block, dL/d(block input) = conv1's data gradient + dL/d(block output) gated by the block's final
+  // ReLU (bn_apply's bitmask: word [row][p >> 8][p & 3], bit (p & 255) >> 2): the gated tensor is never written by BatchNorm backward
   const int l31 = lane & 31, lh = lane >> 5;
   // Fused BatchNorm statistics: per-row (output channel) sum / sum of squares over this wave's pixels, reduced across
   // the 32 lanes of each half-wave (transposing butterfly) and written (no atomics) to stats[m][slot][2]; pfst_bn_finalize_partials
@@ -172,22 +176,50 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
     // otherwise every store below (and every accumulate load, each with its own vmcnt(0) wait) is wrapped in a waterfall
     // loop over the 'divergent' soffset -- measured 120-300 k cycles per workgroup.
     const int row0 = m0 + wm0;
-    if (BNB && accumulate) {
-      // the fused BatchNorm-backward sums below need the FINAL gradient: fold the old values into the accumulators first (the
-      // 16 loads of a 32x32 block issued back to back), then take the plain store path
+    const bool gated = gsrc != nullptr;
+    // what is added to a 32x32 block: the old values of `out`, or the gated tensor (16 loads issued back to back: one latency per block).
+    // Gate bits: the 64 pixel columns of a wave tile start at a multiple of 64, so a lane's bits for both column blocks (pixel pp and
+    // pp + 32: bit + 8) sit in the SAME 32-bit half of the same mask word -- one 4-byte load per accumulator row serves the row's two
+    // blocks, and a sign-extending bit-field extract turns the bit into an AND mask (two vector instructions per element).
+    static_assert(TN <= 2, "the gate words are shared by the column blocks of a 64-pixel wave tile");
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gated ? gsrc : out), 0, M * P * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(gmask), 0, gated ? M * (P >> 6) * 8 : 0, 0x00020000);
+    const int gpp = p0 + wn0 + l31, gbit = (gpp & 255) >> 2;           // column block 0 (block 1: gbit + 8)
+    const unsigned mvoff = 8u * (unsigned)((gpp >> 8) * 4 + (gpp & 3)) + 4u * (unsigned)(gbit >> 5) + 32u * (unsigned)lh * (unsigned)(P >> 6);
+    auto load_gate = [&](int i, int (&gw)[16]) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int r = 0; r < 16; ++r)
+        gw[r] = gated ? __builtin_amdgcn_raw_buffer_load_b32(mrs, mvoff, 8 * (P >> 6) * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0) : 0;
+    };
+    auto load_addend = [&](int i, int j, const int (&gw)[16], float (&old)[16]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+      if (gated) {
+        const unsigned sh = (unsigned)((gbit & 31) + 8 * j);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          old[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, old[r]) & __builtin_amdgcn_sbfe(gw[r], sh, 1u));
+      }
+    };
+    if (BNB && (accumulate || gated)) {
+      // the fused BatchNorm-backward sums below need the FINAL gradient: fold the addend into the accumulators first, then take the plain
+      // store path
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int gw[16];
+        load_gate(i, gw);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+          load_addend(i, j, gw, old);
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] += old[r];
         }
+      }
     }
-    if (BNB || !accumulate) {
+    if (BNB || !(accumulate || gated)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -202,13 +234,13 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
     } else {
       // accumulate: the 16 loads of a 32x32 block are issued back to back, then added and stored (one latency per block, not 64)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        int gw[16];
+        load_gate(i, gw);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], 4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0));
+          load_addend(i, j, gw, old);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
           {
@@ -217,6 +249,7 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
                                                   4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
           }
         }
+      }
     }
     if (BNB) {
       // S1 = sum dz and the RAW second sum S2' = sum dz * x of the layer that owns this gradient (pfst_bnb_fuse_t); pfst_bn_backward turns

@@ -234,12 +234,19 @@ __global__ __launch_bounds__(256) void pack_weight_f16x2_batched_kernel(const pf
 // M % 256 == 0): every thread stages ONE K=16 tile of a pair instead of both, i.e. half the split instructions, activation loads and
 // activation LDS stores per MFMA, and an activation tile is fetched once for 256 output rows.  (Diagnostic: the 128-row loop with the
 // second tile's loads and split removed -- wrong results, timing only -- runs 10-11 % faster at every K.)
+struct PfstResGate {                       // value-initialised = off
+  const float* g = nullptr;                // [N][M][P] tensor added to the output where its bit is set
+  i64 g_bs = 0;
+  const unsigned long long* mask = nullptr;    // bn_apply's ReLU bitmask of an [N][M][P] tensor (dense)
+};
+
 template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false, int BMT = 128>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb) {
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb,
+    const PfstResGate& gate) {
   static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
   static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
   static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE), "the 256-row tile exists for the pixel-to-pixel 32x32 loop");
@@ -534,6 +541,9 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     }
     const int p0 = bx * BN, m0 = by * BM;
     float* const outn = out + (i64)n * out_bs;
+    // the gated addend of a residual block's identity branch (conv_epilogue.h), this image's planes
+    const float* const gsrc = gate.g ? gate.g + (i64)n * gate.g_bs : nullptr;
+    const unsigned long long* const gmask = gate.g ? gate.mask + (i64)n * M * (P >> 6) : nullptr;
     const float ua = unscale_of(ea), ub = unscale_of(eb);
     if constexpr (SHAPE == 32) {
 #pragma unroll
@@ -547,10 +557,11 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         // already hold the next tile's first pair
         static_assert(PAIR_CHUNKS * sizeof(uint4) >= (NT / 64) * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into one pair buffer");
         conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
-                                                    reinterpret_cast<float*>(smem + PAIR_CHUNKS));
+                                                    reinterpret_cast<float*>(smem + PAIR_CHUNKS), gsrc, gmask);
         __syncthreads();                                 // before the next tile's first step stores into that buffer
       } else {
-        conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
+        conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(), nullptr,
+                                         gsrc, gmask);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -605,18 +616,18 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain) {
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, PfstResGate gate) {
   conv_igemm_f16x3_body<SHAPE, 0, BPACK, ONE, BMT>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                               w_amax, in_amax, Y, Z, chain, PfstBnbArgs());
+                               w_amax, in_amax, Y, Z, chain, PfstBnbArgs(), gate);
 }
 template <int BNB, bool ONE = false, int BMT = 128>
 __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_bnb_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
-    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, PfstBnbArgs bnb) {
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, PfstBnbArgs bnb, PfstResGate gate) {
   conv_igemm_f16x3_body<32, BNB, false, ONE, BMT>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
-                                 w_amax, in_amax, Y, Z, chain, bnb);
+                                 w_amax, in_amax, Y, Z, chain, bnb, gate);
 }
 
 
@@ -1340,8 +1351,18 @@ extern "C" int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs
 extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                                      int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
-                                     const pfst_bnb_fuse_t* bnb, pfst_stream_t stream) {
+                                     const pfst_bnb_fuse_t* bnb, const float* gate_dy, long long gate_dy_bs,
+                                     const unsigned long long* gate_mask, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  PfstResGate gate;
+  if (gate_dy) {
+    // out = conv + (bit ? gate_dy : 0): the epilogue's whole-tile path, the mask's 256-element groups, one writer (no old values)
+    PFST_CHECK_ARG(gate_mask && mode == 1 && !accumulate && !bias && !stats && M % 128 == 0 && ((i64)Ho * Wo) % 256 == 0 &&
+                   gate_dy_bs >= (i64)M * Ho * Wo && f16x3_shape() == 32);
+    gate.g = gate_dy;
+    gate.g_bs = gate_dy_bs;
+    gate.mask = gate_mask;
+  }
   PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
@@ -1374,10 +1395,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
     PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_F16_BNB(MODE_, ONE_)                                                                                                    \
     hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_, ONE_>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
-                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb)
+                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb, gate)
 #define PFST_LAUNCH_F16_BNB_BIG(MODE_)                                                                                                      \
     hipLaunchKernelGGL((conv_igemm_f16x3_bnb_kernel<MODE_, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, \
-                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb)
+                       out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb, gate)
     if (big) {
       if (!bnb->relu) PFST_LAUNCH_F16_BNB_BIG(3);
       else if (bnb->y) PFST_LAUNCH_F16_BNB_BIG(2);
@@ -1398,16 +1419,16 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   }
   if (big)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else if (one)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else if (f16x3_shape() == 32)
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain);
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -1428,19 +1449,19 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
   if (big && v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
-                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   else if (big)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
-                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   else if (v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
-                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+                       (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   else if (f16x3_shape() == 32)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   else
     hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain);
+                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

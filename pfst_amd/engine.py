@@ -18,7 +18,7 @@ class Var:
     runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy')
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -31,6 +31,13 @@ class Var:
         # max-pool) normalises the pre-BN tensor `pre` with coef[c] = (mean, invstd, sc, sh) as it loads it (layers.conv_bn_act(defer=True))
         self.lazy = None
         self.amax = None          # device slot with max |data| (scale of the two-piece fp16 split, layers.CONV_MATH == 'f16x3'), set on first use
+        # A residual block's identity branch: dL/d(this Var) = [its other consumers' gradients] + g where the block's final ReLU let the
+        # sum through.  `gate_consumer`: set in forward by the first consumer (= the last gradient writer) when its data-gradient launch can add
+        # such a gated tensor in its epilogue (layers.conv_bn_act); `pending` = (g, mask): set in backward by the residual layer INSTEAD of
+        # writing g * gate into the gradient buffer, taken over by that consumer (take_pending) -- or, if anything else asks for the gradient
+        # first, written out after all (_flush_pending: same values, one more pass).
+        self.gate_consumer = False
+        self.pending = None
 
     def claim_first_use(self):
         """forward: called by every consumer that may fuse; True for the first caller only (= the last gradient writer)"""
@@ -38,11 +45,25 @@ class Var:
         self._claimed = True
         return first and self.parent is None
 
+    def grad_unwritten(self):
+        return self.parent is None and self._grad is None
+
+    def take_pending(self):
+        p, self.pending = self.pending, None
+        return p
+
+    def _flush_pending(self):
+        if self.pending is not None:
+            (g, mask), self.pending = self.pending, None
+            buf, acc = self.grad_target()
+            ops.relu_gate_(buf, g, mask, accumulate=acc)
+
     @property
     def grad(self):
         if self.parent is not None:
             pg = self.parent.grad
             return None if pg is None else pg[:, self.c0:self.c1]
+        self._flush_pending()
         return self._grad
 
     def grad_target(self, final=False):
@@ -51,6 +72,7 @@ class Var:
         if self._sealed:
             raise RuntimeError('gradient written after the launch that fused its BatchNorm-backward sums (a consumer did not '
                                'claim_first_use() in forward order)')
+        self._flush_pending()
         self._sealed = bool(final)
         if self.parent is not None:
             buf, acc = self.parent.grad_target_full()

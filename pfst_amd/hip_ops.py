@@ -303,7 +303,7 @@ def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0
     slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
     st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, _stream())
     return (out, st, slots) if want_stats else out
 
 
@@ -317,10 +317,23 @@ def conv_wgrad_f16x3_(dw, x, dy, x_amax, dy_amax):
     return dw
 
 
-def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False, bnb=None):
-    """bnb: as conv_dgrad (returns (out, partials, slots) then)"""
+def dgrad_gate_ok(cin, in_hw):
+    """can conv_dgrad_f16x3 add a ReLU-gated tensor in its epilogue (gate=...): whole 128-row tiles, whole 256-element mask groups"""
+    return cin % 128 == 0 and (in_hw[0] * in_hw[1]) % 256 == 0
+
+
+def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, dil=1, pad=0, out=None, accumulate=False, bnb=None, gate=None):
+    """bnb: as conv_dgrad (returns (out, partials, slots) then);
+    gate = (g, mask): out = data gradient + (mask bit ? g : 0) -- g an [N, cin, H, W] tensor, mask the ReLU bitmask bn_apply(want_mask=True)
+    returned for a tensor of that shape (the identity branch of a residual block; `out` has no earlier writer: accumulate = False)"""
     n, co, ho, wo = dy.shape
     hi, wi = in_hw
+    g_ptr, g_bs, m_ptr = 0, 0, 0
+    if gate is not None:
+        g, mask = gate
+        assert not accumulate and dgrad_gate_ok(cin, in_hw) and tuple(g.shape) == (n, cin, hi, wi)
+        assert mask.dtype == torch.int64 and mask.numel() == n * cin * hi * wi // 64
+        g_ptr, g_bs, m_ptr = g.data_ptr(), _bs(g), mask.data_ptr()
     assert wk4_d.numel() == 4 * ksize * ksize * co * cin and f16x3_eligible(co, cin, ksize)
     if out is None:
         assert not accumulate
@@ -330,7 +343,7 @@ def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, di
         st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
         fuse = ctypes.addressof(st)
     call('pfst_conv_igemm_f16x3', dy.data_ptr(), _bs(dy), wk4_d.data_ptr(), w_amax.data_ptr(), dy_amax.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, _stream())
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, g_ptr, g_bs, m_ptr, _stream())
     return (out, part, slots) if bnb is not None else out
 
 
@@ -676,6 +689,14 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
          _p(dres), 0 if dres is None else _bs(dres), int(dres_accumulate), _p(dgamma), _p(dbeta),
          n, c, h * w, int(relu), _p(mask), _ws(x.device, 16 * c).data_ptr(), _p(partials), int(slots), _p(amax), _p(None if post is None else _dense(post)), _stream())
     return dx
+
+
+def relu_gate_(out, g, mask, accumulate=False):
+    """out (+)= g where bn_apply's ReLU bitmask `mask` has the element's bit"""
+    n, c, h, w = g.shape
+    assert tuple(out.shape) == tuple(g.shape) and mask.dtype == torch.int64 and mask.numel() == n * c * h * w // 64 and (h * w) % 256 == 0
+    call('pfst_relu_gate', g.data_ptr(), _bs(g), mask.data_ptr(), out.data_ptr(), _bs(out), n, c, h * w, int(accumulate), _stream())
+    return out
 
 
 BN_BWD_REC_BYTES = 40          # sizeof(pfst_bn_bwd_rec_t): three doubles + four floats

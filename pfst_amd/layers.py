@@ -75,6 +75,11 @@ WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', _WINO_DEFAULT_C
 # BatchNorm backward: the two per-channel sums come out of the epilogue of the data-gradient launch that completes dL/dy
 # (csrc/conv_epilogue.h, pfst_bnb_fuse_t) wherever that launch is a K-quad implicit GEMM; elsewhere the two-pass kernels run.
 FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
+# residual blocks: the identity branch's gradient, dL/d(block output) gated by the block's final ReLU, is added in the epilogue of the launch that
+# completes dL/d(block input) (conv1's f16x3 data gradient; a downsample layer's BatchNorm backward takes it as its gated dy) instead of
+# being written by the bn3 layer's BatchNorm backward and read back -- one write of the block's widest tensor less per block.
+# PFST_FUSE_RES_GATE=0: pfst_bn_backward writes it (dres)
+FUSE_RES_GATE = os.environ.get('PFST_FUSE_RES_GATE', '1') == '1'
 # ... but only where that launch is MFMA-bound: with a short contraction (K = Cout * taps of the consuming conv) the data gradient is
 # itself HBM-bound (layer1: 2 * 64 flop per 8 bytes written + accumulated), and reading the pre-BN tensor there costs what the
 # reduction pass would have cost (measured: fusing everywhere moves 11 ms/step out of pfst_bn_backward and 10 ms into the GEMMs)
@@ -169,9 +174,15 @@ class Conv2dP(nn.Module):
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
-    def dgrad(self, dy, in_hw, out, accumulate, bn=None, dy_amax=None):
+    def dgrad_can_gate(self, in_hw):
+        """the data-gradient launch can add a ReLU-gated tensor in its epilogue (ops.conv_dgrad_f16x3(gate=...))"""
+        return FUSE_RES_GATE and self.f16_d and not self.wino and not self.depthwise and ops.dgrad_gate_ok(self.cin, in_hw)
+
+    def dgrad(self, dy, in_hw, out, accumulate, bn=None, dy_amax=None, gate=None):
         """bn: BnBackwardCtx of the layer that produced this conv's input, when this launch completes that gradient;
-        dy_amax: slot group with max |dy| (f16x3 layers; computed here when the producer did not publish it)"""
+        dy_amax: slot group with max |dy| (f16x3 layers; computed here when the producer did not publish it);
+        gate: (g, mask) added where the mask has the bit (Var.pending of a residual block's input; only where dgrad_can_gate)"""
+        assert gate is None or (self.f16_d and not self.wino and not accumulate)
         if self.wino:
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
                                  u_amax=self.ud_amax if self.wino_f16 else None, x_amax=dy_amax if self.wino_f16 else None)
@@ -180,10 +191,10 @@ class Conv2dP(nn.Module):
             if bn is not None:
                 _, bn.partials, bn.slots = ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride,
                                                                 self.dilation, self.padding, out=out, accumulate=accumulate,
-                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu))
+                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu), gate=gate)
                 return out
             return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride, self.dilation,
-                                        self.padding, out=out, accumulate=accumulate)
+                                        self.padding, out=out, accumulate=accumulate, gate=gate)
         if self.split_d:
             if bn is not None:
                 _, bn.partials, bn.slots = ops.conv_dgrad_split(dy, self.w6d, self.cin, in_hw, self.k, self.stride, self.dilation,
@@ -553,8 +564,11 @@ def _dgrad_into(x, conv, dy, final, dy_amax=None):
     """data gradient of `conv` into x's gradient buffer; when this launch completes the gradient of a conv -> BN layer's output
     (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
     fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward()
+    gate = None
+    if x.pending is not None and x.grad_unwritten() and conv.dgrad_can_gate(x.data.shape[-2:]):
+        gate = x.take_pending()           # the identity branch's gated gradient rides in this launch's epilogue (else grad_target writes it out)
     buf, acc = x.grad_target(final=fuse)
-    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax)
+    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax, gate=gate)
 
 
 def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=None):
@@ -664,16 +678,30 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     final = x.claim_first_use()
     if residual is not None:
         residual.claim_first_use()
+    in_hw = xd.shape[-2:]
+    if final and x.lazy is None and x.requires_grad and not WGRAD_STREAM and conv.dgrad_can_gate(in_hw):
+        x.gate_consumer = True            # this layer's data gradient completes dL/dx and can add a gated identity-branch gradient (Var.pending)
+    if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and not defer and not conv.depthwise \
+            and (pre.shape[2] * pre.shape[3]) % 256 == 0:
+        yv.gate_consumer = True           # a downsample layer (conv -> BN, no ReLU): its BatchNorm backward takes (g, mask) as its gated dy
     if coef is not None and out_var is None and post_scale is None and not defer:
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
         yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)
 
     def bwd():
-        dy = yv.grad
+        ext_gate = None
+        if yv.pending is not None and yv.grad_unwritten() and yv.gate_consumer and not relu and residual is None:
+            dy, ext_gate = yv.take_pending()          # downsample layer: dL/dy = g where the block's final ReLU passed; the mask is the gate
+        else:
+            dy = yv.grad
         dres = dacc = None
         if residual is not None and residual.requires_grad:
-            dres, dacc = residual.grad_target()
+            if (FUSE_RES_GATE and gate is not None and relu and residual.gate_consumer and residual.pending is None and residual.parent is None
+                    and residual.grad_unwritten()):
+                residual.pending = (dy, gate)         # dL/dresidual = dy * gate: left to the launch that completes the residual's gradient
+            else:
+                dres, dacc = residual.grad_target()
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
         part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
@@ -690,8 +718,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
                 yv.free_grad()
             return
         dpre = ops.bn_backward(dy, ymask, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad,
-                               relu, dres, bool(dacc), beta=bn.bias.data, mask=gate, partials=part, slots=nslots, amax=dpre_amax,
-                               post=post_scale)
+                               relu or ext_gate is not None, dres, bool(dacc), beta=bn.bias.data, mask=gate if ext_gate is None else ext_gate,
+                               partials=part, slots=nslots, amax=dpre_amax, post=post_scale)
         conv_backward(x, conv, dpre, saved_v, final, dy_amax=dpre_amax)
         if yv.parent is None:
             yv.free_grad()

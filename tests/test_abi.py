@@ -3,6 +3,8 @@ include/pfst_hip.h declares (no compute calls without a GPU)."""
 import ctypes
 import os
 
+import pytest
+
 from pfst_amd import _lib
 
 
@@ -41,3 +43,15 @@ def test_f16x3_chain_grid_policy():
         assert L.pfst_f16x3_chain_grid(0, 1) == 0
     finally:
         L.pfst_f16x3_set_slots(0)
+
+
+def test_call_refuses_a_wrong_argument_count():
+    """ctypes lets surplus arguments through on cdecl functions; _lib.call does not (an appended argument at the wrong call site would move
+    the stream out of its slot and the launch onto the default stream)"""
+    from pfst_amd import _lib
+    _lib.lib()
+    n = len(_lib._decls['pfst_fill_f32'][1])
+    with pytest.raises(TypeError, match='takes'):
+        _lib.call('pfst_fill_f32', *([0] * (n + 1)))
+    with pytest.raises(TypeError, match='takes'):
+        _lib.call('pfst_fill_f32', *([0] * (n - 1)))

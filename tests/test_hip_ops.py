@@ -282,6 +282,39 @@ def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
         assert_close(dw, 2 * dw_ref, 3e-6, 'f16x3 wgrad accumulate')
 
 
+@pytest.mark.parametrize('case', [(2, 256, 128, 16, 16, 1, 1, 1, 0), (2, 128, 160, 16, 32, 3, 1, 2, 2), (1, 512, 128, 32, 32, 1, 1, 1, 0)])
+def test_f16x3_dgrad_adds_the_gated_identity_gradient(ops, case):
+    """pfst_conv_igemm_f16x3(gate_dy, gate_mask): out = data gradient + (bit ? g : 0) -- the identity branch of a residual block folded into
+    conv1's epilogue.  Exactly the sum of the plain launch and the gated tensor written by itself (pfst_relu_gate), with the bitmask
+    pfst_bn_apply writes; also with the fused BatchNorm-backward sums in the same epilogue (they must see the SUM)."""
+    n, ci, co, H, W, k, s, d, p = case
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    w = (torch.randn(co, ci, k, k, generator=g(2)) * 0.1).to(DEV)
+    dy = torch.randn(n, co, H, W, generator=g(4)).to(DEV)
+    _, w4d, wa = ops.pack_weight_f16x2(w, False, True)
+    da = ops.absmax(dy)
+    assert ops.dgrad_gate_ok(ci, (H, W))
+    gsrc = torch.randn(x.shape, generator=g(11)).to(DEV)
+    pre = torch.randn(x.shape, generator=g(12)).to(DEV)
+    one, zero = torch.ones(ci, device=DEV), torch.zeros(ci, device=DEV)
+    mean, invstd, coef = ops.bn_stats(pre, gamma=one, beta=zero)
+    yb, mask = ops.bn_apply(pre, mean, invstd, one, zero, True, residual=torch.zeros_like(pre), want_mask=True)
+    assert mask is not None
+    gated = ops.relu_gate_(torch.empty_like(gsrc), gsrc, mask)
+    assert torch.equal(gated, torch.where(yb > 0, gsrc, torch.zeros_like(gsrc)))
+    dx = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p)
+    dxg = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, gate=(gsrc, mask))
+    assert torch.equal(dxg, dx + gated)
+    assert torch.equal(ops.relu_gate_(dx.clone(), gsrc, mask, accumulate=True), dx + gated)
+    # with the BatchNorm-backward sums of the layer that owns the gradient (a residual layer: gate from y): sums of the gated total
+    pre2 = torch.randn(x.shape, generator=g(13)).to(DEV)
+    m2, i2, coef2 = ops.bn_stats(pre2, gamma=one, beta=zero)
+    y2 = ops.bn_apply(pre2, m2, i2, one, zero, True, residual=torch.randn(x.shape, generator=g(14)).to(DEV))
+    out_a, part_a, slots = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, bnb=(pre2, y2, coef2, True), gate=(gsrc, mask))
+    out_b, part_b, _ = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, out=gated.clone(), accumulate=True, bnb=(pre2, y2, coef2, True))
+    assert torch.equal(out_a, out_b) and torch.equal(part_a, part_b)
+
+
 def test_f16x3_refuses_shapes_it_does_not_cover(ops):
     from pfst_amd._lib import PfstHipError
     x = torch.randn(1, 48, 8, 8, device=DEV)

@@ -71,6 +71,7 @@ def test_every_backward_link_as_wired(wino, math):
 
     # ---- HIP model, wired exactly as in the product
     prev, prev_math, prev_dw, prev_defer = layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY
+    prev_gate = layers.FUSE_RES_GATE
     layers.WINOGRAD, layers.CONV_MATH = wino, math      # both arithmetics of the dense convolutions: fp32-input MFMA and the bf16x6 split
     # one closure per conv -> BN link here: the ASPP head's fused three-branch depthwise launch (one closure for three layers' data and weight
     # gradients) is checked against this per-branch wiring in test_aspp_depthwise_branches_fused_equals_per_branch below
@@ -79,6 +80,9 @@ def test_every_backward_link_as_wired(wino, math):
     # normalisations of the product (stem.6 -> max-pool, sep_bottleneck[0] -> [1]) are checked against this wiring in
     # test_deferred_normalisation_equals_the_materialised_one below
     layers.DEFER_BN_APPLY = False
+    # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
+    # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
+    layers.FUSE_RES_GATE = False
     try:
         model = build_segmentor(model_cfg(C, 3, dropout=0.0))
         model.load_state_dict(student, strict=True)
@@ -211,6 +215,7 @@ def test_every_backward_link_as_wired(wino, math):
         torch.cuda.synchronize()
     finally:
         layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY = prev, prev_math, prev_dw, prev_defer
+        layers.FUSE_RES_GATE = prev_gate
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
     for op, name, k, worst, nrm, fe, de, _, _ in sorted(rows, key=lambda r: -r[3])[:25]:
@@ -598,3 +603,69 @@ def test_published_maxima_cover_every_f16x3_operand():
     assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
     assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'
     assert not [s for s in scanned[:n_fwd_scans] if len(s) == 4 and s[1] in (cat_ch,)], scanned[:n_fwd_scans]
+
+
+def test_residual_gate_in_the_dgrad_epilogue():
+    """layers.FUSE_RES_GATE: dL/d(block input) of a residual block = conv1's data gradient + dL/d(block output) gated by the block's final
+    ReLU.  The product forms the sum in conv1's f16x3 data-gradient epilogue (pfst_conv_igemm_f16x3 gate_dy; a downsample layer's
+    BatchNorm backward takes the pair as its gated dy) instead of letting the bn3 layer's BatchNorm backward write the gated tensor.  Same
+    additions per element: one segmentor forward + backward with the fold on and off gives the same gradients to the summation order of the
+    weight gradients' atomics, and the gated tensor is really not written (no dres argument on any residual layer's pfst_bn_backward)."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if layers.CONV_MATH != 'f16x3':
+        pytest.skip('the gated epilogue exists on the f16x3 data-gradient kernel')
+    C, b, S = 6, 2, 256              # 1/8 maps of 32 x 32 = 1024 pixels: whole 256-element mask groups in layers 2-4; layer1: 64 x 64
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=17)
+    runs, n_dres, n_gated = {}, {}, {}
+    prev = layers.FUSE_RES_GATE
+    try:
+        for fold in (True, False):
+            layers.FUSE_RES_GATE = fold
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            cnt = dict(dres=0, gated=0, flushed=0)
+            o_bnb, o_dg, o_rg = ops.bn_backward, ops.conv_dgrad_f16x3, ops.relu_gate_
+
+            def bnb(*a, **k):
+                dres = a[9] if len(a) > 9 else k.get('dres')
+                cnt['dres'] += dres is not None
+                return o_bnb(*a, **k)
+
+            def dg(*a, **k):
+                cnt['gated'] += k.get('gate') is not None
+                return o_dg(*a, **k)
+
+            def rg(*a, **k):
+                cnt['flushed'] += 1
+                return o_rg(*a, **k)
+
+            ops.bn_backward, ops.conv_dgrad_f16x3, ops.relu_gate_ = bnb, dg, rg
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.bn_backward, ops.conv_dgrad_f16x3, ops.relu_gate_ = o_bnb, o_dg, o_rg
+            runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
+            n_dres[fold], n_gated[fold] = cnt['dres'], cnt['gated']
+            assert cnt['flushed'] == 0, 'every deferred identity gradient must be taken over by a fused consumer'
+    finally:
+        layers.FUSE_RES_GATE = prev
+    # ResNet-50: 16 residual blocks; 4 of them hand the pair to their downsample layer's BatchNorm backward, the other 12 to conv1's epilogue
+    assert n_dres == {True: 0, False: 16} and n_gated == {True: 12, False: 0}, (n_dres, n_gated)
+    assert torch.equal(runs[True][0], runs[False][0])
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    assert e < 1e-5, e
