@@ -70,7 +70,8 @@ class KernelTimer:
         if name == 'pfst_conv_igemm_f16x3':
             n, c, hi, wi, m, ho, wo, ks, mode = a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[19]
             px = ho * wo if mode == 0 else hi * wi
-            return 'conv_igemm_f16x3_kernel', 2.0 * n * m * c * ks * ks * px, 4.0 * (n * c * hi * wi + n * m * ho * wo) + 4.0 * c * ks * ks * m
+            kern = 'conv_igemm_f16x3_kernel' if m > 64 else 'conv_igemm_f16x3_kernel<64>'      # the 64-row tile is a family of its own, like split<64>
+            return kern, 2.0 * n * m * c * ks * ks * px, 4.0 * (n * c * hi * wi + n * m * ho * wo) + 4.0 * c * ks * ks * m
         if name == 'pfst_wino_gemm_f16x3':
             n, k, m, t, nx = a[5], a[6], a[7], a[8], (a[9] + 2) ** 2
             return 'conv_igemm_f16x3_kernel', 2.0 * nx * n * m * k * t, 4.0 * nx * (n * k * t + n * m * t) + 4.0 * nx * k * m

@@ -249,9 +249,15 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const PfstResGate& gate) {
   static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
   static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
-  static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE), "the 256-row tile exists for the pixel-to-pixel 32x32 loop");
-  constexpr int BM = BMT, WAVES_N = 2, NT = 2 * BM;             // NT threads: BM / 64 x 2 waves
-  constexpr int TPT = BM == 128 ? 2 : 1;                        // K=16 activation tiles of a pair one thread stages
+  static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE) || (BMT == 64 && SHAPE == 32 && BNB == 0 && !BPACK),
+                "the 256-row tile exists for the pixel-to-pixel 32x32 loop, the 64-row tile for the plain 32x32 loop");
+  // BMT 64 (layers with 33 ... 64 output rows: layer1 conv2, stem.6): 256 threads as for 128 rows, the four waves 2 x 2 over 64 rows x 128
+  // pixels, i.e. ONE 32-row block per wave (TMW = 1) -- the activation staging is the 128-row tile's (same split work per pixel, spread over
+  // half the MFMAs), a weight tile is one 16-byte chunk per thread
+  constexpr int BM = BMT, WAVES_N = 2, NT = BM == 64 ? 256 : 2 * BM;     // NT threads: BM / 64 x 2 waves (64 rows: 2 x 2 waves of 32 rows)
+  constexpr int TMW = BM == 64 ? 1 : 2;                         // 32-row accumulator blocks of a wave tile
+  constexpr int TPT = BM == 256 ? 1 : 2;                        // K=16 activation tiles of a pair one thread stages
+  constexpr int NA = 2 * (2 * NP * BM) / NT;                    // 16-byte weight chunks of a pair one thread stages: 4 (2 at 64 rows)
   constexpr int TILE_A = 2 * NP * BM, TILE_B = 2 * NP * BN;     // 16-byte chunks of one K=16 tile
   // SHAPE 32: two LDS buffers of a pair (2 x 32 KB; two workgroups per CU either way: 176 registers), so a step needs ONE barrier and the
   // stores of pair k+1 go to the other buffer whenever their data is ready.  SHAPE 16: one buffer, barrier A in the MFMA stream.
@@ -263,7 +269,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   uint4* const Bs = smem + 2 * TILE_A;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wid / WAVES_N) * 64, wn0 = (wid % WAVES_N) * 64;
+  const int wm0 = (wid / WAVES_N) * (32 * TMW), wn0 = (wid % WAVES_N) * 64;
   const int P = Ho * Wo, HiWi = Hi * Wi;
   const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM, X = gx * gy;
   const int total = X * Y * Z, G = gridDim.x;
@@ -290,7 +296,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && chain != 0;
 
   const int pix = tid & (BN - 1), kh = (tid >> 7) & 1;   // activation staging: pixel, k-half ...
-  const int bt = BM == 128 ? 0 : tid >> 8;               // ... and (256-row tile) which K=16 tile of the pair
+  const int bt = BM == 256 ? tid >> 8 : 0;               // ... and (256-row tile) which K=16 tile of the pair
   const int a_seg = tid / BM, a_row = tid - a_seg * BM;  // chunk c = tid + NT i of a tile -> segment seg + 2 i, same row
   constexpr unsigned OOB = 0x80000000u;
   const int a_chunk = 2 * M * 16, a_tile = 2 * NP * M * 16, b_chan = HiWi * 4;
@@ -327,16 +333,16 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     return ok ? 4u * ((unsigned)(kh * 8) * (unsigned)HiWi + (unsigned)(sy * Wi + sx)) : OOB;
   };
 
-  uint4 areg[2][4];                                      // [register set][tile 2][piece 2]: like the activations, two pairs ahead
+  uint4 areg[2][NA];                                     // [register set][tile 2][chunk NA / 2]: like the activations, two pairs ahead
   float breg[2][TPT][8];                                 // [register set][tile][channel kh * 8 + i of the tile's 16]
   f32x4 acc[4][4];                                       // SHAPE 16
-  pfst_f32x16 acc32[2][2];                               // SHAPE 32 (and the epilogue's layout)
+  pfst_f32x16 acc32[TMW][2];                             // SHAPE 32 (and the epilogue's layout)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -348,8 +354,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     breg[SET][v >> 3][v & 7] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, voff, soff + ((v >> 3) * 16 + (v & 7)) * b_chan, 0));
   };
   auto load_a = [&](auto vc, auto setc, int a_soff) {
-    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;                // v = 0..3: tile v / 2, piece v % 2
-    areg[SET][v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / 2) * a_tile + (v % 2) * a_chunk, 0));
+    constexpr int v = decltype(vc)::value, SET = decltype(setc)::value;                // v = 0..NA-1: tile v / (NA / 2), chunk v % (NA / 2)
+    areg[SET][v] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_voff, a_soff + (v / (NA / 2)) * a_tile + (v % (NA / 2)) * a_chunk, 0));
   };
   // pairs are numbered (tap, channel block); the address of pair k+2 advances by one channel block per step, the pixel offset is
   // recomputed only when the tap changes (never for a 1x1 convolution): no integer divisions in the loop
@@ -383,13 +389,10 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     tap2 = sidx2 = 0;
     voff2 = tap_voff(0);
     static_for<8 * TPT>([&](auto vc) { load_b(vc, std::integral_constant<int, 0>(), voff2, 0); });
-    static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 0>(), 0); });
+    static_for<NA>([&](auto vc) { load_a(vc, std::integral_constant<int, 0>(), 0); });
     advance();
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      As[t * TILE_A + tid] = areg[0][t * 2 + 0];
-      As[t * TILE_A + tid + NT] = areg[0][t * 2 + 1];
-    }
+    for (int v = 0; v < NA; ++v) As[(v / (NA / 2)) * TILE_A + tid + NT * (v % (NA / 2))] = areg[0][v];
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
       uint4 ph, pl;
@@ -402,7 +405,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     {
       const int soff = sidx2 * chan_step, a_soff = (tap2 * spt + sidx2) * 2 * a_tile;
       static_for<8 * TPT>([&](auto vc) { load_b(vc, std::integral_constant<int, 1>(), voff2, soff); });
-      static_for<4>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), a_soff); });
+      static_for<NA>([&](auto vc) { load_a(vc, std::integral_constant<int, 1>(), a_soff); });
     }
     advance();
     __syncthreads();
@@ -469,12 +472,14 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   auto step32 = [&](auto setn_c, int k) {
     constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
     constexpr int CUR = SETL * PAIR_CHUNKS, NXT = SETN * PAIR_CHUNKS;       // pair k sits in LDS buffer k & 1 = SETL, pair k+1 goes to the other
-    f16x8 af[2][2][NP], bf[2][2][NP];
+    f16x8 af[2][TMW][NP], bf[2][2][NP];
     auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR + t * TILE_A + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
     auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR + t * TILE_B + (pl * 2 + lh) * BN + wn0 + j * 32 + l31]); };
-    // r = 0..15: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 a1, the MFMAs' order
+    // fragment reads, RG = 2 + TMW per group: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 [a1],
+    // the MFMAs' order
+    constexpr int RG = 2 + TMW;
     auto read_frag = [&](auto rc) {
-      constexpr int r = decltype(rc)::value, grp = r >> 2, e = r & 3, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
+      constexpr int r = decltype(rc)::value, grp = r / RG, e = r % RG, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
       if constexpr (e == 0) rd_a(t, 0, pa);
       else if constexpr (e == 1) rd_b(t, 0, pb);
       else if constexpr (e == 2) rd_b(t, 1, pb);
@@ -482,15 +487,15 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     };
     const int soff2 = sidx2 * chan_step;
     const int a_soff2 = (tap2 * spt + sidx2) * 2 * a_tile;
-    static_for<4>([&](auto rc) { read_frag(rc); });
+    constexpr int PRE = TMW == 2 ? RG : 2 * RG;                    // reads in front of the first MFMA (MFMA m needs read <= PRE + m - 1; with one
+    static_for<PRE>([&](auto rc) { read_frag(rc); });              // block per wave a group of three reads lasts only two MFMAs)
     __builtin_amdgcn_sched_barrier(0);
     SplitF16 s0, s1;
-    static_for<24>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int prod = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
-      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
-      acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc32[i][j], 0, 0, 0);
-      if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
+    // the staging work of one of the 24 issue slots (TMW = 2: one slot per MFMA; TMW = 1: two per MFMA): 0-7 two activation loads each,
+    // 8-11 the weight stores of pair k+1 (to the OTHER LDS buffer: no barrier inside the step), 12-23 four split instructions each, 12-15 the
+    // weight loads of pair k+2, 18 / 23 the activation stores
+    auto filler = [&](auto sc) {
+      constexpr int m = decltype(sc)::value;
       if constexpr (m < 8) {                                        // (256-row tile: one load per slot)
         if constexpr (TPT == 2) {
           load_b(std::integral_constant<int, 2 * m>(), std::integral_constant<int, SETL>(), voff2, soff2);
@@ -499,7 +504,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
           load_b(std::integral_constant<int, m>(), std::integral_constant<int, SETL>(), voff2, soff2);
         }
       }
-      if constexpr (m >= 8 && m < 12) As[NXT + ((m - 8) / 2) * TILE_A + tid + NT * ((m - 8) % 2)] = areg[SETN][m - 8];
+      if constexpr (m >= 8 && m < 8 + NA) As[NXT + ((m - 8) / (NA / 2)) * TILE_A + tid + NT * ((m - 8) % (NA / 2))] = areg[SETN][m - 8];
       if constexpr (m >= 12) {
         constexpr int SPS = 2 * TPT;                                // split instructions per slot: 48 (24: one tile) over slots 12-23
         static_for<SPS>([&](auto kc) {
@@ -513,7 +518,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
           }
         });
       }
-      if constexpr (m >= 12 && m < 16) load_a(std::integral_constant<int, m - 12>(), std::integral_constant<int, SETL>(), a_soff2);
+      if constexpr (m >= 12 && m < 12 + NA) load_a(std::integral_constant<int, m - 12>(), std::integral_constant<int, SETL>(), a_soff2);
       if constexpr (m == 18 && TPT == 2) {
         Bs[NXT + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
         Bs[NXT + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
@@ -525,6 +530,20 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
       if constexpr (m == 23 && TPT == 1) {                          // the thread's one tile
         Bs[NXT + bt * TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
         Bs[NXT + bt * TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
+      }
+    };
+    // 12 TMW MFMAs in the order product-major, tile-minor (al bh | ah bl | ah bh); the remaining fragment reads one per MFMA
+    static_for<12 * TMW>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int prod = m / (4 * TMW), rem = m % (4 * TMW), t = rem / (2 * TMW), i = (rem >> 1) % TMW, j = rem & 1;
+      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
+      acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc32[i][j], 0, 0, 0);
+      if constexpr (PRE + m < 4 * RG) read_frag(std::integral_constant<int, PRE + m>());
+      if constexpr (TMW == 2) {
+        filler(std::integral_constant<int, m>());
+      } else {
+        filler(std::integral_constant<int, 2 * m>());
+        filler(std::integral_constant<int, 2 * m + 1>());
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -547,7 +566,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float ua = unscale_of(ea), ub = unscale_of(eb);
     if constexpr (SHAPE == 32) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -560,11 +579,11 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
                                                     reinterpret_cast<float*>(smem + PAIR_CHUNKS), gsrc, gmask);
         __syncthreads();                                 // before the next tile's first step stores into that buffer
       } else {
-        conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(), nullptr,
-                                         gsrc, gmask);
+        conv_epilogue<TMW, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(), nullptr,
+                                           gsrc, gmask);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -612,7 +631,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
 }
 
 template <int SHAPE, bool BPACK = false, bool ONE = false, int BMT = 128>
-__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_kernel(
+__global__ __launch_bounds__(BMT == 64 ? 256 : 2 * BMT, BMT == 256 ? 1 : 2) void conv_igemm_f16x3_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
@@ -1347,7 +1366,7 @@ extern "C" int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs
   return PFST_OK;
 }
 
-// fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 (1x1: C % 16 == 0) and M > 64.
+// fprop (mode 0) / dgrad (mode 1) on the f16x3 kernel; in_amax: one slot holding max |in|.  Needs C % 32 == 0 (1x1: C % 16 == 0) and M > 32 (33 ... 64 rows: the 64-row tile).
 extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                                      int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
@@ -1371,10 +1390,12 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   PFST_CHECK_ARG((i64)C * Hi * Wi * 4 < (1ll << 31) && (i64)M * Ho * Wo * 4 < (1ll << 31) && (i64)ksize * ksize * C * M * 4 < (1ll << 31));
   // a 1x1 convolution may end in half a channel block: the loads of the 16 missing channels (activations and weight chunks alike) lie
   // outside their buffers' ranges and return zeros (the range check of gfx950 includes the scalar offset: tools/probes/soffset_range_probe.hip)
-  if ((C % 32 != 0 && !(ksize == 1 && C % 16 == 0)) || M <= 64) {
-    pfst_set_error(__FILE__, __LINE__, "f16x3 kernel needs C % 32 == 0 (1x1: C % 16 == 0) and more than 64 output channels (use pfst_conv_igemm_split)");
+  if ((C % 32 != 0 && !(ksize == 1 && C % 16 == 0)) || M <= 32) {
+    pfst_set_error(__FILE__, __LINE__, "f16x3 kernel needs C % 32 == 0 (1x1: C % 16 == 0) and more than 32 output channels (use pfst_conv_igemm_split)");
     return PFST_ERR_UNSUPPORTED;
   }
+  const bool small = M <= 64;                       // 33 ... 64 output rows: the 64-row tile (one 32-row block per wave)
+  PFST_CHECK_ARG(!small || (f16x3_shape() == 32 && !(bnb && bnb->x)));
   const int span = (ksize - 1) * dil;
   if (mode == 0) {
     PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
@@ -1383,10 +1404,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   }
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
-  const int stats_T = N * pfst_conv_stats_slots(M, Ho, Wo);
-  const bool one = ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
+  const int stats_T = N * (int)cdiv((i64)Ho * Wo, BN) * 2;      // two pixel-waves per tile at every tile height (= pfst_conv_stats_slots for M > 64)
+  const bool one = !small && ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
   const bool big = one && M % 256 == 0 && f16x3_bm256();                              // 256-row tiles, 512 threads, one workgroup per CU
-  const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : 128) * N;
+  const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : small ? 64 : 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
   const int chain = f16x3_chain();
@@ -1417,7 +1438,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
     PFST_CHECK_LAUNCH();
     return PFST_OK;
   }
-  if (big)
+  if (small)
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, false, 64>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
+  else if (big)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else if (one)

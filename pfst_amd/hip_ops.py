@@ -244,8 +244,13 @@ def set_f16x3_slots(slots):
 def f16x3_eligible(cin, cout, ksize=3):
     """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks -- a 1x1 convolution also a last half block: the loads of
     the missing 16 channels fall outside their buffers' ranges and return zeros (the range check includes the scalar offset on gfx950:
-    tools/probes/soffset_range_probe.hip) -- and more than 64 output rows"""
-    return (cin % 32 == 0 or (ksize == 1 and cin % 16 == 0)) and cout > 64
+    tools/probes/soffset_range_probe.hip) -- and more than F16X3_MIN_ROWS output rows (33 ... 64: the 64-row tile, one 32-row block per wave;
+    PFST_F16X3_MIN_ROWS=64 leaves those layers on the bf16x6 kernel)"""
+    return (cin % 32 == 0 or (ksize == 1 and cin % 16 == 0)) and cout > F16X3_MIN_ROWS
+
+
+F16X3_MIN_ROWS = int(os.environ.get('PFST_F16X3_MIN_ROWS', '32'))
+assert F16X3_MIN_ROWS in (32, 64)
 
 
 def pack_weight_f16x2(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, amax=None, sets=1):
@@ -300,7 +305,7 @@ def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0
     assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout, ksize)
     if out is None:
         out = torch.empty(n, cout, ho, wo, device=x.device)
-    slots = conv_stats_slots(n, cout, ho, wo) if want_stats else 0
+    slots = n * ((ho * wo + 127) // 128) * 2 if want_stats else 0        # two pixel-waves per 128-pixel tile at every tile height
     st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
     call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
          n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, _stream())

@@ -220,7 +220,9 @@ class Conv2dP(nn.Module):
         self.wino_f16 = self.f16_f = self.f16_d = False
         if self.wino:
             split = _split_mode()                   # transform-domain GEMMs on a split kernel: split-packed filter sets
-            self.wino_f16 = f16 and ops.f16x3_eligible(self.cin, self.cout) and (not need_dgrad or ops.f16x3_eligible(self.cout, self.cin))
+            # (the transform-domain GEMMs have no 64-row tile: more than 64 rows in both directions)
+            self.wino_f16 = (f16 and ops.f16x3_eligible(self.cin, self.cout) and self.cout > 64
+                             and (not need_dgrad or (ops.f16x3_eligible(self.cout, self.cin) and self.cin > 64)))
             n = (ops.WINO_TILE + 2) ** 2 * (self.weight.numel() // 9) * ((4 if self.wino_f16 else 6) if split else 1)
             dt = torch.uint8 if split else torch.float32
             if self.uf is None or self.uf.device != self.weight.device or self.uf.dtype != dt or self.uf.numel() != n:

@@ -235,7 +235,9 @@ def test_winograd_on_the_bf16x6_gemm(ops, case, m):
     assert_close(ops.wino_conv(dy.to(DEV), ud, ci, d, m=m), dx_ref, WINO_TOL[m], 'winograd/bf16x6 dgrad')
 
 
-F16_CASES = [c for c in CONV_CASES if c[1] % 32 == 0 and c[2] > 64] + [
+F16_CASES = [c for c in CONV_CASES if c[1] % 32 == 0 and c[2] > 32] + [
+    # 33 ... 64 output rows: the 64-row tile (layer1 conv2, its data gradient, stem.6; a ragged 48-row case, stride 2, a 1x1)
+    (2, 64, 64, 32, 32, 3, 1, 1, 1), (1, 32, 48, 20, 24, 3, 1, 1, 1), (2, 64, 64, 17, 19, 3, 2, 1, 1), (2, 256, 64, 16, 16, 1, 1, 1, 0),
     # 1x1 contractions that end in half a channel block (the decoder's 560 -> 512 pointwise convolution; 48: a single, half-empty pair)
     (2, 560, 512, 16, 24, 1, 1, 1, 0), (1, 48, 96, 12, 12, 1, 1, 1, 0), (2, 80, 160, 9, 14, 1, 2, 1, 0)]
 
@@ -259,6 +261,13 @@ def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
     assert float(xa.max()) == float(x.abs().max()) and float(wa.max()) == float(w.abs().max())       # the slot group holds the exact maximum
     y = ops.conv_fprop_f16x3(xd, w4f, wa, xa, co, k, s, d, p)
     assert_close(y, ref, 2e-6, 'f16x3 fprop')
+    # BatchNorm statistics from the epilogue's partials (every tile height writes two slots per 128-pixel tile): those of the output itself
+    y_st, st, slots = ops.conv_fprop_f16x3(xd, w4f, wa, xa, co, k, s, d, p, want_stats=True)
+    assert torch.equal(y_st, y)
+    mean, invstd = ops.bn_finalize_partials(st, slots, co, ref.numel() // co)
+    m2, i2 = ops.bn_stats(y)
+    assert_close(mean, m2, 1e-5, 'f16x3 epilogue mean vs bn_stats')
+    assert_close(invstd, i2, 1e-5, 'f16x3 epilogue invstd vs bn_stats')
     # the bf16x6 kernel on the same data, for scale: f16x3 is not allowed to be worse than 1.5x + 1e-7
     w6f, _ = ops.pack_weight_split(wd, True, False)
     e6 = rel_err(ops.conv_fprop_split(xd, w6f, co, k, s, d, p), ref)
@@ -273,7 +282,7 @@ def test_conv_f16x3_is_fp32_faithful(ops, case, spread):
         assert_close(dx, dx_ref, 2e-6, 'f16x3 dgrad')
         dx2 = ops.conv_dgrad_f16x3(dy.to(DEV), w4d, wa, da, ci, (H, W), k, s, d, p, out=dx.clone(), accumulate=True)
         assert_close(dx2, 2 * dx_ref, 2e-6, 'f16x3 dgrad-acc')
-    if k == 1 and s == 1 and (H * W) % 4 == 0:
+    if k == 1 and s == 1 and (H * W) % 4 == 0 and co > 64:          # (the f16x3 weight gradient has no 64-row tile)
         dw_ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 1, 1), dy.double(), 1, 0, 1)
         dw = torch.zeros(co, ci, 1, 1, device=DEV)
         ops.conv_wgrad_f16x3_(dw, xd, dy.to(DEV), xa, ops.absmax(dy.to(DEV)))
@@ -320,7 +329,8 @@ def test_f16x3_refuses_shapes_it_does_not_cover(ops):
     x = torch.randn(1, 48, 8, 8, device=DEV)
     w = torch.randn(128, 48, 3, 3, device=DEV)           # a 3x3 contraction over 1.5 channel blocks per tap
     w4f, _, wa = ops.pack_weight_f16x2(w, True, False)
-    assert not ops.f16x3_eligible(48, 128) and not ops.f16x3_eligible(64, 64) and ops.f16x3_eligible(64, 96)
+    assert not ops.f16x3_eligible(48, 128) and not ops.f16x3_eligible(64, 32) and ops.f16x3_eligible(64, 96)
+    assert ops.f16x3_eligible(64, 64) == (ops.F16X3_MIN_ROWS == 32)           # 33 ... 64 rows: the 64-row tile
     assert ops.f16x3_eligible(48, 128, 1) and not ops.f16x3_eligible(40, 128, 1)
     with pytest.raises((PfstHipError, AssertionError)):
         ops.conv_fprop_f16x3(x, w4f, wa, ops.absmax(x), 128, 3, pad=1)

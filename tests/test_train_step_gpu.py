@@ -113,7 +113,10 @@ def test_two_train_steps_match_reference_golden_and_oracle(conv_math):
         assert_elementwise(dbg['ema_dec'], ex['ema_dec'], 'teacher decoded features')
         assert rel(dbg['mixed_w'], ex['mixed_w']) < 1e-5
         for k in olog:
-            assert abs(lv[k] - olog[k]) <= TOL * max(abs(olog[k]), 1e-2), (it, k, lv[k], olog[k])
+            # acc_seg counts arg-max hits of nearly flat random-init logits: after the AdamW step (it 1, see above) a handful of near-tie
+            # pixels of the 32768 may flip -> an absolute slack of 10 pixels there (measured: 2), as in the option-variant tests below
+            tol = 100.0 * 10 / (2 * 128 * 128) if (it == 1 and k.endswith('acc_seg')) else TOL * max(abs(olog[k]), 1e-2)
+            assert abs(lv[k] - olog[k]) <= tol, (it, k, lv[k], olog[k])
         assert_live_target_side(olog, ex)
         assert_live_target_side(lv)
         if it == 0:
