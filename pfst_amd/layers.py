@@ -22,7 +22,7 @@ _BN_EVAL = False
 #   'f16x3'  -- TWO scaled fp16 pieces per operand, three fp16 MFMAs per product, fp32 accumulate (csrc/conv_f16x3.hip): the default
 #               (round 3).  Every operand tensor is scaled by the power of two its absolute maximum implies (device scalars published by
 #               the producing kernels).  Measured error vs fp64 at or below the fp32-input MFMA's on every layer; covers contractions
-#               over whole 32-channel blocks with more than 64 output rows, the other layers run as under 'bf16x6';
+#               over whole 32-channel blocks with more than 32 output rows (33 ... 64: the 64-row tile), the other layers run as under 'bf16x6';
 #   'bf16x6' -- three bf16 pieces per operand, the six piece-products >= 2^-16 (csrc/conv_split.hip); PFST_CONV_MATH=bf16x6;
 #   'f32'    -- fp32-input MFMA (v_mfma_f32_32x32x2_f32); PFST_CONV_MATH=f32.  Layers whose channel count is not a multiple of 16
 #               (the 3-/10-band stems, the classifiers' data gradient) use it in every mode.
