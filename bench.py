@@ -78,6 +78,9 @@ class KernelTimer:
         if name == 'pfst_conv_wgrad_f16x3':
             n, ci, co, hw = a[5], a[6], a[7], a[8]
             return 'conv_wgrad_f16x3_kernel', 2.0 * n * co * ci * hw, 4.0 * (n * ci * hw + n * co * hw + 2 * co * ci)
+        if name == 'pfst_conv_wgrad_f16x3_q':
+            n, ci, h, w_, co, ks = a[5], a[6], a[7], a[8], a[9], a[10]
+            return 'conv_wgrad_q16_kernel', 2.0 * n * co * ci * ks * ks * h * w_, 4.0 * (n * ci * h * w_ + n * co * h * w_ + 2 * co * ci * ks * ks)
         if name == 'pfst_absmax':
             return name, 0.0, 4.0 * a[1] * a[2]
         if name == 'pfst_wino_gemm_split':
@@ -141,7 +144,8 @@ class KernelTimer:
                    'pfst_wino_gemm': (3, 4, 5, 6), 'pfst_wino_wgrad': (4, 5, 6, 7),
                    'pfst_conv_igemm_split': (6, 7, 8, 10, 13, 15, 17, 18), 'pfst_conv_wgrad_split': (5, 6, 7, 9, 12, 14),
                    'pfst_wino_gemm_split': (3, 4, 5, 6), 'pfst_conv_igemm_f16x3': (8, 9, 10, 12, 15, 17, 19, 20),
-                   'pfst_wino_gemm_f16x3': (5, 6, 7, 8), 'pfst_conv_wgrad_f16x3': (5, 6, 7, 8)}[name]
+                   'pfst_wino_gemm_f16x3': (5, 6, 7, 8), 'pfst_conv_wgrad_f16x3': (5, 6, 7, 8),
+                   'pfst_conv_wgrad_f16x3_q': (5, 6, 7, 9, 10, 11)}[name]
             key = key + (' wino ' if 'wino' in name else ' ') + ' '.join(str(args[i]) for i in idx)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

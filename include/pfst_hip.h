@@ -175,6 +175,10 @@ int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, co
                          int M, int T, int m, int v_packed, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
                           int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream);
+/* the same for the layers that kernel does not take -- stride-1 'same' 3x3 (pad == dil <= 8, W % 16 == 0) and 1x1 with <= 64 output channels
+ * (the stems, layer1: resnet.py:593-624,169-209) -- on the K-quad kernel with both operands split as they are staged (csrc/conv_wgrad_q.hip) */
+int pfst_conv_wgrad_f16x3_q(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int H, int W,
+                            int Cout, int ksize, int dil, const float* x_amax, const float* dy_amax, pfst_stream_t stream);
 
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */

@@ -400,6 +400,17 @@ def conv_wgrad_split_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
     return dw
 
 
+def conv_wgrad_f16q_(dw, x, dy, x_amax, dy_amax, ksize, dil=1):
+    """dw += dL/dw of a stride-1 'same' convolution (1x1, or 3x3 with pad == dil) with the f16x3 split on the K-quad kernel (fp32 atomics):
+    the direct 3x3 layers of the stems / layer1 and the 1x1 layers with <= 64 output channels"""
+    n, ci, h, w = x.shape
+    co = dy.shape[1]
+    assert tuple(dy.shape) == (n, co, h, w) and dw.numel() == co * ci * ksize * ksize
+    call('pfst_conv_wgrad_f16x3_q', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, ci, h, w, co, ksize, dil,
+         x_amax.data_ptr(), dy_amax.data_ptr(), _stream())
+    return dw
+
+
 def bias_grad_(db, dy):
     n, c, h, w = dy.shape
     call('pfst_bias_grad', dy.data_ptr(), _bs(dy), _dense(db).data_ptr(), n, c, h * w, _stream())

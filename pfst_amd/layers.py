@@ -80,6 +80,9 @@ FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
 # being written by the bn3 layer's BatchNorm backward and read back -- one write of the block's widest tensor less per block.
 # PFST_FUSE_RES_GATE=0: pfst_bn_backward writes it (dres)
 FUSE_RES_GATE = os.environ.get('PFST_FUSE_RES_GATE', '1') == '1'
+# f16x3: the weight gradients the whole-line kernel does not take (direct stride-1 3x3, 1x1 with <= 64 output channels) on the K-quad kernel
+# with both operands split as they are staged (csrc/conv_wgrad_q.hip); PFST_F16X3_WGRAD_Q=0: the fp32-input MFMA / bf16x6 kernels
+F16X3_WGRAD_Q = os.environ.get('PFST_F16X3_WGRAD_Q', '1') == '1'
 # ... but only where that launch is MFMA-bound: with a short contraction (K = Cout * taps of the consuming conv) the data gradient is
 # itself HBM-bound (layer1: 2 * 64 flop per 8 bytes written + accumulated), and reading the pre-BN tensor there costs what the
 # reduction pass would have cost (measured: fusing everywhere moves 11 ms/step out of pfst_bn_backward and 10 ms into the GEMMs)
@@ -173,6 +176,16 @@ class Conv2dP(nn.Module):
             return False                  # the f16x3 kernel's fused epilogue needs whole 128-row tiles
         return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
+
+    def wgrad_f16q_ok(self, h, w):
+        """the weight gradient runs on the f16x3 K-quad kernel (ops.conv_wgrad_f16q_): stride-1 'same' 3x3 outside the Winograd dispatch (the
+        stems, layer1 conv2).  The kernel also takes 1x1 layers; those with <= 64 output channels are HBM-bound and measured no faster on it
+        (0.225 vs 0.205 ms for layer1 conv1 on the bf16x6 kernel): they stay where they are"""
+        if not (CONV_MATH == 'f16x3' and WGRAD_SPLIT and F16X3_WGRAD_Q) or self.depthwise or self.stride != 1 or self.cout < 16:
+            return False
+        if self.wino_wgrad_ok(h, w):
+            return False
+        return self.k == 3 and w % 16 == 0 and self.dilation <= 8 and self.padding == self.dilation
 
     def dgrad_can_gate(self, in_hw):
         """the data-gradient launch can add a ReLU-gated tensor in its epilogue (ops.conv_dgrad_f16x3(gate=...))"""
@@ -556,6 +569,9 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
         ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                               dy_amax if dy_amax is not None else ops.absmax(dy))
+    elif conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3]):
+        ops.conv_wgrad_f16q_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
+                             dy_amax if dy_amax is not None else ops.absmax(dy), conv.k, conv.dilation)
     elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
         ops.conv_wgrad_split_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
     else:
@@ -581,8 +597,9 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
     x_bnl = None if x.lazy is None else x.lazy[1]          # the depthwise layer's input is normalised on load (conv_bn_act(defer=True))
     f16w = CONV_MATH == 'f16x3' and not conv.depthwise and conv.cout > 64 and conv.k == 1 and conv.stride == 1
     wino16 = CONV_MATH == 'f16x3' and not conv.depthwise and conv.wino_f16
-    x_amax = amax_of(x) if (f16w or (wino16 and saved_v is None)) else None
-    if (f16w or wino16) and dy_amax is None:
+    f16q = not conv.depthwise and x.lazy is None and conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3])
+    x_amax = amax_of(x) if (f16w or f16q or (wino16 and saved_v is None)) else None
+    if (f16w or f16q or wino16) and dy_amax is None:
         dy_amax = ops.absmax(dy)
     if WGRAD_STREAM and not conv.depthwise:
         def wg():
@@ -708,7 +725,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
         ymask = y if (relu and residual is not None and gate is None) else None
         part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
         need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
-                                                                    or conv.wino_f16)
+                                                                    or conv.wino_f16 or conv.wgrad_f16q_ok(pre.shape[2], pre.shape[3]))
         dpre_amax = ops.amax_slots(pre.device) if need_amax else None
         if (conv.depthwise and FUSE_DW_BNBWD and (FUSE_DW_BWD or x.lazy is not None) and relu and residual is None and gate is None
                 and post_scale is None and x.requires_grad):

@@ -324,6 +324,33 @@ def test_f16x3_dgrad_adds_the_gated_identity_gradient(ops, case):
     assert torch.equal(out_a, out_b) and torch.equal(part_a, part_b)
 
 
+@pytest.mark.parametrize('spread', [0.0, 2.5])
+@pytest.mark.parametrize('case', [(2, 64, 64, 32, 32, 3, 1), (1, 32, 64, 20, 32, 3, 1), (2, 32, 32, 16, 48, 3, 2), (1, 64, 160, 12, 16, 3, 4),
+                                  (2, 256, 64, 16, 16, 1, 1), (1, 48, 24, 10, 12, 1, 1), (3, 16, 40, 9, 16, 3, 1)])
+def test_wgrad_f16x3_on_the_quad_kernel(ops, case, spread):
+    """pfst_conv_wgrad_f16x3_q: the weight gradient of the direct stride-1 3x3 layers (stems, layer1) and of 1x1 layers with <= 64 output
+    channels with the f16x3 split on the K-quad kernel -- interior / edge K-steps, dilations, ragged channel counts, accumulation; as close
+    to fp64 as the whole-line f16x3 kernel is held (3e-6), on wide-range operands too."""
+    n, ci, co, H, W, k, d = case
+    p = d if k == 3 else 0
+    x = torch.randn(n, ci, H, W, generator=g(1))
+    dy = torch.randn(n, co, H, W, generator=g(4))
+    if spread:
+        x = x * 3e4 * torch.exp(spread * torch.randn(x.shape, generator=g(7)))
+        dy = dy * 1e-6 * torch.exp(spread * torch.randn(dy.shape, generator=g(9)))
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, k, k), dy.double(), 1, p, d)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    dw = torch.zeros(co, ci, k, k, device=DEV)
+    ops.conv_wgrad_f16q_(dw, xd, dyd, ops.absmax(xd), ops.absmax(dyd), k, d)
+    assert_close(dw, dw_ref, 3e-6, 'f16x3 quad wgrad')
+    e16 = rel_err(dw, dw_ref)
+    ops.conv_wgrad_f16q_(dw, xd, dyd, ops.absmax(xd), ops.absmax(dyd), k, d)                 # accumulates (fp32 atomics)
+    assert_close(dw, 2 * dw_ref, 3e-6, 'f16x3 quad wgrad accumulate')
+    ref32 = torch.zeros(co, ci, k, k, device=DEV)
+    ops.conv_wgrad_(ref32, xd, dyd, k, 1, d, p)                                               # the fp32-input MFMA kernel on the same data, for scale:
+    assert e16 <= 3 * rel_err(ref32, dw_ref) + 2e-7                                           # both a few 1e-7 (measured 0.8e-7 fp32, 1-2e-7 f16x3)
+
+
 def test_f16x3_refuses_shapes_it_does_not_cover(ops):
     from pfst_amd._lib import PfstHipError
     x = torch.randn(1, 48, 8, 8, device=DEV)

@@ -7,5 +7,5 @@ for L in off on off on; do
   $PRE python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-alt-math 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']; h=d['hbm_kernels']
-print('$L', round(d['value'],3), round(d['ms_per_step'],2), {n:h[n]['ms_per_step'] for n in ('pfst_bn_apply','pfst_bn_backward')}, {n:v for n,v in k.items() if 'igemm' in n or 'wgrad_q' in n})"
+print('$L', round(d['value'],3), round(d['ms_per_step'],2), {n:h[n]['ms_per_step'] for n in ('pfst_bn_apply','pfst_bn_backward')}, {n:v for n,v in k.items() if 'wgrad' in n})"
 done
