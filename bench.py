@@ -11,7 +11,10 @@
 One "step" = one full PFGST.train_step (student fwd/bwd on source + mixed batch, EMA-teacher forward, pseudo labels,
 class mix, PFGSTLoss, backward, gradient all-reduce, AdamW) on a synthetic batch of 8 x 1024x1024x3 tiles per GPU that
 is resident in HBM before the timed region.  value = global images / s (one image = one source+target pair).
-Rank 0 prints ONE JSON line."""
+Rank 0 prints ONE JSON line.  `value` is the product configuration (teacher pass and weight gradients on side streams); the
+dominant kernel's `roofline` comes from a second timed region of the same K steps on ONE stream (`alt_single_stream`), because a
+kernel's duration is only defined while nothing else shares the CUs.  `per_rank` / `rank_spread`: step time min / mean / max,
+the reducer's buckets, the all-reduce time the backward sweep did not hide, the host's wait in the step's one blocking read."""
 import argparse
 import json
 import os
@@ -276,7 +279,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--per-layer', action='store_true', help='debug: per-layer conv timing table on stderr')
-    ap.add_argument('--no-alt-math', action='store_true', help='skip the informational passes: stream overlap, the other arithmetic (N=1 only)')
+    ap.add_argument('--no-alt-math', action='store_true', help='skip the informational passes: the other two arithmetics (N=1 only)')
     ap.add_argument('--math', choices=['f32', 'bf16x6', 'f16x3'], default=None, help='arithmetic of the dense convolutions for `value` '
                     '(default: the product default, pfst_amd.layers.CONV_MATH / PFST_CONV_MATH)')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port when bench.py starts the ranks itself')
@@ -325,6 +328,7 @@ def main():
     assert args.gpus == world, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import pfst_amd  # noqa: F401
+    from pfst_amd import dist as pdist
     from pfst_amd import hip_ops, layers, strong_aug  # noqa: F401
     from pfst_amd.hostinfo import usable_cpus
     from pfst_amd.optim import build_optimizer, poly_lr
@@ -349,20 +353,23 @@ def main():
         model.to(dev)
         return model, build_optimizer(model, OPTIMIZER)
 
-    def run_steps(model, opt, n):
+    def run_steps(model, opt, n, times=None):
         for _ in range(n):
+            t0 = time.perf_counter()
             for g in opt.param_groups:
                 g['lr'] = poly_lr(OPTIMIZER['lr'], state['it'], cfg['max_iters'])
             out = model.train_step(batch, opt)
             state['it'] += 1
+            if times is not None:
+                times.append(time.perf_counter() - t0)      # host clock: every step ends in its one blocking read of the log vector
         return out
 
-    def timed_steps(model, opt, n):
+    def timed_steps(model, opt, n, times=None):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        out = run_steps(model, opt, n)
+        out = run_steps(model, opt, n, times)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -399,10 +406,10 @@ def main():
         fam = {'f32': lambda k: 'split' not in k and 'f16x3' not in k, 'bf16x6': lambda k: 'split' in k, 'f16x3': lambda k: 'f16x3' in k}[math]
         cand = {k: v for k, v in mfma.items() if fam(k)} or mfma
         dom = max(cand.items(), key=lambda kv: kv[1][1])
-        measured_in = 'second pass (all launches bracketed)'
+        measured_in = 'table pass (single stream, all launches bracketed)'
         if dom_agg and dom[0] in dom_agg:          # the expected dominant kernel: its launches inside the TIMED region
             dom = (dom[0], dom_agg[dom[0]])
-            measured_in = 'timed region'
+            measured_in = 'timed single-stream region of this run (the K steps after the `value` region, one stream: a kernel duration needs the device to itself)'
         cnt, ms, fl, nb = dom[1]
         # roofline.achieved = ALGORITHMIC flops per launch / the kernel's average launch duration, against the dense peak of the
         # matrix pipe the kernel runs on.  A split kernel executes `mult` MFMA flops per algorithmic flop (3 for f16x3, 6 for bf16x6):
@@ -448,52 +455,67 @@ def main():
         out['kernel_time_total_ms_per_step'] = tot_ms / args.steps
         return out
 
-    def measure(math, with_overlap_leg):
-        """one arithmetic: warm-up, the timed K steps (only the dominant kernel's launches bracketed), the table pass, the overlap leg"""
+    def measure(math, tables=True):
+        """one arithmetic: warm-up; the timed K steps of the PRODUCT configuration (`value`: teacher pass forked, weight gradients on the
+        side stream -- layers.FORK_TEACHER / WGRAD_STREAM, nothing bracketed); then the same K steps on ONE stream with the dominant
+        kernel's launches bracketed by HIP events (a per-kernel duration is only defined while nothing co-runs on the CUs: `roofline`,
+        and the single-stream step as `alt_single_stream`); then the table pass (every launch bracketed)."""
         model, opt = build(math)
         dominant = DOMINANT_KERNEL[math]
+        product = (layers.WGRAD_STREAM, layers.FORK_TEACHER)
         hip_ops.call = timer.inner
         run_steps(model, opt, args.warmup)
         rec = {}
-        # Timed region: only the dominant kernel's launches are bracketed with events (its roofline figure must come from the very
-        # steps `value` is measured on, and 2700 event pairs per step would cost the step 1.5-2 %).
-        timing = not args.no_kernel_timing
-        if timing and not args.per_layer:
-            hip_ops.call = timer.call
-            timer.records, timer.only, timer.enabled, timer.per_layer = [], dominant, True, False
-        elapsed, out = timed_steps(model, opt, args.steps)
-        timer.enabled = False
-        hip_ops.call = timer.inner
-        dom_agg = timer.summary() if timing and not args.per_layer else None
-        timer.records = []
+        pdist.STEP_STATS = []
+        step_s = []
+        elapsed, out = timed_steps(model, opt, args.steps, step_s)
+        stats, pdist.STEP_STATS = pdist.STEP_STATS, None
+        mine = dict(rank=rank, step_ms=dict(min=round(1e3 * min(step_s), 2), mean=round(1e3 * sum(step_s) / len(step_s), 2), max=round(1e3 * max(step_s), 2)),
+                    **pdist.summarize_step_stats(stats))
         if world > 1:
             t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
         rec.update(value=b * world * args.steps / elapsed, unit='images/s', ms_per_step=1000.0 * elapsed / args.steps,
-                   loss=out['log_vars'].get('decode.loss_ce'))
-        if timing and rank == 0:
-            rec.update(kernel_tables(model, opt, math, dom_agg))
-        elif timing:
-            run_steps(model, opt, args.steps)          # keep the ranks in step (collectives inside train_step)
-        if with_overlap_leg:
-            # informational: the same step with stream-level overlap (weight gradients on a side stream beside the BatchNorm-backward /
-            # data-gradient chain, teacher forward forked beside the student's source pass).  Kept out of `value`: with kernels of several
-            # streams sharing the CUs, per-kernel event durations stop describing the kernel, and the roofline leg is measured in the
-            # same timed region as `value`.
-            layers.set_overlap(True, True)
-            run_steps(model, opt, max(1, args.warmup))
-            dt, _ = timed_steps(model, opt, args.steps)
+                   loss=out['log_vars'].get('decode.loss_ce'), per_rank=per_rank,
+                   streams='teacher forward forked + weight gradients on a side stream' if any(product) else 'one stream')
+        if world > 1:
+            means = [r['step_ms']['mean'] for r in per_rank]
+            rec['rank_spread'] = dict(step_ms_mean_min=min(means), step_ms_mean_max=max(means),
+                                      slowest_rank=int(max(range(world), key=lambda i: means[i])),
+                                      exposed_allreduce_ms_mean_max=max((r['exposed_allreduce_ms'] or {}).get('mean', 0.0) for r in per_rank))
+        timing = not args.no_kernel_timing
+        if timing:
+            # Single-stream region: the same K steps, only the dominant kernel's launches bracketed with events (2700 event pairs per step
+            # would cost the step 1.5-2 %, these 272 cost 1 ms).  Its roofline figure is an average over launches that own the device.
             layers.set_overlap(False, False)
-            rec['with_stream_overlap'] = {'mode': 'weight gradients on a side stream + teacher forward forked (opt-in: PFST_WGRAD_STREAM=1 '
-                                                  'PFST_FORK_TEACHER=1)', 'value': b * args.steps / dt, 'unit': 'images/s',
-                                          'ms_per_step': 1000.0 * dt / args.steps}
+            run_steps(model, opt, 1)
+            if not args.per_layer:
+                hip_ops.call = timer.call
+                timer.records, timer.only, timer.enabled, timer.per_layer = [], dominant, True, False
+            elapsed1, _ = timed_steps(model, opt, args.steps)
+            timer.enabled = False
+            hip_ops.call = timer.inner
+            dom_agg = timer.summary() if not args.per_layer else None
+            timer.records = []
+            rec['single_stream'] = {'mode': 'the same step on one stream (PFST_WGRAD_STREAM=0 PFST_FORK_TEACHER=0), dominant kernel bracketed: the '
+                                            'region `roofline` is measured in', 'value': b * args.steps / elapsed1, 'unit': 'images/s (this rank)',
+                                    'ms_per_step': 1000.0 * elapsed1 / args.steps}
+            if rank == 0 and tables:
+                rec.update(kernel_tables(model, opt, math, dom_agg))
+            elif tables:
+                run_steps(model, opt, args.steps)          # keep the ranks in step (collectives inside train_step)
+            layers.set_overlap(*product)
         rec['hbm_peak_allocated_GB'] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
         del model, opt
         torch.cuda.empty_cache()
         return rec
 
-    main = measure(main_math, with_overlap_leg=world == 1 and not args.no_alt_math)
+    main = measure(main_math)
     res = None
     if rank == 0:
         global_batch = b * world
@@ -512,12 +534,16 @@ def main():
         for k in ('roofline', 'roofline_wgrad', 'mfma_all_convs', 'hbm_kernels', 'kernel_ms_per_step', 'kernel_time_total_ms_per_step'):
             if k in main:
                 res[k] = main[k]
-        if 'with_stream_overlap' in main:
-            res['alt_streams'] = main['with_stream_overlap']
+        for k in ('per_rank', 'rank_spread', 'streams'):
+            if k in main:
+                res[k] = main[k]
+        if 'single_stream' in main:
+            res['alt_single_stream'] = main['single_stream']
     if world == 1 and not args.no_alt_math:
         # the other arithmetic on the same step, same line: fp32-input MFMA (v_mfma_f32_32x32x2_f32) when `value` runs the
         # fp32-faithful bf16x6 split, and vice versa -- with its own roofline leg
-        alt = measure(other_math, with_overlap_leg=True)
+        alt = measure(other_math)
+        alt.pop('per_rank', None)
         alt['mode'] = MATH_DTYPE[other_math] + '; PFST_CONV_MATH=' + other_math
         alt.pop('hbm_kernels', None)
         res['alt_math'] = alt

@@ -574,8 +574,7 @@ extern "C" int pfst_conv_wgrad_f16x3_q(const float* x, long long x_bs, const flo
 
 // true if the quad path applies (the caller has validated the geometry already)
 bool pfst_wgrad_q_eligible(const float* x, i64 x_bs, const float* dy, i64 dy_bs, int Hi, int Wi, int Ho, int Wo, int ksize, int stride, int dil) {
-  static const bool off = getenv("PFST_WGRAD_QUAD") && atoi(getenv("PFST_WGRAD_QUAD")) == 0;
-  if (off || stride != 1) return false;
+  if (stride != 1) return false;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) return false;
   if ((x_bs | dy_bs) & 3) return false;
   if (ksize == 1) return ((i64)Ho * Wo) % 4 == 0 && Hi == Ho && Wi == Wo;

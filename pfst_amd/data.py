@@ -375,11 +375,13 @@ class BatchLoader:
 
     def __init__(self, loader, device):
         self._loader = loader
-        self._it = iter(loader)
-        self._gen = device_prefetch(self._it, device) if device is not None else self._it
+        # read the sampler BEFORE iter(loader): torch's multi-process iterator pulls prefetch_factor * workers batches from it inside its
+        # constructor, which can carry a short epoch's sampler past the epoch the run starts in
         bs = loader.batch_sampler
         self._start_epoch = bs.epoch
         self._per_epoch = max(1, len(epoch_indices(bs.n, bs.world, bs.rank, bs.epoch, bs.seed)) // bs.batch_size)
+        self._it = iter(loader)
+        self._gen = device_prefetch(self._it, device) if device is not None else self._it
         self._delivered = 0
 
     def __iter__(self):

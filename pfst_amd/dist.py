@@ -23,6 +23,45 @@ BUCKET_ELEMS = int(float(os.environ.get('PFST_DDP_BUCKET_MB', '16')) * (1 << 20)
 FORCE_EXCHANGE = os.environ.get('PFST_DDP_FORCE', '0') == '1'
 
 
+# Step statistics of the exchange (bench.py, tests): a list that receives one dict per train step -- sizes of the buckets the reducer launched,
+# the time the main stream stalled in GradReducer.finish() (= the all-reduce the backward sweep did NOT hide; HIP events on CUDA tensors, host
+# clock on gloo), and the host's wait in the step's single blocking read.  None (the default): nothing is recorded, no event is created.
+STEP_STATS = None
+
+
+def step_stats_begin():
+    """-> the dict of the step that starts now, or None when nothing collects statistics"""
+    if STEP_STATS is None:
+        return None
+    STEP_STATS.append(dict(bucket_elems=[], exposed_allreduce=None, host_read_s=None))
+    return STEP_STATS[-1]
+
+
+def resolve_step_stats(stats):
+    """event pairs -> milliseconds (call after a device synchronisation); returns the list"""
+    for d in stats:
+        ev = d.get('exposed_allreduce')
+        if isinstance(ev, tuple):
+            d['exposed_allreduce'] = None
+            d['exposed_allreduce_ms'] = ev[0].elapsed_time(ev[1])
+        elif 'exposed_allreduce_ms' not in d:
+            d['exposed_allreduce_ms'] = None
+    return stats
+
+
+def summarize_step_stats(stats):
+    """per-rank summary for the bench line: the reducer's buckets (sizes of the LAST step: the schedule is static), exposed all-reduce and host
+    read time as min / mean / max over the steps"""
+    def mmm(vals, scale=1.0):
+        vals = [v * scale for v in vals if v is not None]
+        return None if not vals else dict(min=round(min(vals), 3), mean=round(sum(vals) / len(vals), 3), max=round(max(vals), 3))
+    resolve_step_stats(stats)
+    last = stats[-1] if stats else {}
+    return dict(steps=len(stats), buckets=len(last.get('bucket_elems', [])), bucket_MB=[round(4e-6 * n, 2) for n in last.get('bucket_elems', [])],
+                exposed_allreduce_ms=mmm([d.get('exposed_allreduce_ms') for d in stats]),
+                host_read_ms=mmm([d.get('host_read_s') for d in stats], 1000.0))
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_EXCHANGE)
 
@@ -130,6 +169,7 @@ class GradReducer:
         self.hi = flat.numel()               # everything at or above `hi` is already on its way
         self.min_bucket = BUCKET_ELEMS if min_bucket is None else min_bucket
         self.pending = []
+        self.stats = None                    # the step's statistics dict (step_stats_begin), set by the caller that collects them
 
     def _launch(self, lo, hi):
         if hi <= lo:
@@ -137,6 +177,8 @@ class GradReducer:
         from . import layers
         layers.join_side_stream()            # weight gradients queued on a side stream (opt-in overlap) must have landed
         chunk = self.flat[lo:hi]
+        if self.stats is not None:
+            self.stats['bucket_elems'].append(hi - lo)
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         self.pending.append((dist.all_reduce(chunk, op=op, group=self.group, async_op=True), chunk))
 
@@ -150,9 +192,25 @@ class GradReducer:
     def finish(self):
         self._launch(0, self.hi)
         self.hi = 0
+        t0 = ev0 = None
+        if self.stats is not None:
+            # how long this stream stalls for collectives the sweep did not hide: on RCCL work.wait() only orders the stream behind the
+            # collective, so the stall is the time between two events around the waits; on gloo wait() blocks the host
+            if self.flat.is_cuda:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            else:
+                import time
+                t0 = time.perf_counter()
         for work, chunk in self.pending:
             work.wait()
             if not self.avg:
                 chunk.mul_(1.0 / self.world)
+        if ev0 is not None:
+            ev1.record()
+            self.stats['exposed_allreduce'] = (ev0, ev1)
+        elif t0 is not None:
+            import time
+            self.stats['exposed_allreduce_ms'] = 1000.0 * (time.perf_counter() - t0)
         self.pending = []
         return self.flat

@@ -124,6 +124,9 @@ class Tape:
                 obs(tag, 'post')
             else:
                 fn()
+        # weight gradients queued on the side stream (layers.WGRAD_STREAM) are ordered before whatever the caller does next on this stream
+        from . import layers
+        layers.join_side_stream()
 
 
 class ParamArena:

@@ -400,6 +400,12 @@ def conv_wgrad_split_(dw, x, dy, ksize, stride=1, dil=1, pad=0):
     return dw
 
 
+def wgrad_q_operands_ok(x, dy):
+    """the operand layout the K-quad weight-gradient kernels need beyond the layer's shape (pfst_wgrad_q_eligible, csrc/conv_wgrad_q.hip):
+    16-byte aligned planes, batch strides in whole float4s.  A caller that fails this takes the generic kernel instead of an error."""
+    return x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0 and _bs(x) % 4 == 0 and _bs(dy) % 4 == 0
+
+
 def conv_wgrad_f16q_(dw, x, dy, x_amax, dy_amax, ksize, dil=1):
     """dw += dL/dw of a stride-1 'same' convolution (1x1, or 3x3 with pad == dil) with the f16x3 split on the K-quad kernel (fp32 atomics):
     the direct 3x3 layers of the stems / layer1 and the 1x1 layers with <= 64 output channels"""

@@ -37,6 +37,9 @@ def amax_of(v):
     """device slot group with max |v.data| of a Var: published by the kernel that produced the tensor (bn_apply, the Winograd
     transforms) or, failing that, computed once here; kept on the Var -- an activation usually feeds several GEMMs"""
     if v.amax is None:
+        if v.lazy is not None:
+            raise RuntimeError('a deferred conv -> BN -> ReLU output (conv_bn_act(defer=True): never materialised) has a second consumer; '
+                               'only the single depthwise layer / max-pool that normalises on load may read it')
         v.amax = ops.absmax(v.data)
     return v.amax
 
@@ -483,6 +486,9 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
 
 def conv_forward(x, conv, tape, out=None):
     """bare convolution (used by conv_seg); returns Var"""
+    if x.lazy is not None:
+        raise RuntimeError('conv_forward on a deferred conv -> BN -> ReLU output (conv_bn_act(defer=True)): only a depthwise conv_bn_act or the '
+                           'max-pool normalises on load')
     xd = x.data
     if conv.depthwise:
         assert conv.k == 3 and conv.stride == 1 and conv.padding == conv.dilation
@@ -503,12 +509,14 @@ def conv_forward(x, conv, tape, out=None):
     return yv
 
 
-# Stream-level overlap (opt-in): weight gradients on a high-priority side stream beside the BatchNorm-backward /
-# data-gradient chain (with the wgrad kernels capped to 2 workgroups per CU so the chain's HBM-bound kernels find room), and the
-# teacher's forward pass forked beside the student's source pass.  +2.3 % step throughput, but per-kernel durations measured
-# with events then include time-sharing, so bench.py's roofline leg runs with both OFF (the default).
-WGRAD_STREAM = os.environ.get('PFST_WGRAD_STREAM', '0') == '1'
-FORK_TEACHER = os.environ.get('PFST_FORK_TEACHER', '0') == '1'
+# Stream-level overlap (default since round 5): weight gradients on a high-priority side stream beside the
+# BatchNorm-backward / data-gradient chain (with the wgrad kernels capped to 2 workgroups per CU so the chain's HBM-bound kernels find
+# room), and the teacher's forward pass forked beside the student's source pass.  Same-process rotating A/B on one box
+# (tools/ab_streams.py, profiles/r05_ab_streams.txt): 291.0 ms single stream, 288.6 forked teacher, 288.7 side-stream weight
+# gradients, 286.3 both.  Per-kernel durations measured with events then include time-sharing, so bench.py measures its roofline leg
+# in a single-stream region of the same run (set_overlap(False, False)).  PFST_WGRAD_STREAM=0 / PFST_FORK_TEACHER=0: one stream.
+WGRAD_STREAM = os.environ.get('PFST_WGRAD_STREAM', '1') == '1'
+FORK_TEACHER = os.environ.get('PFST_FORK_TEACHER', '1') == '1'
 WGRAD_STREAM_LDS_PAD = 24000
 _side_stream = None
 _teacher_stream = None
@@ -569,7 +577,7 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
         ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                               dy_amax if dy_amax is not None else ops.absmax(dy))
-    elif conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3]):
+    elif conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3]) and ops.wgrad_q_operands_ok(xd, dy):
         ops.conv_wgrad_f16q_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                              dy_amax if dy_amax is not None else ops.absmax(dy), conv.k, conv.dilation)
     elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
@@ -698,7 +706,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     if residual is not None:
         residual.claim_first_use()
     in_hw = xd.shape[-2:]
-    if final and x.lazy is None and x.requires_grad and not WGRAD_STREAM and conv.dgrad_can_gate(in_hw):
+    if final and x.lazy is None and x.requires_grad and conv.dgrad_can_gate(in_hw):
         x.gate_consumer = True            # this layer's data gradient completes dL/dx and can add a gated identity-branch gradient (Var.pending)
     if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and not defer and not conv.depthwise \
             and (pre.shape[2] * pre.shape[3]) % 256 == 0:

@@ -567,6 +567,9 @@ class EncoderDecoder(nn.Module):
         """base.py:74-99: one view -> simple_test, several -> aug_test"""
         if isinstance(imgs, (list, tuple)):
             if len(imgs) != 1:
+                if img_metas is None or len(img_metas) != len(imgs):
+                    raise ValueError(f'forward_test with {len(imgs)} augmented views needs one img_metas list per view (ori_shape, flip), '
+                                     f'got {None if img_metas is None else len(img_metas)}')
                 return self.aug_test(list(imgs), list(img_metas), **kwargs)
             imgs, img_metas = imgs[0], (img_metas[0] if img_metas else None)
         return self.simple_test(imgs, img_metas, **kwargs)

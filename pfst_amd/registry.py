@@ -47,8 +47,12 @@ def _register_builtin_types():
     model code"""
     global _REGISTERED
     if not _REGISTERED:
-        _REGISTERED = True
-        from . import models, uda  # noqa: F401
+        _REGISTERED = True              # set first: the modules' own decorators re-enter the registry while they import
+        try:
+            from . import models, uda  # noqa: F401
+        except BaseException:
+            _REGISTERED = False         # a failed import (libpfst_hip.so missing, ...) must surface on EVERY lookup, not only the first
+            raise
 
 
 MODELS = Registry('models')

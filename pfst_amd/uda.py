@@ -374,8 +374,10 @@ class PFGST(UDADecorator):
         # ---- student on source.  Data-parallel runs: this pass is recorded first, so its closures run LAST in the single backward
         # sweep -- its marker closures tell the reducer which tail of the gradient arena is final (dist.GradReducer)
         reducer = grad_ready = None
+        step_stats = pdist.step_stats_begin()
         if pdist.is_distributed() and pdist.OVERLAP_ALLREDUCE:
             reducer = pdist.GradReducer(arena.grad)
+            reducer.stats = step_stats
             cuts = {'heads': arena.offsets[next(n for n in arena.names if not n.startswith('backbone.'))]}
             for n in arena.names:
                 stage = n.split('.')[1] if n.startswith('backbone.layer') else None
@@ -472,13 +474,26 @@ class PFGST(UDADecorator):
             if reducer is not None:
                 reducer.finish()                       # the tail buckets have been in flight since the source pass's backward
             else:
+                if step_stats is not None:
+                    step_stats['bucket_elems'].append(arena.grad.numel())
+                    if arena.grad.is_cuda:
+                        ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev[0].record()
                 pdist.allreduce_mean_(arena.grad)      # student gradients only; the teacher stays rank-local
+                if step_stats is not None and arena.grad.is_cuda:
+                    ev[1].record()
+                    step_stats['exposed_allreduce'] = ev
             for loss_module in (self.aux_losses if self.apply_aux else []):
                 for p in loss_module.parameters():     # trainable parameters of an auxiliary loss (PFGSTLoss.proj_net)
                     if p.grad is not None:
                         pdist.allreduce_mean_(p.grad.view(-1))
             packed = pdist.reduce_log_vector(packed)
+        if step_stats is not None:
+            import time
+            t_read = time.perf_counter()
         vals = packed.cpu().tolist()                                      # the step's single blocking read
+        if step_stats is not None:
+            step_stats['host_read_s'] = time.perf_counter() - t_read
         log_vars = OrderedDict(zip(names, vals))
         for k in [k for k in log_vars if k.rsplit('.', 1)[-1].startswith('_')]:
             v = log_vars.pop(k)                 # not a log value: the CE kernels' count of labels outside [0, C) / ignore_index

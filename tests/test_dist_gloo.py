@@ -25,6 +25,8 @@ def _worker(rank, world, port, q):
     # the overlapped, bucketed reducer: tails of the arena are launched as they become final, the rest at finish()
     arena = base * (rank + 1)
     red = pdist.GradReducer(arena, min_bucket=1000)
+    pdist.STEP_STATS = []
+    red.stats = pdist.step_stats_begin()      # what bench.py collects per step: bucket sizes, the wait in finish()
     red.ready(90_000)            # [90000, n) goes out
     red.ready(89_500)            # smaller than a bucket: deferred
     arena[:60_000] += 1.0        # "the backward sweep" keeps writing the part that is not final yet
@@ -34,6 +36,10 @@ def _worker(rank, world, port, q):
     expect = base * 1.5
     expect[:60_000] += 1.0
     ok1 = ok1 and torch.allclose(arena, expect, rtol=1e-6, atol=1e-6) and not red.pending
+    summ = pdist.summarize_step_stats(pdist.STEP_STATS)
+    pdist.STEP_STATS = None
+    ok1 = ok1 and summ['buckets'] == 3 and abs(sum(summ['bucket_MB']) - 4e-6 * n) < 0.02 and summ['exposed_allreduce_ms']['mean'] >= 0.0
+    ok1 = ok1 and pdist.step_stats_begin() is None                      # nothing is recorded unless somebody collects
     q.put((rank, bool(ok1), bool(ok2)))
     dist.destroy_process_group()
 

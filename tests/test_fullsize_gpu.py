@@ -233,6 +233,88 @@ def test_whole_train_step_at_baseline_size(math):
         assert float((grads[0].cpu() - g32).norm() / g32.norm()) < 1e-1
 
 
+def test_forward_at_baseline_tile_size_matches_oracle():
+    """HIP vs the oracle at the BASELINE tile size: the teacher's `encode_decode` and the source student's
+    `forward_train` at b = 2 x 1024^2, forward only (the oracle needs ~20-40 s of the box's host cores for the two passes).  At this size
+    the feature planes are 128 x 128 (the whole-plane LDS depthwise kernels of the ASPP head: asserted to have run), a 1/8-grid GEMM has
+    128 pixel tiles per image (256-row tiles walked as chains: asserted), a Winograd layer 1024 tiles per plane.  Checked: logits and
+    decoded features element-wise (1e-3 max|ref| + 1e-3 |ref|), pseudo labels (mismatch < 2e-3 end to end, bit-exact on identical
+    logits), CE / accuracy of both heads to 1e-3.
+    Follows /root/reference/rsiseg/models/segmentors/encoder_decoder.py:72-84,166-217, decode_heads/sep_aspp_head.py:79-111."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from helpers import seeded_pfgst_state, uda_cfg
+    from oracle import pfst_oracle as O
+    import pfst_amd  # noqa: F401
+    from pfst_amd import hip_ops, layers
+    from pfst_amd._lib import lib
+    from pfst_amd.hostinfo import usable_cpus
+    from pfst_amd.registry import UDA
+    from pfst_amd.synthetic import synth_batch
+    assert layers.CONV_MATH == os.environ.get('PFST_CONV_MATH', 'f16x3')
+    b, S, C, thr = 2, 1024, 6, 0.30
+    torch.set_num_threads(usable_cpus())
+    both, student, teacher = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=777)
+    teacher_o, student_o = ({k: v.clone() for k, v in sd.items()} for sd in (teacher, student))      # the oracle updates BN buffers in place
+    with torch.no_grad():
+        o_up, o_dec, o_low = O.encode_decode(teacher_o, batch['target_img'])
+        o_pl, o_w, o_nconf = O.pseudo_label(o_up, thr)
+        del o_up
+        o_losses, _, o_logits, o_sdec, o_aux = O.segmentor_forward_train(student_o, batch['img'], batch['gt_semantic_seg'], None)
+    model = UDA.build(uda_cfg(threshold=thr))
+    model.load_state_dict(both, strict=False)
+    model.cuda()
+    dev = torch.device('cuda')
+    model._ensure_arenas(dev)
+    stu, ema = model.get_model(), model.get_ema_model()
+    stu.repack_weights(need_dgrad=False)
+    ema.repack_weights(need_dgrad=False)
+    seen, inner = {}, hip_ops.call
+
+    def counting(name, *a):
+        seen[name] = seen.get(name, 0) + 1
+        return inner(name, *a)
+    hip_ops.call = counting
+    try:
+        ema_logits, ema_states = ema.encode_decode(batch['target_img'].cuda().contiguous(), batch['target_img_metas'])
+        pl64, pl8, conf = hip_ops.pseudo_label(ema_logits.data, (S, S), thr)[:3]
+        out = stu.forward_train(batch['img'].cuda().contiguous(), batch['img_metas'], hip_ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                return_logits=True, return_decoded_feats=True, tape=None)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.call = inner
+    # the full-size machinery ran: the fused three-branch depthwise launch (whole 128 x 128 planes in LDS), and the large 1x1 GEMMs as
+    # tile chains -- layer4.conv3 has b * 128 pixel tiles * 16 row blocks of 128 = more tiles than resident workgroups
+    assert seen.get('pfst_dwconv3x3_multi_fwd', 0) == 2, seen
+    if layers.CONV_MATH == 'f16x3':
+        tiles = b * (S // 8) * (S // 8) // 128 * (2048 // 128)
+        assert lib().pfst_f16x3_chain_grid(tiles, 1) < tiles
+        assert seen.get('pfst_conv_igemm_f16x3', 0) >= 2 * 40 and seen.get('pfst_wino_gemm_f16x3', 0) >= 2 * 14, seen
+
+    def elementwise(a, ref, what, tol=1e-3):
+        a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
+        bound = tol * float(ref.abs().max()) + tol * ref.abs()
+        worst = float(((a - ref).abs() / bound).max())
+        nrm = float((a - ref).norm() / ref.norm())
+        print(f'   {what}: worst element {worst:.3f} of the bound, norm-wise {nrm:.2e}')
+        assert worst <= 1.0 and nrm < tol, (what, worst, nrm)
+    elementwise(ema_logits.data, o_low, 'teacher logits (1/4 resolution)')
+    elementwise(ema_states['decoded_features'].data, o_dec, 'teacher decoded features (512 x 128 x 128)')
+    elementwise(out['logits'].data, o_logits, 'source-student logits')
+    elementwise(out['decoded_features'].data, o_sdec, 'source-student decoded features')
+    mism = 1.0 - (pl64.cpu() == o_pl).float().mean().item()
+    print(f'   end-to-end pseudo-label mismatch rate {mism:.2e}; confident pixels {int(conf.item())} vs {o_nconf}')
+    assert mism < 2e-3, mism
+    assert abs(int(conf.item()) - o_nconf) <= 2e-3 * b * S * S
+    l64 = hip_ops.pseudo_label(o_low.cuda().contiguous(), (S, S), thr)[0]
+    assert torch.equal(l64.cpu(), o_pl), 'pseudo-label kernel must be bit exact on identical logits'
+    for k in ('decode.loss_ce', 'aux.loss_ce', 'decode.acc_seg', 'aux.acc_seg'):
+        got, ref = float(out[k]), float(o_losses[k])
+        assert abs(got - ref) <= 1e-3 * max(abs(ref), 1e-2), (k, got, ref)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs #4 (INRIA, C=2 @1024^2) and #5 (SeasonNet, C=33, 10 bands, downscale=1 @512^2) at their per-GPU size b=8
 # (VERDICT r1 'What's weak' #4): one whole train step each + the kernel identities that depend on C / Cin.

@@ -83,6 +83,10 @@ def test_every_backward_link_as_wired(wino, math):
     # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
     # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
     layers.FUSE_RES_GATE = False
+    # ... on ONE stream (the observer reads what each closure added to the arena right after it ran; the product queues the weight gradients on
+    # a side stream: pinned to the single-stream schedule by test_stream_overlap_options_do_not_change_the_step)
+    prev_overlap = (layers.WGRAD_STREAM, layers.FORK_TEACHER)
+    layers.set_overlap(False, False)
     try:
         model = build_segmentor(model_cfg(C, 3, dropout=0.0))
         model.load_state_dict(student, strict=True)
@@ -216,6 +220,7 @@ def test_every_backward_link_as_wired(wino, math):
     finally:
         layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY = prev, prev_math, prev_dw, prev_defer
         layers.FUSE_RES_GATE = prev_gate
+        layers.set_overlap(*prev_overlap)
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
     for op, name, k, worst, nrm, fe, de, _, _ in sorted(rows, key=lambda r: -r[3])[:25]:

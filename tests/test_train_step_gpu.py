@@ -485,14 +485,15 @@ def test_step_with_backbone_feature_level(level):
 
 
 def test_stream_overlap_options_do_not_change_the_step():
-    """PFST_WGRAD_STREAM / PFST_FORK_TEACHER (layers.set_overlap): weight gradients on a side stream and the teacher's forward
-    forked beside the student's source pass are pure scheduling -- the step gives the same pseudo labels, losses and gradients
+    """PFST_WGRAD_STREAM / PFST_FORK_TEACHER (layers.set_overlap; the product default since round 5): weight gradients on a side stream and
+    the teacher's forward forked beside the student's source pass are pure scheduling -- the step gives the same pseudo labels, losses and gradients
     as the single-stream schedule (to the fp32 atomics' summation-order noise); a second step (after AdamW, which amplifies
     that noise, see above) stays close."""
     from pfst_amd import layers
     from pfst_amd.synthetic import synth_batch
     batch = to_dev(synth_batch(2, 128, 6, seed=77), 'cuda')
     runs = []
+    default = (layers.WGRAD_STREAM, layers.FORK_TEACHER)
     for overlap in (False, True):
         model, opt, _, _ = _build(0.30)
         model.debug = {}
@@ -506,7 +507,7 @@ def test_stream_overlap_options_do_not_change_the_step():
             log1 = model.train_step(batch, opt)['log_vars']
             torch.cuda.synchronize()
         finally:
-            layers.set_overlap(False, False)
+            layers.set_overlap(*default)
         runs.append((log0, pl0, grad0, log1, model._teacher_arena.data.clone().cpu()))
     assert layers._side_stream is not None and layers._teacher_stream is not None, 'the overlap streams were never used'
     (a0, p0, g0, a1, t0), (b0, p1, g1, b1, t1) = runs
