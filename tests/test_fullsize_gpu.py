@@ -291,7 +291,8 @@ def test_forward_at_baseline_tile_size_matches_oracle():
     if layers.CONV_MATH == 'f16x3':
         tiles = b * (S // 8) * (S // 8) // 128 * (2048 // 128)
         assert lib().pfst_f16x3_chain_grid(tiles, 1) < tiles
-        assert seen.get('pfst_conv_igemm_f16x3', 0) >= 2 * 40 and seen.get('pfst_wino_gemm_f16x3', 0) >= 2 * 14, seen
+        # 12 bottleneck conv2 + the head's bottleneck through the Winograd domain per pass, + the auxiliary head's conv in the student pass
+        assert seen.get('pfst_conv_igemm_f16x3', 0) >= 2 * 40 and seen.get('pfst_wino_gemm_f16x3', 0) == 13 + 14, seen
 
     def elementwise(a, ref, what, tol=1e-3):
         a, ref = a.detach().double().cpu(), ref.detach().double().cpu()
