@@ -104,7 +104,10 @@ int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, in
 int pfst_wino_tiles(int H, int W, int dil, int m);
 int pfst_wino_pack_weight(const float* w, float* U_fprop, float* U_dgrad, int Cout, int Cin, int m, pfst_stream_t stream);
 int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
-                    const float* pack_x_amax, pfst_stream_t stream);
+                    const float* pack_x_amax, const float* bnl, pfst_stream_t stream);
+/* bnl != NULL: coef [C][4] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer whose PRE-normalisation output x is (Bottleneck conv1 ->
+ * bn1 -> relu -> conv2, resnet.py:273-281): elements are normalised as they are loaded, the normalised tensor is never written; pack_x_amax
+ * then is the slot group pfst_bn_finalize_partials published the predicted max |relu(bn(x))| to */
 /* v_amax: NULL, or the slot group (1024 floats, zeroed; csrc/amax.h) that receives max |V| (f16x3 scale).  pack_x_amax != NULL: V is
  * written PRE-SPLIT for the f16x3 GEMMs (one dword per element: the two fp16 pieces of V s), scaled from the slot group holding max |x|
  * through the transform's norm bound, and v_amax receives that bound (pass v_packed = 1 / packed = 1 to the consumers) */
@@ -158,7 +161,10 @@ int pfst_conv_pack_weight_f16x2_batched(const pfst_weight_job_t* jobs_host, cons
 int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, const float* w_amax, const float* in_amax,
                           const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
-                          const float* gate_dy, long long gate_dy_bs, const unsigned long long* gate_mask, pfst_stream_t stream);
+                          const float* gate_dy, long long gate_dy_bs, const unsigned long long* gate_mask, int stats_minmax,
+                          pfst_stream_t stream);
+/* stats_minmax != 0 (with stats): stats has room for 4 * M * slots floats; behind the [M][slots][2] (sum, sum of squares) partials the
+ * launch writes [M][slots][2] (minimum, maximum) partials of the output, from which pfst_bn_finalize_partials predicts max |relu(bn(out))| */
 /* gate_dy != NULL (mode 1, accumulate 0, M % 128 == 0, Ho * Wo % 256 == 0): out = data gradient + (bit ? gate_dy : 0), gate_mask = the ReLU
  * bitmask pfst_bn_apply wrote for an [N][M][Ho * Wo] tensor -- the identity branch of a residual block (resnet.py:149-167, out = relu(bn3 +
  * identity)): dL/d(block input) = conv1's data gradient + dL/d(block output) gated by that ReLU, formed in conv1's epilogue instead of
@@ -227,7 +233,11 @@ int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* m
 /* the same from the conv epilogue's partials[C][T][2] (count = N*H*W elements per channel) */
 int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
                               float* running_mean, float* running_var, float momentum, float eps,
-                              const float* gamma, const float* beta, float* coef, pfst_stream_t stream);
+                              const float* gamma, const float* beta, float* coef, const float* minmax, int relu, float* y_amax,
+                              pfst_stream_t stream);
+/* minmax != NULL (with gamma, beta, y_amax): the producer's [C][T][2] (minimum, maximum) partials (pfst_conv_igemm_f16x3 stats_minmax).  BatchNorm
+ * [+ ReLU] is monotone per channel, so the extreme outputs are the images of the extreme inputs: the slot group y_amax receives
+ * max |[relu](bn(x))| -- exactly what pfst_bn_apply(..., y_amax) would publish -- without the normalised tensor being written. */
 /* y = [relu]( (x-mean)*invstd*gamma + beta [+ residual] ).  relu_mask != NULL (needs relu, HW % 256 == 0, 16-byte aligned planes):
  * also writes the ReLU gate as a bitmask of N*C*HW/64 words for pfst_bn_backward -- the backward of a residual layer then reads
  * 1 bit per element instead of the fp32 output y in both of its passes. */

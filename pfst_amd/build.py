@@ -84,6 +84,32 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, extra_flags):
+    """a second build of the library with extra compiler flags (diagnostic -D switches, alternative tunings) as
+    ab_libs/libpfst_hip_<name>.so -- for same-box A/B runs through PFST_HIP_LIB (tools/ab_lib.sh); git-ignored, travels with gpurun"""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    root = os.path.join(HERE, '..', 'ab_libs')
+    objdir = os.path.join(root, name)
+    os.makedirs(objdir, exist_ok=True)
+    objs, procs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + list(extra_flags) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f'{s}: {out.decode()}')
+    lib = os.path.normpath(os.path.join(root, f'libpfst_hip_{name}.so'))
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+    return lib
+
+
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB)
+    if len(sys.argv) > 2 and sys.argv[1] == '--variant':
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        build(force='--force' in sys.argv)
+        print(LIB)

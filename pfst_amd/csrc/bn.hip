@@ -106,12 +106,34 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
                                                                     float* __restrict__ mean, float* __restrict__ invstd,
                                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                                     float momentum, float eps, const float* __restrict__ gamma,
-                                                                    const float* __restrict__ beta, float4* __restrict__ coef) {
+                                                                    const float* __restrict__ beta, float4* __restrict__ coef,
+                                                                    const float* __restrict__ minmax, int relu, float* __restrict__ y_amax) {
   __shared__ double sm[32];
+  __shared__ float mm[2][4];
   const int c = blockIdx.x;
   double s, ss;
   sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, ss);
   block_sum2_d(s, ss, sm);
+  // minmax != NULL: [C][T][2] (minimum, maximum) partials of the same producer -> the channel's extrema of the pre-activation
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  if (minmax) {
+    const float2* q = reinterpret_cast<const float2*>(minmax) + (i64)c * T;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+      const float2 v = q[i];
+      lo = fminf(lo, v.x);
+      hi = fmaxf(hi, v.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, o));
+      hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      mm[0][threadIdx.x >> 6] = lo;
+      mm[1][threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     const double m = s / count;
     double var = ss / count - m * m;
@@ -119,6 +141,19 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     write_coef(coef, gamma, beta, c, mean[c], invstd[c]);
+    if (minmax && y_amax) {
+      // y = [relu](fma(x, sc, sh)) is monotone in x for fixed (sc, sh) -- fma rounds monotonically --, so the channel's extreme outputs are the
+      // images of its extreme inputs: max |y| of the tensor the normalisation pass WOULD write, exactly, before (or without) writing it
+      for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+        lo = fminf(lo, mm[0][w]);
+        hi = fmaxf(hi, mm[1][w]);
+      }
+      float sc, sh;
+      bn_affine(mean[c], invstd[c], gamma[c], beta[c], sc, sh);
+      const float ya = __fmaf_rn(lo, sc, sh), yb = __fmaf_rn(hi, sc, sh);
+      const float am = relu ? fmaxf(fmaxf(ya, yb), 0.f) : fmaxf(fabsf(ya), fabsf(yb));
+      if (am > 0.f) atomicMax(reinterpret_cast<unsigned*>(y_amax) + (c & (PFST_AMAX_SUB - 1)), __builtin_bit_cast(unsigned, am));
+    }
     if (rmean) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
@@ -460,12 +495,14 @@ extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int H
 
 extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, double count, float* mean, float* invstd,
                                          float* running_mean, float* running_var, float momentum, float eps,
-                                         const float* gamma, const float* beta, float* coef, pfst_stream_t stream) {
+                                         const float* gamma, const float* beta, float* coef, const float* minmax, int relu,
+                                         float* y_amax, pfst_stream_t stream) {
   PFST_CHECK_ARG(partials && mean && invstd && T > 0 && C > 0 && count > 0);
   PFST_CHECK_ARG(!coef || (gamma && beta));
   PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  PFST_CHECK_ARG((minmax == nullptr) == (y_amax == nullptr) && (!minmax || (gamma && beta)));
   hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
-                     running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef));
+                     running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef), minmax, relu, y_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -27,30 +27,37 @@ __device__ __forceinline__ float lane_xchg(float v) {
   if (CTRL == 0) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));   // lane ^ 16
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-template <int H, int CTRL>
+// OP: 0 sum, 1 minimum, 2 maximum (the per-channel extrema of the pre-BatchNorm tensor: pfst_bn_finalize_partials predicts max |y| from them)
+template <int OP>
+__device__ __forceinline__ float lane_combine(float a, float b) {
+  return OP == 0 ? a + b : (OP == 1 ? fminf(a, b) : fmaxf(a, b));
+}
+template <int H, int CTRL, int OP = 0>
 __device__ __forceinline__ void butterfly_step(float* a, bool upper) {   // 2H values -> H values
 #pragma unroll
   for (int k = 0; k < H; ++k) {
     const float send = upper ? a[k] : a[k + H];
     const float keep = upper ? a[k + H] : a[k];
-    a[k] = keep + lane_xchg<CTRL>(send);
+    a[k] = lane_combine<OP>(keep, lane_xchg<CTRL>(send));
   }
 }
-template <int NV>
-__device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31) {
+template <int NV, int OP = 0>
+__device__ __forceinline__ float half_wave_transpose_reduce(float (&a)[NV], int l31) {
   static_assert(NV == 32 || NV == 16, "one value per accumulator row of a 64- or 32-row wave tile");
   if (NV == 32) {
-    butterfly_step<16, 0>(a, (l31 & 16) != 0);
+    butterfly_step<16, 0, OP>(a, (l31 & 16) != 0);
   } else {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a[k] += lane_xchg<0>(a[k]);          // both 16-lane rows need all 16 values: plain add
+    for (int k = 0; k < 16; ++k) a[k] = lane_combine<OP>(a[k], lane_xchg<0>(a[k]));      // both 16-lane rows need all 16 values: plain combine
   }
-  butterfly_step<8, 0x140>(a, (l31 & 8) != 0);     // row_mirror      (lane ^ 15)
-  butterfly_step<4, 0x141>(a, (l31 & 4) != 0);     // row_half_mirror (lane ^ 7)
-  butterfly_step<2, 0x4E>(a, (l31 & 2) != 0);      // quad_perm [2,3,0,1]
-  butterfly_step<1, 0xB1>(a, (l31 & 1) != 0);      // quad_perm [1,0,3,2]
+  butterfly_step<8, 0x140, OP>(a, (l31 & 8) != 0);     // row_mirror      (lane ^ 15)
+  butterfly_step<4, 0x141, OP>(a, (l31 & 4) != 0);     // row_half_mirror (lane ^ 7)
+  butterfly_step<2, 0x4E, OP>(a, (l31 & 2) != 0);      // quad_perm [2,3,0,1]
+  butterfly_step<1, 0xB1, OP>(a, (l31 & 1) != 0);      // quad_perm [1,0,3,2]
   return a[0];
 }
+template <int NV>
+__device__ __forceinline__ float half_wave_transpose_sum(float (&a)[NV], int l31) { return half_wave_transpose_reduce<NV, 0>(a, l31); }
 
 // The same reduction through LDS (16 values per lane = the rows of one 32x32 accumulator block): fp32 MFMA and VALU share the
 // vector pipe, so the butterfly's ~3 VALU instructions per exchange come out of the co-resident waves' matrix throughput; LDS
@@ -92,7 +99,10 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
                                               int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs(),
                                               float* __restrict__ lds = nullptr, const float* __restrict__ gsrc = nullptr,
-                                              const unsigned long long* __restrict__ gmask = nullptr) {
+                                              const unsigned long long* __restrict__ gmask = nullptr, float* __restrict__ stats_mm = nullptr) {
+  // stats_mm (with stats, plain path): [M][stats_T][2] = per-channel (minimum, maximum) of this wave's output values -- BatchNorm + ReLU is a
+  // monotone map of the pre-activation per channel, so max |y| of the NORMALISED tensor is attained at one of the two and is known (exactly:
+  // pfst_bn_finalize_partials evaluates the same fma) before y is written: the consumer that normalises as it loads has its f16x3 scale
   // gsrc / gmask (this image's planes; whole row tiles, P % 256 == 0, no bias, accumulate = 0: checked on the host): out = acc + (bit ? gsrc : 0)
   // -- the identity branch of a residual block, dL/d(block input) = conv1's data gradient + dL/d(block output) gated by the block's final
   // ReLU (bn_apply's bitmask: word [row][p >> 8][p & 3], bit (p & 255) >> 2): the gated tensor is never written by BatchNorm backward
@@ -155,6 +165,28 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
     if (l31 < NV && m < M) {
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)m * stats_T + slot);
       *dst = make_float2(ts, tq);
+    }
+    if (stats_mm) {
+      const float inf = __builtin_inff();
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          float lo = inf, hi = -inf;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int pp = p0 + wn0 + j * 32 + l31;
+            const float v = acc[i][j][rr];
+            lo = pp < P ? fminf(lo, v) : lo;
+            hi = pp < P ? fmaxf(hi, v) : hi;
+          }
+          sv[i * 16 + rr] = lo;
+          sq[i * 16 + rr] = hi;
+        }
+      }
+      const float tlo = half_wave_transpose_reduce<NV, 1>(sv, l31);
+      const float thi = half_wave_transpose_reduce<NV, 2>(sq, l31);
+      if (l31 < NV && m < M) reinterpret_cast<float2*>(stats_mm)[(i64)m * stats_T + slot] = make_float2(tlo, thi);
     }
     }
   }
@@ -227,6 +259,9 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[i][j][r];       // (a float temporary: __builtin_bit_cast of the vector-element lvalue reads element 0)
+#ifdef PFST_DIAG_NO_STORE                       // timing-only build (WRONG results): what the output stores of the plain path cost
+            if (v != 1.2345e-30f) continue;
+#endif
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
                                                   4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
           }

@@ -293,7 +293,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // of the current one: after the first tile there is no prologue and no memory latency in front of a tile's first MFMA.  (K <= 512
   // launches spent 4-6 K-steps' worth of time per tile outside the loop: tools/gemm_k_sweep.py.)  Needs an even number of steps (the
   // LDS buffer / register set of a pair is its parity) and the 32x32 loop; otherwise every tile runs its own prologue.
-  const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && chain != 0;
+  const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && (chain & 1) != 0;       // `chain`: bit 0 the tile chain, bit 1 min / max partials
+  float* const stats_mm = (stats && (chain & 2)) ? stats + (i64)2 * M * stats_T : nullptr;      // behind the (sum, sum of squares) partials
 
   const int pix = tid & (BN - 1), kh = (tid >> 7) & 1;   // activation staging: pixel, k-half ...
   const int bt = BM == 256 ? tid >> 8 : 0;               // ... and (256-row tile) which K=16 tile of the pair
@@ -580,7 +581,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         __syncthreads();                                 // before the next tile's first step stores into that buffer
       } else {
         conv_epilogue<TMW, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(), nullptr,
-                                           gsrc, gmask);
+                                           gsrc, gmask, stats_mm);
       }
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
@@ -1371,8 +1372,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                                      int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
                                      const pfst_bnb_fuse_t* bnb, const float* gate_dy, long long gate_dy_bs,
-                                     const unsigned long long* gate_mask, pfst_stream_t stream) {
+                                     const unsigned long long* gate_mask, int stats_minmax, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  // stats_minmax: `stats` has room for 4 * M * slots floats and also receives the per-channel (minimum, maximum) partials behind the sums
+  PFST_CHECK_ARG(!stats_minmax || (stats && !bias && M % 32 == 0 && !(bnb && bnb->x)));
   PfstResGate gate;
   if (gate_dy) {
     // out = conv + (bit ? gate_dy : 0): the epilogue's whole-tile path, the mask's 256-element groups, one writer (no old values)
@@ -1410,7 +1413,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : small ? 64 : 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
-  const int chain = f16x3_chain();
+  const int chain = f16x3_chain() | (stats_minmax ? 2 : 0);
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
     PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);

@@ -145,7 +145,11 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 template <int M>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ V, int N, int C,
                                                          WinoGeom g, int vec, float* __restrict__ amax, const float* __restrict__ pack_amax,
-                                                         int pack_shift) {
+                                                         int pack_shift, const float4* __restrict__ bnl) {
+  // bnl != NULL: x is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this convolution and coef = bnl[c] = (mean, invstd,
+  // sc, sh) of that layer: every in-image element is normalised as it is loaded, max(fma(x, sc, sh), 0) -- the expression and rounding of
+  // bn_apply -- so the normalised tensor is never written (the padding stays zero: it pads the NORMALISED image).  pack_amax then holds
+  // the PREDICTED max |y| (pfst_bn_finalize_partials with the producer's min / max partials).
   // amax != NULL: max |V| over everything this launch writes -> that slot group (amax.h; the f16x3 GEMM's scale of V).
   // pack_amax != NULL (f16x3): V is written PRE-SPLIT -- every element as the two fp16 pieces of V s in one dword (amax.h
   // pack_f16x2_pieces), exactly what the GEMM's in-register split would produce, so the GEMMs that read V (forward product, weight
@@ -166,6 +170,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
   const float* xp = x + (i64)n * x_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * C * g.T;                        // stride between transform indices
   float* vp = V + ((i64)n * C + c) * g.T;
+  float nsc = 1.f, nsh = 0.f;
+  if (bnl) {
+    const float4 cf = bnl[c];
+    nsc = cf.z;
+    nsh = cf.w;
+  }
+  auto norm = [&](float v, bool in) { return bnl ? (in ? fmaxf(__fmaf_rn(v, nsc, nsh), 0.f) : 0.f) : v; };
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.T; t += gridDim.x * blockDim.x) {
     int sy, sx, ty, tx;
     tile_coord(g, t, sy, sx, ty, tx);
@@ -181,10 +192,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int b = 0; b < M; ++b) mid[b] = 0.f;
         if (in) mid = *reinterpret_cast<const vecM*>(row);
-        d[a][0] = (in && x0 > 0) ? row[-1] : 0.f;
+        const bool inl = in && x0 > 0, inr = in && x0 + M < g.W;
+        d[a][0] = norm(inl ? row[-1] : 0.f, inl);
 #pragma unroll
-        for (int b = 0; b < M; ++b) d[a][1 + b] = mid[b];
-        d[a][R - 1] = (in && x0 + M < g.W) ? row[M] : 0.f;
+        for (int b = 0; b < M; ++b) d[a][1 + b] = norm(mid[b], in);
+        d[a][R - 1] = norm(inr ? row[M] : 0.f, inr);
       }
     } else {
 #pragma unroll
@@ -193,7 +205,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int b = 0; b < R; ++b) {
           const int xx = sx + g.d * (M * tx - 1 + b);
-          d[a][b] = (y >= 0 && y < g.H && xx >= 0 && xx < g.W) ? xp[(i64)y * g.W + xx] : 0.f;
+          const bool in = y >= 0 && y < g.H && xx >= 0 && xx < g.W;
+          d[a][b] = norm(in ? xp[(i64)y * g.W + xx] : 0.f, in);
         }
       }
     }
@@ -516,16 +529,17 @@ extern "C" int pfst_weight_prep_batched(const pfst_weight_job_t* jobs_host, cons
 }
 
 extern "C" int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int H, int W, int dil, int m, float* v_amax,
-                               const float* pack_x_amax, pfst_stream_t stream) {
+                               const float* pack_x_amax, const float* bnl, pfst_stream_t stream) {
   PFST_CHECK_ARG(!pack_x_amax || v_amax);
+  PFST_CHECK_ARG(!bnl || ((uintptr_t)bnl & 15) == 0);
   const int shift_in = m == 4 ? 7 : 3;                // (max row sum of |B^T|)^2: 100 for F(4x4), 4 for F(2x2)
   PFST_CHECK_ARG(x && V && N > 0 && N <= 65535 && C > 0 && C <= 65535 && H > 0 && W > 0 && dil >= 1 && x_bs >= (i64)C * H * W);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const int vec = dil == 1 && W % m == 0 && x_bs % m == 0 && ((uintptr_t)x & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), C, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in),
-              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_input_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in, (const float4*)bnl),
+              hipLaunchKernelGGL(wino_input_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x, x_bs, V, N, C, g, vec, v_amax, pack_x_amax, shift_in, (const float4*)bnl));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

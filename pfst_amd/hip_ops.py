@@ -121,13 +121,21 @@ def conv_stats_slots(n, cout, ho, wo):
     return n * lib().pfst_conv_stats_slots(cout, ho, wo)
 
 
-def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None, beta=None):
-    """gamma / beta given: also returns coef [C,4] = (mean, invstd, sc, sh), the record the fused BatchNorm-backward sums read"""
+def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None, beta=None,
+                         predict_amax=None, relu=True):
+    """gamma / beta given: also returns coef [C,4] = (mean, invstd, sc, sh), the record the fused BatchNorm-backward sums read.
+    predict_amax: a zeroed slot group (amax_slots); `stats` then carries the producer's (minimum, maximum) partials behind the sums
+    (conv_fprop_f16x3(want_minmax=True)) and the group receives max |[relu](bn(x))| -- what bn_apply(amax=...) would publish, known before
+    (or without) the normalised tensor being written"""
     mean = torch.empty(c, device=stats.device)
     invstd = torch.empty(c, device=stats.device)
     coef = torch.empty(c, 4, device=stats.device) if gamma is not None else None
+    mm = 0
+    if predict_amax is not None:
+        assert gamma is not None and stats.numel() >= 4 * c * slots
+        mm = stats.data_ptr() + 4 * 2 * c * slots
     call('pfst_bn_finalize_partials', stats.data_ptr(), slots, c, float(count), mean.data_ptr(), invstd.data_ptr(),
-         _p(running_mean), _p(running_var), momentum, eps, _p(gamma), _p(beta), _p(coef), _stream())
+         _p(running_mean), _p(running_var), momentum, eps, _p(gamma), _p(beta), _p(coef), mm, int(relu), _p(predict_amax), _stream())
     return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
@@ -299,16 +307,19 @@ class WeightJobTable:
         call(name, ctypes.addressof(self.host), self.dev.data_ptr(), self.n, _stream())
 
 
-def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False):
+def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False, want_minmax=False):
+    """want_minmax (with want_stats): the statistics scratch also receives the per-channel (minimum, maximum) partials of the output behind
+    the sums -- bn_finalize_partials(predict_amax=...) turns them into max |relu(bn(out))|"""
     n, c, hi, wi = x.shape
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
     assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout, ksize)
     if out is None:
         out = torch.empty(n, cout, ho, wo, device=x.device)
     slots = n * ((ho * wo + 127) // 128) * 2 if want_stats else 0        # two pixel-waves per 128-pixel tile at every tile height
-    st = _stats_ws(x.device, 2 * cout * slots) if want_stats else None
+    want_minmax = bool(want_minmax and want_stats and bias is None)
+    st = _stats_ws(x.device, (4 if want_minmax else 2) * cout * slots) if want_stats else None
     call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, int(want_minmax), _stream())
     return (out, st, slots) if want_stats else out
 
 
@@ -348,7 +359,7 @@ def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, di
         st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
         fuse = ctypes.addressof(st)
     call('pfst_conv_igemm_f16x3', dy.data_ptr(), _bs(dy), wk4_d.data_ptr(), w_amax.data_ptr(), dy_amax.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, g_ptr, g_bs, m_ptr, _stream())
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, g_ptr, g_bs, m_ptr, 0, _stream())
     return (out, part, slots) if bnb is not None else out
 
 
@@ -506,11 +517,14 @@ def wino_pack_weight_f16(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=
     return uf, ud, af, ad
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None):
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None, bnl=None):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
-    (288 GB of HBM: keeping it resident beats re-transforming the input in backward)."""
+    (288 GB of HBM: keeping it resident beats re-transforming the input in backward).
+    bnl: coef [C, 4] of the conv -> BN -> ReLU layer feeding this one: x is that layer's PRE-normalisation output, normalised by the input
+    transform as it loads (x_amax then = the predicted max of the normalised tensor, bn_finalize_partials(predict_amax=...))"""
     n, c, h, w = x.shape
+    assert bnl is None or (tuple(bnl.shape) == (c, 4) and (u_amax is None or x_amax is not None))
     m, nx = _wino_m(m)
     t = wino_tiles(h, w, dil, m)
     assert u.numel() == nx * c * cout * ((4 if u_amax is not None else 6) if u.dtype == U8 else 1), 'filter set was packed for another tile size'
@@ -525,7 +539,8 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     v_amax = amax_slots(x.device) if u_amax is not None else None
     if u_amax is not None and x_amax is None:
         x_amax = absmax(x)
-    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _p(v_amax), _p(x_amax) if u_amax is not None else 0, _stream())
+    call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, c, h, w, dil, m, _p(v_amax), _p(x_amax) if u_amax is not None else 0,
+         _p(None if bnl is None else _dense(bnl)), _stream())
     if u_amax is not None:              # two-piece fp16 filter sets -> f16x3 GEMM
         call('pfst_wino_gemm_f16x3', v.data_ptr(), u.data_ptr(), u_amax.data_ptr(), v_amax.data_ptr(), mb.data_ptr(), n, c, cout, t, m, 1, _stream())
     else:
@@ -562,7 +577,7 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None, x_amax
         v_amax = amax_slots(x.device) if f16 else None
         if f16 and x_amax is None:
             x_amax = absmax(x)
-        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _p(v_amax), _p(x_amax) if f16 else 0, _stream())
+        call('pfst_wino_input', x.data_ptr(), _bs(x), v.data_ptr(), n, ci, h, w, dil, m, _p(v_amax), _p(x_amax) if f16 else 0, 0, _stream())
     assert v.numel() >= nx * n * ci * t
     dm_amax = amax_slots(x.device) if f16 else None
     if f16 and dy_amax is None:

@@ -151,21 +151,26 @@ class Conv2dP(nn.Module):
     def wino_wgrad_ok(self, h, w):
         return self.wino and self.cin * self.cout >= WINO_MIN_CC_WGRAD and ops.wino_tiles(h, w, self.dilation) % 4 == 0
 
-    def fprop(self, xd, out=None, bias=None, want_stats=False, keep=False, x_amax=None):
+    def fprop(self, xd, out=None, bias=None, want_stats=False, keep=False, x_amax=None, bnl=None, want_minmax=False):
         """keep: training forward -- the Winograd path keeps its transformed input for the weight gradient (self.saved_v);
-        x_amax: the slot with max |xd| when the caller has it (f16x3 layers; computed here otherwise)"""
+        x_amax: the slot with max |xd| when the caller has it (f16x3 layers; computed here otherwise);
+        bnl: xd is the PRE-normalisation output of the layer feeding this one, coef [C, 4] its record: normalised on load (Winograd path only);
+        want_minmax (f16x3 GEMM, with want_stats): the statistics also carry the output's per-channel (min, max) partials"""
         self.saved_v = None
         if self.wino and bias is None:
             keep_v = keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3])
+            assert bnl is None or keep_v or not keep, 'a normalise-on-load input must leave its transform behind for the weight gradient'
             res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats,
-                                u_amax=self.uf_amax if self.wino_f16 else None, x_amax=x_amax if self.wino_f16 else None)
+                                u_amax=self.uf_amax if self.wino_f16 else None, x_amax=x_amax if self.wino_f16 else None, bnl=bnl)
             if keep_v:
                 self.saved_v = res[-1]
                 res = res[:-1] if len(res) > 2 else res[0]
             return res                                     # (y, stats, slots) with want_stats, else y
+        assert bnl is None, 'only the Winograd input transform (and the depthwise / max-pool kernels) normalise on load'
         if self.f16_f:
             return ops.conv_fprop_f16x3(xd, self.w4f, self.w_amax, x_amax if x_amax is not None else ops.absmax(xd), self.cout, self.k,
-                                        self.stride, self.dilation, self.padding, bias=bias, out=out, want_stats=want_stats)
+                                        self.stride, self.dilation, self.padding, bias=bias, out=out, want_stats=want_stats,
+                                        want_minmax=want_minmax)
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                                         want_stats=want_stats)
@@ -406,6 +411,10 @@ FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
 # a conv -> BN -> ReLU output whose ONLY consumer can normalise on load (a depthwise layer: sep_bottleneck[0] -> [1]; the stem's max-pool) is
 # never written: the consumer reads the pre-BN tensor.  PFST_DEFER_BN_APPLY=0: every normalised tensor is materialised (A/B, per-link test)
 DEFER_BN_APPLY = os.environ.get('PFST_DEFER_BN_APPLY', '1') == '1'
+# Bottleneck conv1 -> bn1 -> ReLU -> conv2 with conv2 on the Winograd path: the input transform normalises as it loads, y1 is never written
+# (round 5).  Under f16x3 the transform writes V pre-split and needs max |y1| BEFORE y1 exists: conv1's epilogue emits per-channel
+# (min, max) partials and bn_finalize_partials predicts the maximum exactly.  PFST_FOLD_BN_WINO=0: bn_apply writes y1 (A/B, per-link test)
+FOLD_BN_WINO = os.environ.get('PFST_FOLD_BN_WINO', '1') == '1'
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written); PFST_FUSE_DW_BNBWD=0: the two-pass BatchNorm backward writes it first
 FUSE_DW_BNBWD = os.environ.get('PFST_FUSE_DW_BNBWD', '1') == '1'
@@ -591,10 +600,10 @@ def _dgrad_into(x, conv, dy, final, dy_amax=None):
     (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
     fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward()
     gate = None
-    if x.pending is not None and x.grad_unwritten() and conv.dgrad_can_gate(x.data.shape[-2:]):
+    if x.pending is not None and x.grad_unwritten() and conv.dgrad_can_gate(x.data.shape[-2:]):       # (a pending gate implies a materialised x)
         gate = x.take_pending()           # the identity branch's gated gradient rides in this launch's epilogue (else grad_target writes it out)
     buf, acc = x.grad_target(final=fuse)
-    conv.dgrad(dy, x.data.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax, gate=gate)
+    conv.dgrad(dy, buf.shape[-2:], buf, acc, bn=x.bn if fuse else None, dy_amax=dy_amax, gate=gate)
 
 
 def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=None):
@@ -644,9 +653,13 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     assert post_scale is None or residual is None
     # defer: the caller guarantees that the ONLY consumer of the result normalises on load (a depthwise layer or the stem's max-pool): the
     # normalisation pass is skipped, the returned Var carries (pre, coef) in .lazy and no data.  x.lazy: this layer IS such a consumer.
+    # defer='amax': the consumer is an f16x3 GEMM operand producer (the Winograd input transform, which writes V pre-split) and needs
+    # max |y| of the tensor that is never written: under f16x3 the producing GEMM emits (min, max) partials and the finalize kernel predicts it
     xd = x.data if x.lazy is None else x.lazy[0]
     x_bnl = None if x.lazy is None else x.lazy[1]
-    assert x_bnl is None or conv.depthwise, 'only a depthwise layer (or the max-pool) reads a deferred normalisation'
+    assert x_bnl is None or conv.depthwise or (conv.wino and conv.bias is None), \
+        'only a depthwise layer, the Winograd input transform (or the max-pool) reads a deferred normalisation'
+    need_pred = defer == 'amax' and CONV_MATH == 'f16x3'
     defer = bool(defer and DEFER_BN_APPLY and not _BN_EVAL and relu and residual is None and out is None and post_scale is None)
     # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
     # cancellation: var = E[x^2] - mean^2 from the epilogue's fp32 partial sums of squares loses what torch's two-pass variance keeps
@@ -654,15 +667,19 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     # kernel, whose sums of exact fp64 squares are exact for fp32 inputs.
     tiny = xd.shape[0] * xd.shape[2] * xd.shape[3] <= 64
     fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
+    if need_pred and not (defer and fused_stats and conv.f16_f and not conv.wino and conv.bias is None):
+        defer = need_pred = False           # no producer of (min, max) partials here: the normalised tensor is written as usual
+    need_pred = need_pred and defer
     if conv.depthwise:
         if fused_stats:                            # batch statistics come out of the producing kernel in every case
             pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True, bnl=x_bnl)
         else:
             pre = ops.dwconv(xd, conv.weight.data, conv.dilation, bnl=x_bnl)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
-        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
+        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None,
+                                    bnl=x_bnl, want_minmax=need_pred)
     else:
-        pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None)
+        pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None, bnl=x_bnl)
     saved_v = None if conv.depthwise else conv.saved_v
     if _BN_EVAL:
         assert tape is None, 'eval-mode BN is inference only'
@@ -674,9 +691,11 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {torch.Size(pre.shape)}')
         want_coef = (tape is not None and FUSE_BN_BWD) or defer
         gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
+        pred_amax = ops.amax_slots(pre.device) if need_pred else None
         if fused_stats:
             n, c, h, w = pre.shape
-            res = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
+            res = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, predict_amax=pred_amax,
+                                           relu=relu, **gb)
         else:
             res = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
         mean, invstd = res[:2]
@@ -690,7 +709,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     # f16x3: the normalisation pass publishes max |y| for the GEMMs that will read y (no separate pass over the tensor)
     yv = out_var if out_var is not None else Var(None, tape is not None)
     if defer:
-        yv.lazy, y = (pre, coef), None               # no normalisation pass: the consumer applies (sc, sh) of `coef` and the ReLU as it loads `pre`
+        yv.lazy, y = (pre, coef, bn), None           # no normalisation pass: the consumer applies (sc, sh) of `coef` and the ReLU as it loads `pre`
+        if need_pred:
+            yv.amax = pred_amax                      # max |y| of the tensor that is never written (exact: bn_finalize_partials)
     else:
         y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
                          None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device),

@@ -50,7 +50,11 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(Conv2dP(inplanes, planes * 4, 1, stride), BatchNorm2dP(planes * 4))
 
     def forward(self, x, tape):
-        o = conv_bn_act(x, self.conv1, self.bn1, tape)
+        # conv2 through the Winograd domain (layer2.1 ... layer4.2): its input transform normalises conv1's output as it loads it -- y1 is never
+        # written; the weight gradient of conv2 comes from the transformed input kept in forward, BatchNorm backward of bn1 from the pre-BN tensor
+        h, w = x.data.shape[-2:]
+        fold = layers_mod.FOLD_BN_WINO and self.conv2.wino and self.conv2.bias is None and (tape is None or self.conv2.wino_wgrad_ok(h, w))
+        o = conv_bn_act(x, self.conv1, self.bn1, tape, defer='amax' if fold else False)
         o = conv_bn_act(o, self.conv2, self.bn2, tape)
         idt = x
         if self.downsample is not None:

@@ -42,9 +42,22 @@ def _grad_of(v):
     return None if g is None else g.clone()
 
 
+def _data(v):
+    """the tensor a Var stands for; a deferred conv -> BN -> ReLU output (never written by the product: its consumer normalises on load) is
+    materialised here by the normalisation pass itself -- the same fma / max per element the consumers apply"""
+    if v.lazy is None:
+        return v.data
+    from pfst_amd import hip_ops as ops
+    pre, coef, bn = v.lazy
+    return ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, True)
+
+
 @pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
-@pytest.mark.parametrize('wino', [True, False])
-def test_every_backward_link_as_wired(wino, math):
+@pytest.mark.parametrize('wino,fold', [(True, False), (False, False), (True, True)], ids=['wino', 'direct', 'wino-deferred'])
+def test_every_backward_link_as_wired(wino, fold, math):
+    """fold: the deferred normalisations of the product ON -- stem.6 -> max-pool, sep_bottleneck[0] -> [1] and (round 5) bn1 of the twelve
+    Winograd bottlenecks normalised by conv2's input transform: the links whose input or output is never written are checked at the tensor
+    the normalisation pass would have written (_data)"""
     import pfst_amd  # noqa: F401
     from oracle import pfst_oracle as O
     from pfst_amd import hip_ops as ops
@@ -79,7 +92,8 @@ def test_every_backward_link_as_wired(wino, math):
     # ... and every normalised tensor is materialised here (the observer reads each link's input and output): the two deferred
     # normalisations of the product (stem.6 -> max-pool, sep_bottleneck[0] -> [1]) are checked against this wiring in
     # test_deferred_normalisation_equals_the_materialised_one below
-    layers.DEFER_BN_APPLY = False
+    layers.DEFER_BN_APPLY = bool(fold)
+    prev_fold, layers.FOLD_BN_WINO = layers.FOLD_BN_WINO, bool(fold)
     # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
     # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
     layers.FUSE_RES_GATE = False
@@ -122,7 +136,7 @@ def test_every_backward_link_as_wired(wino, math):
             """fp64 CPU autograd of the oracle's restatement of this one link at the HIP layer's actual input (dt=float32: the same
             link as torch's fp32 CPU path evaluates it -- the yardstick for the one badly conditioned link)"""
             op = tag['op']
-            x = tag['x'].data.detach().cpu().to(dt).requires_grad_(tag['x'].requires_grad)
+            x = _data(tag['x']).detach().cpu().to(dt).requires_grad_(tag['x'].requires_grad)
             leaves, keys = [x] if x.requires_grad else [], ['x'] if x.requires_grad else []
             if op in ('conv_bn_act', 'conv'):
                 cv = tag['conv']
@@ -144,16 +158,16 @@ def test_every_backward_link_as_wired(wino, math):
                             leaves.append(r); keys.append('residual')
                         y = y + r
                     if tag['relu']:
-                        gate = (tag['out'].data.detach().cpu() > 0).to(dt)      # the HIP forward's own ReLU decision
+                        gate = (_data(tag['out']).detach().cpu() > 0).to(dt)      # the HIP forward's own ReLU decision
                         fwd = F.relu(y).detach()
                         y = y * gate
                     else:
                         fwd = y.detach()
-                    state['fwd_err'] = mixed_err(tag['out'].data, fwd)[1]
+                    state['fwd_err'] = mixed_err(_data(tag['out']), fwd)[1]
             elif op == 'maxpool':
                 y = F.max_pool2d(x, 3, 2, 1)
             elif op in ('resize', 'broadcast'):
-                y = F.interpolate(x, size=tag['out'].data.shape[-2:], mode='bilinear', align_corners=False)
+                y = F.interpolate(x, size=_data(tag['out']).shape[-2:], mode='bilinear', align_corners=False)
             elif op == 'gap':
                 y = x.mean((2, 3), keepdim=True)
             elif op == 'ce':
@@ -220,6 +234,7 @@ def test_every_backward_link_as_wired(wino, math):
     finally:
         layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY = prev, prev_math, prev_dw, prev_defer
         layers.FUSE_RES_GATE = prev_gate
+        layers.FOLD_BN_WINO = prev_fold
         layers.set_overlap(*prev_overlap)
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
@@ -548,9 +563,72 @@ def test_deferred_normalisation_equals_the_materialised_one():
             applies[defer] = n_apply[0]
     finally:
         layers.DEFER_BN_APPLY = prev
-    assert applies[False] == 70 and applies[True] == 68, applies
+    # deferred: stem.6 and sep_bottleneck[0]; + bn1 of the 12 bottlenecks whose conv2 runs through the Winograd domain (layers.FOLD_BN_WINO)
+    folded = 12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0
+    assert applies[False] == 70 and applies[True] == 68 - folded, applies
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
+    assert e < 1e-4, e
+
+
+def test_bn1_folded_into_the_winograd_input_transform():
+    """layers.FOLD_BN_WINO (round 5): in the 12 bottlenecks whose conv2 runs through the Winograd domain, conv1 -> bn1 -> ReLU is never
+    written -- conv2's input transform normalises the pre-BN tensor as it loads it (pfst_wino_input bnl), conv2's weight gradient comes from
+    the transformed input kept in forward, bn1's backward from the pre-BN tensor.  Under f16x3 the transform writes V pre-split and needs
+    max |y1| before y1 exists: conv1's epilogue emits per-channel (min, max) partials and pfst_bn_finalize_partials predicts the maximum.
+    Same arithmetic per element (the fma and max of bn_apply), same scale exponent: one segmentor forward + backward with the fold on and
+    off gives bit-identical logits, gradients equal to the atomics' summation order, and 12 normalisation launches less.
+    Follows /root/reference/rsiseg/models/backbones/resnet.py:273-296 (conv1 -> norm1 -> relu -> conv2 of Bottleneck._inner_forward)."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if not (layers.WINOGRAD and layers.DEFER_BN_APPLY):
+        pytest.skip('needs the Winograd dispatch and deferred normalisations')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=23)
+    runs, applies, inputs = {}, {}, {}
+    prev = layers.FOLD_BN_WINO
+    inner = ops.call
+    try:
+        for fold in (True, False):
+            layers.FOLD_BN_WINO = fold
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            seen = {}
+
+            def counting(name, *a):
+                seen[name] = seen.get(name, 0) + 1
+                if name == 'pfst_wino_input' and a[11]:
+                    seen['normalising transforms'] = seen.get('normalising transforms', 0) + 1
+                return inner(name, *a)
+            ops.call = counting
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.call = inner
+            runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
+            applies[fold] = seen
+    finally:
+        layers.FOLD_BN_WINO = prev
+    assert applies[False]['pfst_bn_apply'] - applies[True]['pfst_bn_apply'] == 12, (applies[False]['pfst_bn_apply'], applies[True]['pfst_bn_apply'])
+    assert applies[True].get('normalising transforms', 0) == 12 and applies[False].get('normalising transforms', 0) == 0
+    assert applies[True]['pfst_wino_input'] == applies[False]['pfst_wino_input']            # no transform is re-run in backward: V was kept
+    assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    print(f'   gradient arena, fold on vs off: {e:.2e}')
     assert e < 1e-4, e
 
 
@@ -581,11 +659,20 @@ def test_published_maxima_cover_every_f16x3_operand():
     seen, scanned = {}, []
     orig_of, orig_absmax = layers.amax_of, ops.absmax
 
+    predicted = []
+
     def checked(v):
         had = v.amax is not None
         slots = orig_of(v)
         if had and id(v) not in seen:
-            seen[id(v)] = (tuple(v.data.shape), slots.max().item(), v.data.abs().max().item())
+            data = v.data
+            if v.lazy is not None:
+                # a tensor that is never written (conv1 -> bn1 -> relu of a Winograd bottleneck): its group holds the PREDICTED maximum
+                # (bn_finalize_partials from the GEMM's min / max partials); the true one from the normalisation pass run here for the test
+                pre, coef, bn = v.lazy
+                data = ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, True)
+                predicted.append(tuple(data.shape))
+            seen[id(v)] = (tuple(data.shape), slots.max().item(), data.abs().max().item())
         return slots
 
     def counted(x, *a, **k):
@@ -604,6 +691,8 @@ def test_published_maxima_cover_every_f16x3_operand():
     assert len(seen) > 20, len(seen)
     bad = [s for s in seen.values() if s[1] != s[2]]
     assert not bad, bad
+    if layers.FOLD_BN_WINO and layers.DEFER_BN_APPLY and layers.WINOGRAD:
+        assert len(predicted) == 12, predicted          # bn1 of layer2.1-3, layer3.0-5, layer4.0-2: predicted == true maximum, bit for bit
     shapes = [s[0] for s in seen.values()]
     assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
     assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'

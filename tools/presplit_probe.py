@@ -48,7 +48,7 @@ def main():
             v = torch.empty(nx * n * ci * t, device=dev)
             dm = torch.empty(nx * n * co * t, device=dev)
             va, dma = ops.amax_slots(dev), ops.amax_slots(dev)
-            call('pfst_wino_input', x.data_ptr(), ci * hw * hw, v.data_ptr(), n, ci, hw, hw, 1, m, va.data_ptr(), xa.data_ptr() if packed else 0, st)
+            call('pfst_wino_input', x.data_ptr(), ci * hw * hw, v.data_ptr(), n, ci, hw, hw, 1, m, va.data_ptr(), xa.data_ptr() if packed else 0, 0, st)
             call('pfst_wino_dy', dy.data_ptr(), co * hw * hw, dm.data_ptr(), n, co, hw, hw, 1, m, dma.data_ptr(), da.data_ptr() if packed else 0, st)
             tg = timeit(lambda: call('pfst_wino_gemm_f16x3', v.data_ptr(), uf.data_ptr(), af.data_ptr(), va.data_ptr(), mb.data_ptr(), n, ci, co, t, m, packed, st))
             du = torch.empty(nx * co * ci, device=dev)
