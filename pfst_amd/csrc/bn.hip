@@ -9,6 +9,14 @@
 #include "amax.h"
 #include "../../include/pfst_hip.h"
 
+// cache policy of bn_apply's streams (raw buffer aux bits on gfx950: 2 = nt): build-time knobs for A/B builds
+#ifndef PFST_BN_LOAD_AUX
+#define PFST_BN_LOAD_AUX 0
+#endif
+#ifndef PFST_BN_STORE_AUX
+#define PFST_BN_STORE_AUX 0
+#endif
+
 namespace {
 
 constexpr int BN_SPLIT_TARGET = 2048;  // aim for this many blocks in the reduction passes
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       for (int u = 0; u < U; ++u) {
         const int i = i0 + u * stride;
         off[u] = i < n4 ? 16u * (unsigned)i : OOB;
-        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[u], 0, 0));
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off[u], 0, PFST_BN_LOAD_AUX));
       }
       if (rp) {
 #pragma unroll
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
         if (post) { w.x *= pm; w.y *= pm; w.z *= pm; w.w *= pm; }
         if (i < n4) am = fmaxf(fmaxf(am, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), yr, off[u], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, w), yr, off[u], 0, PFST_BN_STORE_AUX);
       }
     }
   } else {

@@ -2,7 +2,11 @@
 // statistics, bias, accumulate, store.  C/D layout of the 32x32 MFMA accumulator: column = lane & 31 (pixel),
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (output channel).
 #pragma once
+#include <type_traits>
 #include "common.h"
+#ifndef PFST_BNB_LOAD_AUX
+#define PFST_BNB_LOAD_AUX 0      // cache policy of the fused BatchNorm-backward epilogue's x / y loads (read once): A/B builds
+#endif
 #include "../../include/pfst_hip.h"
 
 typedef float pfst_f32x16 __attribute__((ext_vector_type(16)));
@@ -99,7 +103,9 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
                                               float* __restrict__ stats, int stats_T, int accumulate, int M, int P, int m0, int p0,
                                               int wm0, int wn0, int bx, int n, int wid, int lane, const PfstBnbArgs& bnb = PfstBnbArgs(),
                                               float* __restrict__ lds = nullptr, const float* __restrict__ gsrc = nullptr,
-                                              const unsigned long long* __restrict__ gmask = nullptr, float* __restrict__ stats_mm = nullptr) {
+                                              const unsigned long long* __restrict__ gmask = nullptr, float* __restrict__ stats_mm = nullptr,
+                                              bool nt_store = false) {
+  // nt_store (wave-uniform): the plain output stores carry the streaming (nt) cache policy -- see conv_f16x3.hip
   // stats_mm (with stats, plain path): [M][stats_T][2] = per-channel (minimum, maximum) of this wave's output values -- BatchNorm + ReLU is a
   // monotone map of the pre-activation per channel, so max |y| of the NORMALISED tensor is attained at one of the two and is known (exactly:
   // pfst_bn_finalize_partials evaluates the same fma) before y is written: the consumer that normalises as it loads has its f16x3 scale
@@ -252,20 +258,29 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
       }
     }
     if (BNB || !(accumulate || gated)) {
+      auto store_all = [&](auto aux_c) {
+        constexpr int AUX = decltype(aux_c)::value;         // raw_buffer_store aux bits on gfx950: 2 = nt
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+          for (int j = 0; j < TN; ++j) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float v = acc[i][j][r];       // (a float temporary: __builtin_bit_cast of the vector-element lvalue reads element 0)
-#ifdef PFST_DIAG_NO_STORE                       // timing-only build (WRONG results): what the output stores of the plain path cost
-            if (v != 1.2345e-30f) continue;
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[i][j][r];       // (a float temporary: __builtin_bit_cast of the vector-element lvalue reads element 0)
+#ifdef PFST_DIAG_NO_STORE                         // timing-only build (WRONG results): what the output stores of the plain path cost
+              if (v != 1.2345e-30f) continue;
 #endif
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
-                                                  4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff[j],
+                                                    4 * P * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), AUX);
+            }
           }
-        }
+      };
+#ifdef PFST_BNB_NT_STORE
+      if (nt_store) store_all(std::integral_constant<int, 2>());
+#else
+      if (BNB == 0 && nt_store) store_all(std::integral_constant<int, 2>());
+#endif
+      else store_all(std::integral_constant<int, 0>());
     } else {
       // accumulate: the 16 loads of a 32x32 block are issued back to back, then added and stored (one latency per block, not 64)
 #pragma unroll
@@ -314,10 +329,10 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
           float a = 0.f, b = 0.f;
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const float xv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[j], 4 * P * row, 0));
+            const float xv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff[j], 4 * P * row, PFST_BNB_LOAD_AUX));
             float dz = voff[j] != OOB ? acc[i][j][r] : 0.f;
             if (gate_y) {
-              const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, voff[j], 4 * P * row, 0));
+              const float yv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yr, voff[j], 4 * P * row, PFST_BNB_LOAD_AUX));
               dz = yv > 0.f ? dz : 0.f;
             } else if (gate_x) {
               dz = __fmaf_rn(xv, sc, sh) > 0.f ? dz : 0.f;

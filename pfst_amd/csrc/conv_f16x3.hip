@@ -295,6 +295,15 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // LDS buffer / register set of a pair is its parity) and the 32x32 loop; otherwise every tile runs its own prologue.
   const bool CHAIN = ONE && SHAPE == 32 && (KP & 1) == 0 && (chain & 1) != 0;       // `chain`: bit 0 the tile chain, bit 1 min / max partials
   float* const stats_mm = (stats && (chain & 2)) ? stats + (i64)2 * M * stats_T : nullptr;      // behind the (sum, sum of squares) partials
+  // Short contractions write their output almost as fast as HBM takes it (K = 256: 128 KB per tile every ~10 us per CU) and the dirty lines
+  // they park in L2 get in the way of the operand reads: with streaming (nt) stores the same launch runs 15 % (K = 256) / 6 % (K = 512) faster,
+  // a K = 2048 launch 1.6 % slower (profiles/r05_gemm_store_cost.txt; a build whose stores all land in one 64 KB window is as fast as a
+  // build without stores: the cost is the write traffic, not the issue).  chain bit 2: the host enables it
+#ifdef PFST_NT_ALL_K
+  const bool nt_out = (chain & 4) != 0;
+#else
+  const bool nt_out = KP <= 16 && (chain & 4) != 0;
+#endif
 
   const int pix = tid & (BN - 1), kh = (tid >> 7) & 1;   // activation staging: pixel, k-half ...
   const int bt = BM == 256 ? tid >> 8 : 0;               // ... and (256-row tile) which K=16 tile of the pair
@@ -577,11 +586,18 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         // already hold the next tile's first pair
         static_assert(PAIR_CHUNKS * sizeof(uint4) >= (NT / 64) * PFST_ROWSUM_LDS_FLOATS * sizeof(float), "epilogue scratch must fit into one pair buffer");
         conv_epilogue<2, 2, WAVES_N, BN, BNB, true>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, bnb,
-                                                    reinterpret_cast<float*>(smem + PAIR_CHUNKS), gsrc, gmask);
+                                                    reinterpret_cast<float*>(smem + PAIR_CHUNKS), gsrc, gmask, nullptr, nt_out);
         __syncthreads();                                 // before the next tile's first step stores into that buffer
       } else {
+#ifdef PFST_STATS_LDSRED                           // A/B build: the forward statistics' row sums through LDS (as the fused BatchNorm-backward sums) instead of the DPP butterfly
+        if (stats && !stats_mm && BMT != 64) {
+          conv_epilogue<TMW, 2, WAVES_N, BN, 0, true>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(),
+                                                      reinterpret_cast<float*>(smem + PAIR_CHUNKS), gsrc, gmask, nullptr, nt_out);
+          __syncthreads();
+        } else
+#endif
         conv_epilogue<TMW, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane, PfstBnbArgs(), nullptr,
-                                           gsrc, gmask, stats_mm);
+                                           gsrc, gmask, stats_mm, nt_out);
       }
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
@@ -1250,6 +1266,10 @@ unsigned f16x3_grid(i64 total, bool chainable, int wg_per_cu = 2) {
   return (unsigned)best_g;
 }
 
+int f16x3_nt_store() {                                    // PFST_F16X3_NT_STORE=0: ordinary stores everywhere (A/B runs)
+  static const int v = getenv("PFST_F16X3_NT_STORE") ? atoi(getenv("PFST_F16X3_NT_STORE")) : 1;
+  return v != 0;
+}
 int f16x3_shape() {
   static const int v = getenv("PFST_F16X3_SHAPE") ? atoi(getenv("PFST_F16X3_SHAPE")) : 32;
   return v == 16 ? 16 : 32;
@@ -1375,7 +1395,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
                                      const unsigned long long* gate_mask, int stats_minmax, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   // stats_minmax: `stats` has room for 4 * M * slots floats and also receives the per-channel (minimum, maximum) partials behind the sums
-  PFST_CHECK_ARG(!stats_minmax || (stats && !bias && M % 32 == 0 && !(bnb && bnb->x)));
+  PFST_CHECK_ARG(!stats_minmax || (stats && !bias && !(bnb && bnb->x)));
   PfstResGate gate;
   if (gate_dy) {
     // out = conv + (bit ? gate_dy : 0): the epilogue's whole-tile path, the mask's 256-element groups, one writer (no old values)
@@ -1413,7 +1433,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : small ? 64 : 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
-  const int chain = f16x3_chain() | (stats_minmax ? 2 : 0);
+  const int chain = f16x3_chain() | (stats_minmax ? 2 : 0) | (f16x3_nt_store() ? 4 : 0);
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
     PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);
@@ -1472,7 +1492,7 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   const i64 total = (i64)cdiv((i64)T, BN) * cdiv(M, big ? 256 : 128) * nx * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, (v_packed || f16x3_shape() == 32) && (K / 32) % 2 == 0, big ? 1 : 2));
-  const int chain = f16x3_chain();
+  const int chain = f16x3_chain() | (f16x3_nt_store() ? 4 : 0);
   // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
   if (big && v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,

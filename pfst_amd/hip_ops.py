@@ -252,13 +252,11 @@ def set_f16x3_slots(slots):
 def f16x3_eligible(cin, cout, ksize=3):
     """the f16x3 implicit GEMM covers contractions over whole 32-channel blocks -- a 1x1 convolution also a last half block: the loads of
     the missing 16 channels fall outside their buffers' ranges and return zeros (the range check includes the scalar offset on gfx950:
-    tools/probes/soffset_range_probe.hip) -- and more than F16X3_MIN_ROWS output rows (33 ... 64: the 64-row tile, one 32-row block per wave;
-    PFST_F16X3_MIN_ROWS=64 leaves those layers on the bf16x6 kernel)"""
+    tools/probes/soffset_range_probe.hip) -- and more than 32 output rows (33 ... 64: the 64-row tile, one 32-row block per wave)"""
     return (cin % 32 == 0 or (ksize == 1 and cin % 16 == 0)) and cout > F16X3_MIN_ROWS
 
 
-F16X3_MIN_ROWS = int(os.environ.get('PFST_F16X3_MIN_ROWS', '32'))
-assert F16X3_MIN_ROWS in (32, 64)
+F16X3_MIN_ROWS = 32
 
 
 def pack_weight_f16x2(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=None, amax=None, sets=1):
@@ -449,8 +447,7 @@ def _wino_ws(dev, tag, nfloat):
 
 
 # output tile edge m of the Winograd F(m x m, 3x3) transforms: 4 (4x fewer MACs, 36 transform indices) or 2 (2.25x, 16 indices)
-WINO_TILE = int(os.environ.get('PFST_WINO_TILE', '4'))
-assert WINO_TILE in (2, 4), 'PFST_WINO_TILE must be 2 or 4'
+WINO_TILE = 4
 
 
 def _wino_m(m):

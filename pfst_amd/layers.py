@@ -58,41 +58,36 @@ def _amax_target(yv, dev):
         yv.amax = ops.amax_slots(dev)
     return yv.amax
 # bf16x6 mode: the 1x1 and Winograd-domain weight gradients run on the K-quad split kernel (1.5x the fp32-MFMA one); the rare direct
-# 3x3 / strided ones stay on fp32 MFMA unless PFST_WGRAD_SPLIT_ALL=1 (the generic split kernel is slower than fp32 MFMA)
-WGRAD_SPLIT = os.environ.get('PFST_WGRAD_SPLIT', '1') == '1'
-WGRAD_SPLIT_ALL = os.environ.get('PFST_WGRAD_SPLIT_ALL', '0') == '1'
-FUSE_BN_STATS = os.environ.get('PFST_FUSE_BN_STATS', '1') == '1'
-# f16x3: the max-pool and all five writers of the ASPP concat publish max |.| themselves; PFST_PUBLISH_AMAX=0: a pfst_absmax pass per tensor
-PUBLISH_AMAX = os.environ.get('PFST_PUBLISH_AMAX', '1') == '1'
-# depthwise layers: weight and data gradient in one pass (csrc/dwconv.hip, pfst_dwconv3x3_bwd); PFST_FUSE_DW_BWD=0: the two kernels
-FUSE_DW_BWD = os.environ.get('PFST_FUSE_DW_BWD', '1') == '1'
+# 3x3 / strided ones stay on fp32 MFMA (the generic split kernel is slower than fp32 MFMA)
+# Module-level switches below are NOT environment switches (round 5: every settled A/B lost its PFST_* variable): the tests flip the ones whose
+# 'off' wiring they compare against (per-link backward test, fold on / off tests); the product runs the values written here.
+FUSE_BN_STATS = True         # batch statistics out of the producing kernel's epilogue (False: the stand-alone pfst_bn_stats pass)
 # Winograd F(m x m,3x3) for the wide stride-1 3x3 layers (csrc/conv_winograd.hip): fp32 results, 4x (m = 4, default) or 2.25x
 # (PFST_WINO_TILE=2) fewer MACs.
 # Threshold on Cin*Cout from tools/wino_microbench.py / bench.py: Winograd wins for fprop, dgrad and (with the transformed input
 # kept from the forward pass and the grouped launch) the weight gradient from 128x128 channels up with F(4x4) (x1.4 at layer2,
 # x3.0 at the head bottleneck), from 256x256 up with F(2x2); 64x64 (layer1) stays direct (x0.9).
-WINOGRAD = os.environ.get('PFST_WINOGRAD', '1') == '1'
+WINOGRAD = True
 _WINO_DEFAULT_CC = 128 * 128 if ops.WINO_TILE == 4 else 256 * 256
-WINO_MIN_CC = int(os.environ.get('PFST_WINO_MIN_CC', _WINO_DEFAULT_CC))
-WINO_MIN_CC_WGRAD = int(os.environ.get('PFST_WINO_MIN_CC_WGRAD', _WINO_DEFAULT_CC))
+WINO_MIN_CC = _WINO_DEFAULT_CC
+WINO_MIN_CC_WGRAD = _WINO_DEFAULT_CC
 # BatchNorm backward: the two per-channel sums come out of the epilogue of the data-gradient launch that completes dL/dy
 # (csrc/conv_epilogue.h, pfst_bnb_fuse_t) wherever that launch is a K-quad implicit GEMM; elsewhere the two-pass kernels run.
-FUSE_BN_BWD = os.environ.get('PFST_FUSE_BN_BWD', '1') == '1'
+FUSE_BN_BWD = True
 # residual blocks: the identity branch's gradient, dL/d(block output) gated by the block's final ReLU, is added in the epilogue of the launch that
 # completes dL/d(block input) (conv1's f16x3 data gradient; a downsample layer's BatchNorm backward takes it as its gated dy) instead of
 # being written by the bn3 layer's BatchNorm backward and read back -- one write of the block's widest tensor less per block.
-# PFST_FUSE_RES_GATE=0: pfst_bn_backward writes it (dres)
-FUSE_RES_GATE = os.environ.get('PFST_FUSE_RES_GATE', '1') == '1'
+# False: pfst_bn_backward writes it (dres)
+FUSE_RES_GATE = True
 # f16x3: the weight gradients the whole-line kernel does not take (direct stride-1 3x3, 1x1 with <= 64 output channels) on the K-quad kernel
-# with both operands split as they are staged (csrc/conv_wgrad_q.hip); PFST_F16X3_WGRAD_Q=0: the fp32-input MFMA / bf16x6 kernels
-F16X3_WGRAD_Q = os.environ.get('PFST_F16X3_WGRAD_Q', '1') == '1'
+# with both operands split as they are staged (csrc/conv_wgrad_q.hip)
 # ... but only where that launch is MFMA-bound: with a short contraction (K = Cout * taps of the consuming conv) the data gradient is
 # itself HBM-bound (layer1: 2 * 64 flop per 8 bytes written + accumulated), and reading the pre-BN tensor there costs what the
 # reduction pass would have cost (measured: fusing everywhere moves 11 ms/step out of pfst_bn_backward and 10 ms into the GEMMs)
-FUSE_BN_BWD_MIN_K = int(os.environ.get('PFST_FUSE_BN_BWD_MIN_K', '512'))
+FUSE_BN_BWD_MIN_K = 512
 # the bf16x6 data-gradient kernel carries the same epilogue; measured (b=8, 4-step runs): 439.2 ms with every launch fused, 437.7 ms with none --
 # the cost is not VALU-vs-MFMA contention but the longer workgroup lifetime, in either arithmetic
-FUSE_BN_BWD_MIN_K_SPLIT = int(os.environ.get('PFST_FUSE_BN_BWD_MIN_K_SPLIT', '512'))
+FUSE_BN_BWD_MIN_K_SPLIT = 512
 
 
 class BnBackwardCtx:
@@ -189,7 +184,7 @@ class Conv2dP(nn.Module):
         """the weight gradient runs on the f16x3 K-quad kernel (ops.conv_wgrad_f16q_): stride-1 'same' 3x3 outside the Winograd dispatch (the
         stems, layer1 conv2).  The kernel also takes 1x1 layers; those with <= 64 output channels are HBM-bound and measured no faster on it
         (0.225 vs 0.205 ms for layer1 conv1 on the bf16x6 kernel): they stay where they are"""
-        if not (CONV_MATH == 'f16x3' and WGRAD_SPLIT and F16X3_WGRAD_Q) or self.depthwise or self.stride != 1 or self.cout < 16:
+        if CONV_MATH != 'f16x3' or self.depthwise or self.stride != 1 or self.cout < 16:
             return False
         if self.wino_wgrad_ok(h, w):
             return False
@@ -301,8 +296,8 @@ class WeightBatch:
     """The f16x3 weight images of a whole network in three launches per step -- zero the slot groups, one preparation launch (absolute
     maxima of the directly convolved layers; filter transform + per-set maxima of the Winograd layers), one packing launch -- instead
     of two to five 5-12 us launches per convolution (~290 per step for student + teacher, 1 % of the b=8 step).  The job tables
-    (ops.WeightJobTable) are rebuilt only when a buffer or a mode changed.  PFST_BATCHED_PACK=0: the per-layer launches."""
-    enabled = os.environ.get('PFST_BATCHED_PACK', '1') != '0'
+    (ops.WeightJobTable) are rebuilt only when a buffer or a mode changed.  enabled = False: the per-layer launches (tests)."""
+    enabled = True
 
     def __init__(self):
         self.key = None
@@ -406,18 +401,18 @@ class DepthwiseSeparableConvModule(nn.Module):
         return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale, defer=defer)
 
 
-# the atrous depthwise branches of the ASPP head as ONE launch each way (csrc/dwconv.hip, pfst_dwconv3x3_multi_*); PFST_FUSE_ASPP_DW=0: per branch
-FUSE_ASPP_DW = os.environ.get('PFST_FUSE_ASPP_DW', '1') == '1'
+# the atrous depthwise branches of the ASPP head as ONE launch each way (csrc/dwconv.hip, pfst_dwconv3x3_multi_*); False: per branch
+FUSE_ASPP_DW = True
 # a conv -> BN -> ReLU output whose ONLY consumer can normalise on load (a depthwise layer: sep_bottleneck[0] -> [1]; the stem's max-pool) is
-# never written: the consumer reads the pre-BN tensor.  PFST_DEFER_BN_APPLY=0: every normalised tensor is materialised (A/B, per-link test)
-DEFER_BN_APPLY = os.environ.get('PFST_DEFER_BN_APPLY', '1') == '1'
+# never written: the consumer reads the pre-BN tensor.  False: every normalised tensor is materialised (per-link test)
+DEFER_BN_APPLY = True
 # Bottleneck conv1 -> bn1 -> ReLU -> conv2 with conv2 on the Winograd path: the input transform normalises as it loads, y1 is never written
 # (round 5).  Under f16x3 the transform writes V pre-split and needs max |y1| BEFORE y1 exists: conv1's epilogue emits per-channel
-# (min, max) partials and bn_finalize_partials predicts the maximum exactly.  PFST_FOLD_BN_WINO=0: bn_apply writes y1 (A/B, per-link test)
-FOLD_BN_WINO = os.environ.get('PFST_FOLD_BN_WINO', '1') == '1'
+# (min, max) partials and bn_finalize_partials predicts the maximum exactly.  False: bn_apply writes y1 (per-link test).  Same-box A/B of the
+# switch while it still read the environment: profiles/r05_ab_fold_bn_wino.txt
+FOLD_BN_WINO = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
-# operands (dL/dpre is never written); PFST_FUSE_DW_BNBWD=0: the two-pass BatchNorm backward writes it first
-FUSE_DW_BNBWD = os.environ.get('PFST_FUSE_DW_BNBWD', '1') == '1'
+# operands (dL/dpre is never written)
 
 
 def dwsep_branches(x, mods, tape, outs, pool=None):
@@ -479,14 +474,10 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
 
             def bwd_bn(i=i, bn=bn, yv=yv, pre=pre, mean=mean, invstd=invstd):
                 part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
-                if FUSE_DW_BNBWD:
-                    # only the sums here; the fused backward of the branches applies the second pass while it stages (dy, pre)
-                    rec = ops.bn_backward_sums(yv.grad, pre, mean, invstd, bn.weight.data, bn.bias.data, bn.weight.grad, bn.bias.grad,
-                                               partials=part, slots=nslots)
-                    dpres[i], bnbs[i] = yv.grad, (pre, rec)
-                else:
-                    dpres[i] = ops.bn_backward(yv.grad, None, pre, mean, invstd, bn.weight.data, bn.weight.grad, bn.bias.grad, True, None, False,
-                                               beta=bn.bias.data, partials=part, slots=nslots)
+                # only the sums here; the fused backward of the branches applies the second pass while it stages (dy, pre)
+                rec = ops.bn_backward_sums(yv.grad, pre, mean, invstd, bn.weight.data, bn.bias.data, bn.weight.grad, bn.bias.grad,
+                                           partials=part, slots=nslots)
+                dpres[i], bnbs[i] = yv.grad, (pre, rec)
                 yv.free_grad()
             tape.record(bwd_bn, dict(op='dw_bn_act', bn=bn, conv=convs[i], x=x, out=yv))
         ys.append(m.pointwise_conv(yv, tape, out=outs[i]))
@@ -535,8 +526,7 @@ def set_overlap(wgrad_stream, fork_teacher):
     """switch the two overlap features at run time (bench.py's `alt_streams` leg, tests)"""
     global WGRAD_STREAM, FORK_TEACHER
     WGRAD_STREAM, FORK_TEACHER = bool(wgrad_stream), bool(fork_teacher)
-    if 'PFST_WGRAD_LDS_PAD' not in os.environ:
-        ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD if WGRAD_STREAM else 0)
+    ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD if WGRAD_STREAM else 0)
 
 
 def teacher_stream():
@@ -552,8 +542,7 @@ def _on_side_stream(fn, *tensors):
     main = torch.cuda.current_stream()
     if _side_stream is None:
         _side_stream = torch.cuda.Stream(priority=-1)      # high priority: the chain's kernels fill in around the wgrads
-        if 'PFST_WGRAD_LDS_PAD' not in os.environ:
-            ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD)
+        ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD)
     _side_stream.wait_stream(main)
     with torch.cuda.stream(_side_stream):
         fn()
@@ -573,7 +562,7 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     kernel; in the split modes the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 / fp16 matrix cores.
     saved_v: (transformed input, its amax slot group) kept from the forward pass; x_amax / dy_amax: slot groups when the caller has
     them (f16x3)"""
-    split = _split_mode() and WGRAD_SPLIT
+    split = _split_mode()
     f16 = split and CONV_MATH == 'f16x3' and conv.cout > 64
     v, v_amax = saved_v if saved_v is not None else (None, None)
     if conv.wino_wgrad_ok(xd.shape[2], xd.shape[3]):
@@ -589,7 +578,7 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
     elif conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3]) and ops.wgrad_q_operands_ok(xd, dy):
         ops.conv_wgrad_f16q_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                              dy_amax if dy_amax is not None else ops.absmax(dy), conv.k, conv.dilation)
-    elif split and (WGRAD_SPLIT_ALL or (conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0)):
+    elif split and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
         ops.conv_wgrad_split_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
     else:
         ops.conv_wgrad_(conv.weight.grad, xd, dy, conv.k, conv.stride, conv.dilation, conv.padding)
@@ -628,15 +617,12 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
             _dgrad_into(x, conv, dy, final, dy_amax)
         return
     if conv.depthwise:
-        if x.requires_grad and (FUSE_DW_BWD or x_bnl is not None):
+        if x.requires_grad:
             buf, acc = x.grad_target()         # both gradients from one staging of dy and one read of x (3 N of traffic instead of 4 N)
             ops.dwconv_bwd_(conv.weight.grad, xd, dy, conv.weight.data, conv.dilation, buf, accumulate=acc, bnl=x_bnl, bnb=dw_bnb)
         else:
-            assert x_bnl is None and dw_bnb is None
+            assert x_bnl is None and dw_bnb is None          # (a depthwise layer on the network input: weight gradient only)
             ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
-            if x.requires_grad:
-                buf, acc = x.grad_target()
-                ops.dwconv(dy, conv.weight.data, conv.dilation, flip=True, out=buf, accumulate=acc)
     else:
         _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
         if conv.bias is not None:
@@ -756,7 +742,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
         need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
                                                                     or conv.wino_f16 or conv.wgrad_f16q_ok(pre.shape[2], pre.shape[3]))
         dpre_amax = ops.amax_slots(pre.device) if need_amax else None
-        if (conv.depthwise and FUSE_DW_BNBWD and (FUSE_DW_BWD or x.lazy is not None) and relu and residual is None and gate is None
+        if (conv.depthwise and relu and residual is None and gate is None
                 and post_scale is None and x.requires_grad):
             # the depthwise backward forms dL/dpre itself from (dy, pre) and the record of the two sums: 3 N of traffic less
             rec = ops.bn_backward_sums(dy, pre, mean, invstd, bn.weight.data, bn.bias.data, bn.weight.grad, bn.bias.grad, partials=part,

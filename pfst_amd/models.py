@@ -20,9 +20,8 @@ from .layers import (BatchNorm2dP, Conv2dP, ConvModule, DepthwiseSeparableConvMo
 from .registry import BACKBONES, HEADS, LOSSES, SEGMENTORS, add_prefix, build_backbone, build_head, build_loss
 
 
-# PFST_FOLD_DROPOUT=0: the decode head's Dropout2d as a scaling pass of its own (A/B runs); default: folded into sep_bottleneck[1]'s normalisation
-FOLD_DROPOUT = os.environ.get('PFST_FOLD_DROPOUT', '1') == '1'
-FUSE_ASPP_POOL = os.environ.get('PFST_FUSE_ASPP_POOL', '1') == '1'
+# False: the decode head's Dropout2d as a scaling pass of its own (the fold on / off test); default: folded into sep_bottleneck[1]'s normalisation
+FOLD_DROPOUT = True
 
 
 def xin_dev(v):
@@ -137,7 +136,7 @@ class ResNetV1c(nn.Module):
         x = conv_bn_act(x, s[3], s[4], tape)
         x = conv_bn_act(x, s[6], s[7], tape, defer=True)     # its only consumer, the max-pool, normalises on load: stem.6's output is never written
         xin = x
-        pool_amax = ops.amax_slots(xin_dev(xin)) if layers_mod.CONV_MATH == 'f16x3' and layers_mod.PUBLISH_AMAX else None     # layer1's f16x3 GEMMs read the pooled map
+        pool_amax = ops.amax_slots(xin_dev(xin)) if layers_mod.CONV_MATH == 'f16x3' else None     # layer1's f16x3 GEMMs read the pooled map
         if xin.lazy is not None:
             y, idx = ops.maxpool(xin.lazy[0], bnl=xin.lazy[1], amax=pool_amax)
         else:
@@ -321,7 +320,7 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         n, _, h, w = x.data.shape
         ch, nb = self.channels, len(self.dilations) + 1
         cat = Var(torch.empty(n, nb * ch, h, w, device=x.data.device), tape is not None)
-        if layers_mod.CONV_MATH == 'f16x3' and layers_mod.PUBLISH_AMAX:
+        if layers_mod.CONV_MATH == 'f16x3':
             # every writer of the concat publishes max |.| into ONE group (layers._amax_target for the four slices, the broadcast below): the
             # bottleneck's f16x3 scale needs no pass of its own over the 2560-channel buffer
             cat.amax = ops.amax_slots(x.data.device)
@@ -330,8 +329,8 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
         self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
         nd = len(self.dilations)
-        # on the fused path the atrous branches' launch also forms the plane means of x, its backward their adjoint (PFST_FUSE_ASPP_POOL=0: not)
-        pool = {} if FUSE_ASPP_POOL else None
+        # on the fused path the atrous branches' launch also forms the plane means of x, its backward their adjoint
+        pool = {}
         dwsep_branches(x, [self.aspp_modules[i] for i in range(1, nd)], tape, [cat.slice((i + 1) * ch, (i + 2) * ch) for i in range(1, nd)],
                        pool=pool)
         # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)

@@ -1038,6 +1038,37 @@ def test_batched_weight_preparation_matches_the_per_layer_launches(ops, need_dgr
         layers.CONV_MATH, layers.WeightBatch.enabled = old_math, old_enabled
 
 
+@pytest.mark.parametrize('relu', [True, False])
+@pytest.mark.parametrize('case', [(3, 64, 256, 24, 1), (2, 128, 96, 20, 1), (2, 64, 64, 16, 3), (1, 192, 130, 33, 1), (8, 256, 512, 32, 1)])
+def test_f16x3_minmax_partials_predict_the_normalised_maximum(ops, case, relu):
+    """pfst_conv_igemm_f16x3(stats_minmax) + pfst_bn_finalize_partials(minmax): the GEMM epilogue emits per-channel (minimum, maximum)
+    partials of its output beside the (sum, sum of squares) ones, and the finalize kernel maps the channel extrema through the layer's own
+    fma(x, sc, sh) [+ ReLU]: the slot group receives max |[relu](bn(x))| of a tensor that has not been (and need not be) written --
+    bit for bit what pfst_bn_apply(y_amax) publishes when it writes it, with gammas of both signs, ragged row / pixel tiles, chained tiles
+    (8 images of 1024 pixels) and the 64-row tile.  The sums and every output value are unchanged by the extra partials."""
+    n, ci, co, hw, k = case
+    x = (torch.randn(n, ci, hw, hw, generator=g(ci)) * 2.0).to(DEV)
+    w = (torch.randn(co, ci, k, k, generator=g(co)) * 0.1).to(DEV)
+    gamma = (torch.randn(co, generator=g(3)) * 0.8).to(DEV)          # both signs: the maximum output may come from the minimum input
+    gamma[0] = 0.0
+    beta = (torch.randn(co, generator=g(4)) * 0.5).to(DEV)
+    w4f, _, wa = ops.pack_weight_f16x2(w, True, False)
+    xa = ops.absmax(x)
+    pad = k // 2
+    y0, st0, sl = ops.conv_fprop_f16x3(x, w4f, wa, xa, co, k, 1, 1, pad, want_stats=True)
+    sums0 = st0[:2 * co * sl].clone()
+    y, st, sl1 = ops.conv_fprop_f16x3(x, w4f, wa, xa, co, k, 1, 1, pad, want_stats=True, want_minmax=True)
+    assert sl1 == sl and torch.equal(y, y0) and torch.equal(st[:2 * co * sl], sums0)
+    mm = st[2 * co * sl:4 * co * sl].view(co, sl, 2)
+    lo, hi = mm[:, :, 0].min(dim=1)[0], mm[:, :, 1].max(dim=1)[0]
+    assert torch.equal(lo, y.amin(dim=(0, 2, 3))) and torch.equal(hi, y.amax(dim=(0, 2, 3)))
+    slots = ops.amax_slots(x.device)
+    mean, invstd, coef = ops.bn_finalize_partials(st, sl, co, n * hw * hw, gamma=gamma, beta=beta, predict_amax=slots, relu=relu)
+    true = ops.amax_slots(x.device)
+    yn = ops.bn_apply(y, mean, invstd, gamma, beta, relu, amax=true)
+    assert float(slots.max()) == float(true.max()) == float(yn.abs().max()), (float(slots.max()), float(true.max()), float(yn.abs().max()))
+
+
 @pytest.mark.parametrize('slots', [2, 5])
 def test_f16x3_tile_chain_is_the_same_arithmetic(ops, slots):
     """The f16x3 GEMMs walk up to 8 tiles per workgroup as one software pipeline (the next tile's first pairs are loaded, split and stored

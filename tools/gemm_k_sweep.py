@@ -13,6 +13,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--m', default='512,2048')
     ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--stats', type=int, default=0, help='1: with the fused BatchNorm statistics (as every conv -> BN layer runs), 2: + min / max partials')
     args = ap.parse_args()
     n, hw = 8, 128
     for m in [int(v) for v in args.m.split(',')]:
@@ -24,11 +25,11 @@ def main():
             xa = H.absmax(x)
             out = torch.empty(n, m, hw, hw, device='cuda')
             for _ in range(3):
-                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out)
+                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(args.reps):
-                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out)
+                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1)
             e.record()
             torch.cuda.synchronize()
             ms = s.elapsed_time(e) / args.reps
