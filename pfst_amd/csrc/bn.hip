@@ -11,7 +11,10 @@
 
 // cache policy of bn_apply's streams (raw buffer aux bits on gfx950: 2 = nt): build-time knobs for A/B builds
 #ifndef PFST_BN_LOAD_AUX
-#define PFST_BN_LOAD_AUX 0
+#define PFST_BN_LOAD_AUX 2      // the pre-BN tensor is streamed (nt): bn_apply -1.5 ms per step, profiles/r05_ab_cache_policy.txt (nt stores: +0.5 ms)
+#endif
+#ifndef PFST_BN_RES_AUX
+#define PFST_BN_RES_AUX 0
 #endif
 #ifndef PFST_BN_STORE_AUX
 #define PFST_BN_STORE_AUX 0
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
       }
       if (rp) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[u], 0, 0));
+        for (int u = 0; u < U; ++u) r[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, off[u], 0, PFST_BN_RES_AUX));
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -397,8 +400,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const int stride = gridDim.x * blockDim.x;
   if (VEC) {
     for (int i4 = bxi * blockDim.x + threadIdx.x; i4 < (HW >> 2); i4 += stride) {
+#ifdef PFST_BN_BWD_NT                              // A/B build: the apply pass is the last reader of dy and of the pre-BN tensor
+      typedef float pfst_v4f __attribute__((ext_vector_type(4)));
+      float4 g = __builtin_bit_cast(float4, __builtin_nontemporal_load(&reinterpret_cast<const pfst_v4f*>(gp)[i4]));
+      const float4 xv = __builtin_bit_cast(float4, __builtin_nontemporal_load(&reinterpret_cast<const pfst_v4f*>(xp)[i4]));
+#else
       float4 g = reinterpret_cast<const float4*>(gp)[i4];
       const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
+#endif
       if (post) { g.x *= pm; g.y *= pm; g.z *= pm; g.w *= pm; }
       if (relu) {
         bool on[4];
@@ -517,10 +526,7 @@ extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, do
 
 // Traversal order of the streaming BatchNorm kernels (bit 0: normalise pass, bit 1: backward reduction, bit 2: backward apply run from the
 // END of the tensor).  A pass that starts where its producer stopped finds the producer's last ~100-200 MB in the Infinity Cache.
-static int pfst_bn_order() {
-  static const int v = getenv("PFST_BN_ORDER") ? atoi(getenv("PFST_BN_ORDER")) : 3;   // measured: 3 and 7 -0.4 % on the step, 0 = all ascending
-  return v;
-}
+static constexpr int pfst_bn_order() { return 3; }      // measured (round 3): 3 and 7 -0.4 % on the step against 0 = all ascending
 
 extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void pack_weight_f16x2_batched_kernel(const pf
 // is being written to LDS).
 // Issue order is fixed slot by slot (one MFMA + at most two fillers, a scheduling barrier after each slot).
 // ---------------------------------------------------------------------------------------------------------------------------------
-// SHAPE: the MFMA instruction, 16 = v_mfma_f32_16x16x32_f16 (48 per step) or 32 = v_mfma_f32_32x32x16_f16 (24 per step: half the MFMA
+// SHAPE: the MFMA instruction, 32 = v_mfma_f32_32x32x16_f16 (24 per step; round 3's 16 = v_mfma_f32_16x16x32_f16 form, 48 per step, is gone: half the MFMA
 // issue slots, accumulators already in the 32x32 layout of conv_epilogue -- no re-layout through LDS)
 // BNB != 0 (SHAPE 32 only): the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h)
 // BPACK: the activation operand is stored pre-split (Winograd-domain V written by pfst_wino_input in packed mode)
@@ -247,8 +247,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb,
     const PfstResGate& gate) {
-  static_assert(BNB == 0 || SHAPE == 32, "the fused BatchNorm-backward epilogue exists for the 32x32 accumulator layout");
-  static_assert(!BPACK || SHAPE == 32, "the pre-split operand path exists for the 32x32 loop");
+  static_assert(SHAPE == 32, "one MFMA shape: v_mfma_f32_32x32x16_f16 (the 16x16x32 form of round 3 was removed in round 5)");
   static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE) || (BMT == 64 && SHAPE == 32 && BNB == 0 && !BPACK),
                 "the 256-row tile exists for the pixel-to-pixel 32x32 loop, the 64-row tile for the plain 32x32 loop");
   // BMT 64 (layers with 33 ... 64 output rows: layer1 conv2, stem.6): 256 threads as for 128 rows, the four waves 2 x 2 over 64 rows x 128
@@ -263,7 +262,6 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // stores of pair k+1 go to the other buffer whenever their data is ready.  SHAPE 16: one buffer, barrier A in the MFMA stream.
   constexpr int PAIR_CHUNKS = 2 * TILE_A + 2 * TILE_B;
   constexpr int SMEM_CHUNKS = 2 * PAIR_CHUNKS;
-  static_assert(SMEM_CHUNKS * 16 >= 4 * 32 * 68 * 4, "SHAPE 16: the epilogue's re-layout scratch (34 KB) lives in the tile buffers");
   __shared__ uint4 smem[SMEM_CHUNKS];
   uint4* const As = smem;
   uint4* const Bs = smem + 2 * TILE_A;
@@ -345,12 +343,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
 
   uint4 areg[2][NA];                                     // [register set][tile 2][chunk NA / 2]: like the activations, two pairs ahead
   float breg[2][TPT][8];                                 // [register set][tile][channel kh * 8 + i of the tile's 16]
-  f32x4 acc[4][4];                                       // SHAPE 16
-  pfst_f32x16 acc32[TMW][2];                             // SHAPE 32 (and the epilogue's layout)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pfst_f32x16 acc32[TMW][2];                             // the epilogue's 32 x 32 block layout
 #pragma unroll
   for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -425,56 +418,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const int a_frag = (lq >> 1) * TILE_A + (lq & 1) * BM + wm0 + l15;
   const int b_frag = (lq >> 1) * TILE_B + (lq & 1) * BN + wn0 + l15;
 
-  // one step on pair k: SETN = (k + 1) & 1 holds pair k+1 (split and stored here), pair k+2 is loaded into set k & 1
-  auto step = [&](auto setn_c, int k) {
-    constexpr int SETN = decltype(setn_c)::value, SETL = SETN ^ 1;
-    constexpr int CUR = SETL * PAIR_CHUNKS, NXT = SETN * PAIR_CHUNKS;       // as step32: pair k in LDS buffer k & 1, pair k+1 goes to the other
-    f16x8 af[4][NP], bf[4][NP];
-    auto rd_a = [&](int i, int pl) { af[i][pl] = __builtin_bit_cast(f16x8, As[CUR + a_frag + pl * 2 * BM + i * 16]); };
-    auto rd_b = [&](int j, int pl) { bf[j][pl] = __builtin_bit_cast(f16x8, Bs[CUR + b_frag + pl * 2 * BN + j * 16]); };
-    // fragment reads in the order the terms (al bh) (ah bl) (ah bh) need them; r = 0..15, the first five before the first MFMA
-    auto read_frag = [&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      if constexpr (r == 0) rd_a(0, 1);
-      else if constexpr (r < 5) rd_b(r - 1, 0);
-      else if constexpr (r < 8) rd_a(r - 4, 1);
-      else if constexpr (r == 8) rd_a(0, 0);
-      else if constexpr (r < 13) rd_b(r - 9, 1);
-      else rd_a(r - 12, 0);
-    };
-    const int soff2 = sidx2 * chan_step;
-    const int a_soff2 = (tap2 * spt + sidx2) * 2 * a_tile;
-    static_for<5>([&](auto rc) { read_frag(rc); });
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int PA[3] = {1, 0, 0};
-    constexpr int PB[3] = {0, 1, 0};
-    SplitF16 s0, s1;
-    // slots: 0-10 the remaining fragment reads; 4-19 the activations of pair k+2; 11-34 two split instructions each (pair k+1); 36-39 /
-    // 44-47 the eight LDS stores (to the other buffer); 40-43 the weight chunks of pair k+2; one barrier after the last MFMA
-    static_for<48>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int t = m >> 4, i = (m >> 2) & 3, j = m & 3;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-      if constexpr (m < 11) read_frag(std::integral_constant<int, 5 + m>());
-      // (past the last pair the offsets are out of the buffers' ranges: the loads return zeros, no branches in the stream)
-      if constexpr (m >= 4 && m < 20) load_b(std::integral_constant<int, m - 4>(), std::integral_constant<int, SETL>(), voff2, soff2);
-      if constexpr (m >= 11 && m < 35) {
-        constexpr int kk = (m - 11) * 2;
-        if constexpr (kk < 24) { split_op_f16<kk>(breg[SETN][0], sb, s0); split_op_f16<kk + 1>(breg[SETN][0], sb, s0); }
-        else { split_op_f16<kk - 24>(breg[SETN][1], sb, s1); split_op_f16<kk - 23>(breg[SETN][1], sb, s1); }
-      }
-      if constexpr (m >= 36 && m < 40) As[NXT + ((m - 36) / 2) * TILE_A + tid + 256 * ((m - 36) % 2)] = areg[SETN][m - 36];
-      if constexpr (m >= 40 && m < 44) load_a(std::integral_constant<int, m - 40>(), std::integral_constant<int, SETL>(), a_soff2);
-      if constexpr (m == 44) Bs[NXT + (0 * 2 + kh) * BN + pix] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
-      if constexpr (m == 45) Bs[NXT + (1 * 2 + kh) * BN + pix] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
-      if constexpr (m == 46) Bs[NXT + TILE_B + (0 * 2 + kh) * BN + pix] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-      if constexpr (m == 47) Bs[NXT + TILE_B + (1 * 2 + kh) * BN + pix] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    advance();
-    __syncthreads();
-  };
-  // the same step on v_mfma_f32_32x32x16_f16: fragments [k16 tile][32-row block][piece] (lane l31 = row, lh = k-half), 24 MFMAs in the
+  // one step on pair k: SETN = (k + 1) & 1 holds pair k+1 (split and stored here), pair k+2 is loaded into set k & 1.
+  // v_mfma_f32_32x32x16_f16: fragments [k16 tile][32-row block][piece] (lane l31 = row, lh = k-half), 24 MFMAs in the
   // order product-major, tile-minor (al bh | ah bl | ah bh): slots 0-11 one fragment read each, 0-7 two activation loads each, 8-11 the
   // weight stores of pair k+1 (to the OTHER LDS buffer: no barrier inside the step), 12-23 four split instructions each, 12-15 the weight
   // loads of pair k+2, 18 / 23 the activation stores
@@ -574,7 +519,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* const gsrc = gate.g ? gate.g + (i64)n * gate.g_bs : nullptr;
     const unsigned long long* const gmask = gate.g ? gate.mask + (i64)n * M * (P >> 6) : nullptr;
     const float ua = unscale_of(ea), ub = unscale_of(eb);
-    if constexpr (SHAPE == 32) {
+    {
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -605,29 +550,6 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-    } else {
-      float* const ws = reinterpret_cast<float*>(smem) + wid * (32 * 68);
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ws[(i * 16 + 4 * lq + r) * 68 + j * 16 + l15] = acc[hb * 2 + i][j][r] * ua * ub;
-        wave_lds_phase_fence();
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc32[hb][j][r] = ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + j * 32 + l31];
-        wave_lds_phase_fence();
-      }
-      conv_epilogue<2, 2, WAVES_N, BN>(acc32, outn, bias, stats, stats_T, accumulate, M, P, m0, p0, wm0, wn0, bx, n, wid, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      __syncthreads();                                   // the re-layout scratch is the tile buffer the next prologue writes
     }
   };
 
@@ -635,13 +557,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   for (int lin = blockIdx.x; lin < total; lin += G) {
     if (!CHAIN || lin == (int)blockIdx.x) prologue(lin);
     for (int k = 0; k < KP; k += 2) {
-      if constexpr (SHAPE == 32) {
-        step32(std::integral_constant<int, 1>(), k);
-        if (k + 1 < KP) step32(std::integral_constant<int, 0>(), k + 1);
-      } else {
-        step(std::integral_constant<int, 1>(), k);
-        if (k + 1 < KP) step(std::integral_constant<int, 0>(), k + 1);
-      }
+      step32(std::integral_constant<int, 1>(), k);
+      if (k + 1 < KP) step32(std::integral_constant<int, 0>(), k + 1);
     }
     epilogue(lin);
   }
@@ -678,346 +595,12 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_
 // ---------------------------------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// PACK: both operands are stored pre-split (the Winograd-domain V and dM): 2 x 8 permutes per step instead of 2 x 24 split instructions
-template <bool PACK>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x3_kernel(
-    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
-    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
-  constexpr int BM = 128, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
-  constexpr unsigned OOB = 0x80000000u;
-  __shared__ uint4 As[2][2 * NP * BM];
-  __shared__ uint4 Bs[2][2 * NP * BJ];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
-  int bx, by, bz;
-  {
-    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
-    if (lin < tiles * z8) {
-      const int xcd = lin & 7, idx = lin >> 3;
-      const int sl = idx / tiles, t = idx - sl * tiles;
-      bz = sl * 8 + xcd;
-      by = t / gx;
-      bx = t - by * gx;
-    } else {
-      bz = lin / tiles;
-      const int t = lin - bz * tiles;
-      by = t / gx;
-      bx = t - by * gx;
-    }
-  }
-  const int j0 = bx * BJ, m0 = by * BM;
-  const int ng = bz / chunks, chunk = bz - ng * chunks;
-  const int grp = ng / N, n = ng - grp * N;
-  const int pbeg = chunk * chunk_len;
-  const int pend = min(P, pbeg + chunk_len);
-  if (pbeg >= pend) return;
-  x += (i64)grp * x_gs + (i64)n * x_bs;
-  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
-  const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
-  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
-  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
-
-  const int srow = tid >> 1, half = tid & 1;        // staging role: 8 consecutive pixels of one row per operand
-  const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
-  const unsigned b_voff = (j0 + srow < J) ? 4u * ((unsigned)(j0 + srow) * (unsigned)P + 8u * half) : OOB;
-
-  float la[2][8], lb[2][8];                         // two register sets of loaded tiles
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // load q = 0..3 of the tile starting at pixel pk0: (A, B) x (first, second quad); P % 4 == 0 and chunk_len % 16 == 0: a quad is
-  // entirely in or out
-  auto load_quad = [&](auto qc, auto setc, int pk0) {
-    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value;
-    const int p = pk0 + 8 * half + 4 * (q & 1);
-    const bool v = p < pend;
-    const float4 t = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(q < 2 ? a_rsrc : b_rsrc, v ? (q < 2 ? a_voff : b_voff) : OOB,
-                                                                                      pk0 * 4 + 16 * (q & 1), 0));
-    float (&dst)[8] = q < 2 ? la[SET] : lb[SET];
-    dst[4 * (q & 1) + 0] = t.x; dst[4 * (q & 1) + 1] = t.y; dst[4 * (q & 1) + 2] = t.z; dst[4 * (q & 1) + 3] = t.w;
-  };
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  // prologue: tile 0 through the plain split into buffer 0, tile 1 into register set 1
-  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
-  {
-    uint4 ph, pl;
-    if constexpr (PACK) unpack8_f16(la[0], ph, pl);
-    else split8_f16(la[0], sa, ph, pl);
-    As[0][(0 * 2 + half) * BM + srow] = ph; As[0][(1 * 2 + half) * BM + srow] = pl;
-    if constexpr (PACK) unpack8_f16(lb[0], ph, pl);
-    else split8_f16(lb[0], sb, ph, pl);
-    Bs[0][(0 * 2 + half) * BJ + srow] = ph; Bs[0][(1 * 2 + half) * BJ + srow] = pl;
-  }
-  static_for<4>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 16); });
-  __syncthreads();
-
-  // one K-step on LDS buffer CUR = k & 1.  Issue order, a full scheduling barrier after each slot: 4 fragment reads, then 12 slots of
-  // one MFMA + fillers -- slots 0-3 one fragment read and one global load of tile k+2, 0-11 four split instructions of tile k+1 (dy in
-  // slots 0-5, x in 6-11), 6 / 11 (after the MFMA) the LDS stores of the dy / x pieces.
-  auto step = [&](auto curc, int kt) {
-    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
-    f16x8 af[TM][NP], bf[TN][NP];
-    // r = 0..7: al0 bh0 | bh1 al1 | ah0 bl0 | bl1 ah1   (what the MFMAs need, in their order)
-    auto read_frag = [&](int r) {
-      const int e = r & 1, pa = r < 4;                      // first four: the (al, bh) pair
-      if (r == 0 || r == 3) af[r == 0 ? 0 : 1][1] = __builtin_bit_cast(f16x8, As[CUR][(1 * 2 + lh) * BM + wm0 + (r == 0 ? 0 : 1) * 32 + l31]);
-      else if (r == 1 || r == 2) bf[r - 1][0] = __builtin_bit_cast(f16x8, Bs[CUR][(0 * 2 + lh) * BJ + wn0 + (r - 1) * 32 + l31]);
-      else if (r == 4 || r == 7) af[r == 4 ? 0 : 1][0] = __builtin_bit_cast(f16x8, As[CUR][(0 * 2 + lh) * BM + wm0 + (r == 4 ? 0 : 1) * 32 + l31]);
-      else bf[r - 5][1] = __builtin_bit_cast(f16x8, Bs[CUR][(1 * 2 + lh) * BJ + wn0 + (r - 5) * 32 + l31]);
-      (void)e; (void)pa;
-    };
-    static_for<4>([&](auto rc) { read_frag(decltype(rc)::value); });
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int PA[3] = {1, 0, 0};
-    constexpr int PB[3] = {0, 1, 0};
-    SplitF16 s_a, s_b;
-    const int pk2 = pbeg + (kt + 2) * 16;
-    static_for<12>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
-      if constexpr (m < 4) read_frag(4 + m);
-      static_for<4>([&](auto kc) {
-        constexpr int k = m * 4 + decltype(kc)::value;
-        if constexpr (PACK) {
-          if constexpr (k < 8) unpack_op_f16<k>(la[NXT], s_a);
-          else if constexpr (k >= 24 && k < 32) unpack_op_f16<k - 24>(lb[NXT], s_b);
-        } else {
-          if constexpr (k < 24) split_op_f16<k>(la[NXT], sa, s_a);
-          else split_op_f16<k - 24>(lb[NXT], sb, s_b);
-        }
-      });
-      // (the loads of tile k+2 overwrite set CUR: its values were split during the previous step)
-      if constexpr (m < 4) load_quad(mc, curc, pk2);
-      if constexpr (m == 6) {
-        As[NXT][(0 * 2 + half) * BM + srow] = make_uint4(s_a.h[0], s_a.h[1], s_a.h[2], s_a.h[3]);
-        As[NXT][(1 * 2 + half) * BM + srow] = make_uint4(s_a.l[0], s_a.l[1], s_a.l[2], s_a.l[3]);
-      }
-      if constexpr (m == 11) {
-        Bs[NXT][(0 * 2 + half) * BJ + srow] = make_uint4(s_b.h[0], s_b.h[1], s_b.h[2], s_b.h[3]);
-        Bs[NXT][(1 * 2 + half) * BJ + srow] = make_uint4(s_b.l[0], s_b.l[1], s_b.l[2], s_b.l[3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    __syncthreads();
-  };
-  const int KT = (pend - pbeg + 15) / 16;
-  for (int kt = 0; kt < KT; kt += 2) {
-    step(std::integral_constant<int, 0>(), kt);
-    if (kt + 1 < KT) step(std::integral_constant<int, 1>(), kt + 1);
-  }
-  const float ua = unscale_of(ea), ub = unscale_of(eb);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jj = j0 + wn0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r] * ua * ub);
-      }
-    }
-  }
-}
-
-// The same weight gradient with K = 32 per step (a PAIR of K=16 tiles per LDS buffer, the implicit GEMM's step32 shape): 24 MFMAs per
-// barrier instead of 12, so the fragment-read latency in front of a step's first MFMA and the barrier are paid half as often.
-// 64 KB of LDS (two pair buffers of both operands), two workgroups per CU as before.  Per step and thread: 8 wide loads (pair k+2),
-// 96 split instructions (pair k+1; 32 permutes when PACK), 8 LDS stores to the other buffer, 16 fragment reads.
-// BMT = 256: 256 rows of dY per workgroup (512 threads, one workgroup per CU): a thread stages both tiles of its dY row but ONE tile of
-// its X row -- 24 values per step instead of 32, and an X tile is fetched once for 256 rows of dY.
-template <bool PACK, int BMT = 128>
-__global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_pair_kernel(
-    const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
-    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
-  constexpr int BM = BMT, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2;
-  constexpr int TILE_A = 2 * NP * BM, TILE = 2 * NP * BJ;   // chunks of one K=16 tile of dY / of X
-  constexpr int TPTB = BM == 128 ? 2 : 1;                   // X tiles of a pair one thread stages
-  constexpr unsigned OOB = 0x80000000u;
-  __shared__ uint4 As[2][2 * TILE_A];                     // [buffer][tile][piece][k-half][row]
-  __shared__ uint4 Bs[2][2 * TILE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wid / WAVES_N) * WM, wn0 = (wid % WAVES_N) * WN;
-  int bx, by, bz;
-  {
-    const int lin = blockIdx.x, tiles = gx * gy, z8 = gz & ~7;
-    if (lin < tiles * z8) {
-      const int xcd = lin & 7, idx = lin >> 3;
-      const int sl = idx / tiles, t = idx - sl * tiles;
-      bz = sl * 8 + xcd;
-      by = t / gx;
-      bx = t - by * gx;
-    } else {
-      bz = lin / tiles;
-      const int t = lin - bz * tiles;
-      by = t / gx;
-      bx = t - by * gx;
-    }
-  }
-  const int j0 = bx * BJ, m0 = by * BM;
-  const int ng = bz / chunks, chunk = bz - ng * chunks;
-  const int grp = ng / N, n = ng - grp * N;
-  const int pbeg = chunk * chunk_len;
-  const int pend = min(P, pbeg + chunk_len);
-  if (pbeg >= pend) return;
-  x += (i64)grp * x_gs + (i64)n * x_bs;
-  dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
-  const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
-  const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
-  const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
-
-  // staging role: 8 consecutive pixels of one row per operand and tile (256-row tile: row tid / 2 of dY, both tiles; row (tid / 2) % 128
-  // of X, tile tid / 256)
-  const int srow = tid >> 1, half = tid & 1;
-  const int brow = BM == 128 ? srow : srow & 127, bt = BM == 128 ? 0 : tid >> 8;
-  const unsigned a_voff = (m0 + srow < M) ? 4u * ((unsigned)(m0 + srow) * (unsigned)P + 8u * half) : OOB;
-  const unsigned b_voff = (j0 + brow < J) ? 4u * ((unsigned)(j0 + brow) * (unsigned)P + 8u * half + 16u * bt) : OOB;
-
-  float la[2][2][8], lb[2][TPTB][8];                // [register set][tile of the pair][8 pixels]
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // load q = 0..7 of the pair starting at pixel pk0: operand q / 4 (dy, x), tile (q / 2) % 2, quad q % 2.  P % 4 == 0 and
-  // chunk_len % 16 == 0: a quad is entirely in or out (out: zeros -- an odd tile count leaves the pair's second tile empty)
-  // (256-row tile: q = 4, 5 are the two quads of the thread's ONE X tile, whose 16-pixel offset sits in b_voff)
-  auto load_quad = [&](auto qc, auto setc, int pk0) {
-    constexpr int q = decltype(qc)::value, SET = decltype(setc)::value, opb = q >> 2, t = (TPTB == 1 && opb) ? 0 : (q >> 1) & 1, quad = q & 1;
-    const int p = pk0 + 16 * (opb ? t + bt : t) + 8 * half + 4 * quad;
-    const bool v = p < pend;
-    const float4 w = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(opb ? b_rsrc : a_rsrc, v ? (opb ? b_voff : a_voff) : OOB,
-                                                                                      pk0 * 4 + 64 * t + 16 * quad, 0));
-    float (&dst)[8] = opb ? lb[SET][t] : la[SET][t];
-    dst[4 * quad + 0] = w.x; dst[4 * quad + 1] = w.y; dst[4 * quad + 2] = w.z; dst[4 * quad + 3] = w.w;
-  };
-  const int l31 = lane & 31, lh = lane >> 5;
-
-  // prologue: pair 0 through the plain split into buffer 0, pair 1 into register set 1
-  static_for<4 + 2 * TPTB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 0>(), pbeg); });
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    uint4 ph, pl;
-    if constexpr (PACK) unpack8_f16(la[0][t], ph, pl);
-    else split8_f16(la[0][t], sa, ph, pl);
-    As[0][t * TILE_A + (0 * 2 + half) * BM + srow] = ph; As[0][t * TILE_A + (1 * 2 + half) * BM + srow] = pl;
-  }
-#pragma unroll
-  for (int t = 0; t < TPTB; ++t) {
-    uint4 ph, pl;
-    if constexpr (PACK) unpack8_f16(lb[0][t], ph, pl);
-    else split8_f16(lb[0][t], sb, ph, pl);
-    Bs[0][(t + bt) * TILE + (0 * 2 + half) * BJ + brow] = ph; Bs[0][(t + bt) * TILE + (1 * 2 + half) * BJ + brow] = pl;
-  }
-  static_for<4 + 2 * TPTB>([&](auto qc) { load_quad(qc, std::integral_constant<int, 1>(), pbeg + 32); });
-  __syncthreads();
-
-  // one step on LDS buffer CUR = k & 1 (register set NXT holds pair k+1; pair k+2 is loaded into set CUR, whose values were split during
-  // the previous step).  24 MFMAs product-major, tile-minor (al bh | ah bl | ah bh); slots 0-11 one fragment read, 0-7 one wide load,
-  // 0-23 four split instructions (dy tile 0: 0-5, dy tile 1: 6-11, x tile 0: 12-17, x tile 1: 18-23), the LDS stores behind the MFMAs of
-  // slots 6 / 12 / 18 / 23.
-  auto step = [&](auto curc, int kp) {
-    constexpr int CUR = decltype(curc)::value, NXT = CUR ^ 1;
-    f16x8 af[2][TM][NP], bf[2][TN][NP];
-    auto rd_a = [&](int t, int i, int pl) { af[t][i][pl] = __builtin_bit_cast(f16x8, As[CUR][t * TILE_A + (pl * 2 + lh) * BM + wm0 + i * 32 + l31]); };
-    auto rd_b = [&](int t, int j, int pl) { bf[t][j][pl] = __builtin_bit_cast(f16x8, Bs[CUR][t * TILE + (pl * 2 + lh) * BJ + wn0 + j * 32 + l31]); };
-    // r = 0..15: (al, bh) of tile 0, of tile 1, then (ah, bl) of tile 0, of tile 1 -- within a group a0 b0 b1 a1, the MFMAs' order
-    auto read_frag = [&](auto rc) {
-      constexpr int r = decltype(rc)::value, grp = r >> 2, e = r & 3, t = grp & 1, pa = grp < 2 ? 1 : 0, pb = grp < 2 ? 0 : 1;
-      if constexpr (e == 0) rd_a(t, 0, pa);
-      else if constexpr (e == 1) rd_b(t, 0, pb);
-      else if constexpr (e == 2) rd_b(t, 1, pb);
-      else rd_a(t, 1, pa);
-    };
-    static_for<4>([&](auto rc) { read_frag(rc); });
-    __builtin_amdgcn_sched_barrier(0);
-    SplitF16 s0, s1;
-    const int pk2 = pbeg + (kp + 2) * 32;
-    static_for<24>([&](auto mc) {
-      constexpr int m = decltype(mc)::value;
-      constexpr int prod = m >> 3, t = (m >> 2) & 1, i = (m >> 1) & 1, j = m & 1;
-      constexpr int pa = prod == 0 ? 1 : 0, pb = prod == 1 ? 1 : 0;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][i][pa], bf[t][j][pb], acc[i][j], 0, 0, 0);
-      if constexpr (m < 12) read_frag(std::integral_constant<int, 4 + m>());
-      if constexpr (m < 4 + 2 * TPTB) load_quad(mc, curc, pk2);
-      static_for<4>([&](auto kc) {
-        constexpr int k = (m % 6) * 4 + decltype(kc)::value;          // 0..23 within the 8-value group of slot group m / 6
-        constexpr int g = m / 6;                                      // 0: dy tile 0, 1: dy tile 1, 2: x tile 0, 3: x tile 1
-        if constexpr (PACK) {
-          if constexpr (k < 8) {
-            if constexpr (g == 0) unpack_op_f16<k>(la[NXT][0], s0);
-            else if constexpr (g == 1) unpack_op_f16<k>(la[NXT][1], s1);
-            else if constexpr (g == 2) unpack_op_f16<k>(lb[NXT][0], s0);
-            else if constexpr (TPTB == 2) unpack_op_f16<k>(lb[NXT][TPTB - 1], s1);
-          }
-        } else {
-          if constexpr (g == 0) split_op_f16<k>(la[NXT][0], sa, s0);
-          else if constexpr (g == 1) split_op_f16<k>(la[NXT][1], sa, s1);
-          else if constexpr (g == 2) split_op_f16<k>(lb[NXT][0], sb, s0);
-          else if constexpr (TPTB == 2) split_op_f16<k>(lb[NXT][TPTB - 1], sb, s1);
-        }
-      });
-      if constexpr (m == 6) {
-        As[NXT][(0 * 2 + half) * BM + srow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
-        As[NXT][(1 * 2 + half) * BM + srow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
-      }
-      if constexpr (m == 12) {
-        As[NXT][TILE_A + (0 * 2 + half) * BM + srow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-        As[NXT][TILE_A + (1 * 2 + half) * BM + srow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
-      }
-      if constexpr (m == 18) {                                      // (256-row tile: the thread's one X tile)
-        Bs[NXT][bt * TILE + (0 * 2 + half) * BJ + brow] = make_uint4(s0.h[0], s0.h[1], s0.h[2], s0.h[3]);
-        Bs[NXT][bt * TILE + (1 * 2 + half) * BJ + brow] = make_uint4(s0.l[0], s0.l[1], s0.l[2], s0.l[3]);
-      }
-      if constexpr (m == 23 && TPTB == 2) {
-        Bs[NXT][TILE + (0 * 2 + half) * BJ + brow] = make_uint4(s1.h[0], s1.h[1], s1.h[2], s1.h[3]);
-        Bs[NXT][TILE + (1 * 2 + half) * BJ + brow] = make_uint4(s1.l[0], s1.l[1], s1.l[2], s1.l[3]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    __syncthreads();
-  };
-  const int KPAIRS = (pend - pbeg + 31) / 32;
-  for (int kp = 0; kp < KPAIRS; kp += 2) {
-    step(std::integral_constant<int, 0>(), kp);
-    if (kp + 1 < KPAIRS) step(std::integral_constant<int, 1>(), kp + 1);
-  }
-  const float ua = unscale_of(ea), ub = unscale_of(eb);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int jj = j0 + wn0 + j * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < M && jj < J) atomicAdd(&dw[(i64)m * J + jj], acc[i][j][r] * ua * ub);
-      }
-    }
-  }
-}
-
-// The pair kernel with WHOLE-LINE loads.  There a thread loaded 8 consecutive pixels of a row (two lanes per row): one load instruction
+// (Round 5 removed the two earlier forms of this kernel -- K = 16 per step with 8-pixel row pieces, then K = 32 "pair" steps -- together with their
+// PFST_F16X3_WGRAD_PAIR / _LINE switches: the whole-line kernel below has been the only one launched since round 3; git history has them.)
+// PACK: both operands are stored pre-split (the Winograd-domain V and dM): permutes instead of split instructions.
+// BMT = 256: 256 rows of dY per workgroup (512 threads, one workgroup per CU): an X tile is fetched once for 256 rows of dY.
+// K = 32 per step (a pair of K=16 tiles per LDS buffer, the implicit GEMM's step32 shape: 24 MFMAs per barrier) with WHOLE-LINE loads.  The earlier
+// form loaded 8 consecutive pixels of a row per thread (two lanes per row): one load instruction
 // touched 32 rows x 32 bytes, a quarter of each 128-byte line, and the other three quarters came from three more instructions -- the vector
 // L1 had to hold every line across four instructions; timing with fully coalesced (wrong) addresses: 51.8 -> 44.1 ms per step.  Here a
 // row's 32 pixels of a pair (128 bytes) are ONE line read by 8 adjacent lanes, a load instruction covers 8 whole lines: thread
@@ -1232,16 +815,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
 // balance: long chains amortise the one prologue (4-6 K-steps' worth, tools/gemm_k_sweep.py), but the hardware can only even out the
 // CUs' speeds by handing out whole workgroups, and a last round of workgroups that fills a fraction of the slots wastes the rest.
 // -> of the grids total / t (t = 1..8) and one-workgroup-per-slot, the one whose rounds waste the least (ties: the longer chains).
-// PFST_F16X3_CHAIN=0: one workgroup per tile (the launch shape before the chain, for A/B runs).
-int f16x3_chain() {
-  static const int v = getenv("PFST_F16X3_CHAIN") ? atoi(getenv("PFST_F16X3_CHAIN")) : 1;
-  return v != 0;
-}
 int f16x3_slots_override = 0;                             // pfst_f16x3_set_slots
-int f16x3_bm256() {                                       // PFST_F16X3_BM256=0: the 128-row tile everywhere (A/B runs)
-  static const int v = getenv("PFST_F16X3_BM256") ? atoi(getenv("PFST_F16X3_BM256")) : 1;
-  return v != 0;
-}
 unsigned f16x3_grid(i64 total, bool chainable, int wg_per_cu = 2) {
   static int cus = 0;
   if (cus == 0) {
@@ -1251,29 +825,20 @@ unsigned f16x3_grid(i64 total, bool chainable, int wg_per_cu = 2) {
   // resident workgroups: two 256-thread workgroups per CU, one of the 512-thread 256-row tile (the override counts 256-thread slots)
   int slots = (f16x3_slots_override > 0 ? f16x3_slots_override : 2 * cus) * wg_per_cu / 2;
   if (slots < 1) slots = 1;
-  if (!chainable || !f16x3_chain() || total <= slots) return (unsigned)total;
+  if (!chainable || total <= slots) return (unsigned)total;
   i64 best_g = total;
   double best_waste = 1e30;
   for (int t = 0; t <= 32; ++t) {                         // t = 0: one workgroup per slot
     const i64 g = t == 0 ? slots : (total + t - 1) / t;
     if (g < slots) continue;
     const i64 per_wg = (total + g - 1) / g, rounds = (g + slots - 1) / slots;
-    static const int cap = getenv("PFST_F16X3_CHAIN_CAP") ? atoi(getenv("PFST_F16X3_CHAIN_CAP")) : 8;
-    if (per_wg > cap) continue;                           // measured: 4-8 tiles per workgroup beat both 1 and 32 at every K
+    if (per_wg > 8) continue;                             // measured: 4-8 tiles per workgroup beat both 1 and 32 at every K
     const double waste = (double)(rounds * per_wg * slots) / (double)total;
     if (waste < best_waste - 1e-9 || (waste < best_waste + 1e-9 && g < best_g)) { best_waste = waste; best_g = g; }
   }
   return (unsigned)best_g;
 }
 
-int f16x3_nt_store() {                                    // PFST_F16X3_NT_STORE=0: ordinary stores everywhere (A/B runs)
-  static const int v = getenv("PFST_F16X3_NT_STORE") ? atoi(getenv("PFST_F16X3_NT_STORE")) : 1;
-  return v != 0;
-}
-int f16x3_shape() {
-  static const int v = getenv("PFST_F16X3_SHAPE") ? atoi(getenv("PFST_F16X3_SHAPE")) : 32;
-  return v == 16 ? 16 : 32;
-}
 
 }  // namespace
 
@@ -1400,7 +965,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   if (gate_dy) {
     // out = conv + (bit ? gate_dy : 0): the epilogue's whole-tile path, the mask's 256-element groups, one writer (no old values)
     PFST_CHECK_ARG(gate_mask && mode == 1 && !accumulate && !bias && !stats && M % 128 == 0 && ((i64)Ho * Wo) % 256 == 0 &&
-                   gate_dy_bs >= (i64)M * Ho * Wo && f16x3_shape() == 32);
+                   gate_dy_bs >= (i64)M * Ho * Wo);
     gate.g = gate_dy;
     gate.g_bs = gate_dy_bs;
     gate.mask = gate_mask;
@@ -1418,7 +983,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
     return PFST_ERR_UNSUPPORTED;
   }
   const bool small = M <= 64;                       // 33 ... 64 output rows: the 64-row tile (one 32-row block per wave)
-  PFST_CHECK_ARG(!small || (f16x3_shape() == 32 && !(bnb && bnb->x)));
+  PFST_CHECK_ARG(!small || !(bnb && bnb->x));
   const int span = (ksize - 1) * dil;
   if (mode == 0) {
     PFST_CHECK_ARG(Ho == (Hi + 2 * pad - span - 1) / stride + 1 && Wo == (Wi + 2 * pad - span - 1) / stride + 1);
@@ -1428,12 +993,12 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   int a, b, c, d;
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * (int)cdiv((i64)Ho * Wo, BN) * 2;      // two pixel-waves per tile at every tile height (= pfst_conv_stats_slots for M > 64)
-  const bool one = !small && ksize == 1 && stride == 1 && pad == 0 && f16x3_shape() == 32;      // pixel-to-pixel: the tile-chain variant
-  const bool big = one && M % 256 == 0 && f16x3_bm256();                              // 256-row tiles, 512 threads, one workgroup per CU
+  const bool one = !small && ksize == 1 && stride == 1 && pad == 0;      // pixel-to-pixel: the tile-chain variant
+  const bool big = one && M % 256 == 0;                              // 256-row tiles, 512 threads, one workgroup per CU
   const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : small ? 64 : 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
-  const int chain = f16x3_chain() | (stats_minmax ? 2 : 0) | (f16x3_nt_store() ? 4 : 0);
+  const int chain = 1 | (stats_minmax ? 2 : 0) | 4;            // bit 0: tile chains, bit 1: (min, max) partials, bit 2: nt stores for short contractions
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, no forward statistics
     PFST_CHECK_ARG(M % 128 == 0 && !bias && !stats && bnb->coef && bnb->partials);
@@ -1470,11 +1035,8 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   else if (one)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
-  else if (f16x3_shape() == 32)
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
-                       (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
+    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
@@ -1488,11 +1050,11 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   PFST_CHECK_ARG(V && U4 && u_amax && v_amax && Mbuf && N > 0 && N <= 65535 && K > 0 && K % 32 == 0 && M > 64 && T > 0 && (m == 2 || m == 4));
   const int nx = (m + 2) * (m + 2);
   PFST_CHECK_ARG((i64)K * T * 4 < (1ll << 31) && (i64)M * T * 4 < (1ll << 31) && (i64)K * M * 4 < (1ll << 31));
-  const bool big = M % 256 == 0 && f16x3_bm256() && (v_packed || f16x3_shape() == 32);
+  const bool big = M % 256 == 0;
   const i64 total = (i64)cdiv((i64)T, BN) * cdiv(M, big ? 256 : 128) * nx * N;
   PFST_CHECK_ARG(total < (1ll << 31));
-  const dim3 grid(f16x3_grid(total, (v_packed || f16x3_shape() == 32) && (K / 32) % 2 == 0, big ? 1 : 2));
-  const int chain = f16x3_chain() | (f16x3_nt_store() ? 4 : 0);
+  const dim3 grid(f16x3_grid(total, (K / 32) % 2 == 0, big ? 1 : 2));
+  const int chain = 1 | 4;
   // v_packed: V holds pre-split elements (pfst_wino_input with pack_x_amax) and v_amax the bound they were scaled by
   if (big && v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true, 256>), grid, dim3(512), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
@@ -1503,11 +1065,8 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
   else if (v_packed)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, true, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4,
                        (const float*)nullptr, Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
-  else if (f16x3_shape() == 32)
-    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
-                       Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   else
-    hipLaunchKernelGGL(conv_igemm_f16x3_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, true>), grid, dim3(256), 0, (hipStream_t)stream, V, (i64)K * T, (const uint4*)U4, (const float*)nullptr,
                        Mbuf, (i64)M * T, K, 1, T, M, 1, T, 1, 1, 1, 0, 1, 0, (float*)nullptr, 0, u_amax, v_amax, nx, N, chain, PfstResGate());
   PFST_CHECK_LAUNCH();
   return PFST_OK;
@@ -1516,8 +1075,7 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                             i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
-  static const int pair = getenv("PFST_F16X3_WGRAD_PAIR") ? atoi(getenv("PFST_F16X3_WGRAD_PAIR")) : 1;     // 0: the K=16-step kernel (A/B runs)
-  const bool big = pair && M % 256 == 0 && f16x3_bm256();       // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
+  const bool big = M % 256 == 0;                                // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
   const int bm = big ? 256 : 128;
   const int tiles = cdiv(J, 128) * cdiv(M, bm) * groups;
   // split-K chunking: whole rounds of resident workgroups (2 per CU; the 256-row tile: 1)
@@ -1537,17 +1095,10 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
 #define PFST_LAUNCH_WGRAD(KERNEL_, THREADS_)                                                                                               \
   hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, \
                      gx, gy, gz, x_amax, dy_amax)
-  static const int line = getenv("PFST_F16X3_WGRAD_LINE") ? atoi(getenv("PFST_F16X3_WGRAD_LINE")) : 1;     // 0: the pair kernel's 32-byte row pieces
-  if (line && pair && big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
-  else if (line && pair && big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256>), 512);
-  else if (line && pair && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true>), 256);
-  else if (line && pair) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false>), 256);
-  else if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true, 256>), 512);
-  else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false, 256>), 512);
-  else if (pair && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<true>), 256);
-  else if (pair) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_pair_kernel<false>), 256);
-  else if (packed) PFST_LAUNCH_WGRAD(conv_wgrad_f16x3_kernel<true>, 256);
-  else PFST_LAUNCH_WGRAD(conv_wgrad_f16x3_kernel<false>, 256);
+  if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
+  else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256>), 512);
+  else if (packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true>), 256);
+  else PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false>), 256);
 #undef PFST_LAUNCH_WGRAD
   PFST_CHECK_LAUNCH();
   return PFST_OK;

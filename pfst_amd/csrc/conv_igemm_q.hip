@@ -227,9 +227,7 @@ int launch_q(const float* in, i64 in_bs, const float* wq, const float* bias, flo
              int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
              const PfstBnbArgs* bnb, hipStream_t s) {
   dim3 grid(cdiv((i64)Ho * Wo, QBN) * cdiv(M, BM), groups, N);
-  // occupancy cap (diagnostic / stream-overlap experiments, tools/overlap_microbench.py): unused dynamic LDS so that fewer workgroups
-  // fit per CU and a concurrently running HBM-bound kernel of another stream finds registers and wave slots
-  static const int lds_pad = getenv("PFST_IGEMM_LDS_PAD") ? atoi(getenv("PFST_IGEMM_LDS_PAD")) : 0;
+  constexpr int lds_pad = 0;
   if (bnb && bnb->x) {
     // the fused sums use the epilogue's full-tile store path: whole row tiles, no bias, one GEMM group
     PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);

@@ -371,7 +371,6 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
   // whole "rounds": `slots` blocks are resident at once (LDS-limited: 4 per CU at WBK=16, 2 at WBK=32), and e.g.
   // 1152 blocks on 1024 slots leave 7/8 of the CUs idle for the last ninth of the work (measured -10 % on the 3x3
   // layers).  Take the smallest split whose last round is >= 90 % full, else the best one.
-  static const int chunks_env = getenv("PFST_WGRAD_CHUNKS") ? atoi(getenv("PFST_WGRAD_CHUNKS")) : 0;   // tuning knob
   const double slots = 256.0 * (WBK == 16 ? 4 : 2);
   int chunks = 1;
   double best = -1.0;
@@ -381,7 +380,6 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (chunks_env > 0) chunks = chunks_env;
   while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
@@ -401,9 +399,8 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
 template <int BM, int T>
 int launch_wgrad(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                  int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
-  static const int wbk_env = getenv("PFST_WGRAD_BK") ? atoi(getenv("PFST_WGRAD_BK")) : 0;   // tuning knob
   // measured (tools/conv_microbench.py): 3x3 gathers prefer the shallower K tile (4 blocks/CU: +7-10 %), 1x1 the deeper one
-  const int wbk = wbk_env ? wbk_env : (T == 9 ? 16 : 32);
+  const int wbk = T == 9 ? 16 : 32;
   if (wbk == 16) return launch_wgrad_k<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
   return launch_wgrad_k<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
 }

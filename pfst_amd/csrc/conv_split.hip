@@ -53,7 +53,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], uint4& p0, uint4& p1
 
 // BNB != 0: the data-gradient launch also emits the BatchNorm-backward sums of the layer that owns `out` (conv_epilogue.h); on the bf16
 // matrix pipe the epilogue's VALU work co-issues with the other waves' MFMAs
-// DIAG != 0: timing-ablation builds for tools/split_ablation.py (results are WRONG by construction; never launched by the product path):
+// DIAG != 0: the timing-ablation instantiations of round 2 (profiles/r02_split_phase_stamps.txt; results WRONG by construction).  No entry point
+// launches them any more (the PFST_SPLIT_DIAG dispatch and tools/split_ablation.py were removed in round 5); instantiate by hand to repeat it:
 // 1 no split + LDS store, 2 no global loads, 3 no MFMAs, 4 no LDS fragment reads, 5 no in-loop barrier,
 // 6 s_memtime stamps around the four phases of a K-step, summed per wave into the `stats` buffer as 6 (of 8) x u32 (not an output value)
 template <int BM, int BNB = 0, int DIAG = 0>
@@ -502,13 +503,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_split_pipe_kernel(
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
   conv_igemm_split_pipe_body<0>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                 PfstBnbArgs());
-}
-__global__ __launch_bounds__(256, 3) void conv_igemm_split_pipe_shape16_diag_kernel(
-    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk6, const float* __restrict__ bias,
-    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
-    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T) {
-  conv_igemm_split_pipe_body<0, true>(in, in_bs, wk6, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats,
-                                      stats_T, PfstBnbArgs());
 }
 template <int BNB>
 __global__ __launch_bounds__(256, 2) void conv_igemm_split_pipe_bnb_kernel(
@@ -1192,8 +1186,7 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, BM), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  static const int pipe = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;            // 0: the un-pipelined main loop
-  if (BM == 128 && pipe)
+  if (BM == 128)
     hipLaunchKernelGGL(conv_wgrad_split_q_pipe_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
                        N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
   else
@@ -1224,49 +1217,11 @@ int launch_split(const float* in, i64 in_bs, const void* wk6, const float* bias,
                  int Wi, int M, int Ho, int Wo, int ks, int a, int b, int c, int d, int acc, float* stats, int stats_T, int groups,
                  hipStream_t s, const PfstBnbArgs* bnb = nullptr) {
   dim3 grid(cdiv((i64)Ho * Wo, BN) * cdiv(M, BM), groups, N);
-  static const int lds_pad = getenv("PFST_SPLIT_LDS_PAD") ? atoi(getenv("PFST_SPLIT_LDS_PAD")) : 0;   // diagnostic: occupancy cap
-  static const int pipe_env = getenv("PFST_SPLIT_PIPE") ? atoi(getenv("PFST_SPLIT_PIPE")) : 1;        // 0: the un-pipelined main loop
+  constexpr int lds_pad = 0;
   // measured per layer (bf16x6 train step): the pipelined loop wins from K = 512 up, loses 1-5 % on the short 1x1 / Winograd-domain GEMMs
-  const bool pipe = pipe_env == 2 || (pipe_env == 1 && (i64)C * ks * ks >= 512);
-  // timing diagnostics (tools/split_ablation.py): take precedence over every dispatch rule below; plain launches without bias / statistics
-  static const int diag = getenv("PFST_SPLIT_DIAG") ? atoi(getenv("PFST_SPLIT_DIAG")) : 0;
-  if (diag != 0) {
-    if (!getenv("PFST_DIAG_WRONG_RESULTS_OK")) {                  // the ablated variants compute WRONG results: never by accident
-      pfst_set_error(__FILE__, __LINE__, "PFST_SPLIT_DIAG selects timing-only kernels with wrong results; set PFST_DIAG_WRONG_RESULTS_OK=1 as well");
-      return PFST_ERR_UNSUPPORTED;
-    }
-    if (BM == 128 && !(bnb && bnb->x)) {
-#define PFST_DIAG_CASE(D_)                                                                                                                  \
-  case D_:                                                                                                                                  \
-    hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, D_>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, \
-                       C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});                                           \
-    PFST_CHECK_LAUNCH();                                                                                                                    \
-    return PFST_OK;
-      switch (diag) {
-        PFST_DIAG_CASE(1) PFST_DIAG_CASE(2) PFST_DIAG_CASE(3) PFST_DIAG_CASE(4) PFST_DIAG_CASE(5) PFST_DIAG_CASE(6)
-        case 7:
-          hipLaunchKernelGGL(conv_igemm_split_pipe_shape16_diag_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out,
-                             out_bs, C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-          PFST_CHECK_LAUNCH();
-          return PFST_OK;
-        case 8:                                                   // reference points of the ablation: the two un-ablated loops by name
-          hipLaunchKernelGGL((conv_igemm_split_kernel<128, 0, 0>), grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs,
-                             C, Hi, Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T, PfstBnbArgs{});
-          PFST_CHECK_LAUNCH();
-          return PFST_OK;
-        case 9:
-          hipLaunchKernelGGL(conv_igemm_split_pipe_kernel, grid, dim3(256), lds_pad, s, in, in_bs, (const uint4*)wk6, bias, out, out_bs, C, Hi,
-                             Wi, M, Ho, Wo, ks, a, b, c, d, acc, stats, stats_T);
-          PFST_CHECK_LAUNCH();
-          return PFST_OK;
-        default: break;
-      }
-#undef PFST_DIAG_CASE
-    }
-  }
+  const bool pipe = (i64)C * ks * ks >= 512;
   // the K = 32 pairing on the 16x16x32 MFMA shape: whole 32-channel steps per tap
-  static const int pair_env = getenv("PFST_SPLIT_PAIR") ? atoi(getenv("PFST_SPLIT_PAIR")) : 1;
-  if (BM == 128 && pipe && pair_env && C % 32 == 0) {
+  if (BM == 128 && pipe && C % 32 == 0) {
     if (bnb && bnb->x) {
       PFST_CHECK_ARG(M % BM == 0 && !bias && !stats && groups == 1 && bnb->coef && bnb->partials);
 #define PFST_LAUNCH_PAIR_BNB(MODE_)                                                                                                        \

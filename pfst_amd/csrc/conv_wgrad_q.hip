@@ -20,7 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-int g_wgrad_lds_pad = getenv("PFST_WGRAD_LDS_PAD") ? atoi(getenv("PFST_WGRAD_LDS_PAD")) : 0;
+int g_wgrad_lds_pad = 0;                  // pfst_conv_wgrad_set_lds_pad
 
 
 constexpr int QBJ = 128;
@@ -488,7 +488,6 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, QBJ) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident blocks (see launch_wgrad_k in conv_mfma.hip); 32 KB LDS at WBK = 16, 64 KB at 32
-  static const int chunks_env = getenv("PFST_WGRAD_CHUNKS") ? atoi(getenv("PFST_WGRAD_CHUNKS")) : 0;
   const double slots = 256.0 * (WBK == 16 ? 4 : 2);
   int chunks = 1;
   double best = -1.0;
@@ -498,10 +497,9 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (chunks_env > 0) chunks = chunks_env;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
-  static const int xcd_env = getenv("PFST_WGRAD_XCD") ? atoi(getenv("PFST_WGRAD_XCD")) : 1;
+  constexpr int xcd_env = 1;
   const int gx = cdiv(J, QBJ), gy = cdiv(M, BM), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
   dim3 grid(gx * gy * gz);
@@ -516,9 +514,6 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
 template <int BM, int T>
 int launch_q_bk(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                 int Ho, int Wo, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
-  static const int wbk_env = getenv("PFST_WGRADQ_BK") ? atoi(getenv("PFST_WGRADQ_BK")) : 0;   // tuning knob
-  const int wbk = (wbk_env && T == 1) ? wbk_env : 16;        // the 3x3 row walk assumes 16-pixel K-steps
-  if (wbk == 32) return launch_q<BM, T, 32>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
   return launch_q<BM, T, 16>(x, x_bs, dy, dy_bs, dw, N, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
 }
 
@@ -539,7 +534,7 @@ int launch_q16(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, 
   }
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
-  static const int xcd_env = getenv("PFST_WGRAD_XCD") ? atoi(getenv("PFST_WGRAD_XCD")) : 1;
+  constexpr int xcd_env = 1;
   const int gx = cdiv(J, QBJ), gy = cdiv(M, BM), gz = N * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
   hipLaunchKernelGGL((conv_wgrad_q16_kernel<BM, T>), dim3(gx * gy * gz), dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho,

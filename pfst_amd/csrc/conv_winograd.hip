@@ -228,11 +228,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 #pragma unroll
         for (int k = 0; k < R; ++k) a = cmac(a, Wino<M>::bt(j, k), r[i][k]);
         if (pack_amax) {
-#ifdef PFST_WINO_NT
-          __builtin_nontemporal_store(pack_f16x2_pieces(a * ps), &reinterpret_cast<unsigned*>(vp)[(i64)(i * R + j) * plane + t]);
-#else
           reinterpret_cast<unsigned*>(vp)[(i64)(i * R + j) * plane + t] = pack_f16x2_pieces(a * ps);
-#endif
         } else {
           vp[(i64)(i * R + j) * plane + t] = a;
           am = fmaxf(am, fabsf(a));
@@ -260,11 +256,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     tile_coord(g, t, sy, sx, ty, tx);
     float m[R][R];
 #pragma unroll
-#ifdef PFST_WINO_NT
-    for (int i = 0; i < R * R; ++i) m[i / R][i % R] = __builtin_nontemporal_load(&mp[(i64)i * plane + t]);
-#else
-    for (int i = 0; i < R * R; ++i) m[i / R][i % R] = mp[(i64)i * plane + t];
-#endif
+    for (int i = 0; i < R * R; ++i) m[i / R][i % R] = __builtin_nontemporal_load(&mp[(i64)i * plane + t]);      // the GEMM's output is read once, here (streamed: -0.4 ms per step)
     float r[M][R];                                           // A^T m
 #pragma unroll
     for (int i = 0; i < M; ++i)

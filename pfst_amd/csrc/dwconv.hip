@@ -664,7 +664,7 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
   const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
-  static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;   // channels per workgroup of the plane kernel, 0 = off
+  constexpr int cpb = 4;            // channels per workgroup of the plane kernel
   if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl) {      // (the strip kernel carries the normalise-on-load variant)
     static bool set2 = false;
     if (!set2) {
@@ -723,7 +723,7 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
   const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
-  static const int cpb = getenv("PFST_DWCONV_CPB") ? atoi(getenv("PFST_DWCONV_CPB")) : 4;
+  constexpr int cpb = 4;
   float* const none = nullptr;
   if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl && !bn_rec) {
     dim3 gp(1, cdiv(C, cpb), N);
@@ -830,7 +830,6 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   static bool set = false;
   if (!set) {
 #define PFST_DW_MULTI_ATTR(NS_, B_) \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); \
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
     PFST_DW_MULTI_ATTR(1, false); PFST_DW_MULTI_ATTR(2, false); PFST_DW_MULTI_ATTR(3, false);
     PFST_DW_MULTI_ATTR(1, true); PFST_DW_MULTI_ATTR(2, true); PFST_DW_MULTI_ATTR(3, true);
@@ -841,10 +840,9 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   const size_t lds = 2 * (size_t)H * W * sizeof(float);          // gradient plane + forward-input plane
   dim3 gp(1, cdiv(C, cpb), N);
   hipStream_t st = (hipStream_t)stream;
-  static const int nt = [] { const char* e = getenv("PFST_DW_MULTI_NT"); return e && atoi(e) == 512 ? 512 : 1024; }();     // (diagnostic knob)
+  // 1024 threads: 2.33 ms per launch against 2.50 ms with 512 (profiles/r04_dw_multi_microbench.txt)
 #define PFST_DW_MULTI_LAUNCH(NS_, B_) \
-  if (nt == 512) hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 512>), gp, dim3(512), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb); \
-  else hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), gp, dim3(1024), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
+  hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), gp, dim3(1024), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
   if (bnb) {
     if (ns == 1) { PFST_DW_MULTI_LAUNCH(1, true); } else if (ns == 2) { PFST_DW_MULTI_LAUNCH(2, true); } else { PFST_DW_MULTI_LAUNCH(3, true); }
   } else {

@@ -325,8 +325,7 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
                                     float* dlogits, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && label && lse && dlogits && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   int gx = cdiv((i64)h * w, 256);
-  static const bool cells = !(getenv("PFST_CE_CELLS") && atoi(getenv("PFST_CE_CELLS")) == 0);      // PFST_CE_CELLS=0: the per-(cell, class) kernel (A/B)
-  if (C <= 8 && cells)
+  if (C <= 8)          // one thread per low-resolution cell, all classes in registers; more classes: one launch row per class
     hipLaunchKernelGGL(ce_bwd_cells_kernel, dim3(gx, 1, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
                        class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
   else

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void sim_map_bwd_cos_q_kernel(const float* __r
 inline bool simq_ok(const void* a, const void* b, int C, int H, int W, int dil) {
   const int wq = W / 4;
   return (dil == 1 || dil == 2) && W % 4 == 0 && (wq == 16 || wq == 32 || wq == 64) && ((i64)H * W) % 256 == 0 && C % 4 == 0 &&
-         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0 && !getenv("PFST_SIM_MAP_SLOW");
+         ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
 }
 
 // ---- source statistics.  grid: (blocks over H*W, N)

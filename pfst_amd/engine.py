@@ -18,7 +18,7 @@ class Var:
     runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending')
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending', 'coef_table')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -38,6 +38,9 @@ class Var:
         # first, written out after all (_flush_pending: same values, one more pass).
         self.gate_consumer = False
         self.pending = None
+        # a concat buffer whose writers leave their PRE-normalisation outputs in its slices (layers.conv_bn_act(defer='slice')): [C, 4] rows
+        # (mean, invstd, sc, sh) per channel, filled slice by slice; the owner turns the buffer into a lazy Var for its single consumer
+        self.coef_table = None
 
     def claim_first_use(self):
         """forward: called by every consumer that may fuse; True for the first caller only (= the last gradient writer)"""

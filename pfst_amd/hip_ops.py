@@ -122,7 +122,7 @@ def conv_stats_slots(n, cout, ho, wo):
 
 
 def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gamma=None, beta=None,
-                         predict_amax=None, relu=True):
+                         predict_amax=None, relu=True, coef_out=None):
     """gamma / beta given: also returns coef [C,4] = (mean, invstd, sc, sh), the record the fused BatchNorm-backward sums read.
     predict_amax: a zeroed slot group (amax_slots); `stats` then carries the producer's (minimum, maximum) partials behind the sums
     (conv_fprop_f16x3(want_minmax=True)) and the group receives max |[relu](bn(x))| -- what bn_apply(amax=...) would publish, known before
@@ -130,6 +130,9 @@ def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=
     mean = torch.empty(c, device=stats.device)
     invstd = torch.empty(c, device=stats.device)
     coef = torch.empty(c, 4, device=stats.device) if gamma is not None else None
+    if coef_out is not None:                 # rows of a concat buffer's coefficient table (engine.Var.coef_table)
+        assert gamma is not None and tuple(coef_out.shape) == (c, 4) and coef_out.is_contiguous()
+        coef = coef_out
     mm = 0
     if predict_amax is not None:
         assert gamma is not None and stats.numel() >= 4 * c * slots

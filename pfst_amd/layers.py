@@ -411,11 +411,16 @@ DEFER_BN_APPLY = True
 # (min, max) partials and bn_finalize_partials predicts the maximum exactly.  False: bn_apply writes y1 (per-link test).  Same-box A/B of the
 # switch while it still read the environment: profiles/r05_ab_fold_bn_wino.txt
 FOLD_BN_WINO = True
+# the ASPP head's concat (image pool | 1x1 branch | three atrous pointwise layers) -> bottleneck 3x3 through the Winograd domain: the four
+# conv -> BN -> ReLU writers leave their PRE-normalisation outputs in the concat's slices and their (mean, invstd, sc, sh) rows in the
+# buffer's coefficient table; the bottleneck's input transform normalises per channel as it loads (identity rows for the image-pool slice).
+# False: every slice is written normalised (per-link test)
+FOLD_BN_CONCAT = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written)
 
 
-def dwsep_branches(x, mods, tape, outs, pool=None):
+def dwsep_branches(x, mods, tape, outs, pool=None, defer=False):
     """DepthwiseSeparableConvModules `mods` applied to the SAME input x (the ASPP head's atrous branches, sep_aspp_head.py:63-77), results
     into the concat slices `outs`.  Where the fused kernels cover the shape the depthwise stages run as one launch -- every plane of x is
     staged once for all branches -- and their backward as one launch after the branches' BatchNorm-backward passes: x read once, every
@@ -430,7 +435,7 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
     fused = (FUSE_ASPP_DW and len(mods) > 1 and x.parent is None and all(c.depthwise and c.k == 3 and c.stride == 1 and c.padding == c.dilation
                                                                           for c in convs) and ops.dwconv_multi_ok(x.data, dils))
     if not fused:
-        return [m(x, tape, out=o) for m, o in zip(mods, outs)]
+        return [m(x, tape, out=o, defer=defer) for m, o in zip(mods, outs)]
     xd = x.data
     want_stats = FUSE_BN_STATS and not _BN_EVAL
     if pool is not None:
@@ -480,7 +485,7 @@ def dwsep_branches(x, mods, tape, outs, pool=None):
                 dpres[i], bnbs[i] = yv.grad, (pre, rec)
                 yv.free_grad()
             tape.record(bwd_bn, dict(op='dw_bn_act', bn=bn, conv=convs[i], x=x, out=yv))
-        ys.append(m.pointwise_conv(yv, tape, out=outs[i]))
+        ys.append(m.pointwise_conv(yv, tape, out=outs[i], defer=defer))
     return ys
 
 
@@ -645,8 +650,16 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     x_bnl = None if x.lazy is None else x.lazy[1]
     assert x_bnl is None or conv.depthwise or (conv.wino and conv.bias is None), \
         'only a depthwise layer, the Winograd input transform (or the max-pool) reads a deferred normalisation'
-    need_pred = defer == 'amax' and CONV_MATH == 'f16x3'
-    defer = bool(defer and DEFER_BN_APPLY and not _BN_EVAL and relu and residual is None and out is None and post_scale is None)
+    # defer='slice': `out` is a slice of a concat Var with a coefficient table (Var.coef_table): the PRE-normalisation output goes into the slice,
+    # this layer's rows into the table, the predicted maximum into the concat's shared slot group
+    into_slice = slice_requested = defer == 'slice'
+    need_pred = defer in ('amax', 'slice') and CONV_MATH == 'f16x3'
+    if into_slice:
+        defer = bool(isinstance(out, Var) and out.parent is not None and out.parent.coef_table is not None and DEFER_BN_APPLY and not _BN_EVAL and relu
+                     and residual is None and post_scale is None and not conv.depthwise and not conv.wino and (not need_pred or out.parent.amax is not None))
+        into_slice = defer
+    else:
+        defer = bool(defer and DEFER_BN_APPLY and not _BN_EVAL and relu and residual is None and out is None and post_scale is None)
     # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
     # cancellation: var = E[x^2] - mean^2 from the epilogue's fp32 partial sums of squares loses what torch's two-pass variance keeps
     # (per-link test: 1.3e-3 on that layer's backward against 6e-5 for torch-fp32).  Those tiny layers take the stand-alone statistics
@@ -654,16 +667,23 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     tiny = xd.shape[0] * xd.shape[2] * xd.shape[3] <= 64
     fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
     if need_pred and not (defer and fused_stats and conv.f16_f and not conv.wino and conv.bias is None):
-        defer = need_pred = False           # no producer of (min, max) partials here: the normalised tensor is written as usual
+        defer = need_pred = into_slice = False           # no producer of (min, max) partials here: the normalised tensor is written as usual
+    if into_slice and not fused_stats:
+        defer = into_slice = False
+    if slice_requested and not into_slice and isinstance(out, Var) and out.parent is not None and out.parent.coef_table is not None:
+        # this writer normalises its slice itself after all: identity rows, max(fma(y, 1, 0), 0) = y for its ReLU'd (non-negative) values
+        assert relu
+        out.parent.coef_table[out.c0:out.c1] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=out.data.device)
     need_pred = need_pred and defer
+    pre_out = out.data if into_slice else None           # the convolution writes straight into the concat slice
     if conv.depthwise:
         if fused_stats:                            # batch statistics come out of the producing kernel in every case
             pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True, bnl=x_bnl)
         else:
             pre = ops.dwconv(xd, conv.weight.data, conv.dilation, bnl=x_bnl)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform
-        pre, st, slots = conv.fprop(xd, want_stats=True, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None,
-                                    bnl=x_bnl, want_minmax=need_pred)
+        pre, st, slots = conv.fprop(xd, out=pre_out, want_stats=True, keep=tape is not None,
+                                    x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None, bnl=x_bnl, want_minmax=need_pred)
     else:
         pre = conv.fprop(xd, keep=tape is not None, x_amax=amax_of(x) if (conv.f16_f or conv.wino_f16) else None, bnl=x_bnl)
     saved_v = None if conv.depthwise else conv.saved_v
@@ -677,11 +697,11 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
             raise ValueError(f'Expected more than 1 value per channel when training, got input size {torch.Size(pre.shape)}')
         want_coef = (tape is not None and FUSE_BN_BWD) or defer
         gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
-        pred_amax = ops.amax_slots(pre.device) if need_pred else None
+        pred_amax = (out.parent.amax if into_slice else ops.amax_slots(pre.device)) if need_pred else None
         if fused_stats:
             n, c, h, w = pre.shape
             res = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, predict_amax=pred_amax,
-                                           relu=relu, **gb)
+                                           relu=relu, coef_out=out.parent.coef_table[out.c0:out.c1] if into_slice else None, **gb)
         else:
             res = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
         mean, invstd = res[:2]
@@ -696,7 +716,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     yv = out_var if out_var is not None else Var(None, tape is not None)
     if defer:
         yv.lazy, y = (pre, coef, bn), None           # no normalisation pass: the consumer applies (sc, sh) of `coef` and the ReLU as it loads `pre`
-        if need_pred:
+        if need_pred and not into_slice:
             yv.amax = pred_amax                      # max |y| of the tensor that is never written (exact: bn_finalize_partials)
     else:
         y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,

@@ -327,12 +327,22 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
         # The ASPP branches first, the image-pool branch after them (they write disjoint slices, so the forward result does not
         # depend on the order): in backward the pool branch's broadcast then lands in dL/dx BEFORE the 1x1 branch's data gradient,
         # which completes dL/dx and can emit the BatchNorm-backward sums of the layer that produced x (layers._dgrad_into).
-        self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch))
+        # layers.FOLD_BN_CONCAT: the four conv -> BN -> ReLU writers leave their pre-normalisation outputs in the slices; the bottleneck's Winograd
+        # input transform normalises per channel (the image-pool slice holds final values: identity rows) -- four normalisation passes over
+        # 512-channel maps less per pass
+        bconv = self.bottleneck.conv
+        fold = (layers_mod.FOLD_BN_CONCAT and layers_mod.DEFER_BN_APPLY and not layers_mod._BN_EVAL and bconv.wino and bconv.bias is None
+                and (tape is None or bconv.wino_wgrad_ok(h, w)))
+        if fold:
+            cat.coef_table = torch.empty(nb * ch, 4, device=x.data.device)
+            cat.coef_table[:ch] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=x.data.device)          # y = max(fma(v, 1, 0), 0) = v for the (non-negative) pooled values
+        sl = 'slice' if fold else False
+        self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch), defer=sl)
         nd = len(self.dilations)
         # on the fused path the atrous branches' launch also forms the plane means of x, its backward their adjoint
         pool = {}
         dwsep_branches(x, [self.aspp_modules[i] for i in range(1, nd)], tape, [cat.slice((i + 1) * ch, (i + 2) * ch) for i in range(1, nd)],
-                       pool=pool)
+                       pool=pool, defer=sl)
         # image pool branch: GAP -> 1x1 conv -> BN over the n samples -> ReLU -> broadcast (bilinear from 1x1)
         fused_pool = pool is not None and 'mean' in pool
         pooled = Var(pool['mean'] if fused_pool else ops.global_avgpool(x.data), tape is not None)
@@ -358,6 +368,9 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
             # order on the tape: gap-backward must run AFTER the image_pool conv's backward, pool-broadcast before it
             self._reorder_pool(tape, (bwd_gap, dict(op='gap', name='decode_head.gap', x=x, out=pooled)),
                                (bwd_pool, dict(op='broadcast', name='decode_head.image_pool.up', x=pa, out=cat.slice(0, ch))))
+        if fold:
+            # every writer deferred?  (a writer that could not -- no (min, max) partials for its shape -- wrote its slice normalised: identity rows)
+            cat.lazy = (cat.data, cat.coef_table, None)
         feats = self.bottleneck(cat, tape)
         # decoder: upsample x2 to c1 size, concat with the 48-channel c1 projection
         H, W = c1.data.shape[-2:]

@@ -49,6 +49,9 @@ def _data(v):
         return v.data
     from pfst_amd import hip_ops as ops
     pre, coef, bn = v.lazy
+    if bn is None:          # a concat buffer with a coefficient table (the ASPP head's, layers.FOLD_BN_CONCAT): rows (mean, invstd, sc, sh) per channel
+        # (the kernels' fma rounds once: the product and sum in fp64, then one rounding to fp32)
+        return torch.relu((pre.double() * coef[:, 2].double().view(1, -1, 1, 1) + coef[:, 3].double().view(1, -1, 1, 1)).float())
     return ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, True)
 
 
@@ -564,7 +567,7 @@ def test_deferred_normalisation_equals_the_materialised_one():
     finally:
         layers.DEFER_BN_APPLY = prev
     # deferred: stem.6 and sep_bottleneck[0]; + bn1 of the 12 bottlenecks whose conv2 runs through the Winograd domain (layers.FOLD_BN_WINO)
-    folded = 12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0
+    folded = (12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0) + (4 if (layers.FOLD_BN_CONCAT and layers.WINOGRAD) else 0)
     assert applies[False] == 70 and applies[True] == 68 - folded, applies
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
@@ -593,11 +596,13 @@ def test_bn1_folded_into_the_winograd_input_transform():
     _, student, _ = seeded_pfgst_state(O, 9)
     batch = synth_batch(b, S, C, seed=23)
     runs, applies, inputs = {}, {}, {}
-    prev = layers.FOLD_BN_WINO
+    prev, prev_cat = layers.FOLD_BN_WINO, layers.FOLD_BN_CONCAT
+    n_cat = 4 if prev_cat else 0             # the ASPP head's four concat writers, folded into the bottleneck's input transform by the same mechanism
     inner = ops.call
     try:
         for fold in (True, False):
             layers.FOLD_BN_WINO = fold
+            layers.FOLD_BN_CONCAT = fold and prev_cat
             model = build_segmentor(model_cfg(C, 3, dropout=0.0))
             model.load_state_dict(student, strict=True)
             model.cuda()
@@ -622,9 +627,9 @@ def test_bn1_folded_into_the_winograd_input_transform():
             runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
             applies[fold] = seen
     finally:
-        layers.FOLD_BN_WINO = prev
-    assert applies[False]['pfst_bn_apply'] - applies[True]['pfst_bn_apply'] == 12, (applies[False]['pfst_bn_apply'], applies[True]['pfst_bn_apply'])
-    assert applies[True].get('normalising transforms', 0) == 12 and applies[False].get('normalising transforms', 0) == 0
+        layers.FOLD_BN_WINO, layers.FOLD_BN_CONCAT = prev, prev_cat
+    assert applies[False]['pfst_bn_apply'] - applies[True]['pfst_bn_apply'] == 12 + n_cat, (applies[False]['pfst_bn_apply'], applies[True]['pfst_bn_apply'])
+    assert applies[True].get('normalising transforms', 0) == 12 + n_cat // 4 and applies[False].get('normalising transforms', 0) == 0
     assert applies[True]['pfst_wino_input'] == applies[False]['pfst_wino_input']            # no transform is re-run in backward: V was kept
     assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
@@ -669,8 +674,7 @@ def test_published_maxima_cover_every_f16x3_operand():
             if v.lazy is not None:
                 # a tensor that is never written (conv1 -> bn1 -> relu of a Winograd bottleneck): its group holds the PREDICTED maximum
                 # (bn_finalize_partials from the GEMM's min / max partials); the true one from the normalisation pass run here for the test
-                pre, coef, bn = v.lazy
-                data = ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, True)
+                data = _data(v)
                 predicted.append(tuple(data.shape))
             seen[id(v)] = (tuple(data.shape), slots.max().item(), data.abs().max().item())
         return slots
@@ -692,7 +696,8 @@ def test_published_maxima_cover_every_f16x3_operand():
     bad = [s for s in seen.values() if s[1] != s[2]]
     assert not bad, bad
     if layers.FOLD_BN_WINO and layers.DEFER_BN_APPLY and layers.WINOGRAD:
-        assert len(predicted) == 12, predicted          # bn1 of layer2.1-3, layer3.0-5, layer4.0-2: predicted == true maximum, bit for bit
+        # bn1 of layer2.1-3, layer3.0-5, layer4.0-2 (+ the ASPP concat with its four deferred writers): predicted == true maximum, bit for bit
+        assert len(predicted) == 12 + (1 if layers.FOLD_BN_CONCAT else 0), predicted
     shapes = [s[0] for s in seen.values()]
     assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
     assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'

@@ -1,4 +1,6 @@
-# usage (GPU box): bash tools/ab_env.sh "PFST_FOLD_DROPOUT=0 PFST_CE_CELLS=0"
+# usage (GPU box): bash tools/ab_env.sh "PFST_WGRAD_STREAM=0 PFST_FORK_TEACHER=0"
+# (round 5 removed the per-fold PFST_* switches once their A/B was on file: profiles/r04_ab_*.txt, r05_ab_*.txt; what is left to flip at run time
+# is listed in README.md -- a fold that needs a new A/B gets a -D variant build instead: python -m pfst_amd.build --variant NAME -DFLAG, tools/ab_lib.sh)
 # Same-box A/B of run-time switches of ONE build (boxes of the pool differ by 2-3 %): alternates the given environment (`off`) with the
 # default (`on`) over four bench.py runs and prints the step plus the kernels the switches touch.
 OFF="$1"

@@ -1,4 +1,4 @@
-"""usage (GPU box): python tools/dw_multi_microbench.py        (PFST_DW_MULTI_NT=512: the eight-wave form of the backward kernel)
+"""usage (GPU box): python tools/dw_multi_microbench.py        (round 4 compared the 512- and 1024-thread forms of the backward kernel with it: profiles/r04_dw_multi_microbench.txt; the 512-thread form was removed in round 5)
 The ASPP head's fused depthwise launches at the bench shape (b = 8, 2048 channels, 128 x 128 planes, dilations 12 / 24 / 36): time per launch
 and algorithmic GB/s (forward: x + 3 y; backward with BatchNorm backward folded in: x + 3 (dy + pre) + dx written)."""
 import os
@@ -45,7 +45,7 @@ def main():
     mg = torch.randn(n, c, device=dev, generator=g)
     for label, kw, passes in (('multi_bwd (plain)        ', {}, 5), ('multi_bwd (+BN backward) ', {'bnb': list(zip(ys, recs))}, 8)):
         t = timed(lambda: ops.dwconv_multi_bwd_(dws, x, dys, ws, dils, dx, mean_grad=mg, **kw))
-        print(f'{label} NT={os.environ.get("PFST_DW_MULTI_NT", "1024"):>4s} {t:7.3f} ms  {passes * plane / t / 1e6:7.0f} GB/s')
+        print(f'{label} NT=1024 {t:7.3f} ms  {passes * plane / t / 1e6:7.0f} GB/s')
 
 
 if __name__ == '__main__':

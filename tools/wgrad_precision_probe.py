@@ -1,5 +1,5 @@
 """Where does the 1x1 weight gradient's error come from?  fp32-input MFMA kernel vs the bf16x6 split kernel against fp64, full dw,
-for several operand distributions and pixel counts.  PFST_SPLIT_PIPE=0 selects the un-pipelined split kernel (read at first launch)."""
+for several operand distributions and pixel counts."""
 import os
 import sys
 import torch
@@ -12,7 +12,6 @@ def rel(a, ref):
 
 
 def main():
-    print('PFST_SPLIT_PIPE =', os.environ.get('PFST_SPLIT_PIPE', '(default 1)'))
     for (n, ci, co, hw) in [(8, 64, 64, 256), (8, 64, 64, 128), (8, 64, 64, 64), (2, 128, 128, 256), (8, 512, 128, 128)]:
         for dist in ('relu_tail x 1e-4 randn', 'randn x randn', 'uniform(1,2) x uniform(1,2)'):
             g = torch.Generator().manual_seed(1)
