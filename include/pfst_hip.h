@@ -23,6 +23,11 @@ typedef void* pfst_stream_t; /* hipStream_t */
 
 int pfst_abi_version(void);
 const char* pfst_last_error(void);
+/* Deterministic mode, the counterpart of torch.backends.cudnn.deterministic = True that the reference's `--deterministic` sets
+ * (rsiseg/apis/train.py:52-68): weight gradients, BatchNorm-backward sums and depthwise weight gradients are summed in a fixed order instead of
+ * by atomic adds of several workgroups -- the gradient of a step is bit-identical run to run; slower.  Process-wide, read at every launch. */
+int pfst_set_deterministic(int on);
+int pfst_get_deterministic(void);
 
 /* ---- elementwise utilities -------------------------------------------------------------- */
 int pfst_fill_f32(float* p, long long n, float value, pfst_stream_t stream);

@@ -10,6 +10,17 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libpfst_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_igemm_q.hip', 'conv_wgrad_q.hip', 'conv_winograd.hip', 'conv_split.hip', 'conv_f16x3.hip', 'dwconv.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'pfgst_loss.hip', 'optim.hip', 'strong_aug.hip', 'api.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+# No packed-fp32 (v_pk_*_f32) code in the streaming kernels: round 5 found the depthwise backward kernel (dwconv3x3_kernel<3, true>: a packed add
+# on a pair of weight-gradient accumulators) returning WRONG sums -- one accumulator of a few channels off by O(1) -- whenever it ran on the
+# same CUs as the f16x3 weight-gradient kernel of the side stream, and only then (alone, or beside a rocBLAS GEMM: exact; tools/race_probe.py,
+# profiles/r05_packed_fp32_corruption.txt).  Without the SLP vectoriser clang forms no <2 x float> operations, the kernels are exact under any
+# co-residency and 5-14 % FASTER (they are LDS / HBM bound, the packed forms bought nothing).  The matrix kernels keep the default: their
+# packed epilogue arithmetic is worth 9 ms per step and is pinned bit for bit by the deterministic-mode test under stream overlap.
+NO_SLP = {'dwconv.hip', 'bn.hip', 'spatial.hip', 'loss.hip', 'pfgst_loss.hip', 'optim.hip', 'strong_aug.hip', 'conv_winograd.hip'}
+
+
+def _flags(src_name):
+    return FLAGS + (['-fno-slp-vectorize'] if src_name in NO_SLP else [])
 
 
 def _deps(src, seen=None):
@@ -62,7 +73,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, src):
-            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+            cmd = [hipcc] + _flags(s) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -96,7 +107,7 @@ def build_variant(name, extra_flags):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + list(extra_flags) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+        cmd = [hipcc] + _flags(s) + list(extra_flags) + (['-x', 'hip'] if s.endswith('.cpp') else []) + ['-c', src, '-o', obj]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         out, _ = p.communicate()

@@ -25,8 +25,10 @@ namespace {
 constexpr int BN_SPLIT_TARGET = 2048;  // aim for this many blocks in the reduction passes
 
 // grid: (splits, C, N); each block reduces a contiguous chunk of one (image, channel) plane
+// det_part != NULL (deterministic mode, api.cpp): this block's two sums go to slot (n, split) of det_part[c][gridDim.z * gridDim.x][2] instead of
+// being added atomically into ws; bn_det_sum_kernel adds the slots in index order
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, i64 x_bs, int HW, int chunk,
-                                                       double* __restrict__ ws) {
+                                                       double* __restrict__ ws, double* __restrict__ det_part = nullptr) {
   __shared__ double sm[32];
   const int c = blockIdx.y, n = blockIdx.z;
   const float* xp = x + (i64)n * x_bs + (i64)c * HW;
@@ -48,9 +50,28 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   }
   block_sum2_d(s, ss, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s);
-    atomicAdd(&ws[2 * c + 1], ss);
+    if (det_part) {
+      double* d = det_part + (((i64)c * gridDim.z + n) * gridDim.x + blockIdx.x) * 2;
+      d[0] = s;
+      d[1] = ss;
+    } else {
+      atomicAdd(&ws[2 * c], s);
+      atomicAdd(&ws[2 * c + 1], ss);
+    }
   }
+}
+
+// deterministic mode: ws[2c], ws[2c+1] = the T slots of channel c summed in index order     grid: ceil(C / 256)
+__global__ __launch_bounds__(256) void bn_det_sum_kernel(const double* __restrict__ part, int T, int C, double* __restrict__ ws) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < T; ++k) {
+    a += part[((i64)c * T + k) * 2];
+    b += part[((i64)c * T + k) * 2 + 1];
+  }
+  ws[2 * c] = a;
+  ws[2 * c + 1] = b;
 }
 
 // coef[c] = (mean, invstd, sc, sh): what the fused BatchNorm-backward sums of a data-gradient launch read (pfst_bnb_fuse_t)
@@ -279,7 +300,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             int HW, int chunk, int relu, const unsigned long long* __restrict__ mask,
-                                                            double* __restrict__ ws, int rev, const float* __restrict__ post) {
+                                                            double* __restrict__ ws, int rev, const float* __restrict__ post,
+                                                            double* __restrict__ det_part = nullptr) {
   // post != NULL: the incoming gradient is the gradient of y * post[n][c] (bn_apply's folded Dropout2d factor): dz = dy * post * gate
   __shared__ double sm[32];
   const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
@@ -344,8 +366,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
   block_sum2_d(s, sx, sm);
   if (threadIdx.x == 0) {
-    atomicAdd(&ws[2 * c], s);
-    atomicAdd(&ws[2 * c + 1], sx);
+    if (det_part) {                                  // deterministic mode: slot (n, chunk) of channel c (see bn_stats_kernel)
+      double* d = det_part + (((i64)c * gridDim.z + n) * gridDim.x + bxi) * 2;
+      d[0] = s;
+      d[1] = sx;
+    } else {
+      atomicAdd(&ws[2 * c], s);
+      atomicAdd(&ws[2 * c + 1], sx);
+    }
   }
 }
 
@@ -491,6 +519,15 @@ __global__ __launch_bounds__(256) void relu_gate_kernel(const float* __restrict_
   }
 }
 
+// deterministic mode: the [C][N * splits][2] partial slots of a reduction launch (NULL when the mode is off; `ok` false if the scratch failed)
+inline double* bn_det_part(int C, int N, int splits, hipStream_t s, bool& ok) {
+  ok = true;
+  if (!pfst_deterministic()) return nullptr;
+  double* p = static_cast<double*>(pfst_det_scratch((size_t)C * N * splits * 2 * sizeof(double), s));
+  ok = p != nullptr;
+  return p;
+}
+
 }  // namespace
 
 extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int HW, float* mean, float* invstd,
@@ -503,7 +540,11 @@ extern "C" int pfst_bn_stats(const float* x, long long x_bs, int N, int C, int H
   if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C, N), dim3(256), 0, s, x, x_bs, HW, chunk, ws);
+  bool det_ok;
+  double* const det = bn_det_part(C, N, splits, s, det_ok);
+  PFST_CHECK_ARG(det_ok);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(splits, C, N), dim3(256), 0, s, x, x_bs, HW, chunk, ws, det);
+  if (det) hipLaunchKernelGGL(bn_det_sum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, det, N * splits, C, ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, C, (double)N * HW, mean, invstd, running_mean,
                      running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef));
   PFST_CHECK_LAUNCH();
@@ -562,6 +603,9 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   else if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
   int splits, chunk;
   split_for(HW, C, N, splits, chunk);
+  bool det_ok = true;
+  double* const det = fused ? nullptr : bn_det_part(C, N, splits, s, det_ok);      // deterministic mode: slots + ordered sum instead of atomics
+  PFST_CHECK_ARG(det_ok);
   const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs | dx_bs | (y ? y_bs : 0) | (dres ? dres_bs : 0)) & 3) == 0 &&
                    (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)y | (uintptr_t)dres) & 15) == 0;
   int gx = cdiv(HW, 256 * 4);
@@ -570,13 +614,15 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   if (vec) {
     if (!fused)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale);
+                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale, det);
+    if (!fused && det) hipLaunchKernelGGL(bn_det_sum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, det, N * splits, C, ws);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   } else {
     if (!fused)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale);
+                         beta, HW, chunk, relu, relu_mask, ws, (pfst_bn_order() >> 1) & 1, post_scale, det);
+    if (!fused && det) hipLaunchKernelGGL(bn_det_sum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, det, N * splits, C, ws);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   }
@@ -599,12 +645,16 @@ extern "C" int pfst_bn_backward_sums(const float* dy, long long dy_bs, const flo
     const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs) & 3) == 0 && (((uintptr_t)dy | (uintptr_t)x) & 15) == 0;
     const float* none = nullptr;
     const unsigned long long* nomask = nullptr;
+    bool det_ok;
+    double* const det = bn_det_part(C, N, splits, s, det_ok);
+    PFST_CHECK_ARG(det_ok);
     if (vec)
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, none, (i64)0, x, (i64)x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none);
+                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none, det);
     else
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, none, (i64)0, x, (i64)x_bs, mean, invstd, gamma,
-                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none);
+                         beta, HW, chunk, 1, nomask, ws, (pfst_bn_order() >> 1) & 1, none, det);
+    if (det) hipLaunchKernelGGL(bn_det_sum_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, det, N * splits, C, ws);
   }
   hipLaunchKernelGGL(bn_bwd_rec_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, mean, invstd, gamma, beta, dgamma, dbeta, C,
                      1.0 / ((double)N * HW), rec);

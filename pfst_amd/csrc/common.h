@@ -26,6 +26,8 @@
   } while (0)
 
 void pfst_set_error(const char* file, int line, const char* msg);
+int pfst_deterministic(void);            // api.cpp: pfst_set_deterministic -- fixed-order sums instead of atomics between workgroups
+void* pfst_det_scratch(size_t bytes, void* stream);   // api.cpp: that mode's partial-sum scratch of `stream` (NULL: allocation failed)
 
 typedef long long i64;
 

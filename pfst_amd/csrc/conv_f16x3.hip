@@ -994,7 +994,8 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
   if (mode == 0) { a = stride; b = dil; c = -pad; d = 1; } else { a = 1; b = -dil; c = pad; d = stride; }
   const int stats_T = N * (int)cdiv((i64)Ho * Wo, BN) * 2;      // two pixel-waves per tile at every tile height (= pfst_conv_stats_slots for M > 64)
   const bool one = !small && ksize == 1 && stride == 1 && pad == 0;      // pixel-to-pixel: the tile-chain variant
-  const bool big = one && M % 256 == 0;                              // 256-row tiles, 512 threads, one workgroup per CU
+  const bool big = one && M % 256 == 0;                              // 256-row tiles, 512 threads, one workgroup per CU (measured and not kept: the 128-row
+                                                                     // tile for K <= 512 launches with a memory-heavy epilogue, profiles/r05_ab_heavy_epilogue.txt)
   const i64 total = (i64)cdiv((i64)Ho * Wo, BN) * cdiv(M, big ? 256 : small ? 64 : 128) * N;
   PFST_CHECK_ARG(total < (1ll << 31));
   const dim3 grid(f16x3_grid(total, one && ((C + 31) / 32) % 2 == 0, big ? 1 : 2));
@@ -1075,6 +1076,14 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                             i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = pfst_wgrad_f16x3_launch(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, J, M, P, groups, x_gs, dy_gs, dw_gs, x_amax, dy_amax, packed, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   const bool big = M % 256 == 0;                                // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
   const int bm = big ? 256 : 128;
   const int tiles = cdiv(J, 128) * cdiv(M, bm) * groups;
@@ -1088,6 +1097,7 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, bm), gz = N * groups * chunks;

@@ -365,6 +365,14 @@ int launch_igemm_generic(const float* in, i64 in_bs, const float* wk, const floa
 template <int BM, int T, int WBK>
 int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                    int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = launch_wgrad_k<BM, T, WBK>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, WBJ) * cdiv(M, BM);
   // Split the pixel (K) range (chunks of >= 512 pixels, fp32 atomics combine) so that the launch fills the chip in
@@ -381,6 +389,7 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
     if (eff >= 0.93) break;
   }
   while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
@@ -470,6 +479,12 @@ extern "C" int pfst_conv_wgrad(const float* x, long long x_bs, const float* dy, 
 
 extern "C" int pfst_bias_grad(const float* dy, long long dy_bs, float* db, int N, int C, int HW, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && db && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  if (pfst_deterministic()) {          // one workgroup per channel and launch, one image per launch: a single, ordered writer per db[c]
+    for (int n = 0; n < N; ++n)
+      hipLaunchKernelGGL(bias_grad_kernel, dim3(1, C, 1), dim3(256), 0, (hipStream_t)stream, dy + (i64)n * dy_bs, dy_bs, db, C, HW, HW);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   int splits = cdiv(HW, 4096);
   if (splits > 256) splits = 256;
   const int chunk = cdiv(HW, splits);

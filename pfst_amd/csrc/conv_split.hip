@@ -1171,6 +1171,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_q_pipe_kernel(
 template <int BM>
 int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                          i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = launch_wgrad_split_q<BM>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, J, M, P, groups, x_gs, dy_gs, dw_gs, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   const int tiles = cdiv(J, 128) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident workgroups (49 KB of LDS: 3 per CU)
   const double slots = 256.0 * 3;
@@ -1182,6 +1190,7 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, BM), gz = N * groups * chunks;
@@ -1199,10 +1208,19 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
 template <int BM, int T>
 int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                        int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = launch_wgrad_split<BM, T>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, 128) * cdiv(M, BM);
   int chunks = 1;
   while ((i64)tiles * N * chunks < 1024 && P / (chunks * 2) >= 512) chunks *= 2;
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, 128), cdiv(M, BM), N * chunks);

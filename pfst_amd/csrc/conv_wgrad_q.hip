@@ -485,6 +485,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_q16_kernel(
 template <int BM, int T, int WBK>
 int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
              int Ho, int Wo, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = launch_q<BM, T, WBK>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, QBJ) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident blocks (see launch_wgrad_k in conv_mfma.hip); 32 KB LDS at WBK = 16, 64 KB at 32
@@ -497,6 +505,7 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   constexpr int xcd_env = 1;
@@ -520,6 +529,14 @@ int launch_q_bk(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw,
 template <int BM, int T>
 int launch_q16(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil,
                int pad, const float* x_amax, const float* dy_amax, hipStream_t s) {
+  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
+  if (pfst_deterministic() && N > 1) {
+    for (int n = 0; n < N; ++n) {
+      const int rc = launch_q16<BM, T>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, dil, pad, x_amax, dy_amax, s);
+      if (rc != PFST_OK) return rc;
+    }
+    return PFST_OK;
+  }
   constexpr int WBK = 16;
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, QBJ) * cdiv(M, BM);
@@ -532,6 +549,7 @@ int launch_q16(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, 
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
+  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   constexpr int xcd_env = 1;

@@ -66,6 +66,9 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ plane, floa
 // pre-normalisation value like bn_apply decided it, projections subtracted in fp64)
 __device__ __forceinline__ float bn_bwd_elem(float g, float xv, const pfst_bn_bwd_rec_t& r) {
   const float dz = __fmaf_rn(xv, r.sc, r.sh) > 0.f ? g : 0.f;
+#ifdef PFST_DIAG_DW_F32
+  return (float)r.gs * (dz - (float)r.m1 - ((xv - r.mu) * r.is) * (float)r.m2);
+#endif
   return (float)(r.gs * ((double)dz - r.m1 - (((double)xv - (double)r.mu) * (double)r.is) * r.m2));
 }
 __device__ __forceinline__ float4 bn_bwd_elem4(float4 g, float4 xv, const pfst_bn_bwd_rec_t& r) {
@@ -142,6 +145,19 @@ __device__ __forceinline__ void block_add9(const float (&acc)[9], float* __restr
   }
 }
 
+// Deterministic mode (api.cpp): det_T > 0 = the weight gradient of channel c goes to slot `slot` of a zeroed [C][det_T][9] scratch instead of
+// being added into dw[c] by every workgroup of the channel (each slot has ONE writer); dw_det_reduce_kernel then adds the slots in index order.
+__device__ __forceinline__ float* dw_dst(float* __restrict__ dw, int c, int det_T, int slot) {
+  return det_T > 0 ? dw + ((i64)c * det_T + slot) * 9 : dw + c * 9;
+}
+__global__ __launch_bounds__(64) void dw_det_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int T) {
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (c >= C || t >= 9) return;
+  float v = 0.f;
+  for (int k = 0; k < T; ++k) v += part[((i64)c * T + k) * 9 + t];
+  dw[c * 9 + t] += v;
+}
+
 // MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation;
 // MODE 3: float4 outputs, dilation 1 (row_taps_d1)
 // WG (backward only, flip = 1: x = dY, y = dX): the same pass also forms the WEIGHT gradient.  With v_t = dY[p + off(t)] the nine
@@ -154,7 +170,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
                                                         int flip, int accumulate, float* __restrict__ stats,
                                                         const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
                                                         const float4* __restrict__ bnl = nullptr, const float* __restrict__ bnpre = nullptr,
-                                                        i64 bnpre_bs = 0, const pfst_bn_bwd_rec_t* __restrict__ bnrec = nullptr) {
+                                                        i64 bnpre_bs = 0, const pfst_bn_bwd_rec_t* __restrict__ bnrec = nullptr, int det_T = 0) {
   // bnrec != NULL (WG): x = the gradient of this layer's BatchNorm + ReLU output, bnpre = the layer's own convolution output: the rows
   // staged are dL/dpre = the second pass of BatchNorm backward, formed on the fly (stage_rows_bnbwd)
   // bnl != NULL: coef[C] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer whose PRE-normalisation output is this convolution's
@@ -253,7 +269,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       *dst = make_float2((float)bs, (float)bq);
     }
   }
-  if (WG) block_add9(accw, dw + c * 9, reinterpret_cast<float*>(red));
+  if (WG) block_add9(accw, dw_dst(dw, c, det_T, blockIdx.z * gridDim.x + blockIdx.x), reinterpret_cast<float*>(red));
 }
 
 // Whole-plane variant (the plane fits the LDS budget: the 128x128 ASPP planes): a workgroup walks `cpb` consecutive channels of one image
@@ -264,7 +280,8 @@ template <int MODE, bool WG = false>
 __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ w,
                                                               float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int cpb,
                                                               int flip, int accumulate, float* __restrict__ stats,
-                                                              const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr) {
+                                                              const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
+                                                              int det_T = 0) {
   extern __shared__ float tile[];
   __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
@@ -331,7 +348,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
       block_sum2_d<true>(bs, bq, red);
       if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
     }
-    if (WG) block_add9(accw, dw + c * 9, reinterpret_cast<float*>(red));
+    if (WG) block_add9(accw, dw_dst(dw, c, det_T, blockIdx.z), reinterpret_cast<float*>(red));
     __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
   }
 }
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
 // dw[c][t] += sum_{n,p} dy[n][c][p] * x[n][c][p + off(t)]     VEC: W % 4 == 0 and 16-byte aligned planes
 template <bool VEC, bool ALIGNED, bool D1 = false>
 __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy,
-                                                              i64 dy_bs, float* __restrict__ dw, int C, int H, int W, int dil, int R) {
+                                                              i64 dy_bs, float* __restrict__ dw, int C, int H, int W, int dil, int R, int det_T = 0) {
   extern __shared__ float tile[];
   __shared__ float red[8][9];
   const int c = blockIdx.y, n = blockIdx.z;
@@ -433,7 +450,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_wgrad_kernel(const float* __res
   if (threadIdx.x < 9) {
     float v = 0.f;
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) v += red[k][threadIdx.x];
-    atomicAdd(&dw[c * 9 + threadIdx.x], v);
+    atomicAdd(&dw_dst(dw, c, det_T, blockIdx.z * gridDim.x + blockIdx.x)[threadIdx.x], v);
   }
 }
 
@@ -528,7 +545,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
 // tools/dw_multi_microbench.py).  [Gradient planes two iterations ahead in two register sets: 65+ spilled registers at either size.]
 template <int NS, bool BNB, int NT>
 __global__ __launch_bounds__(NT) void dwconv3x3_multi_bwd_kernel(const float* __restrict__ x, i64 x_bs, DwSets S, float* __restrict__ dx,
-                                                                  i64 dx_bs, int accumulate, int C, int H, int W, int cpb) {
+                                                                  i64 dx_bs, int accumulate, int C, int H, int W, int cpb, int det_T = 0) {
   // LDS: [gradient plane | forward-input plane].  BNB: the gradient plane staged is dL/dpre = BatchNorm-backward(dy, pre), formed from the two
   // planes fetched into registers one branch ahead (bn_bwd_elem4) -- the branches' dL/dpre tensors are never written.
   extern __shared__ float tile[];
@@ -603,7 +620,7 @@ __global__ __launch_bounds__(NT) void dwconv3x3_multi_bwd_kernel(const float* __
           }
         }
       }
-      block_add9(accw, S.dw[si] + c * 9, reinterpret_cast<float*>(red));
+      block_add9(accw, dw_dst(S.dw[si], c, det_T, blockIdx.z), reinterpret_cast<float*>(red));
       __syncthreads();                             // every tap of this gradient plane has been read: the tile may be overwritten
     }
     float4* out = reinterpret_cast<float4*>(dx + (i64)n * dx_bs + (i64)c * HW);
@@ -720,30 +737,42 @@ extern "C" int pfst_dwconv3x3_bwd(const float* dy, long long dy_bs, const float*
   }
   const bool vec = (W % 4 == 0) && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)x) % 16 == 0) && (dy_bs % 4 == 0) && (dx_bs % 4 == 0) &&
                    (x_bs % 4 == 0) && (((i64)H * W) % 4 == 0) && (!bn_pre || (((uintptr_t)bn_pre % 16 == 0) && bn_pre_bs % 4 == 0));
+#ifdef PFST_DIAG_DW_MODE2
+  const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : 2);
+#else
   const int mode = !vec ? 0 : (dil % 4 == 0 ? 1 : (dil == 1 ? 3 : 2));
+#endif
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
   constexpr int cpb = 4;
   float* const none = nullptr;
-  if (mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl && !bn_rec) {
+  const bool plane = mode != 0 && R == H && (i64)H * W <= 8 * 512 * 4 && cpb > 0 && !bnl && !bn_rec;
+  // deterministic mode: per-workgroup slots of a zeroed scratch + an ordered reduction instead of the workgroups' atomic adds into dw
+  const int det_T = pfst_deterministic() ? (plane ? N : (int)grid.x * N) : 0;
+  float* dwk = dw;
+  if (det_T) {
+    const size_t bytes = (size_t)C * det_T * 9 * sizeof(float);
+    dwk = static_cast<float*>(pfst_det_scratch(bytes, st));
+    PFST_CHECK_ARG(dwk != nullptr);
+    if (hipMemsetAsync(dwk, 0, bytes, st) != hipSuccess) return PFST_ERR_LAUNCH;
+  }
+  if (plane) {
     dim3 gp(1, cdiv(C, cpb), N);
     if (mode == 1)
-      hipLaunchKernelGGL((dwconv3x3_plane_kernel<1, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<1, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dwk, det_T);
     else if (mode == 3)
-      hipLaunchKernelGGL((dwconv3x3_plane_kernel<3, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<3, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dwk, det_T);
     else
-      hipLaunchKernelGGL((dwconv3x3_plane_kernel<2, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dw);
-    PFST_CHECK_LAUNCH();
-    return PFST_OK;
-  }
-  if (mode == 1)
-    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
+      hipLaunchKernelGGL((dwconv3x3_plane_kernel<2, true>), gp, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, cpb, 1, accumulate, none, x, (i64)x_bs, dwk, det_T);
+  } else if (mode == 1)
+    hipLaunchKernelGGL((dwconv3x3_kernel<1, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dwk, bnl, bn_pre, (i64)bn_pre_bs, bn_rec, det_T);
   else if (mode == 2)
-    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
+    hipLaunchKernelGGL((dwconv3x3_kernel<2, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dwk, bnl, bn_pre, (i64)bn_pre_bs, bn_rec, det_T);
   else if (mode == 3)
-    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
+    hipLaunchKernelGGL((dwconv3x3_kernel<3, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dwk, bnl, bn_pre, (i64)bn_pre_bs, bn_rec, det_T);
   else
-    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dw, bnl, bn_pre, (i64)bn_pre_bs, bn_rec);
+    hipLaunchKernelGGL((dwconv3x3_kernel<0, true>), grid, dim3(512), lds, st, dy, dy_bs, w, dx, dx_bs, C, H, W, dil, R, 1, accumulate, none, x, (i64)x_bs, dwk, bnl, bn_pre, (i64)bn_pre_bs, bn_rec, det_T);
+  if (det_T) hipLaunchKernelGGL(dw_det_reduce_kernel, dim3(C), dim3(64), 0, st, dwk, dw, C, det_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -840,15 +869,27 @@ extern "C" int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, 
   const size_t lds = 2 * (size_t)H * W * sizeof(float);          // gradient plane + forward-input plane
   dim3 gp(1, cdiv(C, cpb), N);
   hipStream_t st = (hipStream_t)stream;
+  // deterministic mode (see pfst_dwconv3x3_bwd): every branch's weight gradient through [C][N][9] slots of the scratch
+  const int det_T = pfst_deterministic() ? N : 0;
+  float* real_dw[3] = {S.dw[0], S.dw[1], S.dw[2]};
+  if (det_T) {
+    const size_t per = (size_t)C * det_T * 9, bytes = per * ns * sizeof(float);
+    float* part = static_cast<float*>(pfst_det_scratch(bytes, st));
+    PFST_CHECK_ARG(part != nullptr);
+    if (hipMemsetAsync(part, 0, bytes, st) != hipSuccess) return PFST_ERR_LAUNCH;
+    for (int i = 0; i < 3; ++i) S.dw[i] = part + (size_t)(i < ns ? i : 0) * per;
+  }
   // 1024 threads: 2.33 ms per launch against 2.50 ms with 512 (profiles/r04_dw_multi_microbench.txt)
 #define PFST_DW_MULTI_LAUNCH(NS_, B_) \
-  hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), gp, dim3(1024), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb)
+  hipLaunchKernelGGL((dwconv3x3_multi_bwd_kernel<NS_, B_, 1024>), gp, dim3(1024), lds, st, x, (i64)x_bs, S, dx, (i64)dx_bs, accumulate, C, H, W, cpb, det_T)
   if (bnb) {
     if (ns == 1) { PFST_DW_MULTI_LAUNCH(1, true); } else if (ns == 2) { PFST_DW_MULTI_LAUNCH(2, true); } else { PFST_DW_MULTI_LAUNCH(3, true); }
   } else {
     if (ns == 1) { PFST_DW_MULTI_LAUNCH(1, false); } else if (ns == 2) { PFST_DW_MULTI_LAUNCH(2, false); } else { PFST_DW_MULTI_LAUNCH(3, false); }
   }
 #undef PFST_DW_MULTI_LAUNCH
+  if (det_T)
+    for (int i = 0; i < ns; ++i) hipLaunchKernelGGL(dw_det_reduce_kernel, dim3(C), dim3(64), 0, st, S.dw[i], real_dw[i], C, det_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -871,14 +912,23 @@ extern "C" int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float*
                    (((i64)H * W) % 4 == 0);
   dim3 grid(cdiv(H, R), C, N);
   hipStream_t st = (hipStream_t)stream;
+  const int det_T = pfst_deterministic() ? (int)grid.x * N : 0;        // deterministic mode: see pfst_dwconv3x3_bwd
+  float* dwk = dw;
+  if (det_T) {
+    const size_t bytes = (size_t)C * det_T * 9 * sizeof(float);
+    dwk = static_cast<float*>(pfst_det_scratch(bytes, st));
+    PFST_CHECK_ARG(dwk != nullptr);
+    if (hipMemsetAsync(dwk, 0, bytes, st) != hipSuccess) return PFST_ERR_LAUNCH;
+  }
   if (vec && dil % 4 == 0)
-    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dwk, C, H, W, dil, R, det_T);
   else if (vec && dil == 1)
-    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false, true>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dwk, C, H, W, dil, R, det_T);
   else if (vec)
-    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<true, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dwk, C, H, W, dil, R, det_T);
   else
-    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dw, C, H, W, dil, R);
+    hipLaunchKernelGGL((dwconv3x3_wgrad_kernel<false, false>), grid, dim3(512), lds, st, x, x_bs, dy, dy_bs, dwk, C, H, W, dil, R, det_T);
+  if (det_T) hipLaunchKernelGGL(dw_det_reduce_kernel, dim3(C), dim3(64), 0, st, dwk, dw, C, det_T);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -462,7 +462,10 @@ __global__ void src_sel_scan_kernel(SrcSel* __restrict__ sel, unsigned int* __re
 // pairs and relu(s - m1)^e for negative pairs, e = loss_type (:116-131).
 __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict__ sim, const unsigned char* __restrict__ gt, int H, int W,
                                                         int Hg, int Wg, int dil, int loss_type, float m0, float m1,
-                                                        double* __restrict__ stats, const SrcSel* __restrict__ sel) {
+                                                        double* __restrict__ stats, const SrcSel* __restrict__ sel,
+                                                        double* __restrict__ det_part = nullptr) {
+  // det_part != NULL (deterministic mode, api.cpp): this block's six sums go to slot blockIdx.y * gridDim.x + blockIdx.x of det_part[slots][6]
+  // instead of being added atomically into stats; src_stats_det_sum_kernel adds the slots in index order
   __shared__ double sm[16];
   const int n = blockIdx.y, HW = H * W;
   const unsigned char* g = gt + (i64)n * Hg * Wg;
@@ -490,8 +493,18 @@ __global__ __launch_bounds__(256) void src_stats_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const double r = block_sum_d(a[i], sm);
-    if (threadIdx.x == 0 && r != 0.0) atomicAdd(&stats[i], r);
+    if (threadIdx.x == 0) {
+      if (det_part) det_part[((i64)blockIdx.y * gridDim.x + blockIdx.x) * 6 + i] = r;
+      else if (r != 0.0) atomicAdd(&stats[i], r);
+    }
   }
+}
+__global__ void src_stats_det_sum_kernel(const double* __restrict__ part, int T, double* __restrict__ stats) {
+  const int i = threadIdx.x;
+  if (i >= 6) return;
+  double a = 0.0;
+  for (int k = 0; k < T; ++k) a += part[(i64)k * 6 + i];
+  stats[i] = a;
 }
 
 struct SrcMoments { double n, mean, std; };
@@ -810,8 +823,15 @@ extern "C" int pfst_src_sim_stats(const float* sim, const unsigned char* gt, int
   PFST_CHECK_ARG(loss_type >= 0 && loss_type <= 2);
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(stats, 0, 6 * sizeof(double), s) != hipSuccess) return PFST_ERR_LAUNCH;
-  hipLaunchKernelGGL(src_stats_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, loss_type, margin_pos,
-                     margin_neg, stats, reinterpret_cast<const SrcSel*>(select));
+  const int gxs = px_blocks((i64)H * W);
+  double* det = nullptr;
+  if (pfst_deterministic()) {
+    det = static_cast<double*>(pfst_det_scratch((size_t)gxs * N * 6 * sizeof(double), s));
+    PFST_CHECK_ARG(det != nullptr);
+  }
+  hipLaunchKernelGGL(src_stats_kernel, dim3(gxs, N), dim3(256), 0, s, sim, gt, H, W, Hg, Wg, dil, loss_type, margin_pos,
+                     margin_neg, stats, reinterpret_cast<const SrcSel*>(select), det);
+  if (det) hipLaunchKernelGGL(src_stats_det_sum_kernel, dim3(1), dim3(64), 0, s, det, gxs * N, stats);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -49,6 +49,19 @@ def _p(t):
 
 
 # ---------------------------------------------------------------- utilities
+def set_deterministic(on=True):
+    """pfst_set_deterministic: sums that are normally completed by atomic adds of several workgroups (split-K weight gradients, BatchNorm-backward
+    reductions, depthwise weight gradients, bias gradients, PFGSTLoss source statistics) are formed in a fixed order -- one image per
+    weight-gradient launch with no pixel chunking, per-workgroup partial slots + an ordered reduction for the small sums.  The gradient arena of a
+    step is then bit-identical run to run (tests/test_deterministic_gpu.py); the step is slower.  What the reference's `--deterministic`
+    (cudnn.deterministic = True, rsiseg/apis/train.py:63-66) asks for."""
+    call('pfst_set_deterministic', int(bool(on)))
+
+
+def is_deterministic():
+    return bool(lib().pfst_get_deterministic())
+
+
 def fill_(t, value):
     _dense(t)
     call('pfst_fill_f32', t.data_ptr(), t.numel(), float(value), _stream())

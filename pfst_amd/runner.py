@@ -16,14 +16,14 @@ from .optim import poly_lr
 
 
 def set_random_seed(seed, deterministic=False):
-    """rsiseg/apis/train.py:52-68.  `deterministic` (the reference: cudnn.deterministic = True, benchmark = False, i.e. run-to-run
-    reproducible kernels) is refused rather than accepted and ignored: the weight gradients, the BatchNorm-backward reductions and the depthwise
-    weight gradients of this build end in fp32 / fp64 atomic adds whose order varies between runs (two runs of one full-size step differ by up to
-    5e-2 norm-wise on the gradient arena after ~70 train-mode BatchNorm layers, tests/test_fullsize_gpu.py)."""
+    """rsiseg/apis/train.py:52-68.  `deterministic` (the reference: cudnn.deterministic = True, benchmark = False, i.e. run-to-run reproducible
+    kernels) switches the kernel library to its fixed-order mode (hip_ops.set_deterministic): split-K weight gradients one image per launch,
+    BatchNorm-backward / depthwise / bias reductions through ordered partial slots -- no sum depends on the order in which workgroups finish, the
+    gradient of a step is bit-identical between runs.  Costs throughput (the caller logs it); without the flag runs are reproducible up to that
+    summation order only (two runs of one full-size step differ by up to 5e-2 norm-wise on the gradient after ~70 train-mode BatchNorm layers)."""
     if deterministic:
-        raise NotImplementedError('--deterministic: pfst_amd has no fixed-order reduction mode for its atomically accumulated weight gradients '
-                                  'and BatchNorm-backward sums; runs are reproducible up to that summation order (seeds, data order, '
-                                  'pseudo labels and class mixes are)')
+        from . import hip_ops
+        hip_ops.set_deterministic(True)
     random.seed(seed)
     np.random.seed(seed)
     torch.manual_seed(seed)

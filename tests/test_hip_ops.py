@@ -1069,6 +1069,50 @@ def test_f16x3_minmax_partials_predict_the_normalised_maximum(ops, case, relu):
     assert float(slots.max()) == float(true.max()) == float(yn.abs().max()), (float(slots.max()), float(true.max()), float(yn.abs().max()))
 
 
+def test_depthwise_backward_is_exact_beside_a_weight_gradient_kernel(ops):
+    """Round 5: the fused depthwise backward with the BatchNorm-backward fold (dwconv3x3_kernel<3, true>) returned wrong sums for one of its
+    nine weight-gradient accumulators, on a few channels, whenever the f16x3 weight-gradient kernel of another stream shared the CUs --
+    the schedule the product's stream overlap creates -- in the build whose streaming kernels contained packed-fp32 (v_pk_*) code; exact
+    without it (pfst_amd/build.py NO_SLP, tools/race_probe.py).  Eight launches beside a busy side stream must reproduce the quiet launch bit
+    for bit (one image per weight-gradient slot here: two workgroups per channel, their fp32 atomics commute exactly only if ... they do
+    not: the comparison runs in deterministic mode)."""
+    n, c, h, w = 2, 560, 32, 32
+    x = torch.randn(n, c, h, w, generator=g(1)).to(DEV)
+    dy = torch.randn(n, c, h, w, generator=g(2)).to(DEV)
+    wt = torch.randn(c, 1, 3, 3, generator=g(3)).to(DEV)
+    gamma = (torch.rand(c, generator=g(4)) + 0.5).to(DEV)
+    beta = (torch.randn(c, generator=g(5)) * 0.1).to(DEV)
+    pre = ops.dwconv(x, wt, 1)
+    mean, invstd, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+    X = torch.randn(2, 512, 64, 64, generator=g(6)).to(DEV)
+    DY = torch.randn(2, 512, 64, 64, generator=g(7)).to(DEV)
+    DW = torch.zeros(512 * 512, device=DEV)
+    xa, dya = ops.absmax(X), ops.absmax(DY)
+    side = torch.cuda.Stream()
+    ops.set_deterministic(True)
+    try:
+        rec = ops.bn_backward_sums(dy, pre, mean, invstd, gamma, beta, torch.zeros(c, device=DEV), torch.zeros(c, device=DEV))
+        for bnl in (None, coef):
+            ref = torch.zeros(c * 9, device=DEV)
+            dxr = torch.empty_like(x)
+            ops.dwconv_bwd_(ref, x, dy, wt, 1, dxr, bnl=bnl, bnb=(pre, rec))
+            torch.cuda.synchronize()
+            for rep in range(8):
+                dw = torch.zeros(c * 9, device=DEV)
+                dx = torch.empty_like(x)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        ops.conv_wgrad_f16x3_(DW, X, DY, xa, dya)
+                ops.dwconv_bwd_(dw, x, dy, wt, 1, dx, bnl=bnl, bnb=(pre, rec))
+                torch.cuda.synchronize()
+                assert torch.equal(dx, dxr)
+                bad = (dw != ref).nonzero().flatten().tolist()
+                assert not bad, f'run {rep}: weight-gradient elements {bad[:8]} (taps {[i % 9 for i in bad[:8]]}) differ from the quiet launch'
+    finally:
+        ops.set_deterministic(False)
+
+
 @pytest.mark.parametrize('slots', [2, 5])
 def test_f16x3_tile_chain_is_the_same_arithmetic(ops, slots):
     """The f16x3 GEMMs walk up to 8 tiles per workgroup as one software pipeline (the next tile's first pairs are loaded, split and stored

@@ -26,14 +26,7 @@ def test_train_cli_flags_of_the_reference_parse():
     assert a.config == 'cfg.py' and a.work_dir == 'w' and a.seed == 3 and a.launcher == 'pytorch' and a.local_rank == 2
     from pfst_amd.config import parse_cfg_options
     assert parse_cfg_options(a.cfg_options) == {'a.b': 1, 'c': [1, 2]}
-    # --deterministic parses (the reference's flag surface) but is REFUSED when it would take effect: this build's weight gradients end in
-    # atomics, and a flag that is accepted and ignored would promise a reproducibility it does not deliver
-    import pytest
-    from pfst_amd.runner import set_random_seed
-    assert a.deterministic is True
-    set_random_seed(3, False)
-    with pytest.raises(NotImplementedError, match='deterministic'):
-        set_random_seed(3, True)
+    assert a.deterministic is True          # switches the kernel library to fixed-order sums (tests/test_deterministic_gpu.py)
 
 
 def test_checkpoint_roundtrip_keeps_reference_layout_and_local_iter(tmp_path):

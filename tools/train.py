@@ -122,6 +122,11 @@ def main(argv=None):
         ev = cfg.get('evaluation') or {}
         eval_fn = build_eval_fn(data_cfg['val'], nc, dev, metric=ev.get('metric', 'mIoU'))
     runner = IterBasedRunner(model, optimizer, cfg, work_dir, eval_fn=eval_fn)
+    if args.deterministic and rank == 0:
+        # the cost is in the `time` column of the log: split-K weight gradients run one image per launch (a fraction of the chip each), the
+        # small reductions through ordered partial slots -- about 2x the step of the default mode at b = 8 x 1024^2
+        runner.log('deterministic mode: weight gradients / BatchNorm-backward / depthwise / bias sums in a fixed order (bit-reproducible '
+                   'gradients run to run); expect a slower step -- compare the `time` values with a run without --deterministic')
     if load_from:
         runner.load_checkpoint(load_from)
     if resume:
