@@ -10,11 +10,11 @@ void pfst_set_error(const char* file, int line, const char* msg) {
   snprintf(g_err, sizeof(g_err), "%s:%d: %s", file, line, msg);
 }
 
-// Deterministic mode (pfst_set_deterministic): every sum that is normally completed by fp32 / fp64 atomic adds of several workgroups --
-// split-K weight gradients, the BatchNorm-backward reductions, the depthwise weight gradients -- is formed in a fixed order instead: the
-// launchers issue ONE K slice (image) per launch with no pixel chunking, so every address has a single writer per launch and the launches
-// are ordered by the stream; the small reductions go through per-workgroup partials summed in index order.  Slower (the weight-gradient
-// launches fill a fraction of the chip), bit-reproducible run to run.
+// Deterministic mode (pfst_set_deterministic): every sum that is normally completed by fp32 / fp64 atomic adds of several workgroups -- the
+// split-K slices of the weight gradients, the BatchNorm-backward reductions, the depthwise and bias gradients, PFGSTLoss's source statistics --
+// goes through per-workgroup (per grid slice) partials in a scratch and is added up by a second kernel in index order (det.h, bn.hip,
+// dwconv.hip): same launch shapes, no sum depends on which workgroup finishes first.  +3 % on the b = 8 x 1024^2 step; the gradient of a step is
+// bit-identical run to run and for any stream schedule (tests/test_deterministic_gpu.py, tools/det_repro_fullsize.py).
 static int g_deterministic = 0;
 int pfst_deterministic(void) { return g_deterministic; }
 extern "C" int pfst_set_deterministic(int on) {

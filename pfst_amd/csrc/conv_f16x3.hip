@@ -17,6 +17,7 @@
 // on the bf16x6 or fp32-input MFMA kernels.
 #include "conv_epilogue.h"
 #include "amax.h"
+#include "det.h"
 #include "weight_jobs.h"
 #include <math.h>
 #include <stdlib.h>
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
   if (pbeg >= pend) return;
   x += (i64)grp * x_gs + (i64)n * x_bs;
   dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
+  dw += dw_gs >= 0 ? (i64)grp * dw_gs : (i64)bz * -dw_gs;      // < 0: deterministic mode, one scratch tile-set per grid slice (det.h)
   const int ea = amax_exponent(amax_read(dy_amax)), eb = amax_exponent(amax_read(x_amax));
   const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(ea))));
   const float sb = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, scale_of(eb))));
@@ -1076,14 +1077,6 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                             i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = pfst_wgrad_f16x3_launch(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, J, M, P, groups, x_gs, dy_gs, dw_gs, x_amax, dy_amax, packed, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   const bool big = M % 256 == 0;                                // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
   const int bm = big ? 256 : 128;
   const int tiles = cdiv(J, 128) * cdiv(M, bm) * groups;
@@ -1097,19 +1090,25 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, bm), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, gz, s, det_ok);          // deterministic mode (det.h): one scratch tile-set per grid slice
+  PFST_CHECK_ARG(det_ok);
+  float* const dwk = ws ? ws : dw;
+  const i64 gsk = ws ? -elems : dw_gs;
 #define PFST_LAUNCH_WGRAD(KERNEL_, THREADS_)                                                                                               \
-  hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, \
+  hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dwk, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, gsk, \
                      gx, gy, gz, x_amax, dy_amax)
   if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
   else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256>), 512);
   else if (packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true>), 256);
   else PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false>), 256);
 #undef PFST_LAUNCH_WGRAD
+  if (ws) wgrad_det_reduce(ws, dw, elems, groups, N * chunks, dw_gs, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

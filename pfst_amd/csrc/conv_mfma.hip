@@ -18,6 +18,7 @@
 //   sub-tile as 32x32 MFMA accumulators; K advances 16 per step through a double-buffered LDS
 //   tile with register-staged prefetch (one barrier per step).
 #include "conv_epilogue.h"
+#include "det.h"
 #include "../../include/pfst_hip.h"
 #include <stdlib.h>
 
@@ -161,7 +162,7 @@ constexpr int WBJ = 128;
 template <int BM, int T, int WBK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len) {
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len, i64 det_stride = 0) {
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   if (pbeg >= pend) return;
   x += (i64)n * x_bs;
   dy += (i64)n * dy_bs;
+  dw += (i64)blockIdx.z * det_stride;         // deterministic mode (det.h): one scratch tile-set per grid slice
 
   if (tid < WBJ) {
     const int j = j0 + tid;
@@ -365,14 +367,6 @@ int launch_igemm_generic(const float* in, i64 in_bs, const float* wk, const floa
 template <int BM, int T, int WBK>
 int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                    int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = launch_wgrad_k<BM, T, WBK>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, WBJ) * cdiv(M, BM);
   // Split the pixel (K) range (chunks of >= 512 pixels, fp32 atomics combine) so that the launch fills the chip in
@@ -389,7 +383,6 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
     if (eff >= 0.93) break;
   }
   while ((i64)N * chunks > 65535 && chunks > 1) --chunks;       // gridDim.z limit
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, WBJ), cdiv(M, BM), N * chunks);
@@ -399,8 +392,13 @@ int launch_wgrad_k(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* 
     hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<BM, T, WBK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, T, WBK>), grid, dim3(256), lds, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
-                     stride, dil, pad, chunks, chunk_len);
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, (i64)N * chunks, s, det_ok);          // deterministic mode (det.h)
+  PFST_CHECK_ARG(det_ok);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, T, WBK>), grid, dim3(256), lds, s, x, x_bs, dy, dy_bs, ws ? ws : dw, Cin, Hi, Wi, M, Ho, Wo,
+                     stride, dil, pad, chunks, chunk_len, ws ? elems : (i64)0);
+  if (ws) wgrad_det_reduce(ws, dw, elems, 1, N * chunks, 0, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -11,6 +11,7 @@
 // pfst_conv_pack_weight_split into the exact LDS image [k16-group][piece][k-half][row][8 x bf16]; activations are split
 // in registers on their way from HBM to LDS (fp32 NCHW stays the storage format everywhere).
 #include "conv_epilogue.h"
+#include "det.h"
 #include <math.h>
 #include <type_traits>
 #include <utility>
@@ -763,7 +764,7 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, uint4* __r
 template <int BM, int T>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
-    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len) {
+    int Cin, int Hi, int Wi, int M, int Ho, int Wo, int stride, int dil, int pad, int chunks, int chunk_len, i64 det_stride = 0) {
   constexpr int BJ = 128;
   constexpr int WM = BM >= 64 ? 64 : 32;
   constexpr int WAVES_M = BM / WM;
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(
   if (pbeg >= pend) return;
   x += (i64)n * x_bs;
   dy += (i64)n * dy_bs;
+  dw += (i64)blockIdx.z * det_stride;         // deterministic mode (det.h): one scratch tile-set per grid slice
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
 
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_q_kernel(
   if (pbeg >= pend) return;
   x += (i64)grp * x_gs + (i64)n * x_bs;
   dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
+  dw += dw_gs >= 0 ? (i64)grp * dw_gs : (i64)bz * -dw_gs;      // < 0: deterministic mode, one scratch tile-set per grid slice (det.h)
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
 
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_q_pipe_kernel(
   if (pbeg >= pend) return;
   x += (i64)grp * x_gs + (i64)n * x_bs;
   dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
+  dw += dw_gs >= 0 ? (i64)grp * dw_gs : (i64)bz * -dw_gs;      // < 0: deterministic mode, one scratch tile-set per grid slice (det.h)
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, J * P * 4, 0x00020000);
 
@@ -1171,14 +1173,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_split_q_pipe_kernel(
 template <int BM>
 int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
                          i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = launch_wgrad_split_q<BM>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, J, M, P, groups, x_gs, dy_gs, dw_gs, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   const int tiles = cdiv(J, 128) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident workgroups (49 KB of LDS: 3 per CU)
   const double slots = 256.0 * 3;
@@ -1190,17 +1184,23 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   const int gx = cdiv(J, 128), gy = cdiv(M, BM), gz = N * groups * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, gz, s, det_ok);          // deterministic mode (det.h): one scratch tile-set per grid slice
+  PFST_CHECK_ARG(det_ok);
+  float* const dwk = ws ? ws : dw;
+  const i64 gsk = ws ? -elems : dw_gs;
   if (BM == 128)
-    hipLaunchKernelGGL(conv_wgrad_split_q_pipe_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
-                       N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
+    hipLaunchKernelGGL(conv_wgrad_split_q_pipe_kernel, dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dwk, J, M, P, chunks, chunk_len,
+                       N, x_gs, dy_gs, gsk, gx, gy, gz, 1);
   else
-    hipLaunchKernelGGL((conv_wgrad_split_q_kernel<BM>), dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, J, M, P, chunks, chunk_len,
-                       N, x_gs, dy_gs, dw_gs, gx, gy, gz, 1);
+    hipLaunchKernelGGL((conv_wgrad_split_q_kernel<BM>), dim3(gx * gy * gz), dim3(256), 0, s, x, x_bs, dy, dy_bs, dwk, J, M, P, chunks, chunk_len,
+                       N, x_gs, dy_gs, gsk, gx, gy, gz, 1);
+  if (ws) wgrad_det_reduce(ws, dw, elems, groups, N * chunks, dw_gs, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -1208,24 +1208,20 @@ int launch_wgrad_split_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, f
 template <int BM, int T>
 int launch_wgrad_split(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
                        int Ho, int Wo, int stride, int dil, int pad, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = launch_wgrad_split<BM, T>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, stride, dil, pad, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, 128) * cdiv(M, BM);
   int chunks = 1;
   while ((i64)tiles * N * chunks < 1024 && P / (chunks * 2) >= 512) chunks *= 2;
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + 15) / 16) * 16;
   chunks = cdiv(P, chunk_len);
   dim3 grid(cdiv(J, 128), cdiv(M, BM), N * chunks);
-  hipLaunchKernelGGL((conv_wgrad_split_kernel<BM, T>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo, stride,
-                     dil, pad, chunks, chunk_len);
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, (i64)N * chunks, s, det_ok);          // deterministic mode (det.h)
+  PFST_CHECK_ARG(det_ok);
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<BM, T>), grid, dim3(256), 0, s, x, x_bs, dy, dy_bs, ws ? ws : dw, Cin, Hi, Wi, M, Ho, Wo, stride,
+                     dil, pad, chunks, chunk_len, ws ? elems : (i64)0);
+  if (ws) wgrad_det_reduce(ws, dw, elems, 1, N * chunks, 0, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

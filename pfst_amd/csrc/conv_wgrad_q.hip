@@ -12,6 +12,7 @@
 // Split-K over images and pixel chunks, fp32 atomics into the flat gradient arena -- as conv_wgrad_kernel (conv_mfma.hip),
 // which remains the generic path (stride 2, ragged widths).
 #include "common.h"
+#include "det.h"
 #include "amax.h"
 #include "../../include/pfst_hip.h"
 #include <stdlib.h>
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_q_kernel(
   if (pbeg >= pend) return;
   x += (i64)grp * x_gs + (i64)n * x_bs;
   dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
+  dw += dw_gs >= 0 ? (i64)grp * dw_gs : (i64)bz * -dw_gs;      // < 0: deterministic mode, one scratch tile-set per grid slice (det.h)
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
 
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_q16_kernel(
   if (pbeg >= pend) return;
   x += (i64)grp * x_gs + (i64)n * x_bs;
   dy += (i64)grp * dy_gs + (i64)n * dy_bs;
-  dw += (i64)grp * dw_gs;
+  dw += dw_gs >= 0 ? (i64)grp * dw_gs : (i64)bz * -dw_gs;      // < 0: deterministic mode, one scratch tile-set per grid slice (det.h)
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, M * P * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, Cin * HiWi * 4, 0x00020000);
 
@@ -485,14 +486,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_q16_kernel(
 template <int BM, int T, int WBK>
 int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M,
              int Ho, int Wo, int dil, int pad, int groups, i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = launch_q<BM, T, WBK>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, dil, pad, groups, x_gs, dy_gs, dw_gs, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, QBJ) * cdiv(M, BM) * groups;
   // split-K chunking: whole rounds of resident blocks (see launch_wgrad_k in conv_mfma.hip); 32 KB LDS at WBK = 16, 64 KB at 32
@@ -505,7 +498,6 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   constexpr int xcd_env = 1;
@@ -514,8 +506,13 @@ int launch_q(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, in
   dim3 grid(gx * gy * gz);
   // occupancy cap (pfst_conv_wgrad_set_lds_pad): unused dynamic LDS, so that fewer workgroups fit per CU and a concurrently running
   // HBM-bound kernel of another stream finds registers and wave slots
-  hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho, Wo,
-                     dil, pad, chunks, chunk_len, N, x_gs, dy_gs, dw_gs, gx, gy, gz, xcd_env);
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, gz, s, det_ok);          // deterministic mode (det.h): one scratch tile-set per grid slice
+  PFST_CHECK_ARG(det_ok);
+  hipLaunchKernelGGL((conv_wgrad_q_kernel<BM, T, WBK>), grid, dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, ws ? ws : dw, Cin, Hi, Wi, M, Ho, Wo,
+                     dil, pad, chunks, chunk_len, N, x_gs, dy_gs, ws ? -elems : dw_gs, gx, gy, gz, xcd_env);
+  if (ws) wgrad_det_reduce(ws, dw, elems, groups, N * chunks, dw_gs, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -529,14 +526,6 @@ int launch_q_bk(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw,
 template <int BM, int T>
 int launch_q16(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int Cin, int Hi, int Wi, int M, int Ho, int Wo, int dil,
                int pad, const float* x_amax, const float* dy_amax, hipStream_t s) {
-  // deterministic mode (api.cpp): one image per launch and no pixel chunking -- a single writer per address and launch, launches in stream order
-  if (pfst_deterministic() && N > 1) {
-    for (int n = 0; n < N; ++n) {
-      const int rc = launch_q16<BM, T>(x + (i64)n * x_bs, x_bs, dy + (i64)n * dy_bs, dy_bs, dw, 1, Cin, Hi, Wi, M, Ho, Wo, dil, pad, x_amax, dy_amax, s);
-      if (rc != PFST_OK) return rc;
-    }
-    return PFST_OK;
-  }
   constexpr int WBK = 16;
   const int P = Ho * Wo, J = Cin * T;
   const int tiles = cdiv(J, QBJ) * cdiv(M, BM);
@@ -549,14 +538,18 @@ int launch_q16(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, 
     if (eff > best + 0.02) { best = eff; chunks = c; }
     if (eff >= 0.93) break;
   }
-  if (pfst_deterministic()) chunks = 1;
   int chunk_len = ((cdiv(P, chunks) + WBK - 1) / WBK) * WBK;
   chunks = cdiv(P, chunk_len);
   constexpr int xcd_env = 1;
   const int gx = cdiv(J, QBJ), gy = cdiv(M, BM), gz = N * chunks;
   PFST_CHECK_ARG((i64)gx * gy * gz < (1ll << 31));
-  hipLaunchKernelGGL((conv_wgrad_q16_kernel<BM, T>), dim3(gx * gy * gz), dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, dw, Cin, Hi, Wi, M, Ho,
-                     Wo, dil, pad, chunks, chunk_len, N, (i64)0, (i64)0, (i64)0, gx, gy, gz, xcd_env, x_amax, dy_amax);
+  const i64 elems = (i64)M * J;
+  bool det_ok;
+  float* const ws = wgrad_det_scratch(elems, gz, s, det_ok);          // deterministic mode (det.h): one scratch tile-set per grid slice
+  PFST_CHECK_ARG(det_ok);
+  hipLaunchKernelGGL((conv_wgrad_q16_kernel<BM, T>), dim3(gx * gy * gz), dim3(256), g_wgrad_lds_pad, s, x, x_bs, dy, dy_bs, ws ? ws : dw, Cin, Hi, Wi, M, Ho,
+                     Wo, dil, pad, chunks, chunk_len, N, (i64)0, (i64)0, ws ? -elems : (i64)0, gx, gy, gz, xcd_env, x_amax, dy_amax);
+  if (ws) wgrad_det_reduce(ws, dw, elems, 1, N * chunks, 0, s);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -51,9 +51,9 @@ def _p(t):
 # ---------------------------------------------------------------- utilities
 def set_deterministic(on=True):
     """pfst_set_deterministic: sums that are normally completed by atomic adds of several workgroups (split-K weight gradients, BatchNorm-backward
-    reductions, depthwise weight gradients, bias gradients, PFGSTLoss source statistics) are formed in a fixed order -- one image per
-    weight-gradient launch with no pixel chunking, per-workgroup partial slots + an ordered reduction for the small sums.  The gradient arena of a
-    step is then bit-identical run to run (tests/test_deterministic_gpu.py); the step is slower.  What the reference's `--deterministic`
+    reductions, depthwise weight gradients, bias gradients, PFGSTLoss source statistics) are formed in a fixed order -- per-workgroup (per grid
+    slice) partials in a scratch + an ordered reduction; same launch shapes.  The gradient arena of a step is then bit-identical run to run and for
+    any stream schedule (tests/test_deterministic_gpu.py); the b = 8 x 1024^2 step is about 3 % slower (tools/det_cost.py).  What the reference's `--deterministic`
     (cudnn.deterministic = True, rsiseg/apis/train.py:63-66) asks for."""
     call('pfst_set_deterministic', int(bool(on)))
 

@@ -17,10 +17,10 @@ from .optim import poly_lr
 
 def set_random_seed(seed, deterministic=False):
     """rsiseg/apis/train.py:52-68.  `deterministic` (the reference: cudnn.deterministic = True, benchmark = False, i.e. run-to-run reproducible
-    kernels) switches the kernel library to its fixed-order mode (hip_ops.set_deterministic): split-K weight gradients one image per launch,
-    BatchNorm-backward / depthwise / bias reductions through ordered partial slots -- no sum depends on the order in which workgroups finish, the
-    gradient of a step is bit-identical between runs.  Costs throughput (the caller logs it); without the flag runs are reproducible up to that
-    summation order only (two runs of one full-size step differ by up to 5e-2 norm-wise on the gradient after ~70 train-mode BatchNorm layers)."""
+    kernels) switches the kernel library to its fixed-order mode (hip_ops.set_deterministic): the split-K slices of the weight gradients and the
+    BatchNorm-backward / depthwise / bias reductions go through per-workgroup partials summed in index order -- no sum depends on the order in which
+    workgroups finish, the gradient of a step is bit-identical between runs and stream schedules.  About 3 % slower; without the flag runs are
+    reproducible up to that summation order only (two runs of one full-size step differ by up to 5e-2 norm-wise on the gradient after ~70 train-mode BatchNorm layers)."""
     if deterministic:
         from . import hip_ops
         hip_ops.set_deterministic(True)

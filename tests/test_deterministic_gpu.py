@@ -13,14 +13,18 @@ from helpers import seeded_pfgst_state, to_dev, uda_cfg
 pytestmark = pytest.mark.gpu
 
 
-def _one_step(det, seed=123):
+def _one_step(det, seed=123, overlap=None):
     import pfst_amd  # noqa: F401
     from oracle import pfst_oracle as O
     from pfst_amd import hip_ops
     from pfst_amd.optim import build_optimizer
     from pfst_amd.registry import UDA
     from pfst_amd.synthetic import synth_batch
+    from pfst_amd import layers
     hip_ops.set_deterministic(det)
+    prev_overlap = (layers.WGRAD_STREAM, layers.FORK_TEACHER)
+    if overlap is not None:
+        layers.set_overlap(*overlap)
     try:
         model = UDA.build(uda_cfg(threshold=0.30, dropout=0.1))
         both, _, _ = seeded_pfgst_state(O, 9)
@@ -38,6 +42,7 @@ def _one_step(det, seed=123):
         return out0, g0.cpu(), out1, arena.grad.clone().cpu(), arena.data.clone().cpu(), layout
     finally:
         hip_ops.set_deterministic(False)
+        layers.set_overlap(*prev_overlap)
 
 
 def test_deterministic_mode_gives_bit_identical_gradients():
@@ -54,6 +59,13 @@ def test_deterministic_mode_gives_bit_identical_gradients():
     # log values: the cross-entropy / similarity loss SUMS still meet in fp64 atomics (they feed no gradient): equal to fp64 round-off
     for k in a[0]:
         assert abs(a[0][k] - b[0][k]) <= 1e-12 * max(1.0, abs(a[0][k])), k
+    # ... whatever the stream schedule: with the teacher pass and the weight gradients on side streams (the product default) or everything on one
+    # stream, the fixed-order step is the SAME step bit for bit -- co-running kernels must not change a single gradient element (round 5 found
+    # one kernel that did: tests/test_hip_ops.py::test_depthwise_backward_is_exact_beside_a_weight_gradient_kernel)
+    on, off = _one_step(True, overlap=(True, True)), _one_step(True, overlap=(False, False))
+    diff = [n for n, o, k in on[5] if not torch.equal(on[1][o:o + k], off[1][o:o + k])]
+    assert not diff, f'gradient tensors that depend on the stream schedule: {diff[:12]}'
+    assert torch.equal(on[3], off[3]) and torch.equal(on[4], off[4])
     # and the fixed-order sums are the same mathematics as the default ones
     c = _one_step(False)
     rel = float((a[1].double() - c[1].double()).norm() / c[1].double().norm())

@@ -14,6 +14,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--runs', type=int, default=3)
+    ap.add_argument('--last-single-stream', action='store_true', help='the last run on one stream: the step must not depend on the stream schedule either')
     args = ap.parse_args()
     import bench
     from pfst_amd import hip_ops, layers
@@ -28,6 +29,9 @@ def main():
     print('stream overlap:', layers.WGRAD_STREAM, layers.FORK_TEACHER)
     grads = []
     for r in range(args.runs):
+        if args.last_single_stream and r == args.runs - 1:
+            layers.set_overlap(False, False)
+            print('last run: one stream')
         model = UDA.build(cfg)
         fill_state_dict(model.state_dict(), 0)
         model.to(dev)

@@ -123,10 +123,11 @@ def main(argv=None):
         eval_fn = build_eval_fn(data_cfg['val'], nc, dev, metric=ev.get('metric', 'mIoU'))
     runner = IterBasedRunner(model, optimizer, cfg, work_dir, eval_fn=eval_fn)
     if args.deterministic and rank == 0:
-        # the cost is in the `time` column of the log: split-K weight gradients run one image per launch (a fraction of the chip each), the
-        # small reductions through ordered partial slots -- about 2x the step of the default mode at b = 8 x 1024^2
-        runner.log('deterministic mode: weight gradients / BatchNorm-backward / depthwise / bias sums in a fixed order (bit-reproducible '
-                   'gradients run to run); expect a slower step -- compare the `time` values with a run without --deterministic')
+        # measured at b = 8 x 1024^2 (tools/det_cost.py): 296 ms against 288 ms per step -- the split-K slices of the weight gradients go through a
+        # scratch and an ordered reduction instead of atomics, the launch shapes are the default mode's
+        runner.log('deterministic mode: weight gradients / BatchNorm-backward / depthwise / bias sums in a fixed order -- bit-reproducible '
+                   'gradients run to run and for any stream schedule; about 3 % slower (compare the `time` column with a run without '
+                   '--deterministic)')
     if load_from:
         runner.load_checkpoint(load_from)
     if resume:
