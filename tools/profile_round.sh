@@ -7,8 +7,18 @@ set -e
 R=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+# Per-kernel durations are only comparable with bench.py's `roofline` (measured in its single-stream region) when nothing co-runs: the stats and
+# counter passes run the whole command on ONE stream (exported, not `env`: the program must sit directly after `--`); a second stats pass
+# records the product schedule (teacher pass and weight gradients on side streams) for the co-running picture.
+export PFST_WGRAD_STREAM=0 PFST_FORK_TEACHER=0
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o s -- python3 bench.py --no-alt-math > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/b_under_rocprof.err
 echo stats done
+unset PFST_WGRAD_STREAM PFST_FORK_TEACHER
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_ov -o s -- python3 bench.py --no-alt-math --no-cpu-baseline > gpurun_out/${R}_bench_under_rocprof_overlap.json 2> gpurun_out/b_under_rocprof_ov.err
+find gpurun_out/prof_stats_ov -name "*kernel_stats.csv" -exec cp {} gpurun_out/${R}_kernel_stats_overlap.csv \;
+rm -rf gpurun_out/prof_stats_ov
+echo overlap stats done
+export PFST_WGRAD_STREAM=0 PFST_FORK_TEACHER=0
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-kernel-timing"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py $ARGS > gpurun_out/pmc_f.log 2>&1
 echo fetch done
