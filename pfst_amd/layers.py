@@ -542,24 +542,30 @@ def teacher_stream():
 
 
 def _on_side_stream(fn, *tensors):
-    """run fn (weight-gradient launches) on the side stream, ordered after everything queued on the current stream so far"""
+    """run fn (weight-gradient launches) on the current stream's side stream, ordered after everything queued on the current stream so far"""
     global _side_stream
     main = torch.cuda.current_stream()
     if _side_stream is None:
-        _side_stream = torch.cuda.Stream(priority=-1)      # high priority: the chain's kernels fill in around the wgrads
+        _side_stream = {}
         ops.set_wgrad_lds_pad(WGRAD_STREAM_LDS_PAD)
-    _side_stream.wait_stream(main)
-    with torch.cuda.stream(_side_stream):
+    side = _side_stream.get(main.cuda_stream)
+    if side is None:
+        side = _side_stream[main.cuda_stream] = torch.cuda.Stream(priority=-1)      # high priority: the chain's kernels fill in around the wgrads
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
         fn()
     for t in tensors:
         if t is not None:
-            t.record_stream(_side_stream)
+            t.record_stream(side)
 
 
 def join_side_stream():
-    """the current stream waits for the weight gradients queued on the side stream (before the optimizer / all-reduce)"""
+    """the current stream waits for the weight gradients queued on its side stream (before the optimizer / all-reduce)"""
     if _side_stream is not None:
-        torch.cuda.current_stream().wait_stream(_side_stream)
+        main = torch.cuda.current_stream()
+        side = _side_stream.get(main.cuda_stream)
+        if side is not None:
+            main.wait_stream(side)
 
 
 def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):

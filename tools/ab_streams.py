@@ -7,7 +7,7 @@ One model, one process; the legs are run in rotating order so that no leg is sys
   single+events   -- one stream with the dominant kernel's launches bracketed by HIP events (what bench.py's timed region does for `value`)
   fork            -- teacher forward forked beside the student's source pass
   wgrad           -- weight gradients on the high-priority side stream
-  fork+wgrad      -- both (bench.py's `alt_streams` leg)
+  fork+wgrad      -- both (the product schedule since round 5)
 Each leg: `--warm` untimed steps after the switch, then `--steps` timed ones.  Prints one line per leg and round, then per-leg medians.
 
   python tools/ab_streams.py --rounds 4 --steps 8 --warm 2"""
