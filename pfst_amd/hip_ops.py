@@ -62,6 +62,32 @@ def is_deterministic():
     return bool(lib().pfst_get_deterministic())
 
 
+_h2d_stage = {}
+_h2d_const = {}
+
+
+def h2d_small(t_cpu, dev, tag):
+    """a small per-step host tensor (augmentation parameters, class choices) to the device WITHOUT the stream synchronisation a pageable
+    copy implies (`.to(dev)` of pageable memory makes the host wait for everything queued on the stream -- the host then starts the next
+    pass with no lead over the device): staged through a pinned buffer cached per (tag, shape, dtype), copied asynchronously.  A buffer is
+    reused one step later at the earliest; the step's blocking read of its log values lies in between"""
+    key = (tag, tuple(t_cpu.shape), t_cpu.dtype)
+    st = _h2d_stage.get(key)
+    if st is None:
+        st = _h2d_stage[key] = torch.empty(t_cpu.shape, dtype=t_cpu.dtype, pin_memory=True)
+    st.copy_(t_cpu)
+    return st.to(dev, non_blocking=True)
+
+
+def const_tensor(values, dev, dtype=F32):
+    """a device tensor of a few host constants (normalisation mean / std ...), built once per (values, device)"""
+    key = (tuple(float(v) for v in values), str(dev), dtype)
+    t = _h2d_const.get(key)
+    if t is None:
+        t = _h2d_const[key] = torch.tensor(list(values), dtype=dtype, device=dev)
+    return t
+
+
 def fill_(t, value):
     _dense(t)
     call('pfst_fill_f32', t.data_ptr(), t.numel(), float(value), _stream())

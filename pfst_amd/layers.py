@@ -522,6 +522,9 @@ def conv_forward(x, conv, tape, out=None):
 # in a single-stream region of the same run (set_overlap(False, False)).  PFST_WGRAD_STREAM=0 / PFST_FORK_TEACHER=0: one stream.
 WGRAD_STREAM = os.environ.get('PFST_WGRAD_STREAM', '1') == '1'
 FORK_TEACHER = os.environ.get('PFST_FORK_TEACHER', '1') == '1'
+# the step boundary (uda.PFGST): the optimizer step queued before the host blocks on the step's log values, the student's weight images
+# packed behind the forked teacher pass -- the device has work while the host crosses from one step into the next (tools/gap_analysis.py)
+STEP_BOUNDARY_OVERLAP = True
 WGRAD_STREAM_LDS_PAD = 24000
 _side_stream = None
 _teacher_stream = None
@@ -642,6 +645,19 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
             _dgrad_into(x, conv, dy, final, dy_amax)
 
 
+_identity_rows = {}
+
+
+def identity_coef_row(dev):
+    """(mean, invstd, sc, sh) = (0, 1, 1, 0) on the device: the coefficient row under which a normalise-on-load consumer leaves a channel's
+    (non-negative) values alone.  Cached per device: building it from a Python list is a pageable host-to-device copy, i.e. a host-side
+    wait for the stream in the middle of every forward pass"""
+    row = _identity_rows.get(dev)
+    if row is None:
+        row = _identity_rows[dev] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev)
+    return row
+
+
 def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scale=None, defer=False):
     """y = [relu](BN_train(conv(x)) [+ residual]); `out` may be a channel slice of a concat buffer
     (then the returned Var is expected to be obtained from the concat Var's .slice()).
@@ -679,7 +695,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     if slice_requested and not into_slice and isinstance(out, Var) and out.parent is not None and out.parent.coef_table is not None:
         # this writer normalises its slice itself after all: identity rows, max(fma(y, 1, 0), 0) = y for its ReLU'd (non-negative) values
         assert relu
-        out.parent.coef_table[out.c0:out.c1] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=out.data.device)
+        out.parent.coef_table[out.c0:out.c1] = identity_coef_row(out.data.device)
     need_pred = need_pred and defer
     pre_out = out.data if into_slice else None           # the convolution writes straight into the concat slice
     if conv.depthwise:

@@ -335,7 +335,7 @@ class DepthwiseSeparableASPPHead(BaseDecodeHead):
                 and (tape is None or bconv.wino_wgrad_ok(h, w)))
         if fold:
             cat.coef_table = torch.empty(nb * ch, 4, device=x.data.device)
-            cat.coef_table[:ch] = torch.tensor([0.0, 1.0, 1.0, 0.0], device=x.data.device)          # y = max(fma(v, 1, 0), 0) = v for the (non-negative) pooled values
+            cat.coef_table[:ch] = layers_mod.identity_coef_row(x.data.device)          # y = max(fma(v, 1, 0), 0) = v for the (non-negative) pooled values
         sl = 'slice' if fold else False
         self.aspp_modules[0](x, tape, out=cat.slice(ch, 2 * ch), defer=sl)
         nd = len(self.dilations)

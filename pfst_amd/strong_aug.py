@@ -42,9 +42,9 @@ def apply_strong_aug(mixed_img, img_metas, jitter_draw, jitter_p, jitter_s, blur
             hu = torch.empty(1).uniform_(-s['hue'], s['hue']) * 2 * math.pi
             prm[i] = torch.cat([b, ct, sa, hu, torch.randperm(4).float()])
         meta = img_metas[0]['img_norm_cfg']
-        mean = torch.tensor(meta['mean'], dtype=torch.float32, device=dev)
-        std = torch.tensor(meta['std'], dtype=torch.float32, device=dev)
-        ops.color_jitter_(mixed_img, prm.to(dev), mean, std, denorm_type == 'mean_std')
+        mean = ops.const_tensor(meta['mean'], dev)
+        std = ops.const_tensor(meta['std'], dev)
+        ops.color_jitter_(mixed_img, ops.h2d_small(prm, dev, 'jitter'), mean, std, denorm_type == 'mean_std')
     if blur_draw > 0.5:
         ky, kx = _blur_kernel_size(h), _blur_kernel_size(w)
         ty, tx = torch.empty(n, ky), torch.empty(n, kx)
@@ -54,5 +54,5 @@ def apply_strong_aug(mixed_img, img_metas, jitter_draw, jitter_p, jitter_s, blur
             smax = max(smax, sigma)
             ty[i], tx[i] = _gauss_taps(ky, sigma), _gauss_taps(kx, sigma)
         reach = int(math.ceil(smax * 10.0)) + 1      # exp(-50) ~ 2e-22: dropped taps are below fp32 resolution
-        mixed_img = ops.gaussian_blur(mixed_img, ty.to(dev), tx.to(dev), reach)
+        mixed_img = ops.gaussian_blur(mixed_img, ops.h2d_small(ty, dev, 'blur_y'), ops.h2d_small(tx, dev, 'blur_x'), reach)
     return mixed_img

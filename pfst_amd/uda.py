@@ -304,8 +304,15 @@ class PFGST(UDADecorator):
     # ------------------------------------------------------------------ the hot path
     def train_step(self, data_batch, optimizer, **kwargs):
         optimizer.zero_grad()
-        log_vars, vis_states = self(**data_batch)
-        optimizer.step()
+        # optimizer.step() is queued by forward_train right before it blocks on the step's log values (same position in stream order as
+        # after it; a batch with labels outside [0, C) therefore raises AFTER its update has been applied -- the run is over either way)
+        self._before_read = optimizer.step
+        try:
+            log_vars, vis_states = self(**data_batch)
+        finally:
+            pending, self._before_read = self._before_read, None
+        if pending is not None:                  # forward_train never reached its read (an exception): nothing was stepped
+            raise RuntimeError('PFGST.train_step: forward_train returned without reading its log values')
         log_vars.pop('loss', None)
         return dict(log_vars=log_vars, num_samples=len(data_batch['img_metas']), states=vis_states)
 
@@ -327,8 +334,15 @@ class PFGST(UDADecorator):
 
         # the optimizer's zero_grad() may have detached .grad views (set_to_none): re-attach + zero the arena
         arena = self._student_arena
-        for name, p in model.named_parameters():
-            if p.grad is None or p.grad.data_ptr() != arena.view(arena.grad, name).data_ptr():
+        # (the expected addresses are cached: building 161 views per step to compare pointers cost ~1 ms of host time at the step boundary,
+        # where the device has nothing queued -- tools/host_profile.py, tools/gap_analysis.py)
+        gp = getattr(self, '_grad_ptrs', None)
+        if gp is None or gp[0] != arena.grad.data_ptr():
+            base = arena.grad.data_ptr()
+            gp = self._grad_ptrs = (base, [(name, p, base + 4 * arena.offsets[name]) for name, p in model.named_parameters()])
+        for name, p, ptr in gp[1]:
+            g = p.grad
+            if g is None or g.data_ptr() != ptr:
                 p.grad = arena.view(arena.grad, name)
         arena.zero_grad()
 
@@ -336,8 +350,14 @@ class PFGST(UDADecorator):
             self._init_ema_weights()
         else:
             self._update_ema(self.local_iter)
-        model.repack_weights(need_dgrad=True)
+        # Step boundary: the previous step ended with a blocking read, so the device idles until this step's first long kernels are
+        # queued.  The teacher's weight images first, then its forward pass (forked: ~35 ms of device work queued in ~10 ms of host
+        # time), and the student's weight images behind that -- their ~1.3 ms of host-side packing then runs while the device is busy.
+        fork = layers.FORK_TEACHER
         ema.repack_weights(need_dgrad=False)
+        late_pack = fork and layers.STEP_BOUNDARY_OVERLAP
+        if not late_pack:
+            model.repack_weights(need_dgrad=True)
 
         # strong-augmentation parameters: same Python-RNG draws as the reference (pfgst.py:212-222)
         jitter_draw = random.uniform(0, 1)
@@ -362,7 +382,6 @@ class PFGST(UDADecorator):
         # ---- teacher on target, optionally forked onto a second stream (layers.FORK_TEACHER): it is independent of the
         # student's source pass, so its HBM-bound kernels can run beside the other pass's MFMA-bound ones.  The host order of
         # RNG draws is unchanged (the teacher draws none: dropout is off)
-        fork = layers.FORK_TEACHER
         if fork:
             main_s = torch.cuda.current_stream()
             side_s = layers.teacher_stream()
@@ -370,6 +389,8 @@ class PFGST(UDADecorator):
             with torch.cuda.stream(side_s):
                 ema_logits, ema_states = ema.encode_decode(target_img.contiguous(), target_img_metas)
             ema_dec = ema_states['decoded_features'] if self.use_decoded_feats else ema_states['feats']
+            if late_pack:
+                model.repack_weights(need_dgrad=True)
 
         # ---- student on source.  Data-parallel runs: this pass is recorded first, so its closures run LAST in the single backward
         # sweep -- its marker closures tell the reducer which tail of the gradient arena is final (dist.GradReducer)
@@ -423,7 +444,7 @@ class PFGST(UDADecorator):
         # ---- class mix
         presence_evt.synchronize()
         classes = self._choose_mix_classes(presence_host.numpy(), batch_size)
-        classes_dev = torch.from_numpy(np.ascontiguousarray(classes)).to(dev, non_blocking=True)
+        classes_dev = ops.h2d_small(torch.from_numpy(np.ascontiguousarray(classes)), dev, 'mix_classes')
         mix_masks = ops.class_mask(gt8, classes_dev)
         if self.apply_no_mix:                          # pfgst.py:283-289: the classes were drawn (same RNG stream), then nothing is pasted
             mix_masks.zero_()
@@ -491,7 +512,21 @@ class PFGST(UDADecorator):
         if step_stats is not None:
             import time
             t_read = time.perf_counter()
-        vals = packed.cpu().tolist()                                      # the step's single blocking read
+        # the step's single blocking read: an asynchronous copy into pinned memory + an event, so that the optimizer step (train_step hands
+        # it over as `_before_read`) can be queued BEHIND the copy and run while the host wakes up, unpacks the values and enters the next step
+        host = getattr(self, '_log_host', None)
+        if host is None or host.numel() < packed.numel():
+            host = self._log_host = torch.empty(max(64, packed.numel()), dtype=torch.float32, pin_memory=True)
+        host[:packed.numel()].copy_(packed, non_blocking=True)
+        read_evt = torch.cuda.Event()
+        read_evt.record()
+        before_read, self._before_read = getattr(self, '_before_read', None), None
+        if before_read is not None and layers.STEP_BOUNDARY_OVERLAP:
+            before_read()
+        read_evt.synchronize()
+        if before_read is not None and not layers.STEP_BOUNDARY_OVERLAP:
+            before_read()
+        vals = host[:packed.numel()].tolist()
         if step_stats is not None:
             step_stats['host_read_s'] = time.perf_counter() - t_read
         log_vars = OrderedDict(zip(names, vals))

@@ -42,6 +42,8 @@ def _worker(rank, world, port, outdir):
 
     def recording_launch(self, lo, hi):                       # this rank's values of a bucket at the moment its marker fires
         if hi > lo:
+            from pfst_amd import layers
+            layers.join_side_stream()                         # as _launch does before it hands the range to the collective
             snaps.append((lo, hi, self.flat[lo:hi].clone()))
         return launch(self, lo, hi)
     pdist.GradReducer._launch = recording_launch

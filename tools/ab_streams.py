@@ -7,7 +7,7 @@ One model, one process; the legs are run in rotating order so that no leg is sys
   single+events   -- one stream with the dominant kernel's launches bracketed by HIP events (what bench.py's timed region does for `value`)
   fork            -- teacher forward forked beside the student's source pass
   wgrad           -- weight gradients on the high-priority side stream
-  fork+wgrad      -- both (the product schedule since round 5)
+  fork+wgrad      -- both (the product schedule since round 5); `+old`: without the step-boundary overlap (layers.STEP_BOUNDARY_OVERLAP)
 Each leg: `--warm` untimed steps after the switch, then `--steps` timed ones.  Prints one line per leg and round, then per-leg medians.
 
   python tools/ab_streams.py --rounds 4 --steps 8 --warm 2"""
@@ -59,6 +59,7 @@ def main():
     def leg(name):
         wg, fk = 'wgrad' in name, 'fork' in name
         layers.set_overlap(wg, fk)
+        layers.STEP_BOUNDARY_OVERLAP = 'old' not in name
         events = name.endswith('+events')
         hip_ops.call = timer.inner
         run(args.warm)
@@ -74,6 +75,7 @@ def main():
         hip_ops.call = timer.inner
         timer.records = []
         layers.set_overlap(False, False)
+        layers.STEP_BOUNDARY_OVERLAP = True
         return 1000.0 * dt / args.steps
 
     names = args.legs.split(',')

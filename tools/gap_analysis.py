@@ -31,6 +31,19 @@ print(f'kernels {len(rows)}  span {span / 1e6:.2f} ms  sum of durations {busy / 
 gaps.sort()
 for q in (0.5, 0.9, 0.99):
     print(f'  gap p{int(q * 100)} {gaps[int(q * (len(gaps) - 1))] / 1e3:.2f} us')
+for lo in (20e3, 100e3, 1e6):
+    big = [g for g in gaps if g >= lo]
+    print(f'  gaps >= {lo / 1e3:.0f} us: {len(big)}  total {sum(big) / 1e6:.3f} ms')
 print('largest idle totals, by the kernel BEFORE the gap:')
 for k, (c, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f'  {k:42s} gaps {c:5d}  total {t / 1e6:7.3f} ms  mean {t / c / 1e3:6.2f} us')
+print('the 25 largest gaps (us): kernel before -> kernel after')
+big = []
+cur_end = rows[0][1]
+for i in range(1, len(rows)):
+    g = rows[i][0] - cur_end
+    if g > 0:
+        big.append((g, rows[i - 1][2].split('(')[0][-44:], rows[i][2].split('(')[0][-44:], (rows[i][0] - rows[0][0]) / 1e6))
+    cur_end = max(cur_end, rows[i][1])
+for g, a, b, t in sorted(big, reverse=True)[:25]:
+    print(f'  {g / 1e3:9.1f}  at {t:8.2f} ms  {a:44s} -> {b}')
