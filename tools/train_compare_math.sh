@@ -24,4 +24,16 @@ for it in sorted(a):
     if it in b and it in c:
         print('%4d  ' % it + '  '.join('%11.4f |%11.4f |%11.4f ' % (a[it].get(k, float('nan')), b[it].get(k, float('nan')), c[it].get(k, float('nan'))) for k in keys))
 PY
+# --deterministic (round 5): the same f16x3 run twice with every floating-point summation order fixed -- the log lines must be identical
+PFST_CONV_MATH=f16x3 python3 tools/train.py $ARGS --deterministic --work-dir /tmp/w_d1 > /tmp/train_d1.log 2>&1
+PFST_CONV_MATH=f16x3 python3 tools/train.py $ARGS --deterministic --work-dir /tmp/w_d2 > /tmp/train_d2.log 2>&1
+python3 - <<PY >> gpurun_out/${R}_train_compare_math.txt
+import re
+def rows(p):
+    return [re.sub(r'^.*?(Iter \\[)', r'\\1', re.sub(r'(time|data_time|memory|eta): [^,]*,? ?', '', l)).strip() for l in open(p) if re.match(r'.*Iter \\[\\d+/', l)]
+a, b = rows('/tmp/train_d1.log'), rows('/tmp/train_d2.log')
+print()
+print('--deterministic, two runs of the f16x3 training: %d log lines each, %s' % (len(a), 'IDENTICAL in every logged value' if a == b and a else 'DIFFERENT'))
+print('last line: ' + (a[-1] if a else '-'))
+PY
 cat gpurun_out/${R}_train_compare_math.txt
