@@ -118,8 +118,9 @@ int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int 
  * through the transform's norm bound, and v_amax receives that bound (pass v_packed = 1 / packed = 1 to the consumers) */
 int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                     float* stats, int m, pfst_stream_t stream);
-/* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2] */
+                     float* stats, int stats_minmax, int m, pfst_stream_t stream);
+/* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2]; stats_minmax != 0: `stats` has room
+ * for twice that and also receives the per-channel (minimum, maximum) partials behind the sums (as pfst_conv_igemm_f16x3's stats_minmax) */
 int pfst_wino_stats_slots(int H, int W, int dil, int m);
 int pfst_wino_dy(const float* dy, long long dy_bs, float* dM, int N, int Cout, int H, int W, int dil, int m, float* dm_amax,
                  const float* pack_dy_amax, pfst_stream_t stream);
@@ -167,7 +168,11 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
                           const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
                           const float* gate_dy, long long gate_dy_bs, const unsigned long long* gate_mask, int stats_minmax,
-                          pfst_stream_t stream);
+                          const float* bnl, pfst_stream_t stream);
+/* bnl != NULL (forward 1x1 launches, M % 256 == 0, C <= 512): `in` is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this
+ * convolution (Bottleneck conv2 -> bn2 -> relu -> conv3, resnet.py:282-290) and bnl its coef [C][4] = (mean, invstd, sc, sh): elements are
+ * normalised between their load and their split, the normalised tensor is never written; in_amax = the slot group
+ * pfst_bn_finalize_partials published the predicted max |relu(bn(in))| to */
 /* stats_minmax != 0 (with stats): stats has room for 4 * M * slots floats; behind the [M][slots][2] (sum, sum of squares) partials the
  * launch writes [M][slots][2] (minimum, maximum) partials of the output, from which pfst_bn_finalize_partials predicts max |relu(bn(out))| */
 /* gate_dy != NULL (mode 1, accumulate 0, M % 128 == 0, Ho * Wo % 256 == 0): out = data gradient + (bit ? gate_dy : 0), gate_mask = the ReLU
@@ -185,7 +190,8 @@ int pfst_f16x3_split_probe(const float* x, long long n, const float* amax, unsig
 int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float* u_amax, const float* v_amax, float* Mbuf, int N, int K,
                          int M, int T, int m, int v_packed, pfst_stream_t stream);
 int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
-                          int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream);
+                          int HW, const float* x_amax, const float* dy_amax, const float* bnl, pfst_stream_t stream);
+/* bnl != NULL: x is the PRE-normalisation tensor the forward launch read with its own bnl (pfst_conv_igemm_f16x3): rows normalised on load */
 /* the same for the layers that kernel does not take -- stride-1 'same' 3x3 (pad == dil <= 8, W % 16 == 0) and 1x1 with <= 64 output channels
  * (the stems, layer1: resnet.py:593-624,169-209) -- on the K-quad kernel with both operands split as they are staged (csrc/conv_wgrad_q.hip) */
 int pfst_conv_wgrad_f16x3_q(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int H, int W,

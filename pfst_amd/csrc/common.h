@@ -153,7 +153,7 @@ int pfst_wgrad_split_q_launch(const float* x, i64 x_bs, const float* dy, i64 dy_
                               i64 x_gs, i64 dy_gs, i64 dw_gs, hipStream_t s);
 // internal: f16x3 weight gradient of 1x1 / grouped transform-domain products (P % 4 == 0, Cout > 64), conv_f16x3.hip
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
-                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s);
+                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s, const float* bnl = nullptr);
 // internal: K-quad implicit-GEMM convolution (Cin % 16 == 0), conv_igemm_q.hip
 struct pfst_bnb_fuse;
 typedef struct pfst_bnb_fuse PfstBnbArgs;   // include/pfst_hip.h: fused BatchNorm-backward sums of a data-gradient launch (null = off)

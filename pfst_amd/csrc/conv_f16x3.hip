@@ -241,13 +241,18 @@ struct PfstResGate {                       // value-initialised = off
   const unsigned long long* mask = nullptr;    // bn_apply's ReLU bitmask of an [N][M][P] tensor (dense)
 };
 
-template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false, int BMT = 128>
+// BNL (256-row pixel-to-pixel tile, plain operand): `in` is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this 1x1
+// convolution (Bottleneck conv2 -> bn2 -> relu -> conv3); every activation element is normalised -- max(fma(x, sc, sh), 0) with the (sc, sh)
+// of its channel from bnl[C] = (mean, invstd, sc, sh) -- between its load and its split, the normalised tensor is never written; in_amax
+// then holds the PREDICTED max of the normalised tensor (pfst_bn_finalize_partials).  The coefficients sit in LDS (C <= 512).
+template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false, int BMT = 128, bool BNL = false>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
     float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
     int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
     const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const PfstBnbArgs& bnb,
-    const PfstResGate& gate) {
+    const PfstResGate& gate, const float4* __restrict__ bnl = nullptr) {
+  static_assert(!BNL || (BMT == 256 && ONE && !BPACK && BNB == 0), "normalise-on-load exists for the 256-row 1x1 forward tile");
   static_assert(SHAPE == 32, "one MFMA shape: v_mfma_f32_32x32x16_f16 (the 16x16x32 form of round 3 was removed in round 5)");
   static_assert(BMT == 128 || (BMT == 256 && SHAPE == 32 && ONE) || (BMT == 64 && SHAPE == 32 && BNB == 0 && !BPACK),
                 "the 256-row tile exists for the pixel-to-pixel 32x32 loop, the 64-row tile for the plain 32x32 loop");
@@ -270,6 +275,15 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wid / WAVES_N) * (32 * TMW), wn0 = (wid % WAVES_N) * 64;
   const int P = Ho * Wo, HiWi = Hi * Wi;
+  constexpr int BNL_ROWS = 512 + 32;                     // C <= 512 (host) + the zero rows a last half block reads
+  __shared__ uint4 bnl_s[BNL ? BNL_ROWS / 2 : 1];        // [(sc, sh) of two channels]
+  if constexpr (BNL) {
+    for (int i = tid; i < BNL_ROWS; i += NT) {
+      const float4 cf = i < C ? bnl[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float2*>(bnl_s)[i] = make_float2(cf.z, cf.w);
+    }
+    __syncthreads();
+  }
   const int gx = (P + BN - 1) / BN, gy = (M + BM - 1) / BM, X = gx * gy;
   const int total = X * Y * Z, G = gridDim.x;
   // tile number -> (pixel tile, row tile, filter set y, image z): the tiles of one GEMM fastest, then the IMAGES of one filter set, then
@@ -364,8 +378,10 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   // pairs are numbered (tap, channel block); the address of pair k+2 advances by one channel block per step, the pixel offset is
   // recomputed only when the tap changes (never for a 1x1 convolution): no integer divisions in the loop
   int tap2 = 0, sidx2 = 0;                               // (tap, channel block) of the pair whose activations are loaded next
+  int sidx1 = 0;                                         // channel block of the pair loaded last (BNL: the one a step normalises and splits)
   unsigned voff2 = OOB;
   auto advance = [&]() {
+    sidx1 = sidx2;
     if (++sidx2 == spt) {
       sidx2 = 0;
       ++tap2;
@@ -400,6 +416,11 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
 #pragma unroll
     for (int t = 0; t < TPT; ++t) {
       uint4 ph, pl;
+      if constexpr (BNL) {                               // pair 0: channel block 0
+        const float2* cf = reinterpret_cast<const float2*>(bnl_s) + (t + bt) * 16 + kh * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) breg[0][t][i] = fmaxf(__fmaf_rn(breg[0][t][i], cf[i].x, cf[i].y), 0.f);
+      }
       if constexpr (BPACK) unpack8_f16(breg[0][t], ph, pl);
       else split8_f16(breg[0][t], sb, ph, pl);
       Bs[(t + bt) * TILE_B + (0 * 2 + kh) * BN + pix] = ph;
@@ -447,6 +468,8 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
     static_for<PRE>([&](auto rc) { read_frag(rc); });              // block per wave a group of three reads lasts only two MFMAs)
     __builtin_amdgcn_sched_barrier(0);
     SplitF16 s0, s1;
+    uint4 cfr[BNL ? 4 : 1];                                          // BNL: (sc, sh) of the 8 channels this thread stages for pair k+1
+    const int cf_at = BNL ? sidx1 * 16 + bt * 8 + kh * 4 : 0;        // in two-channel uint4 rows
     // the staging work of one of the 24 issue slots (TMW = 2: one slot per MFMA; TMW = 1: two per MFMA): 0-7 two activation loads each,
     // 8-11 the weight stores of pair k+1 (to the OTHER LDS buffer: no barrier inside the step), 12-23 four split instructions each, 12-15 the
     // weight loads of pair k+2, 18 / 23 the activation stores
@@ -461,6 +484,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
         }
       }
       if constexpr (m >= 8 && m < 8 + NA) As[NXT + ((m - 8) / (NA / 2)) * TILE_A + tid + NT * ((m - 8) % (NA / 2))] = areg[SETN][m - 8];
+      if constexpr (BNL && m >= 8 && m < 12) cfr[m - 8] = bnl_s[cf_at + (m - 8)];          // one 16-byte LDS read per slot (a wave-uniform address)
       if constexpr (m >= 12) {
         constexpr int SPS = 2 * TPT;                                // split instructions per slot: 48 (24: one tile) over slots 12-23
         static_for<SPS>([&](auto kc) {
@@ -469,6 +493,12 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
             if constexpr (kk < 8) unpack_op_f16<kk>(breg[SETN][0], s0);
             else if constexpr (kk < 16 && TPT == 2) unpack_op_f16<kk - 8>(breg[SETN][TPT - 1], s1);
           } else {
+            if constexpr (BNL && kk < 24 && kk % 6 < 2) {            // the two empty slots of a pair's six: normalise the pair's two elements
+              constexpr int e = 2 * (kk / 6) + kk % 6;
+              const uint4 c2 = cfr[e >> 1];
+              const float sc = __builtin_bit_cast(float, (e & 1) ? c2.z : c2.x), sh = __builtin_bit_cast(float, (e & 1) ? c2.w : c2.y);
+              breg[SETN][0][e] = fmaxf(__fmaf_rn(breg[SETN][0][e], sc, sh), 0.f);
+            }
             if constexpr (kk < 24) split_op_f16<kk>(breg[SETN][0], sb, s0);
             else split_op_f16<kk - 24>(breg[SETN][TPT - 1], sb, s1);
           }
@@ -574,6 +604,14 @@ __global__ __launch_bounds__(BMT == 64 ? 256 : 2 * BMT, BMT == 256 ? 1 : 2) void
   conv_igemm_f16x3_body<SHAPE, 0, BPACK, ONE, BMT>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats, stats_T,
                                w_amax, in_amax, Y, Z, chain, PfstBnbArgs(), gate);
 }
+__global__ __launch_bounds__(512, 1) void conv_igemm_f16x3_bnl_kernel(
+    const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
+    float* __restrict__ out, i64 out_bs, int C, int Hi, int Wi, int M, int Ho, int Wo, int ks,
+    int ca, int cb, int cc, int cdivv, int accumulate, float* __restrict__ stats, int stats_T,
+    const float* __restrict__ w_amax, const float* __restrict__ in_amax, int Y, int Z, int chain, const float4* __restrict__ bnl) {
+  conv_igemm_f16x3_body<32, 0, false, true, 256, true>(in, in_bs, wk4, bias, out, out_bs, C, Hi, Wi, M, Ho, Wo, ks, ca, cb, cc, cdivv, accumulate, stats,
+                                                       stats_T, w_amax, in_amax, Y, Z, chain, PfstBnbArgs(), PfstResGate(), bnl);
+}
 template <int BNB, bool ONE = false, int BMT = 128>
 __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_igemm_f16x3_bnb_kernel(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
@@ -645,11 +683,15 @@ __device__ __forceinline__ void unpack4_op_f16(const float (&v)[4], Split4& st) 
   else asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(st.l[q]) : "v"(v[2 * q + 1]), "v"(v[2 * q]), "s"(0x07060302u));
 }
 
-template <bool PACK, int BMT = 128>
+// BNL: x is the PRE-normalisation output of the conv -> BN -> ReLU layer whose (never written) result this 1x1 convolution read in forward
+// (conv_igemm_f16x3_body BNL): the rows of X are normalised -- max(fma(x, sc, sh), 0), (sc, sh) of row j from bnl[J] = (mean, invstd, sc, sh) --
+// between their load and their split; a thread's rows are fixed for the whole launch, so their coefficients sit in registers.
+template <bool PACK, int BMT = 128, bool BNL = false>
 __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_line_kernel(
     const float* __restrict__ x, i64 x_bs, const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dw,
     int J, int M, int P, int chunks, int chunk_len, int N, i64 x_gs, i64 dy_gs, i64 dw_gs, int gx, int gy, int gz,
-    const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
+    const float* __restrict__ x_amax, const float* __restrict__ dy_amax, const float4* __restrict__ bnl) {
+  static_assert(!BNL || !PACK, "a pre-split operand is already normalised");
   constexpr int BM = BMT, BJ = 128, WM = 64, WAVES_N = 2, WN = 64, TM = 2, TN = 2, NT = 2 * BM;
   constexpr int RPP = NT / 8;                               // rows per load pass
   constexpr int PA = BM / RPP, PB = BJ / RPP;               // passes (= loads per thread and pair) over the dY / X rows: 4 + 4, or 4 + 2
@@ -702,6 +744,20 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
   const int b_half = 2 * ((seg >> 2) * TILE_B + ((seg >> 1) & 1) * ROWS_B + rslot) + (seg & 1);
 
   float la[2][PA][4], lb[2][PB][4];                 // [register set][pass][4 pixels]
+  float bsc[BNL ? PB : 1], bsh[BNL ? PB : 1];       // BNL: (sc, sh) of this thread's X rows (rows past J: zeros, like their data)
+  if constexpr (BNL) {
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int j = j0 + rslot + p * RPP;
+      const float4 cf = j < J ? bnl[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      bsc[p] = cf.z;
+      bsh[p] = cf.w;
+    }
+  }
+  auto normalise = [&](float (&v)[4], int p) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(__fmaf_rn(v[e], bsc[p], bsh[p]), 0.f);
+  };
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -740,6 +796,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
   static_for<PA + PB>([&](auto qc) {
     constexpr int q = decltype(qc)::value, opb = q >= PA, pass = opb ? q - PA : q;
     Split4 st;
+    if constexpr (BNL && opb) normalise(lb[0][pass], pass);
     static_for<PACK ? 4 : 12>([&](auto kc) {
       if constexpr (PACK) unpack4_op_f16<decltype(kc)::value>(opb ? lb[0][pass] : la[0][pass], st);
       else split4_op_f16<decltype(kc)::value>(opb ? lb[0][pass] : la[0][pass], opb ? sb : sa, st);
@@ -778,6 +835,7 @@ __global__ __launch_bounds__(2 * BMT, BMT == 128 ? 2 : 1) void conv_wgrad_f16x3_
       constexpr int q = m / 3, part = m % 3;                          // half chunk q = 0 .. 7 in slots 3 q .. 3 q + 2
       if constexpr (q < PA + PB) {
         constexpr int opb = q >= PA, pass = opb ? q - PA : q;
+        if constexpr (BNL && opb && part == 0) normalise(lb[NXT][pass], pass);       // in front of the half chunk's first split instructions
         static_for<4>([&](auto kc) {
           constexpr int k = part * 4 + decltype(kc)::value;
           if constexpr (PACK) {
@@ -958,8 +1016,11 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
                                      const float* bias, float* out, long long out_bs, int N, int C, int Hi, int Wi, int M, int Ho, int Wo,
                                      int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats,
                                      const pfst_bnb_fuse_t* bnb, const float* gate_dy, long long gate_dy_bs,
-                                     const unsigned long long* gate_mask, int stats_minmax, pfst_stream_t stream) {
+                                     const unsigned long long* gate_mask, int stats_minmax, const float* bnl, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
+  // bnl: the input is normalised as it is loaded (1x1 forward launches on the 256-row tile; C <= 512 coefficient rows in LDS)
+  PFST_CHECK_ARG(!bnl || (mode == 0 && ksize == 1 && stride == 1 && pad == 0 && M % 256 == 0 && C <= 512 && !bias && !gate_dy && !(bnb && bnb->x) &&
+                          !accumulate));
   // stats_minmax: `stats` has room for 4 * M * slots floats and also receives the per-channel (minimum, maximum) partials behind the sums
   PFST_CHECK_ARG(!stats_minmax || (stats && !bias && !(bnb && bnb->x)));
   PfstResGate gate;
@@ -1028,7 +1089,10 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
     PFST_CHECK_LAUNCH();
     return PFST_OK;
   }
-  if (small)
+  if (bnl)
+    hipLaunchKernelGGL(conv_igemm_f16x3_bnl_kernel, grid, dim3(512), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out, (i64)out_bs, C, Hi, Wi,
+                       M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, reinterpret_cast<const float4*>(bnl));
+  else if (small)
     hipLaunchKernelGGL((conv_igemm_f16x3_kernel<32, false, false, 64>), grid, dim3(256), 0, (hipStream_t)stream, in, (i64)in_bs, (const uint4*)wk4, bias, out,
                        (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, gate);
   else if (big)
@@ -1076,7 +1140,9 @@ extern "C" int pfst_wino_gemm_f16x3(const float* V, const void* U4, const float*
 
 // internal: dW[grp][M][J] += sum over images and pixels; x [grp][N][J][P], dy [grp][N][M][P]; needs P % 4 == 0, M > 64
 int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs, float* dw, int N, int J, int M, int P, int groups,
-                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s) {
+                            i64 x_gs, i64 dy_gs, i64 dw_gs, const float* x_amax, const float* dy_amax, int packed, hipStream_t s, const float* bnl) {
+  PFST_CHECK_ARG(!bnl || (!packed && groups == 1));             // bnl: the rows of x are normalised as they are loaded (coef [J][4])
+  const float4* const bnl4 = reinterpret_cast<const float4*>(bnl);
   const bool big = M % 256 == 0;                                // 256 rows of dY per workgroup (512 threads, one workgroup per CU)
   const int bm = big ? 256 : 128;
   const int tiles = cdiv(J, 128) * cdiv(M, bm) * groups;
@@ -1102,8 +1168,10 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
   const i64 gsk = ws ? -elems : dw_gs;
 #define PFST_LAUNCH_WGRAD(KERNEL_, THREADS_)                                                                                               \
   hipLaunchKernelGGL(KERNEL_, dim3(gx * gy * gz), dim3(THREADS_), 0, s, x, x_bs, dy, dy_bs, dwk, J, M, P, chunks, chunk_len, N, x_gs, dy_gs, gsk, \
-                     gx, gy, gz, x_amax, dy_amax)
-  if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
+                     gx, gy, gz, x_amax, dy_amax, bnl4)
+  if (bnl && big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256, true>), 512);
+  else if (bnl) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 128, true>), 256);
+  else if (big && packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true, 256>), 512);
   else if (big) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false, 256>), 512);
   else if (packed) PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<true>), 256);
   else PFST_LAUNCH_WGRAD((conv_wgrad_f16x3_line_kernel<false>), 256);
@@ -1115,7 +1183,7 @@ int pfst_wgrad_f16x3_launch(const float* x, i64 x_bs, const float* dy, i64 dy_bs
 
 // dw[co][ci] += sum_{n,p} dy[n][co][p] x[n][ci][p]: the weight gradient of a stride-1 1x1 convolution (atomic fp32 adds)
 extern "C" int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float* dy, long long dy_bs, float* dw, int N, int Cin, int Cout,
-                                     int HW, const float* x_amax, const float* dy_amax, pfst_stream_t stream) {
+                                     int HW, const float* x_amax, const float* dy_amax, const float* bnl, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && dy && dw && x_amax && dy_amax && N > 0 && Cin > 0 && Cout > 0 && HW > 0);
   PFST_CHECK_ARG(x_bs >= (i64)Cin * HW && dy_bs >= (i64)Cout * HW && (x_bs & 3) == 0 && (dy_bs & 3) == 0);
   PFST_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && (i64)Cin * HW * 4 < (1ll << 31) && (i64)Cout * HW * 4 < (1ll << 31));
@@ -1123,5 +1191,5 @@ extern "C" int pfst_conv_wgrad_f16x3(const float* x, long long x_bs, const float
     pfst_set_error(__FILE__, __LINE__, "f16x3 weight gradient needs HW % 4 == 0 and more than 64 output channels (use pfst_conv_wgrad_split)");
     return PFST_ERR_UNSUPPORTED;
   }
-  return pfst_wgrad_f16x3_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, HW, 1, 0, 0, 0, x_amax, dy_amax, 0, (hipStream_t)stream);
+  return pfst_wgrad_f16x3_launch(x, x_bs, dy, dy_bs, dw, N, Cin, Cout, HW, 1, 0, 0, 0, x_amax, dy_amax, 0, (hipStream_t)stream, bnl);
 }

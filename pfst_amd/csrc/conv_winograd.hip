@@ -242,11 +242,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M outputs of a tile row are adjacent -> one wide store
 template <int M>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, i64 y_bs, int N, int Cout,
-                                                          WinoGeom g, int accumulate, int vec, float* __restrict__ stats) {
+                                                          WinoGeom g, int accumulate, int vec, float* __restrict__ stats, int stats_minmax) {
   constexpr int R = M + 2;
   typedef float vecM __attribute__((ext_vector_type(M)));
   __shared__ double red[32];
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of the outputs this block writes (stats != NULL)
+  float st_lo = __builtin_inff(), st_hi = -__builtin_inff();      // stats_minmax: and their (minimum, maximum), for the predicted max |relu(bn(y))|
   const int c = blockIdx.y, n = blockIdx.z;
   float* yp = y + (i64)n * y_bs + (i64)c * g.H * g.W;
   const i64 plane = (i64)N * Cout * g.T;
@@ -292,6 +293,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
           const float e = v[j];
           st_s += e;
           st_q = fmaf(e, e, st_q);
+          st_lo = fminf(st_lo, e);
+          st_hi = fmaxf(st_hi, e);
         }
         continue;
       }
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
           *q = v;
           st_s += v;
           st_q = fmaf(v, v, st_q);
+          st_lo = fminf(st_lo, v);
+          st_hi = fmaxf(st_hi, v);
         }
       }
     }
@@ -315,6 +320,24 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
       const i64 T = (i64)gridDim.x * gridDim.z;
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);
       *dst = make_float2((float)bs, (float)bq);
+    }
+    if (stats_minmax) {                              // [Cout][T][2] behind the sums, as the GEMM epilogue's stats_mm (conv_epilogue.h)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        st_lo = fminf(st_lo, __shfl_xor(st_lo, o));
+        st_hi = fmaxf(st_hi, __shfl_xor(st_hi, o));
+      }
+      float* mm = reinterpret_cast<float*>(red);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) { mm[threadIdx.x >> 6] = st_lo; mm[8 + (threadIdx.x >> 6)] = st_hi; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) { st_lo = fminf(st_lo, mm[i]); st_hi = fmaxf(st_hi, mm[8 + i]); }
+        const i64 T = (i64)gridDim.x * gridDim.z;
+        float2* dst = reinterpret_cast<float2*>(stats) + ((i64)Cout * T + (i64)c * T + (i64)n * gridDim.x + blockIdx.x);
+        *dst = make_float2(st_lo, st_hi);
+      }
     }
   }
 }
@@ -559,14 +582,15 @@ extern "C" int pfst_wino_stats_slots(int H, int W, int dil, int m) {
 }
 
 extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                                float* stats, int m, pfst_stream_t stream) {
+                                float* stats, int stats_minmax, int m, pfst_stream_t stream) {
   PFST_CHECK_ARG(Mbuf && y && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && y_bs >= (i64)Cout * H * W);
+  PFST_CHECK_ARG(!stats_minmax || stats);
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const int vec = dil == 1 && W % m == 0 && y_bs % m == 0 && ((uintptr_t)y & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), Cout, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats),
-              hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax),
+              hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

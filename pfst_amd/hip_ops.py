@@ -347,10 +347,19 @@ class WeightJobTable:
         call(name, ctypes.addressof(self.host), self.dev.data_ptr(), self.n, _stream())
 
 
-def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False, want_minmax=False):
+def conv_fprop_bnl_ok(cin, cout, ksize, stride=1, pad=0):
+    """can conv_fprop_f16x3 normalise its input as it loads (bnl=...): the 256-row pixel-to-pixel tile, coefficient rows in LDS"""
+    return ksize == 1 and stride == 1 and pad == 0 and cout % 256 == 0 and cin <= 512 and f16x3_eligible(cin, cout, 1)
+
+
+def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False, want_minmax=False,
+                     bnl=None):
     """want_minmax (with want_stats): the statistics scratch also receives the per-channel (minimum, maximum) partials of the output behind
-    the sums -- bn_finalize_partials(predict_amax=...) turns them into max |relu(bn(out))|"""
+    the sums -- bn_finalize_partials(predict_amax=...) turns them into max |relu(bn(out))|.
+    bnl: coef [C, 4] of the conv -> BN -> ReLU layer feeding this one: x is that layer's PRE-normalisation output, normalised between load and
+    split (x_amax = the predicted max of the normalised tensor)"""
     n, c, hi, wi = x.shape
+    assert bnl is None or (tuple(bnl.shape) == (c, 4) and bias is None and conv_fprop_bnl_ok(c, cout, ksize, stride, pad))
     ho, wo = conv_out_size(hi, ksize, stride, dil, pad), conv_out_size(wi, ksize, stride, dil, pad)
     assert wk4.numel() == 4 * ksize * ksize * c * cout and f16x3_eligible(c, cout, ksize)
     if out is None:
@@ -359,17 +368,19 @@ def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0
     want_minmax = bool(want_minmax and want_stats and bias is None)
     st = _stats_ws(x.device, (4 if want_minmax else 2) * cout * slots) if want_stats else None
     call('pfst_conv_igemm_f16x3', x.data_ptr(), _bs(x), wk4.data_ptr(), w_amax.data_ptr(), x_amax.data_ptr(), _p(bias), out.data_ptr(), _bs(out),
-         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, int(want_minmax), _stream())
+         n, c, hi, wi, cout, ho, wo, ksize, stride, dil, pad, 0, 0, _p(st), 0, 0, 0, 0, int(want_minmax), _p(None if bnl is None else _dense(bnl)),
+         _stream())
     return (out, st, slots) if want_stats else out
 
 
-def conv_wgrad_f16x3_(dw, x, dy, x_amax, dy_amax):
-    """dw += dL/dw of a stride-1 1x1 convolution with the f16x3 split (fp32 atomics)"""
+def conv_wgrad_f16x3_(dw, x, dy, x_amax, dy_amax, bnl=None):
+    """dw += dL/dw of a stride-1 1x1 convolution with the f16x3 split (fp32 atomics); bnl: as conv_fprop_f16x3 (x is the pre-normalisation
+    tensor, x_amax the predicted maximum of the normalised one)"""
     n, ci, h, w = x.shape
     co = dy.shape[1]
-    assert dy.shape == (n, co, h, w) and dw.numel() == co * ci
+    assert dy.shape == (n, co, h, w) and dw.numel() == co * ci and (bnl is None or tuple(bnl.shape) == (ci, 4))
     call('pfst_conv_wgrad_f16x3', x.data_ptr(), _bs(x), dy.data_ptr(), _bs(dy), _dense(dw).data_ptr(), n, ci, co, h * w,
-         x_amax.data_ptr(), dy_amax.data_ptr(), _stream())
+         x_amax.data_ptr(), dy_amax.data_ptr(), _p(None if bnl is None else _dense(bnl)), _stream())
     return dw
 
 
@@ -399,7 +410,7 @@ def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, di
         st, part, slots = _bnb_struct(bnb, n, cin, hi, wi, co, dy.device)
         fuse = ctypes.addressof(st)
     call('pfst_conv_igemm_f16x3', dy.data_ptr(), _bs(dy), wk4_d.data_ptr(), w_amax.data_ptr(), dy_amax.data_ptr(), 0, out.data_ptr(), _bs(out),
-         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, g_ptr, g_bs, m_ptr, 0, _stream())
+         n, co, ho, wo, cin, hi, wi, ksize, stride, dil, pad, 1, int(accumulate), 0, fuse, g_ptr, g_bs, m_ptr, 0, 0, _stream())
     return (out, part, slots) if bnb is not None else out
 
 
@@ -556,7 +567,8 @@ def wino_pack_weight_f16(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=
     return uf, ud, af, ad
 
 
-def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None, bnl=None):
+def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None, bnl=None,
+              want_minmax=False):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
     (288 GB of HBM: keeping it resident beats re-transforming the input in backward).
@@ -588,8 +600,9 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     slots, st = 0, None
     if want_stats:                      # BN partial sums of the output come out of the output transform
         slots = n * lib().pfst_wino_stats_slots(h, w, dil, m)
-        st = _stats_ws(x.device, 2 * cout * slots)
-    call('pfst_wino_output', mb.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st), m, _stream())
+        st = _stats_ws(x.device, (4 if want_minmax else 2) * cout * slots)
+    call('pfst_wino_output', mb.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st),
+         int(bool(want_minmax and want_stats)), m, _stream())
     res = (out, st, slots) if want_stats else (out,)
     if keep_v:
         res = res + ((v, v_amax),)          # the transformed input and the slot group with its absolute maximum (None unless f16x3)

@@ -156,21 +156,29 @@ class Conv2dP(nn.Module):
             keep_v = keep and self.wino_wgrad_ok(xd.shape[2], xd.shape[3])
             assert bnl is None or keep_v or not keep, 'a normalise-on-load input must leave its transform behind for the weight gradient'
             res = ops.wino_conv(xd, self.uf, self.cout, self.dilation, out=out, keep_v=keep_v, want_stats=want_stats,
-                                u_amax=self.uf_amax if self.wino_f16 else None, x_amax=x_amax if self.wino_f16 else None, bnl=bnl)
+                                u_amax=self.uf_amax if self.wino_f16 else None, x_amax=x_amax if self.wino_f16 else None, bnl=bnl,
+                                want_minmax=want_minmax)
             if keep_v:
                 self.saved_v = res[-1]
                 res = res[:-1] if len(res) > 2 else res[0]
             return res                                     # (y, stats, slots) with want_stats, else y
-        assert bnl is None, 'only the Winograd input transform (and the depthwise / max-pool kernels) normalise on load'
+        assert bnl is None or (self.fprop_bnl_ok() and bias is None and x_amax is not None), \
+            'only the Winograd input transform, the 256-row 1x1 f16x3 GEMM (and the depthwise / max-pool kernels) normalise on load'
         if self.f16_f:
             return ops.conv_fprop_f16x3(xd, self.w4f, self.w_amax, x_amax if x_amax is not None else ops.absmax(xd), self.cout, self.k,
                                         self.stride, self.dilation, self.padding, bias=bias, out=out, want_stats=want_stats,
-                                        want_minmax=want_minmax)
+                                        want_minmax=want_minmax, bnl=bnl)
         if self.split_f:
             return ops.conv_fprop_split(xd, self.w6f, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                                         want_stats=want_stats)
         return ops.conv_fprop(xd, self.wf, self.cout, self.k, self.stride, self.dilation, self.padding, bias=bias, out=out,
                               want_stats=want_stats)
+
+    def fprop_bnl_ok(self):
+        """the forward GEMM can normalise its input as it loads it (ops.conv_fprop_f16x3(bnl=...)) and the weight gradient likewise
+        (ops.conv_wgrad_f16x3_(bnl=...)): a 1x1 f16x3 layer on the 256-row tile -- every Bottleneck conv3"""
+        return (CONV_MATH == 'f16x3' and self.f16_f and not self.wino and not self.depthwise and self.bias is None and self.cout > 64
+                and ops.conv_fprop_bnl_ok(self.cin, self.cout, self.k, self.stride, self.padding))
 
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
@@ -416,6 +424,12 @@ FOLD_BN_WINO = True
 # buffer's coefficient table; the bottleneck's input transform normalises per channel as it loads (identity rows for the image-pool slice).
 # False: every slice is written normalised (per-link test)
 FOLD_BN_CONCAT = True
+# Bottleneck conv2 -> bn2 -> ReLU -> conv3 (1x1): conv3's f16x3 GEMM normalises conv2's PRE-normalisation output between load and split
+# (coefficient rows in LDS), its weight gradient the same rows (coefficients in registers), BatchNorm backward of bn2 reads the pre-BN tensor:
+# y2 is never written.  The predicted max |y2| comes from the (min, max) partials of conv2's producer -- the Winograd output transform or, in
+# layer1, the direct GEMM's epilogue.  False: bn_apply writes y2 (per-link test).  Same-box A/B while the switch read the environment:
+# profiles/r05_ab_fold_bn_gemm.txt (-1.05 ms per step: bn_apply -2.2, the normalising GEMMs and weight gradients +1.2)
+FOLD_BN_GEMM = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written)
 
@@ -571,7 +585,7 @@ def join_side_stream():
             main.wait_stream(side)
 
 
-def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
+def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None, x_bnl=None):
     """weight gradient of a dense convolution into conv.weight.grad (fp32 atomics): Winograd-domain, 1x1 / 3x3 K-quad or generic
     kernel; in the split modes the 1x1 and Winograd-domain products use the fp32-faithful split on the bf16 / fp16 matrix cores.
     saved_v: (transformed input, its amax slot group) kept from the forward pass; x_amax / dy_amax: slot groups when the caller has
@@ -587,8 +601,13 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None):
         ops.wino_wgrad_(conv.weight.grad, xd, dy, conv.dilation, v=v, split=2 if f16w else split, v_amax=v_amax if f16w else None,
                         x_amax=x_amax if f16w else None, dy_amax=dy_amax if f16w else None)
     elif f16 and conv.k == 1 and conv.stride == 1 and (xd.shape[2] * xd.shape[3]) % 4 == 0:
+        # x_bnl: xd is the pre-normalisation tensor the forward GEMM normalised as it loaded it (conv_bn_act(defer='amax') -> conv3)
+        assert x_bnl is None or x_amax is not None
         ops.conv_wgrad_f16x3_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
-                              dy_amax if dy_amax is not None else ops.absmax(dy))
+                              dy_amax if dy_amax is not None else ops.absmax(dy), bnl=x_bnl)
+        return
+    elif x_bnl is not None:
+        raise RuntimeError('a normalise-on-load input reached a weight-gradient kernel that reads the tensor as stored')
     elif conv.wgrad_f16q_ok(xd.shape[2], xd.shape[3]) and ops.wgrad_q_operands_ok(xd, dy):
         ops.conv_wgrad_f16q_(conv.weight.grad, xd, dy, x_amax if x_amax is not None else ops.absmax(xd),
                              dy_amax if dy_amax is not None else ops.absmax(dy), conv.k, conv.dilation)
@@ -622,8 +641,10 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
     if (f16w or f16q or wino16) and dy_amax is None:
         dy_amax = ops.absmax(dy)
     if WGRAD_STREAM and not conv.depthwise:
+        wg_bnl = x_bnl if not (conv.depthwise or conv.wino) else None       # (the Winograd layers' weight gradient reads the kept transform)
+
         def wg():
-            _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
+            _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax, wg_bnl)
         _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0])
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
@@ -638,7 +659,7 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
             assert x_bnl is None and dw_bnb is None          # (a depthwise layer on the network input: weight gradient only)
             ops.dwconv_wgrad_(conv.weight.grad, xd, dy, conv.dilation)
     else:
-        _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax)
+        _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax, x_bnl if not conv.wino else None)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
@@ -670,8 +691,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     # max |y| of the tensor that is never written: under f16x3 the producing GEMM emits (min, max) partials and the finalize kernel predicts it
     xd = x.data if x.lazy is None else x.lazy[0]
     x_bnl = None if x.lazy is None else x.lazy[1]
-    assert x_bnl is None or conv.depthwise or (conv.wino and conv.bias is None), \
-        'only a depthwise layer, the Winograd input transform (or the max-pool) reads a deferred normalisation'
+    assert x_bnl is None or conv.depthwise or (conv.wino and conv.bias is None) or conv.fprop_bnl_ok(), \
+        'only a depthwise layer, the Winograd input transform, a 256-row 1x1 f16x3 GEMM (or the max-pool) reads a deferred normalisation'
     # defer='slice': `out` is a slice of a concat Var with a coefficient table (Var.coef_table): the PRE-normalisation output goes into the slice,
     # this layer's rows into the table, the predicted maximum into the concat's shared slot group
     into_slice = slice_requested = defer == 'slice'
@@ -688,7 +709,9 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     # kernel, whose sums of exact fp64 squares are exact for fp32 inputs.
     tiny = xd.shape[0] * xd.shape[2] * xd.shape[3] <= 64
     fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
-    if need_pred and not (defer and fused_stats and conv.f16_f and not conv.wino and conv.bias is None):
+    # producers of (min, max) partials: the f16x3 GEMM epilogue and (not into a concat slice) the Winograd output transform
+    mm_producer = conv.bias is None and ((conv.f16_f and not conv.wino) or (conv.wino and not into_slice))
+    if need_pred and not (defer and fused_stats and mm_producer):
         defer = need_pred = into_slice = False           # no producer of (min, max) partials here: the normalised tensor is written as usual
     if into_slice and not fused_stats:
         defer = into_slice = False
@@ -760,7 +783,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and not defer and not conv.depthwise \
             and (pre.shape[2] * pre.shape[3]) % 256 == 0:
         yv.gate_consumer = True           # a downsample layer (conv -> BN, no ReLU): its BatchNorm backward takes (g, mask) as its gated dy
-    if coef is not None and out_var is None and post_scale is None and not defer:
+    if coef is not None and out_var is None and post_scale is None and (not defer or (need_pred and not into_slice)):
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
         yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)

@@ -54,7 +54,11 @@ class Bottleneck(nn.Module):
         h, w = x.data.shape[-2:]
         fold = layers_mod.FOLD_BN_WINO and self.conv2.wino and self.conv2.bias is None and (tape is None or self.conv2.wino_wgrad_ok(h, w))
         o = conv_bn_act(x, self.conv1, self.bn1, tape, defer='amax' if fold else False)
-        o = conv_bn_act(o, self.conv2, self.bn2, tape)
+        # conv3 (1x1 on the 256-row f16x3 tile) normalises conv2's output between load and split, and so does its weight gradient: y2 is never
+        # written either (layers.FOLD_BN_GEMM); conv2 -- the Winograd output transform, or layer1's direct GEMM -- emits the (min, max) partials
+        # that predict max |y2|
+        fold2 = layers_mod.FOLD_BN_GEMM and self.conv3.fprop_bnl_ok() and (h // self.conv2.stride) * (w // self.conv2.stride) % 128 == 0
+        o = conv_bn_act(o, self.conv2, self.bn2, tape, defer='amax' if fold2 else False)
         idt = x
         if self.downsample is not None:
             idt = conv_bn_act(x, self.downsample[0], self.downsample[1], tape, relu=False)

@@ -1069,6 +1069,68 @@ def test_f16x3_minmax_partials_predict_the_normalised_maximum(ops, case, relu):
     assert float(slots.max()) == float(true.max()) == float(yn.abs().max()), (float(slots.max()), float(true.max()), float(yn.abs().max()))
 
 
+@pytest.mark.parametrize('case', [(2, 256, 512, 16, 16), (1, 64, 256, 32, 16), (3, 80, 256, 16, 8), (2, 96, 512, 8, 16), (8, 512, 2048, 32, 32),
+                                  (2, 128, 256, 12, 16)])
+def test_f16x3_gemm_and_wgrad_normalise_on_load(ops, case):
+    """pfst_conv_igemm_f16x3(bnl) / pfst_conv_wgrad_f16x3(bnl): the 1x1 convolution after a conv -> BN -> ReLU layer reads that layer's
+    PRE-normalisation output and applies max(fma(x, sc, sh), 0) between load and split (Bottleneck conv2 -> bn2 -> relu -> conv3,
+    /root/reference/rsiseg/models/backbones/resnet.py:282-290): the same fma and max per element as pfst_bn_apply, the same scale (the
+    maximum of the normalised tensor), so output, fused statistics and -- in deterministic mode -- the weight gradient are BIT-IDENTICAL to the
+    launches on the written tensor.  Cases: even / odd step counts (tile chains or not), a last half channel block (80), gammas of both signs,
+    eight images of chained tiles, ragged pixel tiles (12 x 16: the tail columns hold normalised zeros and must stay out of the statistics)."""
+    n, ci, co, H, W = case
+    pre = (torch.randn(n, ci, H, W, generator=g(ci)) * 1.5).to(DEV)
+    gamma = (torch.randn(ci, generator=g(3)) * 0.8).to(DEV)
+    gamma[0] = 0.0
+    beta = (torch.randn(ci, generator=g(4)) * 0.5).to(DEV)
+    w = (torch.randn(co, ci, 1, 1, generator=g(co)) * 0.1).to(DEV)
+    dy = torch.randn(n, co, H, W, generator=g(7)).to(DEV)
+    assert ops.conv_fprop_bnl_ok(ci, co, 1)
+    mean, invstd, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+    ya = ops.amax_slots(pre.device)
+    y = ops.bn_apply(pre, mean, invstd, gamma, beta, True, amax=ya)
+    w4f, _, wa = ops.pack_weight_f16x2(w, True, False)
+    ref, st_ref, sl = ops.conv_fprop_f16x3(y, w4f, wa, ya, co, 1, want_stats=True, want_minmax=True)
+    st_ref = st_ref[:4 * co * sl].clone()
+    out, st, sl1 = ops.conv_fprop_f16x3(pre, w4f, wa, ya, co, 1, want_stats=True, want_minmax=True, bnl=coef)
+    assert sl1 == sl and torch.equal(out, ref), float((out - ref).abs().max())
+    assert torch.equal(st[:4 * co * sl], st_ref)
+    assert torch.equal(ops.conv_fprop_f16x3(pre, w4f, wa, ya, co, 1, bnl=coef), ref)                 # without the statistics epilogue
+    da = ops.absmax(dy)
+    ops.set_deterministic(True)
+    try:
+        dw_ref = ops.conv_wgrad_f16x3_(torch.zeros(co, ci, 1, 1, device=DEV), y, dy, ya, da)
+        dw = ops.conv_wgrad_f16x3_(torch.zeros(co, ci, 1, 1, device=DEV), pre, dy, ya, da, bnl=coef)
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(dw, dw_ref), float((dw - dw_ref).abs().max())
+    dw2 = ops.conv_wgrad_f16x3_(torch.zeros(co, ci, 1, 1, device=DEV), pre, dy, ya, da, bnl=coef)   # the default (atomic) mode: to summation order
+    assert_close(dw2, dw_ref.double(), 1e-6, 'wgrad bnl')
+
+
+@pytest.mark.parametrize('case', [(2, 128, 128, 16, 16, 1), (1, 256, 192, 32, 24, 2), (8, 128, 256, 32, 32, 1)])
+def test_wino_output_emits_minmax_partials(ops, case):
+    """pfst_wino_output(stats_minmax): the Winograd output transform writes per-channel (minimum, maximum) partials of its output behind the
+    (sum, sum of squares) ones -- what pfst_bn_finalize_partials needs to predict max |relu(bn(y))| for a consumer that normalises on load
+    (Bottleneck conv2 through the Winograd domain -> bn2 -> conv3).  Output and sums unchanged, extrema exact."""
+    n, ci, co, H, W, d = case
+    x = torch.randn(n, ci, H, W, generator=g(1)).to(DEV)
+    w = (torch.randn(co, ci, 3, 3, generator=g(2)) * 0.1).to(DEV)
+    uf, _ = ops.wino_pack_weight(w, True, False)
+    y0, st0, sl = ops.wino_conv(x, uf, co, d, want_stats=True)
+    sums0 = st0[:2 * co * sl].clone()
+    y, st, sl1 = ops.wino_conv(x, uf, co, d, want_stats=True, want_minmax=True)
+    assert sl1 == sl and torch.equal(y, y0) and torch.equal(st[:2 * co * sl], sums0)
+    mm = st[2 * co * sl:4 * co * sl].view(co, sl, 2)
+    assert torch.equal(mm[:, :, 0].min(dim=1)[0], y.amin(dim=(0, 2, 3))) and torch.equal(mm[:, :, 1].max(dim=1)[0], y.amax(dim=(0, 2, 3)))
+    gamma = (torch.randn(co, generator=g(3)) * 0.8).to(DEV)
+    beta = (torch.randn(co, generator=g(4)) * 0.5).to(DEV)
+    slots, true = ops.amax_slots(x.device), ops.amax_slots(x.device)
+    mean, invstd, coef = ops.bn_finalize_partials(st, sl, co, n * H * W, gamma=gamma, beta=beta, predict_amax=slots, relu=True)
+    yn = ops.bn_apply(y, mean, invstd, gamma, beta, True, amax=true)
+    assert float(slots.max()) == float(true.max()) == float(yn.abs().max())
+
+
 def test_depthwise_backward_is_exact_beside_a_weight_gradient_kernel(ops):
     """Round 5: the fused depthwise backward with the BatchNorm-backward fold (dwconv3x3_kernel<3, true>) returned wrong sums for one of its
     nine weight-gradient accumulators, on a few channels, whenever the f16x3 weight-gradient kernel of another stream shared the CUs --

@@ -97,6 +97,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
     # test_deferred_normalisation_equals_the_materialised_one below
     layers.DEFER_BN_APPLY = bool(fold)
     prev_fold, layers.FOLD_BN_WINO = layers.FOLD_BN_WINO, bool(fold)
+    prev_fold2, layers.FOLD_BN_GEMM = layers.FOLD_BN_GEMM, bool(fold)      # ... and bn2 -> conv3 normalised inside conv3's GEMM and weight gradient
     # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
     # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
     layers.FUSE_RES_GATE = False
@@ -238,6 +239,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
         layers.WINOGRAD, layers.CONV_MATH, layers.FUSE_ASPP_DW, layers.DEFER_BN_APPLY = prev, prev_math, prev_dw, prev_defer
         layers.FUSE_RES_GATE = prev_gate
         layers.FOLD_BN_WINO = prev_fold
+        layers.FOLD_BN_GEMM = prev_fold2
         layers.set_overlap(*prev_overlap)
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
@@ -568,6 +570,7 @@ def test_deferred_normalisation_equals_the_materialised_one():
         layers.DEFER_BN_APPLY = prev
     # deferred: stem.6 and sep_bottleneck[0]; + bn1 of the 12 bottlenecks whose conv2 runs through the Winograd domain (layers.FOLD_BN_WINO)
     folded = (12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0) + (4 if (layers.FOLD_BN_CONCAT and layers.WINOGRAD) else 0)
+    folded += 16 if (layers.FOLD_BN_GEMM and layers.CONV_MATH == 'f16x3') else 0          # bn2 of every bottleneck: normalised inside conv3's GEMM
     assert applies[False] == 70 and applies[True] == 68 - folded, applies
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
@@ -637,6 +640,72 @@ def test_bn1_folded_into_the_winograd_input_transform():
     assert e < 1e-4, e
 
 
+def test_bn2_folded_into_conv3s_gemm():
+    """layers.FOLD_BN_GEMM (round 5): in every bottleneck conv2 -> bn2 -> ReLU is never written -- conv3's f16x3 GEMM normalises the pre-BN
+    tensor between load and split (pfst_conv_igemm_f16x3 bnl), conv3's weight gradient likewise (pfst_conv_wgrad_f16x3 bnl), bn2's backward
+    reads the pre-BN tensor, and the data gradient of conv3 still emits bn2's BatchNorm-backward sums where it did.  max |y2| is predicted from
+    the (min, max) partials of conv2's producer (the Winograd output transform; layer1 and the stride-2 block: the direct GEMM's epilogue).
+    Same arithmetic per element, same scale exponent: one segmentor forward + backward with the fold on and off gives bit-identical logits,
+    gradients equal to the atomics' summation order, and 16 normalisation launches less.
+    Follows /root/reference/rsiseg/models/backbones/resnet.py:282-290 (conv2 -> norm2 -> relu -> conv3 of Bottleneck._inner_forward)."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if not (layers.DEFER_BN_APPLY and layers.CONV_MATH == 'f16x3'):
+        pytest.skip('needs deferred normalisations under the f16x3 arithmetic')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=29)
+    runs, seen_by = {}, {}
+    prev = layers.FOLD_BN_GEMM
+    inner = ops.call
+    try:
+        for fold in (True, False):
+            layers.FOLD_BN_GEMM = fold
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            seen = {}
+
+            def counting(name, *a):
+                seen[name] = seen.get(name, 0) + 1
+                if name == 'pfst_conv_igemm_f16x3' and a[27]:
+                    seen['normalising GEMMs'] = seen.get('normalising GEMMs', 0) + 1
+                if name == 'pfst_conv_wgrad_f16x3' and a[11]:
+                    seen['normalising weight gradients'] = seen.get('normalising weight gradients', 0) + 1
+                if name == 'pfst_conv_igemm_f16x3' and a[22]:
+                    seen['fused BatchNorm-backward sums'] = seen.get('fused BatchNorm-backward sums', 0) + 1
+                return inner(name, *a)
+            ops.call = counting
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.call = inner
+            runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
+            seen_by[fold] = seen
+    finally:
+        layers.FOLD_BN_GEMM = prev
+    on, off = seen_by[True], seen_by[False]
+    assert off['pfst_bn_apply'] - on['pfst_bn_apply'] == 16, (off['pfst_bn_apply'], on['pfst_bn_apply'])
+    assert on.get('normalising GEMMs', 0) == 16 and on.get('normalising weight gradients', 0) == 16 and off.get('normalising GEMMs', 0) == 0
+    assert on.get('fused BatchNorm-backward sums', 0) == off.get('fused BatchNorm-backward sums', 0) > 0     # conv3's data gradient still emits bn2's sums
+    assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    print(f'   gradient arena, fold on vs off: {e:.2e}')
+    assert e < 1e-4, e
+
+
 def test_published_maxima_cover_every_f16x3_operand():
     """f16x3 mode: the scale of an activation operand comes from the slot group its producer(s) published max |.| into -- the normalisation
     pass, the max-pool (layer1's input) and, for the ASPP head's concat, all five writers of the buffer into ONE group (four normalisation
@@ -697,7 +766,7 @@ def test_published_maxima_cover_every_f16x3_operand():
     assert not bad, bad
     if layers.FOLD_BN_WINO and layers.DEFER_BN_APPLY and layers.WINOGRAD:
         # bn1 of layer2.1-3, layer3.0-5, layer4.0-2 (+ the ASPP concat with its four deferred writers): predicted == true maximum, bit for bit
-        assert len(predicted) == 12 + (1 if layers.FOLD_BN_CONCAT else 0), predicted
+        assert len(predicted) == 12 + (16 if layers.FOLD_BN_GEMM else 0) + (1 if layers.FOLD_BN_CONCAT else 0), predicted
     shapes = [s[0] for s in seen.values()]
     assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
     assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'
