@@ -116,7 +116,7 @@ class KernelTimer:
         if name == 'pfst_dwconv3x3_bwd':                  # both gradients in one pass: read dy, x (+ the pre-BN tensor when BN backward is folded in), write dx
             return name, 0.0, 4.0 * a[8] * a[9] * a[10] * a[11] * (3 + (1 if a[13] else 0) + (1 if a[15] else 0))
         if name == 'pfst_dwconv3x3_multi_fwd':            # ASPP: read x once, write the ns branch outputs
-            return name, 0.0, 4.0 * a[9] * a[10] * a[11] * a[12] * (1 + a[2])
+            return name, 0.0, 4.0 * a[10] * a[11] * a[12] * a[13] * (1 + a[2])
         if name == 'pfst_dwconv3x3_multi_bwd':            # read x and ns x (dy [+ pre-BN tensor]), write (read-modify-write) dx
             return name, 0.0, 4.0 * a[14] * a[15] * a[16] * a[17] * (2 + (1 if a[11] else 0) + a[2] * (2 if a[12] else 1))
         if name == 'pfst_bn_backward_sums':               # the reduction pass alone (no fused partials): read dy, x

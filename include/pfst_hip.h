@@ -169,7 +169,7 @@ int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const void* wk4, con
                           int ksize, int stride, int dil, int pad, int mode, int accumulate, float* stats, const pfst_bnb_fuse_t* bnb,
                           const float* gate_dy, long long gate_dy_bs, const unsigned long long* gate_mask, int stats_minmax,
                           const float* bnl, pfst_stream_t stream);
-/* bnl != NULL (forward 1x1 launches, M % 256 == 0, C <= 512): `in` is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this
+/* bnl != NULL (forward 1x1 launches, M % 256 == 0, C <= 2048): `in` is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this
  * convolution (Bottleneck conv2 -> bn2 -> relu -> conv3, resnet.py:282-290) and bnl its coef [C][4] = (mean, invstd, sc, sh): elements are
  * normalised between their load and their split, the normalised tensor is never written; in_amax = the slot group
  * pfst_bn_finalize_partials published the predicted max |relu(bn(in))| to */
@@ -200,8 +200,11 @@ int pfst_conv_wgrad_f16x3_q(const float* x, long long x_bs, const float* dy, lon
 /* ---- depthwise 3x3 convolution, stride 1, pad = dil (mmcv DepthwiseSeparableConvModule,
  * sep_aspp_head.py:17-26,63-77).  flip != 0 mirrors the taps (= data gradient). */
 int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                   int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, const float* bn_on_load_coef,
-                   pfst_stream_t stream);
+                   int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, int stats_minmax,
+                   const float* bn_on_load_coef, pfst_stream_t stream);
+/* stats_minmax != 0 (with stats): `stats` has room for twice the partials and also receives the per-channel (minimum, maximum) partials
+ * behind the sums (as pfst_conv_igemm_f16x3's): the pointwise layer of the DepthwiseSeparableConvModule then normalises this output as it
+ * loads it (pfst_conv_igemm_f16x3 bnl) from the predicted maximum */
 /* bn_on_load_coef: NULL, or coef[C][4] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer that feeds this depthwise layer: x is then that
  * layer's PRE-normalisation output, normalised + rectified while it is staged (forward only; the normalised tensor is never written) */
 /* stats != NULL: per-channel partial (sum, sum of squares) of the outputs, stats[C][N * pfst_dwconv_stats_slots(H, W, dil)][2],
@@ -218,7 +221,8 @@ int pfst_dwconv3x3_wgrad(const float* x, long long x_bs, const float* dy, long l
  *        x read once, every dy[i] once, dx written once. */
 int pfst_dwconv3x3_multi_ok(int H, int W, int ns, const int* dils);
 int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float* const* w, float* const* y, const long long* y_bs,
-                             float* const* stats, const int* dils, float* plane_mean, int N, int C, int H, int W, pfst_stream_t stream);
+                             float* const* stats, int stats_minmax, const int* dils, float* plane_mean, int N, int C, int H, int W,
+                             pfst_stream_t stream);
 int pfst_dwconv3x3_multi_bwd(const float* x, long long x_bs, int ns, const float* const* w, const float* const* dy,
                              const long long* dy_bs, float* const* dw, const int* dils, const float* plane_mean_grad, float* dx,
                              long long dx_bs, int accumulate, const float* const* bn_pre, const pfst_bn_bwd_rec_t* const* bn_rec,

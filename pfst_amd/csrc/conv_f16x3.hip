@@ -244,7 +244,7 @@ struct PfstResGate {                       // value-initialised = off
 // BNL (256-row pixel-to-pixel tile, plain operand): `in` is the PRE-normalisation output of the conv -> BN -> ReLU layer feeding this 1x1
 // convolution (Bottleneck conv2 -> bn2 -> relu -> conv3); every activation element is normalised -- max(fma(x, sc, sh), 0) with the (sc, sh)
 // of its channel from bnl[C] = (mean, invstd, sc, sh) -- between its load and its split, the normalised tensor is never written; in_amax
-// then holds the PREDICTED max of the normalised tensor (pfst_bn_finalize_partials).  The coefficients sit in LDS (C <= 512).
+// then holds the PREDICTED max of the normalised tensor (pfst_bn_finalize_partials).  The coefficients sit in LDS (C <= 2048: 16 KB).
 template <int SHAPE, int BNB = 0, bool BPACK = false, bool ONE = false, int BMT = 128, bool BNL = false>
 __device__ __forceinline__ void conv_igemm_f16x3_body(
     const float* __restrict__ in, i64 in_bs, const uint4* __restrict__ wk4, const float* __restrict__ bias,
@@ -275,7 +275,7 @@ __device__ __forceinline__ void conv_igemm_f16x3_body(
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wid / WAVES_N) * (32 * TMW), wn0 = (wid % WAVES_N) * 64;
   const int P = Ho * Wo, HiWi = Hi * Wi;
-  constexpr int BNL_ROWS = 512 + 32;                     // C <= 512 (host) + the zero rows a last half block reads
+  constexpr int BNL_ROWS = 2048 + 32;                    // C <= 2048 (host) + the zero rows a last half block reads
   __shared__ uint4 bnl_s[BNL ? BNL_ROWS / 2 : 1];        // [(sc, sh) of two channels]
   if constexpr (BNL) {
     for (int i = tid; i < BNL_ROWS; i += NT) {
@@ -1019,7 +1019,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
                                      const unsigned long long* gate_mask, int stats_minmax, const float* bnl, pfst_stream_t stream) {
   PFST_CHECK_ARG(in && wk4 && w_amax && in_amax && out && N > 0 && C > 0 && M > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0);
   // bnl: the input is normalised as it is loaded (1x1 forward launches on the 256-row tile; C <= 512 coefficient rows in LDS)
-  PFST_CHECK_ARG(!bnl || (mode == 0 && ksize == 1 && stride == 1 && pad == 0 && M % 256 == 0 && C <= 512 && !bias && !gate_dy && !(bnb && bnb->x) &&
+  PFST_CHECK_ARG(!bnl || (mode == 0 && ksize == 1 && stride == 1 && pad == 0 && M % 256 == 0 && C <= 2048 && !bias && !gate_dy && !(bnb && bnb->x) &&
                           !accumulate));
   // stats_minmax: `stats` has room for 4 * M * slots floats and also receives the per-channel (minimum, maximum) partials behind the sums
   PFST_CHECK_ARG(!stats_minmax || (stats && !bias && !(bnb && bnb->x)));

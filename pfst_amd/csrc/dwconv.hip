@@ -158,6 +158,23 @@ __global__ __launch_bounds__(64) void dw_det_reduce_kernel(const float* __restri
   dw[c * 9 + t] += v;
 }
 
+// block-wide (minimum, maximum) of per-thread running extrema: thread 0 gets the result (scratch: >= 32 floats of LDS, barriers inside)
+__device__ __forceinline__ void block_minmax(float& lo, float& hi, float* scratch) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o));
+    hi = fmaxf(hi, __shfl_xor(hi, o));
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) { scratch[wid] = lo; scratch[16 + wid] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 1; i < nw; ++i) { lo = fminf(lo, scratch[i]); hi = fmaxf(hi, scratch[16 + i]); }
+  }
+}
+
 // MODE 0: scalar (any W); MODE 1: float4 outputs, dilation % 4 == 0 (ds_read_b128 taps); MODE 2: float4 outputs, any dilation;
 // MODE 3: float4 outputs, dilation 1 (row_taps_d1)
 // WG (backward only, flip = 1: x = dY, y = dX): the same pass also forms the WEIGHT gradient.  With v_t = dY[p + off(t)] the nine
@@ -170,7 +187,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
                                                         int flip, int accumulate, float* __restrict__ stats,
                                                         const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
                                                         const float4* __restrict__ bnl = nullptr, const float* __restrict__ bnpre = nullptr,
-                                                        i64 bnpre_bs = 0, const pfst_bn_bwd_rec_t* __restrict__ bnrec = nullptr, int det_T = 0) {
+                                                        i64 bnpre_bs = 0, const pfst_bn_bwd_rec_t* __restrict__ bnrec = nullptr, int det_T = 0,
+                                                        int stats_minmax = 0) {
   // bnrec != NULL (WG): x = the gradient of this layer's BatchNorm + ReLU output, bnpre = the layer's own convolution output: the rows
   // staged are dL/dpre = the second pass of BatchNorm backward, formed on the fly (stage_rows_bnbwd)
   // bnl != NULL: coef[C] = (mean, invstd, sc, sh) of the conv -> BN -> ReLU layer whose PRE-normalisation output is this convolution's
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
   extern __shared__ float tile[];
   __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   float st_s = 0.f, st_q = 0.f;                    // fused BatchNorm statistics of this block's outputs (stats != NULL)
+  float st_lo = __builtin_inff(), st_hi = -__builtin_inff();      // stats_minmax: and their extrema (predicted max |relu(bn(y))|, bn.hip)
   const int c = blockIdx.y, n = blockIdx.z;
   const Strip s = make_strip(blockIdx.x, R, H, dil);
   const float* xp = x + (i64)n * x_bs + (i64)c * H * W;
@@ -230,6 +249,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       *out = acc;
       st_s += (acc.x + acc.y) + (acc.z + acc.w);
       st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
+      st_lo = fminf(fminf(st_lo, fminf(acc.x, acc.y)), fminf(acc.z, acc.w));
+      st_hi = fmaxf(fmaxf(st_hi, fmaxf(acc.x, acc.y)), fmaxf(acc.z, acc.w));
     }
   } else {
     const int total = (s.y1 - s.y0) * W;
@@ -256,6 +277,8 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       yp[o] = acc;
       st_s += acc;
       st_q = fmaf(acc, acc, st_q);
+      st_lo = fminf(st_lo, acc);
+      st_hi = fmaxf(st_hi, acc);
     }
   }
   // per-(channel, strip, image) partial sums for pfst_bn_finalize_partials: stats[c][n * gridDim.x + strip][2]  (the kernel is
@@ -267,6 +290,13 @@ __global__ __launch_bounds__(512) void dwconv3x3_kernel(const float* __restrict_
       const i64 T = (i64)gridDim.x * gridDim.z;
       float2* dst = reinterpret_cast<float2*>(stats) + ((i64)c * T + (i64)n * gridDim.x + blockIdx.x);
       *dst = make_float2((float)bs, (float)bq);
+    }
+    if (stats_minmax) {                              // [C][T][2] behind the sums
+      block_minmax(st_lo, st_hi, reinterpret_cast<float*>(red));
+      if (threadIdx.x == 0) {
+        const i64 T = (i64)gridDim.x * gridDim.z;
+        reinterpret_cast<float2*>(stats)[(i64)gridDim.y * T + (i64)c * T + (i64)n * gridDim.x + blockIdx.x] = make_float2(st_lo, st_hi);
+      }
     }
   }
   if (WG) block_add9(accw, dw_dst(dw, c, det_T, blockIdx.z * gridDim.x + blockIdx.x), reinterpret_cast<float*>(red));
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
                                                               float* __restrict__ y, i64 y_bs, int C, int H, int W, int dil, int cpb,
                                                               int flip, int accumulate, float* __restrict__ stats,
                                                               const float* __restrict__ fx = nullptr, i64 fx_bs = 0, float* __restrict__ dw = nullptr,
-                                                              int det_T = 0) {
+                                                              int det_T = 0, int stats_minmax = 0) {
   extern __shared__ float tile[];
   __shared__ double red[40];                       // (also the 8 x 9 floats of block_add9)
   const int n = blockIdx.z, c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
@@ -306,6 +336,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
     for (int t = 0; t < 9; ++t) wt[t] = w[c * 9 + (flip ? 8 - t : t)];
     float* yp = y + (i64)n * y_bs + (i64)c * HW;
     float st_s = 0.f, st_q = 0.f;
+    float st_lo = __builtin_inff(), st_hi = -__builtin_inff();
     float accw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) accw[t] = 0.f;
@@ -342,11 +373,17 @@ __global__ __launch_bounds__(512) void dwconv3x3_plane_kernel(const float* __res
       *out = acc;
       st_s += (acc.x + acc.y) + (acc.z + acc.w);
       st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
+      st_lo = fminf(fminf(st_lo, fminf(acc.x, acc.y)), fminf(acc.z, acc.w));
+      st_hi = fmaxf(fmaxf(st_hi, fmaxf(acc.x, acc.y)), fmaxf(acc.z, acc.w));
     }
     if (stats) {                                   // stats[c][n][2]: one strip per plane (pfst_dwconv_stats_slots == 1)
       double bs = (double)st_s, bq = (double)st_q;
       block_sum2_d<true>(bs, bq, red);
       if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
+      if (stats_minmax) {                          // [C][N][2] behind the sums
+        block_minmax(st_lo, st_hi, reinterpret_cast<float*>(red));
+        if (tid == 0) reinterpret_cast<float2*>(stats)[(i64)C * gridDim.z + (i64)c * gridDim.z + n] = make_float2(st_lo, st_hi);
+      }
     }
     if (WG) block_add9(accw, dw_dst(dw, c, det_T, blockIdx.z), reinterpret_cast<float*>(red));
     __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
@@ -465,6 +502,7 @@ struct DwSets {
   const float* dy[3];       // backward: output gradients
   float* dw[3];             // backward: weight gradients (+=)
   float* stats[3];          // forward: BatchNorm partials [C][N][2] or NULL
+  int stats_minmax;         // forward: the partials are followed by the (minimum, maximum) partials [C][N][2]
   long long bs[3];          // batch strides of y / dy
   int dil[3];
   const float* pre[3];      // backward with rec: the branches' own convolution outputs (pre-normalisation), batch stride bs[i]
@@ -511,6 +549,7 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
       for (int t = 0; t < 9; ++t) wt[t] = S.w[si][c * 9 + t];
       float* yp = S.y[si] + (i64)n * S.bs[si] + (i64)c * HW;
       float st_s = 0.f, st_q = 0.f;
+      float st_lo = __builtin_inff(), st_hi = -__builtin_inff();
       for (int i = tid; i < n4; i += 512) {
         const int yy = i / W4, c4 = i - yy * W4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,11 +568,17 @@ __global__ __launch_bounds__(512) void dwconv3x3_multi_fwd_kernel(const float* _
         reinterpret_cast<float4*>(yp)[i] = acc;
         st_s += (acc.x + acc.y) + (acc.z + acc.w);
         st_q = fmaf(acc.x, acc.x, fmaf(acc.y, acc.y, fmaf(acc.z, acc.z, fmaf(acc.w, acc.w, st_q))));
+        st_lo = fminf(fminf(st_lo, fminf(acc.x, acc.y)), fminf(acc.z, acc.w));
+        st_hi = fmaxf(fmaxf(st_hi, fmaxf(acc.x, acc.y)), fmaxf(acc.z, acc.w));
       }
       if (S.stats[si]) {                           // same partial layout as dwconv3x3_plane_kernel: stats[c][n][2]
         double bs = (double)st_s, bq = (double)st_q;
         block_sum2_d<true>(bs, bq, red);
         if (tid == 0) reinterpret_cast<float2*>(S.stats[si])[(i64)c * gridDim.z + n] = make_float2((float)bs, (float)bq);
+        if (S.stats_minmax) {                      // [C][N][2] behind the sums
+          block_minmax(st_lo, st_hi, reinterpret_cast<float*>(red));
+          if (tid == 0) reinterpret_cast<float2*>(S.stats[si])[(i64)C * gridDim.z + (i64)c * gridDim.z + n] = make_float2(st_lo, st_hi);
+        }
       }
     }
     __syncthreads();                               // every tap of this plane has been read: the tile may be overwritten
@@ -659,9 +704,10 @@ extern "C" int pfst_dwconv_stats_slots(int H, int W, int dil) {
 }
 
 extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, float* y, long long y_bs,
-                              int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, const float* bn_on_load_coef,
-                              pfst_stream_t stream) {
+                              int N, int C, int H, int W, int dil, int flip, int accumulate, float* stats, int stats_minmax,
+                              const float* bn_on_load_coef, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && N > 0 && C > 0 && H > 0 && W > 0 && dil >= 1);
+  PFST_CHECK_ARG(!stats_minmax || stats);
   PFST_CHECK_ARG(!bn_on_load_coef || !flip);         // the forward input is normalised on load; a data gradient has nothing to normalise
   const float4* bnl = reinterpret_cast<const float4*>(bn_on_load_coef);
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && y_bs >= (i64)C * H * W && C <= 65535 && N <= 65535);
@@ -692,22 +738,29 @@ extern "C" int pfst_dwconv3x3(const float* x, long long x_bs, const float* w, fl
     }
     dim3 gp(1, cdiv(C, cpb), N);
     if (mode == 1)
-      hipLaunchKernelGGL(dwconv3x3_plane_kernel<1>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<1>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats,
+                         (const float*)nullptr, (i64)0, (float*)nullptr, 0, stats_minmax);
     else if (mode == 3)
-      hipLaunchKernelGGL(dwconv3x3_plane_kernel<3>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<3>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats,
+                         (const float*)nullptr, (i64)0, (float*)nullptr, 0, stats_minmax);
     else
-      hipLaunchKernelGGL(dwconv3x3_plane_kernel<2>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats);
+      hipLaunchKernelGGL(dwconv3x3_plane_kernel<2>, gp, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, cpb, flip, accumulate, stats,
+                         (const float*)nullptr, (i64)0, (float*)nullptr, 0, stats_minmax);
     PFST_CHECK_LAUNCH();
     return PFST_OK;
   }
   if (mode == 1)
-    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
+    hipLaunchKernelGGL(dwconv3x3_kernel<1>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl,
+                       (const float*)nullptr, (i64)0, (const pfst_bn_bwd_rec_t*)nullptr, 0, stats_minmax);
   else if (mode == 2)
-    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
+    hipLaunchKernelGGL(dwconv3x3_kernel<2>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl,
+                       (const float*)nullptr, (i64)0, (const pfst_bn_bwd_rec_t*)nullptr, 0, stats_minmax);
   else if (mode == 3)
-    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
+    hipLaunchKernelGGL(dwconv3x3_kernel<3>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl,
+                       (const float*)nullptr, (i64)0, (const pfst_bn_bwd_rec_t*)nullptr, 0, stats_minmax);
   else
-    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl);
+    hipLaunchKernelGGL(dwconv3x3_kernel<0>, grid, dim3(512), lds, st, x, x_bs, w, y, y_bs, C, H, W, dil, R, flip, accumulate, stats, (const float*)nullptr, (i64)0, (float*)nullptr, bnl,
+                       (const float*)nullptr, (i64)0, (const pfst_bn_bwd_rec_t*)nullptr, 0, stats_minmax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -792,6 +845,7 @@ static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const*
   S.pool = nullptr;
   S.pool_grad = nullptr;
   S.pool_scale = 0.f;
+  S.stats_minmax = 0;
   for (int i = 0; i < 3; ++i) {
     const int k = i < ns ? i : 0;
     S.pre[i] = nullptr;
@@ -810,14 +864,17 @@ static int dw_multi_sets(DwSets& S, int ns, const float* const* w, float* const*
 }
 
 extern "C" int pfst_dwconv3x3_multi_fwd(const float* x, long long x_bs, int ns, const float* const* w, float* const* y, const long long* y_bs,
-                                        float* const* stats, const int* dils, float* plane_mean, int N, int C, int H, int W, pfst_stream_t stream) {
+                                        float* const* stats, int stats_minmax, const int* dils, float* plane_mean, int N, int C, int H, int W,
+                                        pfst_stream_t stream) {
   PFST_CHECK_ARG(x && w && y && y_bs && dils && N > 0 && C > 0 && C <= 65535 && N <= 65535 && pfst_dwconv3x3_multi_ok(H, W, ns, dils));
+  PFST_CHECK_ARG(!stats_minmax || stats);
   PFST_CHECK_ARG(x_bs >= (i64)C * H * W && (x_bs & 3) == 0 && ((uintptr_t)x & 15) == 0);
   DwSets S;
   PFST_CHECK_ARG(dw_multi_sets(S, ns, w, y, nullptr, nullptr, stats, y_bs, dils, (i64)C * H * W));
   for (int i = 0; i < ns; ++i) PFST_CHECK_ARG(y[i] != nullptr);
   S.pool = plane_mean;
   S.pool_scale = 1.0f / (float)(H * W);
+  S.stats_minmax = stats_minmax;
   static bool set = false;
   if (!set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dwconv3x3_multi_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -347,9 +347,12 @@ class WeightJobTable:
         call(name, ctypes.addressof(self.host), self.dev.data_ptr(), self.n, _stream())
 
 
+BNL_MAX_C = 2048          # coefficient rows the normalising GEMM keeps in LDS (conv_f16x3.hip BNL_ROWS)
+
+
 def conv_fprop_bnl_ok(cin, cout, ksize, stride=1, pad=0):
     """can conv_fprop_f16x3 normalise its input as it loads (bnl=...): the 256-row pixel-to-pixel tile, coefficient rows in LDS"""
-    return ksize == 1 and stride == 1 and pad == 0 and cout % 256 == 0 and cin <= 512 and f16x3_eligible(cin, cout, 1)
+    return ksize == 1 and stride == 1 and pad == 0 and cout % 256 == 0 and cin <= BNL_MAX_C and f16x3_eligible(cin, cout, 1)
 
 
 def conv_fprop_f16x3(x, wk4, w_amax, x_amax, cout, ksize, stride=1, dil=1, pad=0, bias=None, out=None, want_stats=False, want_minmax=False,
@@ -641,8 +644,9 @@ def wino_wgrad_(dw, x, dy, dil, v=None, m=None, split=False, v_amax=None, x_amax
 
 
 # ---------------------------------------------------------------- depthwise
-def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False, bnl=None):
-    """want_stats: also return (stats_ws, slots), per-channel BN partial sums of the output (as conv_fprop);
+def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False, bnl=None, want_minmax=False):
+    """want_stats: also return (stats_ws, slots), per-channel BN partial sums of the output (as conv_fprop); want_minmax: followed by the
+    (minimum, maximum) partials (as conv_fprop_f16x3);
     bnl: coef [C, 4] of the conv -> BN -> ReLU layer feeding this one: x is that layer's PRE-normalisation output, normalised on load"""
     n, c, h, wd = x.shape
     assert w.numel() == c * 9
@@ -652,9 +656,9 @@ def dwconv(x, w, dil, flip=False, out=None, accumulate=False, want_stats=False, 
     slots, st = 0, None
     if want_stats:
         slots = n * lib().pfst_dwconv_stats_slots(h, wd, dil)
-        st = _stats_ws(x.device, 2 * c * slots)
+        st = _stats_ws(x.device, (4 if want_minmax else 2) * c * slots)
     call('pfst_dwconv3x3', x.data_ptr(), _bs(x), _dense(w).data_ptr(), out.data_ptr(), _bs(out), n, c, h, wd, dil,
-         int(flip), int(accumulate), _p(st), _p(bnl), _stream())
+         int(flip), int(accumulate), _p(st), int(bool(want_minmax and want_stats)), _p(bnl), _stream())
     return (out, st, slots) if want_stats else out
 
 
@@ -679,17 +683,19 @@ def dwconv_multi_ok(x, dils):
             and bool(lib().pfst_dwconv3x3_multi_ok(h, w, len(dils), (ctypes.c_int * len(dils))(*dils))))
 
 
-def dwconv_multi(x, ws, dils, want_stats=False, want_mean=False):
+def dwconv_multi(x, ws, dils, want_stats=False, want_mean=False, want_minmax=False):
     """y_i = depthwise 3x3 conv of x with filters ws[i] at dilation dils[i], every input plane staged ONCE for all branches
     -> [(y_i, stats_i, slots_i)] (stats as dwconv(want_stats=True): per-channel BN partials, one slot per image);
     want_mean: -> (that list, [N, C, 1, 1] plane means of x = global_avgpool(x)) from the same pass"""
     n, c, h, w = x.shape
     k = len(ws)
     ys = [torch.empty(n, c, h, w, device=x.device) for _ in range(k)]
-    sts = [(_stats_ws_multi(x.device, 2 * c * n, i) if want_stats else None) for i in range(k)]
+    want_minmax = bool(want_minmax and want_stats)          # the (minimum, maximum) partials behind each branch's sums
+    sts = [(_stats_ws_multi(x.device, (4 if want_minmax else 2) * c * n, i) if want_stats else None) for i in range(k)]
     mean = torch.empty(n, c, 1, 1, device=x.device) if want_mean else None
     call('pfst_dwconv3x3_multi_fwd', x.data_ptr(), _bs(x), k, _ptr_array([_dense(t) for t in ws]), _ptr_array(ys),
-         (ctypes.c_longlong * k)(*[_bs(y) for y in ys]), _ptr_array(sts), (ctypes.c_int * k)(*dils), _p(mean), n, c, h, w, _stream())
+         (ctypes.c_longlong * k)(*[_bs(y) for y in ys]), _ptr_array(sts), int(want_minmax), (ctypes.c_int * k)(*dils), _p(mean), n, c, h, w,
+         _stream())
     res = [(ys[i], sts[i], n if want_stats else 0) for i in range(k)]
     return (res, mean) if want_mean else res
 

@@ -406,7 +406,11 @@ class DepthwiseSeparableConvModule(nn.Module):
         self.pointwise_conv = ConvModule(cin, cout, 1)
 
     def forward(self, x, tape, out=None, post_scale=None, defer=False):
-        return self.pointwise_conv(self.depthwise_conv(x, tape), tape, out=out, post_scale=post_scale, defer=defer)
+        # FOLD_BN_DWSEP: the depthwise stage's conv -> BN -> ReLU output is never written -- the pointwise layer's f16x3 GEMM and weight gradient
+        # normalise the depthwise output as they load it (the depthwise kernel emits the (min, max) partials of the predicted maximum)
+        h, w = (x.data if x.lazy is None else x.lazy[0]).shape[-2:]
+        fold = FOLD_BN_DWSEP and self.pointwise_conv.conv.fprop_bnl_ok() and (h * w) % 128 == 0
+        return self.pointwise_conv(self.depthwise_conv(x, tape, defer='amax' if fold else False), tape, out=out, post_scale=post_scale, defer=defer)
 
 
 # the atrous depthwise branches of the ASPP head as ONE launch each way (csrc/dwconv.hip, pfst_dwconv3x3_multi_*); False: per branch
@@ -430,6 +434,13 @@ FOLD_BN_CONCAT = True
 # layer1, the direct GEMM's epilogue.  False: bn_apply writes y2 (per-link test).  Same-box A/B while the switch read the environment:
 # profiles/r05_ab_fold_bn_gemm.txt (-1.05 ms per step: bn_apply -2.2, the normalising GEMMs and weight gradients +1.2)
 FOLD_BN_GEMM = True
+# DepthwiseSeparableConvModule (the ASPP head's three atrous branches, sep_bottleneck[0] / [1]): depthwise conv -> BN -> ReLU -> pointwise 1x1.
+# The same fold: the pointwise GEMM (up to 2048 coefficient rows in LDS) and its weight gradient normalise the depthwise kernel's output on
+# load, the depthwise kernels (strip, whole-plane, three-branch) emit the (min, max) partials; the depthwise layer's BatchNorm backward never
+# read y anyway (its second pass runs inside the depthwise backward).  Five tensors of 1.07-1.17 GB per pass are not written and not re-read:
+# -3.0 ms per step in the same-box A/B taken while the switch read the environment (profiles/r05_ab_fold_bn_dwsep.txt: bn_apply -5.1 ms, the
+# normalising GEMMs and weight gradients +2.1)
+FOLD_BN_DWSEP = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written)
 
@@ -452,10 +463,14 @@ def dwsep_branches(x, mods, tape, outs, pool=None, defer=False):
         return [m(x, tape, out=o, defer=defer) for m, o in zip(mods, outs)]
     xd = x.data
     want_stats = FUSE_BN_STATS and not _BN_EVAL
+    # FOLD_BN_DWSEP: the branches' normalised depthwise outputs are never written, the pointwise GEMMs normalise on load (see the flag)
+    n_, c_, h_, w_ = xd.shape
+    fold = (FOLD_BN_DWSEP and DEFER_BN_APPLY and CONV_MATH == 'f16x3' and want_stats and (h_ * w_) % 128 == 0
+            and all(m.pointwise_conv.conv.fprop_bnl_ok() for m in mods))
     if pool is not None:
-        res, pool['mean'] = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats, want_mean=True)
+        res, pool['mean'] = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats, want_mean=True, want_minmax=fold)
     else:
-        res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats)
+        res = ops.dwconv_multi(xd, [c.weight.data for c in convs], dils, want_stats=want_stats, want_minmax=fold)
     dpres, bnbs = [None] * len(mods), [None] * len(mods)
     if tape is not None:
         x.claim_first_use()
@@ -475,20 +490,25 @@ def dwsep_branches(x, mods, tape, outs, pool=None, defer=False):
             assert tape is None, 'eval-mode BN is inference only'
             mean, invstd, coef = bn.running_mean, torch.rsqrt(bn.running_var + BN_EPS), None
         else:
-            want_coef = tape is not None and FUSE_BN_BWD
+            want_coef = (tape is not None and FUSE_BN_BWD) or fold
             gb = dict(gamma=bn.weight.data, beta=bn.bias.data) if want_coef else {}
             n, c, h, w = pre.shape
+            pred_amax = ops.amax_slots(pre.device) if fold else None
             if want_stats:
-                out3 = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
+                out3 = ops.bn_finalize_partials(st, slots, c, n * h * w, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS,
+                                                predict_amax=pred_amax, relu=True, **gb)
             else:
                 out3 = ops.bn_stats(pre, bn.running_mean, bn.running_var, BN_MOMENTUM, BN_EPS, **gb)
             mean, invstd = out3[:2]
             coef = out3[2] if want_coef else None
             bn._pending_batches += 1
         yv = Var(None, tape is not None)
-        yv.data = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, True, None, amax=_amax_target(yv, pre.device))
+        if fold:
+            yv.lazy, yv.amax = (pre, coef, bn), pred_amax          # never written: the pointwise GEMM and its weight gradient normalise on load
+        else:
+            yv.data = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, True, None, amax=_amax_target(yv, pre.device))
         if tape is not None:
-            if coef is not None:
+            if coef is not None and FUSE_BN_BWD:
                 yv.bn = BnBackwardCtx(pre, None, coef, True)       # the pointwise layer's data gradient may emit this layer's sums
 
             def bwd_bn(i=i, bn=bn, yv=yv, pre=pre, mean=mean, invstd=invstd):
@@ -710,7 +730,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     tiny = xd.shape[0] * xd.shape[2] * xd.shape[3] <= 64
     fused_stats = FUSE_BN_STATS and not _BN_EVAL and not tiny
     # producers of (min, max) partials: the f16x3 GEMM epilogue and (not into a concat slice) the Winograd output transform
-    mm_producer = conv.bias is None and ((conv.f16_f and not conv.wino) or (conv.wino and not into_slice))
+    mm_producer = conv.bias is None and ((conv.f16_f and not conv.wino) or (conv.wino and not into_slice) or (conv.depthwise and not into_slice))
     if need_pred and not (defer and fused_stats and mm_producer):
         defer = need_pred = into_slice = False           # no producer of (min, max) partials here: the normalised tensor is written as usual
     if into_slice and not fused_stats:
@@ -723,7 +743,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     pre_out = out.data if into_slice else None           # the convolution writes straight into the concat slice
     if conv.depthwise:
         if fused_stats:                            # batch statistics come out of the producing kernel in every case
-            pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True, bnl=x_bnl)
+            pre, st, slots = ops.dwconv(xd, conv.weight.data, conv.dilation, want_stats=True, bnl=x_bnl, want_minmax=need_pred)
         else:
             pre = ops.dwconv(xd, conv.weight.data, conv.dilation, bnl=x_bnl)
     elif fused_stats:                              # GEMM epilogue, or the Winograd output transform

@@ -1070,7 +1070,7 @@ def test_f16x3_minmax_partials_predict_the_normalised_maximum(ops, case, relu):
 
 
 @pytest.mark.parametrize('case', [(2, 256, 512, 16, 16), (1, 64, 256, 32, 16), (3, 80, 256, 16, 8), (2, 96, 512, 8, 16), (8, 512, 2048, 32, 32),
-                                  (2, 128, 256, 12, 16)])
+                                  (2, 128, 256, 12, 16), (2, 2048, 512, 16, 16), (2, 560, 512, 16, 24)])
 def test_f16x3_gemm_and_wgrad_normalise_on_load(ops, case):
     """pfst_conv_igemm_f16x3(bnl) / pfst_conv_wgrad_f16x3(bnl): the 1x1 convolution after a conv -> BN -> ReLU layer reads that layer's
     PRE-normalisation output and applies max(fma(x, sc, sh), 0) between load and split (Bottleneck conv2 -> bn2 -> relu -> conv3,
@@ -1129,6 +1129,41 @@ def test_wino_output_emits_minmax_partials(ops, case):
     mean, invstd, coef = ops.bn_finalize_partials(st, sl, co, n * H * W, gamma=gamma, beta=beta, predict_amax=slots, relu=True)
     yn = ops.bn_apply(y, mean, invstd, gamma, beta, True, amax=true)
     assert float(slots.max()) == float(true.max()) == float(yn.abs().max())
+
+
+@pytest.mark.parametrize('case', [(2, 64, 40, 48, 1), (2, 40, 32, 32, 4), (1, 24, 33, 37, 2), (2, 16, 256, 256, 1)])
+def test_depthwise_kernels_emit_minmax_partials(ops, case):
+    """pfst_dwconv3x3(stats_minmax) / pfst_dwconv3x3_multi_fwd(stats_minmax): the depthwise kernels (strips, whole planes, the three-branch
+    launch) write per-channel (minimum, maximum) partials of their outputs behind the sums, for the pointwise layer that normalises on load
+    (layers.FOLD_BN_DWSEP).  Outputs and sums unchanged, extrema exact, predicted max |relu(bn(y))| = what bn_apply publishes."""
+    n, c, H, W, d = case
+    x = torch.randn(n, c, H, W, generator=g(1)).to(DEV)
+    w = torch.randn(c, 1, 3, 3, generator=g(2)).to(DEV)
+    gamma = (torch.randn(c, generator=g(3)) * 0.8).to(DEV)
+    beta = (torch.randn(c, generator=g(4)) * 0.5).to(DEV)
+
+    def check(y, st, sl, y0, sums0):
+        assert torch.equal(y, y0) and torch.equal(st[:2 * c * sl], sums0)
+        mm = st[2 * c * sl:4 * c * sl].view(c, sl, 2)
+        assert torch.equal(mm[:, :, 0].min(dim=1)[0], y.amin(dim=(0, 2, 3))) and torch.equal(mm[:, :, 1].max(dim=1)[0], y.amax(dim=(0, 2, 3)))
+        slots, true = ops.amax_slots(x.device), ops.amax_slots(x.device)
+        mean, invstd, coef = ops.bn_finalize_partials(st, sl, c, n * H * W, gamma=gamma, beta=beta, predict_amax=slots, relu=True)
+        yn = ops.bn_apply(y, mean, invstd, gamma, beta, True, amax=true)
+        assert float(slots.max()) == float(true.max()) == float(yn.abs().max())
+
+    y0, st0, sl = ops.dwconv(x, w, d, want_stats=True)
+    sums0 = st0[:2 * c * sl].clone()
+    y, st, sl1 = ops.dwconv(x, w, d, want_stats=True, want_minmax=True)
+    assert sl1 == sl
+    check(y, st, sl, y0, sums0)
+    dils = [4 * d, 8 * d]
+    if ops.dwconv_multi_ok(x, dils):
+        ws = [w, torch.randn(c, 1, 3, 3, generator=g(5)).to(DEV)]
+        r0 = ops.dwconv_multi(x, ws, dils, want_stats=True)
+        keep = [(a.clone(), b[:2 * c * k].clone()) for a, b, k in r0]
+        r1 = ops.dwconv_multi(x, ws, dils, want_stats=True, want_minmax=True)
+        for (yy, ss, kk), (ya, sa) in zip(r1, keep):
+            check(yy, ss, kk, ya, sa)
 
 
 def test_depthwise_backward_is_exact_beside_a_weight_gradient_kernel(ops):

@@ -98,6 +98,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
     layers.DEFER_BN_APPLY = bool(fold)
     prev_fold, layers.FOLD_BN_WINO = layers.FOLD_BN_WINO, bool(fold)
     prev_fold2, layers.FOLD_BN_GEMM = layers.FOLD_BN_GEMM, bool(fold)      # ... and bn2 -> conv3 normalised inside conv3's GEMM and weight gradient
+    prev_fold3, layers.FOLD_BN_DWSEP = layers.FOLD_BN_DWSEP, bool(fold)    # ... and the depthwise stages' outputs inside their pointwise GEMMs
     # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
     # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
     layers.FUSE_RES_GATE = False
@@ -240,6 +241,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
         layers.FUSE_RES_GATE = prev_gate
         layers.FOLD_BN_WINO = prev_fold
         layers.FOLD_BN_GEMM = prev_fold2
+        layers.FOLD_BN_DWSEP = prev_fold3
         layers.set_overlap(*prev_overlap)
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
@@ -571,6 +573,7 @@ def test_deferred_normalisation_equals_the_materialised_one():
     # deferred: stem.6 and sep_bottleneck[0]; + bn1 of the 12 bottlenecks whose conv2 runs through the Winograd domain (layers.FOLD_BN_WINO)
     folded = (12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0) + (4 if (layers.FOLD_BN_CONCAT and layers.WINOGRAD) else 0)
     folded += 16 if (layers.FOLD_BN_GEMM and layers.CONV_MATH == 'f16x3') else 0          # bn2 of every bottleneck: normalised inside conv3's GEMM
+    folded += 5 if (layers.FOLD_BN_DWSEP and layers.CONV_MATH == 'f16x3') else 0          # the five depthwise stages: inside their pointwise GEMMs
     assert applies[False] == 70 and applies[True] == 68 - folded, applies
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
@@ -698,12 +701,78 @@ def test_bn2_folded_into_conv3s_gemm():
         layers.FOLD_BN_GEMM = prev
     on, off = seen_by[True], seen_by[False]
     assert off['pfst_bn_apply'] - on['pfst_bn_apply'] == 16, (off['pfst_bn_apply'], on['pfst_bn_apply'])
-    assert on.get('normalising GEMMs', 0) == 16 and on.get('normalising weight gradients', 0) == 16 and off.get('normalising GEMMs', 0) == 0
+    assert on.get('normalising GEMMs', 0) - off.get('normalising GEMMs', 0) == 16           # (the depthwise-separable modules' pointwise layers: in both runs)
+    assert on.get('normalising weight gradients', 0) - off.get('normalising weight gradients', 0) == 16
     assert on.get('fused BatchNorm-backward sums', 0) == off.get('fused BatchNorm-backward sums', 0) > 0     # conv3's data gradient still emits bn2's sums
     assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
     print(f'   gradient arena, fold on vs off: {e:.2e}')
     assert e < 1e-4, e
+
+
+def test_depthwise_stage_folded_into_the_pointwise_gemm():
+    """layers.FOLD_BN_DWSEP (round 5): in the five DepthwiseSeparableConvModules (the ASPP head's three atrous branches -- one fused launch --,
+    sep_bottleneck[0] and [1]) the depthwise conv -> BN -> ReLU output is never written: the pointwise layer's f16x3 GEMM (2048 / 560 / 512
+    coefficient rows in LDS) and its weight gradient normalise the depthwise kernel's output as they load it, from the maximum predicted out of
+    the depthwise kernels' (min, max) partials.  One segmentor forward + backward with the fold on and off: bit-identical logits, gradients
+    equal to the atomics' summation order, five normalisation launches less.
+    Follows /root/reference/rsiseg/models/decode_heads/sep_aspp_head.py:17-26,63-77 and mmcv's DepthwiseSeparableConvModule."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if not (layers.DEFER_BN_APPLY and layers.CONV_MATH == 'f16x3'):
+        pytest.skip('needs deferred normalisations under the f16x3 arithmetic')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=37)
+    prev, prev_dw = layers.FOLD_BN_DWSEP, layers.FUSE_ASPP_DW
+    inner = ops.call
+    try:
+        for fused_aspp in (True, False):               # the three-branch launch, and the per-branch depthwise kernels
+            layers.FUSE_ASPP_DW = fused_aspp
+            runs, seen_by = {}, {}
+            for fold in (True, False):
+                layers.FOLD_BN_DWSEP = fold
+                model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+                model.load_state_dict(student, strict=True)
+                model.cuda()
+                arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+                model.repack_weights(need_dgrad=True)
+                seen = {}
+
+                def counting(name, *a):
+                    seen[name] = seen.get(name, 0) + 1
+                    if name == 'pfst_conv_igemm_f16x3' and a[27]:
+                        seen['normalising GEMMs'] = seen.get('normalising GEMMs', 0) + 1
+                    if name == 'pfst_conv_wgrad_f16x3' and a[11]:
+                        seen['normalising weight gradients'] = seen.get('normalising weight gradients', 0) + 1
+                    return inner(name, *a)
+                ops.call = counting
+                try:
+                    tape = Tape()
+                    out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                              return_logits=True, tape=tape)
+                    tape.backward()
+                    torch.cuda.synchronize()
+                finally:
+                    ops.call = inner
+                runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
+                seen_by[fold] = seen
+            on, off = seen_by[True], seen_by[False]
+            assert off['pfst_bn_apply'] - on['pfst_bn_apply'] == 5, (fused_aspp, off['pfst_bn_apply'], on['pfst_bn_apply'])
+            assert on.get('normalising GEMMs', 0) - off.get('normalising GEMMs', 0) == 5
+            assert on.get('normalising weight gradients', 0) - off.get('normalising weight gradients', 0) == 5
+            assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
+            _, e = mixed_err(runs[True][1], runs[False][1])
+            print(f'   fused ASPP launch {fused_aspp}: gradient arena, fold on vs off: {e:.2e}')
+            assert e < 1e-4, e
+    finally:
+        layers.FOLD_BN_DWSEP, layers.FUSE_ASPP_DW = prev, prev_dw
 
 
 def test_published_maxima_cover_every_f16x3_operand():
@@ -766,7 +835,7 @@ def test_published_maxima_cover_every_f16x3_operand():
     assert not bad, bad
     if layers.FOLD_BN_WINO and layers.DEFER_BN_APPLY and layers.WINOGRAD:
         # bn1 of layer2.1-3, layer3.0-5, layer4.0-2 (+ the ASPP concat with its four deferred writers): predicted == true maximum, bit for bit
-        assert len(predicted) == 12 + (16 if layers.FOLD_BN_GEMM else 0) + (1 if layers.FOLD_BN_CONCAT else 0), predicted
+        assert len(predicted) == 12 + (16 if layers.FOLD_BN_GEMM else 0) + (5 if layers.FOLD_BN_DWSEP else 0) + (1 if layers.FOLD_BN_CONCAT else 0), predicted
     shapes = [s[0] for s in seen.values()]
     assert (b, cat_ch, S // 8, S // 8) in shapes, 'the ASPP concat must arrive with its shared group'
     assert (b, 64, S // 4, S // 4) in shapes or (b, 128, S // 4, S // 4) in shapes, 'the pooled map must arrive with its group'
