@@ -258,7 +258,10 @@ int pfst_bn_finalize_partials(const float* partials, int T, int C, double count,
  * 1 bit per element instead of the fp32 output y in both of its passes. */
 int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                   const float* mean, const float* invstd, const float* gamma, const float* beta,
-                  int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, const float* post_scale, pfst_stream_t stream);
+                  int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, const float* post_scale,
+                  const float* residual_coef, pfst_stream_t stream);
+/* residual_coef: NULL, or coef [C][4] = (mean, invstd, sc, sh) of the downsample conv -> BN layer (no ReLU, resnet.py:298-303) whose
+ * PRE-normalisation output `residual` then is: normalised as it is loaded, the normalised identity branch is never written */
 /* y_amax: NULL, or the slot group (1024 floats, zeroed) that receives max |y|: the scale of an f16x3 GEMM reading y.
  * post_scale: NULL, or [N][C] factors y is multiplied by after the ReLU -- nn.Dropout2d's keep / (1 - p) mask of the layer feeding conv_seg
  * (decode_head.py:103-107,242-247) folded into this pass (no residual then) */

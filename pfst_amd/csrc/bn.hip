@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        int C, int HW, int relu, unsigned long long* __restrict__ mask, int rev,
-                                                       float* __restrict__ amax, const float* __restrict__ post) {
+                                                       float* __restrict__ amax, const float* __restrict__ post,
+                                                       const float4* __restrict__ res_coef) {
+  // res_coef != NULL: `res` is the PRE-normalisation output of the downsample conv -> BN layer of a residual block (resnet.py:298-303: no
+  // ReLU there) and res_coef[C] = (mean, invstd, sc, sh) its record: the residual is normalised as it is loaded -- fma(r, sc, sh), the value the
+  // layer's own normalisation pass would have written -- and that tensor is never written
   // post != NULL: y is multiplied by post[n][c] after the ReLU -- nn.Dropout2d's keep / (1 - p) factor of the layer that feeds conv_seg
   // (decode_head.py:103-107,242-247) folded into this pass: the same product the separate scaling pass formed, one tensor round trip less
   // rev: walk the tensor from its end (planes, images and blocks in descending order) -- see pfst_bn_order()
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   float sc, sh;
   bn_affine(mean[c], invstd[c], gamma[c], beta[c], sc, sh);
   const float pm = post ? post[n * C + c] : 1.f;
+  const float rsc = res_coef ? res_coef[c].z : 1.f, rsh = res_coef ? res_coef[c].w : 0.f;
   const float* xp = x + (i64)n * x_bs + (i64)c * HW;
   const float* rp = res ? res + (i64)n * res_bs + (i64)c * HW : nullptr;
   float* yp = y + (i64)n * y_bs + (i64)c * HW;
@@ -241,7 +246,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const int i = i0 + u * stride;
         float4 w = v[u];
         w.x = __fmaf_rn(w.x, sc, sh); w.y = __fmaf_rn(w.y, sc, sh); w.z = __fmaf_rn(w.z, sc, sh); w.w = __fmaf_rn(w.w, sc, sh);
-        if (rp) { w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w; }
+        if (rp) {
+          if (res_coef) { r[u].x = __fmaf_rn(r[u].x, rsc, rsh); r[u].y = __fmaf_rn(r[u].y, rsc, rsh); r[u].z = __fmaf_rn(r[u].z, rsc, rsh); r[u].w = __fmaf_rn(r[u].w, rsc, rsh); }
+          w.x += r[u].x; w.y += r[u].y; w.z += r[u].z; w.w += r[u].w;
+        }
         if (mask && i < n4) {
           // ReLU bitmask for the backward pass (the host guarantees HW % 256 == 0, so all 64 lanes are here and hold 256
           // consecutive elements): word [i >> 6][k] bit (lane) <-> component k of lane's float4, i.e. element 4*lane + k
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   } else {
     for (int i = bxi * blockDim.x + threadIdx.x; i < HW; i += stride) {
       float v = __fmaf_rn(xp[i], sc, sh);
-      if (rp) v += rp[i];
+      if (rp) v += res_coef ? __fmaf_rn(rp[i], rsc, rsh) : rp[i];
       if (relu) v = fmaxf(v, 0.f);
       if (post) v *= pm;
       am = fmaxf(am, fabsf(v));
@@ -572,8 +580,9 @@ static constexpr int pfst_bn_order() { return 3; }      // measured (round 3): 3
 extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residual, long long res_bs, float* y, long long y_bs,
                              const float* mean, const float* invstd, const float* gamma, const float* beta,
                              int N, int C, int HW, int relu, unsigned long long* relu_mask, float* y_amax, const float* post_scale,
-                             pfst_stream_t stream) {
+                             const float* residual_coef, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && y && mean && invstd && gamma && beta && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!residual_coef || residual);
   PFST_CHECK_ARG(!post_scale || !residual);          // the folded Dropout2d factor belongs to a plain conv -> BN -> ReLU layer
   // the bitmask comes out of the float4 path only: whole 256-element groups per wave, 16-byte aligned planes
   PFST_CHECK_ARG(!relu_mask || (relu && HW % 256 == 0 && ((x_bs | y_bs | (residual ? res_bs : 0)) & 3) == 0 &&
@@ -581,7 +590,8 @@ extern "C" int pfst_bn_apply(const float* x, long long x_bs, const float* residu
   int gx = cdiv(HW, 256 * 4 * 4);
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, residual, res_bs, y, y_bs, mean,
-                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1, y_amax, post_scale);
+                     invstd, gamma, beta, C, HW, relu, relu_mask, pfst_bn_order() & 1, y_amax, post_scale,
+                     reinterpret_cast<const float4*>(residual_coef));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

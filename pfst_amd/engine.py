@@ -18,7 +18,8 @@ class Var:
     runs closures in reverse recording order, so the LAST writer is the FIRST consumer recorded in forward -- `claim_first_use()`.
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
-    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending', 'coef_table')
+    __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending', 'coef_table',
+                 'lazy_norelu')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -30,6 +31,7 @@ class Var:
         # (pre, coef): a conv -> BN -> ReLU output that is never materialised -- data is None, the ONE consumer (a depthwise layer, the stem's
         # max-pool) normalises the pre-BN tensor `pre` with coef[c] = (mean, invstd, sc, sh) as it loads it (layers.conv_bn_act(defer=True))
         self.lazy = None
+        self.lazy_norelu = False      # lazy, and the deferred layer has NO ReLU (a downsample conv -> BN: read only as bn_apply's residual operand)
         self.amax = None          # device slot with max |data| (scale of the two-piece fp16 split, layers.CONV_MATH == 'f16x3'), set on first use
         # A residual block's identity branch: dL/d(this Var) = [its other consumers' gradients] + g where the block's final ReLU let the
         # sum through.  `gate_consumer`: set in forward by the first consumer (= the last gradient writer) when its data-gradient launch can add

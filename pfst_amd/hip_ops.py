@@ -751,12 +751,13 @@ def bn_stats(x, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, gam
     return (mean, invstd, coef) if gamma is not None else (mean, invstd)
 
 
-def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False, amax=None, post=None):
+def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, want_mask=False, amax=None, post=None, residual_coef=None):
     """want_mask: also return the ReLU gate as a bitmask (int64 words) for bn_backward, or None where the kernel cannot
     produce it (plane size not a multiple of 256, unaligned slices) -- the caller then keeps using y.
     post: [N, C] factors applied after the ReLU (the Dropout2d mask of the layer feeding conv_seg, folded into this pass)"""
     n, c, h, w = x.shape
     assert post is None or (residual is None and post.numel() == n * c)
+    assert residual_coef is None or (residual is not None and tuple(residual_coef.shape) == (c, 4))      # the residual is normalised on load
     if out is None:
         out = torch.empty(n, c, h, w, device=x.device)
     assert out.shape == x.shape
@@ -766,7 +767,7 @@ def bn_apply(x, mean, invstd, gamma, beta, relu=True, residual=None, out=None, w
         mask = torch.empty(n * c * h * w // 64, dtype=torch.int64, device=x.device)
     call('pfst_bn_apply', x.data_ptr(), _bs(x), _p(residual), 0 if residual is None else _bs(residual), out.data_ptr(), _bs(out),
          mean.data_ptr(), invstd.data_ptr(), _dense(gamma).data_ptr(), _dense(beta).data_ptr(), n, c, h * w, int(relu), _p(mask),
-         _p(amax), _p(None if post is None else _dense(post)), _stream())
+         _p(amax), _p(None if post is None else _dense(post)), _p(None if residual_coef is None else _dense(residual_coef)), _stream())
     return (out, mask) if want_mask else out
 
 

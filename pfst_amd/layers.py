@@ -441,6 +441,11 @@ FOLD_BN_GEMM = True
 # -3.0 ms per step in the same-box A/B taken while the switch read the environment (profiles/r05_ab_fold_bn_dwsep.txt: bn_apply -5.1 ms, the
 # normalising GEMMs and weight gradients +2.1)
 FOLD_BN_DWSEP = True
+# the downsample branch of a residual block (conv 1x1 -> BN, no ReLU; resnet.py:298-303): its normalised output has one reader, the residual
+# operand of the block's bn3 normalisation pass -- which applies fma(r, sc, sh) itself as it loads the branch's pre-BN tensor
+# (pfst_bn_apply residual_coef).  Four tensors of 0.27-1.07 GB per pass are not written and not re-read: -2.1 ms per step in the same-box A/B
+# taken while the switch read the environment (profiles/r05_ab_fold_bn_residual.txt).  False: bn_apply writes them
+FOLD_BN_RESIDUAL = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written)
 
@@ -665,7 +670,9 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
 
         def wg():
             _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax, wg_bnl)
-        _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0])
+        # (every tensor the side stream reads is recorded on it: the host drops its references when this closure returns, long before the
+        # queued launch runs -- the coefficient rows of a normalise-on-load input included)
+        _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0], wg_bnl)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
@@ -711,16 +718,24 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     # max |y| of the tensor that is never written: under f16x3 the producing GEMM emits (min, max) partials and the finalize kernel predicts it
     xd = x.data if x.lazy is None else x.lazy[0]
     x_bnl = None if x.lazy is None else x.lazy[1]
+    assert x.lazy is None or not x.lazy_norelu, 'a deferred downsample output (no ReLU) is only read as a residual'
     assert x_bnl is None or conv.depthwise or (conv.wino and conv.bias is None) or conv.fprop_bnl_ok(), \
         'only a depthwise layer, the Winograd input transform, a 256-row 1x1 f16x3 GEMM (or the max-pool) reads a deferred normalisation'
     # defer='slice': `out` is a slice of a concat Var with a coefficient table (Var.coef_table): the PRE-normalisation output goes into the slice,
     # this layer's rows into the table, the predicted maximum into the concat's shared slot group
+    # defer='residual' (a downsample conv -> BN layer, no ReLU): the ONLY consumer is the residual operand of the block's bn3 normalisation
+    # pass, which applies fma(r, sc, sh) as it loads r (ops.bn_apply(residual_coef=...)); the returned Var is marked lazy_norelu
+    as_residual = defer == 'residual'
     into_slice = slice_requested = defer == 'slice'
     need_pred = defer in ('amax', 'slice') and CONV_MATH == 'f16x3'
     if into_slice:
         defer = bool(isinstance(out, Var) and out.parent is not None and out.parent.coef_table is not None and DEFER_BN_APPLY and not _BN_EVAL and relu
                      and residual is None and post_scale is None and not conv.depthwise and not conv.wino and (not need_pred or out.parent.amax is not None))
         into_slice = defer
+    elif as_residual:
+        defer = bool(FOLD_BN_RESIDUAL and DEFER_BN_APPLY and not _BN_EVAL and not relu and residual is None and out is None and post_scale is None
+                     and not conv.depthwise)
+        as_residual = defer
     else:
         defer = bool(defer and DEFER_BN_APPLY and not _BN_EVAL and relu and residual is None and out is None and post_scale is None)
     # Batch statistics over a handful of values per channel (the ASPP image-pool branch: N x C x 1 x 1, i.e. b values) are a
@@ -781,12 +796,15 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     yv = out_var if out_var is not None else Var(None, tape is not None)
     if defer:
         yv.lazy, y = (pre, coef, bn), None           # no normalisation pass: the consumer applies (sc, sh) of `coef` and the ReLU as it loads `pre`
+        yv.lazy_norelu = as_residual                 # (a downsample layer: no ReLU -- only bn_apply's residual operand reads it)
         if need_pred and not into_slice:
             yv.amax = pred_amax                      # max |y| of the tensor that is never written (exact: bn_finalize_partials)
     else:
+        res_lazy = residual is not None and residual.lazy is not None     # a downsample layer's pre-BN output: normalised by this pass as it loads it
+        assert not res_lazy or residual.lazy_norelu, 'only a deferred downsample layer (conv -> BN, no ReLU) may arrive as a lazy residual'
         y = ops.bn_apply(pre, mean, invstd, bn.weight.data, bn.bias.data, relu,
-                         None if residual is None else residual.data, out=out, want_mask=want_mask, amax=_amax_target(yv, pre.device),
-                         post=post_scale)
+                         None if residual is None else (residual.lazy[0] if res_lazy else residual.data), out=out, want_mask=want_mask,
+                         amax=_amax_target(yv, pre.device), post=post_scale, residual_coef=residual.lazy[1] if res_lazy else None)
     gate = None
     if want_mask:
         y, gate = y
@@ -800,7 +818,7 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     in_hw = xd.shape[-2:]
     if final and x.lazy is None and x.requires_grad and conv.dgrad_can_gate(in_hw):
         x.gate_consumer = True            # this layer's data gradient completes dL/dx and can add a gated identity-branch gradient (Var.pending)
-    if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and not defer and not conv.depthwise \
+    if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and (not defer or as_residual) and not conv.depthwise \
             and (pre.shape[2] * pre.shape[3]) % 256 == 0:
         yv.gate_consumer = True           # a downsample layer (conv -> BN, no ReLU): its BatchNorm backward takes (g, mask) as its gated dy
     if coef is not None and out_var is None and post_scale is None and (not defer or (need_pred and not into_slice)):

@@ -61,7 +61,7 @@ class Bottleneck(nn.Module):
         o = conv_bn_act(o, self.conv2, self.bn2, tape, defer='amax' if fold2 else False)
         idt = x
         if self.downsample is not None:
-            idt = conv_bn_act(x, self.downsample[0], self.downsample[1], tape, relu=False)
+            idt = conv_bn_act(x, self.downsample[0], self.downsample[1], tape, relu=False, defer='residual')     # layers.FOLD_BN_RESIDUAL: normalised by bn3's pass
         return conv_bn_act(o, self.conv3, self.bn3, tape, relu=True, residual=idt)
 
 

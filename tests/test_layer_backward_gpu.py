@@ -52,7 +52,7 @@ def _data(v):
     if bn is None:          # a concat buffer with a coefficient table (the ASPP head's, layers.FOLD_BN_CONCAT): rows (mean, invstd, sc, sh) per channel
         # (the kernels' fma rounds once: the product and sum in fp64, then one rounding to fp32)
         return torch.relu((pre.double() * coef[:, 2].double().view(1, -1, 1, 1) + coef[:, 3].double().view(1, -1, 1, 1)).float())
-    return ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, True)
+    return ops.bn_apply(pre, coef[:, 0].contiguous(), coef[:, 1].contiguous(), bn.weight.data, bn.bias.data, not v.lazy_norelu)
 
 
 @pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
@@ -99,6 +99,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
     prev_fold, layers.FOLD_BN_WINO = layers.FOLD_BN_WINO, bool(fold)
     prev_fold2, layers.FOLD_BN_GEMM = layers.FOLD_BN_GEMM, bool(fold)      # ... and bn2 -> conv3 normalised inside conv3's GEMM and weight gradient
     prev_fold3, layers.FOLD_BN_DWSEP = layers.FOLD_BN_DWSEP, bool(fold)    # ... and the depthwise stages' outputs inside their pointwise GEMMs
+    prev_fold4, layers.FOLD_BN_RESIDUAL = layers.FOLD_BN_RESIDUAL, bool(fold)    # ... and the downsample branches inside bn3's normalisation pass
     # ... and every link writes its input gradients itself (the observer compares them closure by closure): the identity-branch gradient that
     # the product folds into conv1's data-gradient epilogue is checked against this wiring in test_residual_gate_in_the_dgrad_epilogue below
     layers.FUSE_RES_GATE = False
@@ -158,7 +159,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
                     leaves += [gam, bet]; keys += ['gamma', 'beta']
                     y = F.batch_norm(y, None, None, gam, bet, True, 0.0, O.BN_EPS)
                     if tag['residual'] is not None:
-                        r = tag['residual'].data.detach().cpu().to(dt).requires_grad_(tag['residual'].requires_grad)
+                        r = _data(tag['residual']).detach().cpu().to(dt).requires_grad_(tag['residual'].requires_grad)
                         if r.requires_grad:
                             leaves.append(r); keys.append('residual')
                         y = y + r
@@ -242,6 +243,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
         layers.FOLD_BN_WINO = prev_fold
         layers.FOLD_BN_GEMM = prev_fold2
         layers.FOLD_BN_DWSEP = prev_fold3
+        layers.FOLD_BN_RESIDUAL = prev_fold4
         layers.set_overlap(*prev_overlap)
 
     print(f'\n{len(rows)} checked tensors over {n_closures} closures (winograd={wino}); worst element error / bound, norm-wise rel:')
@@ -574,6 +576,7 @@ def test_deferred_normalisation_equals_the_materialised_one():
     folded = (12 if (layers.FOLD_BN_WINO and layers.WINOGRAD) else 0) + (4 if (layers.FOLD_BN_CONCAT and layers.WINOGRAD) else 0)
     folded += 16 if (layers.FOLD_BN_GEMM and layers.CONV_MATH == 'f16x3') else 0          # bn2 of every bottleneck: normalised inside conv3's GEMM
     folded += 5 if (layers.FOLD_BN_DWSEP and layers.CONV_MATH == 'f16x3') else 0          # the five depthwise stages: inside their pointwise GEMMs
+    folded += 4 if layers.FOLD_BN_RESIDUAL else 0                                         # the four downsample branches: inside bn3's pass
     assert applies[False] == 70 and applies[True] == 68 - folded, applies
     assert torch.equal(runs[True][0], runs[False][0]), 'deferred and materialised normalisation must give bit-identical logits'
     _, e = mixed_err(runs[True][1], runs[False][1])
@@ -773,6 +776,69 @@ def test_depthwise_stage_folded_into_the_pointwise_gemm():
             assert e < 1e-4, e
     finally:
         layers.FOLD_BN_DWSEP, layers.FUSE_ASPP_DW = prev, prev_dw
+
+
+def test_downsample_branch_folded_into_bn3s_normalisation_pass():
+    """layers.FOLD_BN_RESIDUAL (round 5): the downsample branch of the first block of every stage (conv 1x1 -> BN, no ReLU;
+    /root/reference/rsiseg/models/backbones/resnet.py:298-303) is never written normalised -- the block's bn3 normalisation pass applies the
+    branch's (sc, sh) to its pre-BN tensor as it loads the residual (pfst_bn_apply residual_coef): fma(r, sc, sh) is the value the branch's own
+    pass would have written, so the block outputs are bit-identical; the branch's BatchNorm backward never read its output.  One segmentor
+    forward + backward with the fold on and off: bit-identical logits, gradients equal to the atomics' summation order, four normalisation
+    launches less, and the identity-branch gradient still rides in the gated form (layers.FUSE_RES_GATE)."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if not layers.DEFER_BN_APPLY:
+        pytest.skip('needs deferred normalisations')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=41)
+    runs, seen_by = {}, {}
+    prev = layers.FOLD_BN_RESIDUAL
+    inner = ops.call
+    try:
+        for fold in (True, False):
+            layers.FOLD_BN_RESIDUAL = fold
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            seen = {}
+
+            def counting(name, *a):
+                seen[name] = seen.get(name, 0) + 1
+                if name == 'pfst_bn_apply' and a[17]:
+                    seen['normalising residual passes'] = seen.get('normalising residual passes', 0) + 1
+                if name == 'pfst_bn_backward' and a[12]:
+                    seen['written identity gradients'] = seen.get('written identity gradients', 0) + 1
+                return inner(name, *a)
+            ops.call = counting
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.call = inner
+            runs[fold] = (out['logits'].data.clone(), arena.grad.clone())
+            seen_by[fold] = seen
+    finally:
+        layers.FOLD_BN_RESIDUAL = prev
+    on, off = seen_by[True], seen_by[False]
+    assert off['pfst_bn_apply'] - on['pfst_bn_apply'] == 4, (off['pfst_bn_apply'], on['pfst_bn_apply'])
+    assert on.get('normalising residual passes', 0) == 4 and off.get('normalising residual passes', 0) == 0
+    assert on.get('written identity gradients', 0) == off.get('written identity gradients', 0)          # the gate fold is untouched
+    assert torch.equal(runs[True][0], runs[False][0]), 'folded and materialised normalisation must give bit-identical logits'
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    print(f'   gradient arena, fold on vs off: {e:.2e}')
+    assert e < 1e-4, e
 
 
 def test_published_maxima_cover_every_f16x3_operand():

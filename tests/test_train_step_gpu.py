@@ -521,6 +521,27 @@ def test_stream_overlap_options_do_not_change_the_step():
     assert rel(t1, t0) < 1e-5
 
 
+def test_side_stream_reads_survive_freed_host_references():
+    """Every tensor a queued side-stream launch reads must be recorded on that stream: the host drops its references when a backward closure
+    returns, long before the weight-gradient launch it queued runs, and the caching allocator hands the block to the next allocation of the
+    main stream.  Round 5: the coefficient rows of a normalise-on-load input (layers.FOLD_BN_GEMM / FOLD_BN_DWSEP) were not -- the third model
+    built in one process (recycled, no longer zero-filled memory) produced NaN weight gradients for 485 input channels of an ASPP pointwise
+    layer.  Four models built one after another, same seeds: every step must reproduce the first model's gradients."""
+    from pfst_amd.synthetic import synth_batch
+    batch = to_dev(synth_batch(2, 128, 6, seed=1234), 'cuda')
+    grads = []
+    for _ in range(4):
+        model, opt, _, _ = _build(0.30)
+        random.seed(106); np.random.seed(106)
+        model.train_step(batch, opt)
+        g = model.student_arena.grad.clone().cpu()
+        assert bool(torch.isfinite(g).all()), int((~torch.isfinite(g)).sum())
+        grads.append(g)
+        del model, opt
+    for g in grads[1:]:
+        assert rel(g, grads[0]) < 1e-4, rel(g, grads[0])
+
+
 def test_fused_bn_backward_does_not_change_the_step():
     """layers.FUSE_BN_BWD: the BatchNorm-backward sums come out of the epilogue of the data-gradient launch that completes dL/dy
     (csrc/conv_epilogue.h) instead of a reduction pass -- same mathematics, so one whole train step (both student graphs, as
