@@ -672,7 +672,8 @@ def conv_backward(x, conv, dy, saved_v=None, final=False, dy_amax=None, dw_bnb=N
             _wgrad(conv, xd, dy, saved_v, x_amax, dy_amax, wg_bnl)
         # (every tensor the side stream reads is recorded on it: the host drops its references when this closure returns, long before the
         # queued launch runs -- the coefficient rows of a normalise-on-load input included)
-        _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0], wg_bnl)
+        _on_side_stream(wg, dy, xd, None if saved_v is None else saved_v[0], wg_bnl, x_amax, dy_amax,
+                        None if saved_v is None else saved_v[1])          # (the slot groups are views of an arena block that is replaced every ~10 steps)
         if conv.bias is not None:
             ops.bias_grad_(conv.bias.grad, dy)
         if x.requires_grad:
