@@ -234,11 +234,17 @@ class Conv2dP(nn.Module):
         return ops.conv_dgrad(dy, self.wd, self.cin, in_hw, self.k, self.stride, self.dilation, self.padding,
                               out=out, accumulate=accumulate)
 
-    def repack(self, need_dgrad, batch=None):
+    def repack(self, need_dgrad, batch=None, rec=None):
         """batch: a WeightBatch collecting the f16x3 images of the whole network for its three launches (the other packings, a few
-        small layers, are launched here either way)"""
+        small layers, are launched here either way); rec: a list that receives those other launches as (function, args) -- the model replays
+        them on later steps instead of walking its layers again (EncoderDecoder.repack_weights)"""
         if self.depthwise:
             return
+
+        def launch(fn, *a):
+            if rec is not None:
+                rec.append((fn, a))
+            return fn(*a)
         self.wino = self._wino_eligible()
         f16 = CONV_MATH == 'f16x3'
         self.wino_f16 = self.f16_f = self.f16_d = False
@@ -261,7 +267,7 @@ class Conv2dP(nn.Module):
                                                                             self.ud if need_dgrad else None)
             else:
                 pack = ops.wino_pack_weight_split if split else ops.wino_pack_weight
-                pack(self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
+                launch(pack, self.weight.data, True, need_dgrad, self.uf, self.ud if need_dgrad else None)
             if self.bias is None:
                 return                    # the direct-convolution packings are not needed
         self.f16_f = f16 and ops.f16x3_eligible(self.cin, self.cout, self.k)
@@ -276,7 +282,7 @@ class Conv2dP(nn.Module):
                 self.wd = None
             if fp32_d and self.wd is None:
                 self.wd = torch.empty(self.k * self.k * self.cout, self.cin, device=self.weight.device)
-            ops.pack_weight(self.weight.data, fp32_f, fp32_d, self.wf if fp32_f else None, self.wd if fp32_d else None)
+            launch(ops.pack_weight, self.weight.data, fp32_f, fp32_d, self.wf if fp32_f else None, self.wd if fp32_d else None)
         if self.f16_f or self.f16_d:
             nbytes = 4 * self.weight.numel()
             if self.f16_f and (self.w4f is None or self.w4f.device != self.weight.device):
@@ -296,8 +302,14 @@ class Conv2dP(nn.Module):
                 self.w6f = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
             if self.split_d and (self.w6d is None or self.w6d.device != self.weight.device):
                 self.w6d = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
-            ops.pack_weight_split(self.weight.data, self.split_f, self.split_d, self.w6f if self.split_f else None,
-                                  self.w6d if self.split_d else None)
+            launch(ops.pack_weight_split, self.weight.data, self.split_f, self.split_d, self.w6f if self.split_f else None,
+                   self.w6d if self.split_d else None)
+
+
+def repack_key(need_dgrad):
+    """everything Conv2dP.repack's decisions depend on besides the layer itself: a model replays its recorded packing launches while this (and
+    its weight buffers) stay the same"""
+    return (CONV_MATH, bool(need_dgrad), WINOGRAD, WINO_MIN_CC, WINO_MIN_CC_WGRAD, ops.WINO_TILE, ops.F16X3_MIN_ROWS, WeightBatch.enabled)
 
 
 class WeightBatch:
@@ -335,6 +347,16 @@ class WeightBatch:
             self._build()
             self.key = key
         for c, attr, view in self.views:      # a per-layer repack() in between may have replaced them
+            setattr(c, attr, view)
+        self.slots.zero_()
+        self.prep.run('pfst_weight_prep_batched')
+        self.pack.run('pfst_conv_pack_weight_f16x2_batched')
+
+    def replay(self):
+        """the launches of the last flush() again (same layers, same buffers: the caller checked)"""
+        if not self.items:
+            return
+        for c, attr, view in self.views:
             setattr(c, attr, view)
         self.slots.zero_()
         self.prep.run('pfst_weight_prep_batched')
