@@ -108,7 +108,7 @@ class KernelTimer:
         if name in ('pfst_wino_input', 'pfst_wino_dy'):          # read the image once, write X transform planes of T = HW/m^2 tiles
             return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * (1.0 + (a[8] + 2) ** 2 / a[8] ** 2)
         if name == 'pfst_wino_output':
-            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * ((a[11] + 2) ** 2 / a[11] ** 2 + (2 if a[8] else 1))
+            return name, 0.0, 4.0 * a[3] * a[4] * a[5] * a[6] * ((a[15] + 2) ** 2 / a[15] ** 2 + (2 if a[8] else 1) + (1 if a[11] else 0))
         # HBM-bound kernels: read-once / write-once algorithmic bytes, fp32
         if name == 'pfst_dwconv3x3':
             n, c, h, w_, acc = a[5], a[6], a[7], a[8], a[11]

@@ -118,7 +118,12 @@ int pfst_wino_input(const float* x, long long x_bs, float* V, int N, int C, int 
  * through the transform's norm bound, and v_amax receives that bound (pass v_packed = 1 / packed = 1 to the consumers) */
 int pfst_wino_gemm(const float* V, const float* U, float* Mbuf, int N, int K, int M, int T, int m, pfst_stream_t stream);
 int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                     float* stats, int stats_minmax, int m, pfst_stream_t stream);
+                     float* stats, int stats_minmax, const float* bnb_x, long long bnb_x_bs, const float* bnb_coef, int bnb_relu, int m,
+                     pfst_stream_t stream);
+/* bnb_x != NULL (the output transform of a DATA-GRADIENT launch whose `y` is the complete gradient of a conv -> BN [-> ReLU] layer's output,
+ * no residual -- Bottleneck bn1 behind a Winograd conv2): bnb_x = that layer's pre-BN tensor, bnb_coef its coef [Cout][4]; `stats` then
+ * receives the layer's BatchNorm-backward partials (sum dz, sum dz * x) [Cout][N * pfst_wino_stats_slots][2] for pfst_bn_backward(bwd_partials),
+ * as pfst_conv_igemm's bnb does for the GEMM data gradients: the layer's reduction pass is not launched */
 /* stats != NULL: BatchNorm partials of the output, stats[Cout][N * pfst_wino_stats_slots(H, W, dil, m)][2]; stats_minmax != 0: `stats` has room
  * for twice that and also receives the per-channel (minimum, maximum) partials behind the sums (as pfst_conv_igemm_f16x3's stats_minmax) */
 int pfst_wino_stats_slots(int H, int W, int dil, int m);

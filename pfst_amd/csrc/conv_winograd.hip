@@ -242,7 +242,12 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 // vec != 0 (host: dilation 1, W % M == 0, M-float aligned planes): the M outputs of a tile row are adjacent -> one wide store
 template <int M>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ Mb, float* __restrict__ y, i64 y_bs, int N, int Cout,
-                                                          WinoGeom g, int accumulate, int vec, float* __restrict__ stats, int stats_minmax) {
+                                                          WinoGeom g, int accumulate, int vec, float* __restrict__ stats, int stats_minmax,
+                                                          const float* __restrict__ bnb_x, i64 bnb_x_bs, const float4* __restrict__ bnb_coef, int bnb_relu) {
+  // bnb_x != NULL (data-gradient launches): y is the COMPLETE gradient of a conv -> BN [-> ReLU] layer's output (no residual), bnb_x that
+  // layer's pre-BN tensor and bnb_coef its (mean, invstd, sc, sh) rows: `stats` receives the layer's BatchNorm-backward partials
+  // (sum dz, sum dz * x) per block instead of forward statistics -- dz = the value written, gated by fma(x, sc, sh) > 0 --, in the layout
+  // pfst_bn_backward(bwd_partials) reads (as the GEMM epilogue's fused sums, conv_epilogue.h): the layer's reduction pass is not launched
   constexpr int R = M + 2;
   typedef float vecM __attribute__((ext_vector_type(M)));
   __shared__ double red[32];
@@ -250,6 +255,8 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   float st_lo = __builtin_inff(), st_hi = -__builtin_inff();      // stats_minmax: and their (minimum, maximum), for the predicted max |relu(bn(y))|
   const int c = blockIdx.y, n = blockIdx.z;
   float* yp = y + (i64)n * y_bs + (i64)c * g.H * g.W;
+  const float* bxp = bnb_x ? bnb_x + (i64)n * bnb_x_bs + (i64)c * g.H * g.W : nullptr;
+  const float bsc = bnb_x ? bnb_coef[c].z : 0.f, bsh = bnb_x ? bnb_coef[c].w : 0.f;
   const i64 plane = (i64)N * Cout * g.T;
   const float* mp = Mb + ((i64)n * Cout + c) * g.T;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < g.T; t += gridDim.x * blockDim.x) {
@@ -288,6 +295,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         for (int j = 0; j < M; ++j) v[j] = o[j];
         if (accumulate) v += *q;
         *q = v;
+        if (bxp) {
+          const vecM xv = *reinterpret_cast<const vecM*>(bxp + (i64)yy * g.W + x0);
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            const float dz = (!bnb_relu || __fmaf_rn(xv[j], bsc, bsh) > 0.f) ? v[j] : 0.f;
+            st_s += dz;
+            st_q = fmaf(dz, xv[j], st_q);
+          }
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < M; ++j) {
           const float e = v[j];
@@ -305,10 +322,17 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
           float* q = yp + (i64)yy * g.W + xx;
           const float v = accumulate ? *q + o[j] : o[j];
           *q = v;
-          st_s += v;
-          st_q = fmaf(v, v, st_q);
-          st_lo = fminf(st_lo, v);
-          st_hi = fmaxf(st_hi, v);
+          if (bxp) {
+            const float xs = bxp[(i64)yy * g.W + xx];
+            const float dz = (!bnb_relu || __fmaf_rn(xs, bsc, bsh) > 0.f) ? v : 0.f;
+            st_s += dz;
+            st_q = fmaf(dz, xs, st_q);
+          } else {
+            st_s += v;
+            st_q = fmaf(v, v, st_q);
+            st_lo = fminf(st_lo, v);
+            st_hi = fmaxf(st_hi, v);
+          }
         }
       }
     }
@@ -582,15 +606,19 @@ extern "C" int pfst_wino_stats_slots(int H, int W, int dil, int m) {
 }
 
 extern "C" int pfst_wino_output(const float* Mbuf, float* y, long long y_bs, int N, int Cout, int H, int W, int dil, int accumulate,
-                                float* stats, int stats_minmax, int m, pfst_stream_t stream) {
+                                float* stats, int stats_minmax, const float* bnb_x, long long bnb_x_bs, const float* bnb_coef, int bnb_relu, int m,
+                                pfst_stream_t stream) {
   PFST_CHECK_ARG(Mbuf && y && N > 0 && N <= 65535 && Cout > 0 && Cout <= 65535 && H > 0 && W > 0 && dil >= 1 && y_bs >= (i64)Cout * H * W);
   PFST_CHECK_ARG(!stats_minmax || stats);
+  PFST_CHECK_ARG(!bnb_x || (stats && !stats_minmax && bnb_coef && bnb_x_bs >= (i64)Cout * H * W && (bnb_x_bs % 4) == 0 && ((uintptr_t)bnb_x & 15) == 0));
   PFST_CHECK_TILE(m);
   const WinoGeom g = wino_geom(H, W, dil, m);
   const int vec = dil == 1 && W % m == 0 && y_bs % m == 0 && ((uintptr_t)y & (4 * m - 1)) == 0;
   const dim3 grid(tile_blocks(g.T), Cout, N);
-  PFST_WINO_M(m, hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax),
-              hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax));
+  PFST_WINO_M(m, hipLaunchKernelGGL(wino_output_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax, bnb_x,
+                                 (i64)bnb_x_bs, reinterpret_cast<const float4*>(bnb_coef), bnb_relu),
+              hipLaunchKernelGGL(wino_output_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, Mbuf, y, y_bs, N, Cout, g, accumulate, vec, stats, stats_minmax, bnb_x,
+                                 (i64)bnb_x_bs, reinterpret_cast<const float4*>(bnb_coef), bnb_relu));
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -571,7 +571,7 @@ def wino_pack_weight_f16(w, want_fprop=True, want_dgrad=True, out_f=None, out_d=
 
 
 def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_stats=False, m=None, u_amax=None, x_amax=None, bnl=None,
-              want_minmax=False):
+              want_minmax=False, bnb=None):
     """'same' 3x3 stride-1 convolution (or its data gradient, with the dgrad filter) through the transform domain.
     keep_v: the transformed input goes to a tensor of its own and is returned as (out, V) for the weight gradient
     (288 GB of HBM: keeping it resident beats re-transforming the input in backward).
@@ -604,9 +604,19 @@ def wino_conv(x, u, cout, dil, out=None, accumulate=False, keep_v=False, want_st
     if want_stats:                      # BN partial sums of the output come out of the output transform
         slots = n * lib().pfst_wino_stats_slots(h, w, dil, m)
         st = _stats_ws(x.device, (4 if want_minmax else 2) * cout * slots)
+    bx, bx_bs, bcoef, brelu = 0, 0, 0, 0
+    if bnb is not None:
+        # a data-gradient launch that completes the gradient of a conv -> BN [-> ReLU] layer's output (no residual): bnb = (pre, coef, relu) of
+        # that layer -> returns (out, partials, slots) with its BatchNorm-backward sums for bn_backward(partials=...), no reduction pass
+        assert not want_stats
+        pre, coef, relu = bnb
+        assert tuple(pre.shape) == (n, cout, h, w) and tuple(coef.shape) == (cout, 4)
+        slots = n * lib().pfst_wino_stats_slots(h, w, dil, m)
+        st = torch.empty(2 * cout * slots, dtype=F32, device=x.device)        # owned by the layer's context until its bn_backward ran
+        bx, bx_bs, bcoef, brelu = pre.data_ptr(), _bs(pre), _dense(coef).data_ptr(), int(relu)
     call('pfst_wino_output', mb.data_ptr(), out.data_ptr(), _bs(out), n, cout, h, w, dil, int(accumulate), _p(st),
-         int(bool(want_minmax and want_stats)), m, _stream())
-    res = (out, st, slots) if want_stats else (out,)
+         int(bool(want_minmax and want_stats)), bx, bx_bs, bcoef, brelu, m, _stream())
+    res = (out, st, slots) if (want_stats or bnb is not None) else (out,)
     if keep_v:
         res = res + ((v, v_amax),)          # the transformed input and the slot group with its absolute maximum (None unless f16x3)
     return res if len(res) > 1 else res[0]

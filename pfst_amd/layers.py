@@ -88,6 +88,10 @@ FUSE_BN_BWD_MIN_K = 512
 # the bf16x6 data-gradient kernel carries the same epilogue; measured (b=8, 4-step runs): 439.2 ms with every launch fused, 437.7 ms with none --
 # the cost is not VALU-vs-MFMA contention but the longer workgroup lifetime, in either arithmetic
 FUSE_BN_BWD_MIN_K_SPLIT = 512
+# the same sums out of the Winograd output transform of a data-gradient launch (bn1 behind a Winograd conv2, the aux head's / ASPP bottleneck's
+# inputs where they have a single producer ...): saves the reduction pass of those layers -- -0.95 ms per step in the same-box A/B taken while the
+# switch read the environment (profiles/r05_ab_bnb_wino.txt)
+FUSE_BN_BWD_WINO = True
 
 
 class BnBackwardCtx:
@@ -182,10 +186,12 @@ class Conv2dP(nn.Module):
 
     def can_fuse_bn_backward(self):
         """the data gradient runs on the K-quad implicit-GEMM kernel with whole row tiles (its epilogue can emit the sums)"""
+        if self.wino:                     # the Winograd output transform carries the sums (ops.wino_conv(bnb=...)): one more read of the pre-BN tensor in
+            return FUSE_BN_BWD and FUSE_BN_BWD_WINO            # an HBM-bound kernel instead of the reduction pass's two
         min_k = FUSE_BN_BWD_MIN_K_SPLIT if (self.split_d or self.f16_d) else FUSE_BN_BWD_MIN_K
         if self.f16_d and self.cin % 128 != 0:
             return False                  # the f16x3 kernel's fused epilogue needs whole 128-row tiles
-        return (FUSE_BN_BWD and not self.depthwise and not self.wino and self.cout % 16 == 0
+        return (FUSE_BN_BWD and not self.depthwise and self.cout % 16 == 0
                 and self.cin % ops.bnb_tile_rows(self.cin) == 0 and self.cout * self.k * self.k >= min_k)
 
     def wgrad_f16q_ok(self, h, w):
@@ -208,6 +214,12 @@ class Conv2dP(nn.Module):
         gate: (g, mask) added where the mask has the bit (Var.pending of a residual block's input; only where dgrad_can_gate)"""
         assert gate is None or (self.f16_d and not self.wino and not accumulate)
         if self.wino:
+            if bn is not None:           # the output transform emits the BatchNorm-backward sums of the layer that owns `out` (no residual there)
+                assert bn.y is None
+                _, bn.partials, bn.slots = ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
+                                                         u_amax=self.ud_amax if self.wino_f16 else None,
+                                                         x_amax=dy_amax if self.wino_f16 else None, bnb=(bn.pre, bn.coef, bn.relu))
+                return out
             return ops.wino_conv(dy, self.ud, self.cin, self.dilation, out=out, accumulate=accumulate,
                                  u_amax=self.ud_amax if self.wino_f16 else None, x_amax=dy_amax if self.wino_f16 else None)
         if self.f16_d:
@@ -667,7 +679,7 @@ def _wgrad(conv, xd, dy, saved_v, x_amax=None, dy_amax=None, x_bnl=None):
 def _dgrad_into(x, conv, dy, final, dy_amax=None):
     """data gradient of `conv` into x's gradient buffer; when this launch completes the gradient of a conv -> BN layer's output
     (final) and runs on the K-quad kernel, it also emits that layer's BatchNorm-backward sums (x.bn.partials)"""
-    fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward()
+    fuse = final and x.bn is not None and x.parent is None and conv.can_fuse_bn_backward() and (not conv.wino or x.bn.y is None)
     gate = None
     if x.pending is not None and x.grad_unwritten() and conv.dgrad_can_gate(x.data.shape[-2:]):       # (a pending gate implies a materialised x)
         gate = x.take_pending()           # the identity branch's gated gradient rides in this launch's epilogue (else grad_target writes it out)

@@ -111,3 +111,31 @@ def test_a_late_gradient_writer_after_the_fused_launch_is_an_error():
     v.grad_target(final=True)
     with pytest.raises(RuntimeError):
         v.grad_target()
+
+
+@pytest.mark.parametrize('case', [(2, 128, 128, 16, 16, 1, False, True), (2, 128, 256, 16, 24, 2, True, True), (1, 256, 128, 32, 32, 4, False, False)])
+def test_wino_output_emits_the_bn_backward_sums(ops, case):
+    """pfst_wino_output(bnb_x): the output transform of a Winograd DATA-GRADIENT launch that completes the gradient of a conv -> BN [-> ReLU]
+    layer's output (Bottleneck conv1 -> bn1 -> relu behind a Winograd conv2) also emits that layer's BatchNorm-backward partials, and
+    pfst_bn_backward skips its reduction pass: same dx / dgamma / dbeta as the two-pass kernels on the same gradient tensor (to the
+    summation order), with accumulation into an earlier writer's values and without the ReLU."""
+    n, c, co, h, w, dil, acc, relu = case
+    g = torch.Generator().manual_seed(c + co + h)
+    pre = (torch.randn(n, c, h, w, generator=g) * 1.7 + 0.8).to(DEV)
+    gamma = (0.6 + 0.8 * torch.rand(c, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(c, generator=g)).to(DEV)
+    wc = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).to(DEV)
+    dyc = torch.randn(n, co, h, w, generator=g).to(DEV)
+    old = torch.randn(n, c, h, w, generator=g).to(DEV) if acc else None
+    mean, invstd, coef = ops.bn_stats(pre, gamma=gamma, beta=beta)
+    _, ud = ops.wino_pack_weight(wc, False, True)
+    plain = ops.wino_conv(dyc, ud, c, dil, out=old.clone() if acc else None, accumulate=acc)
+    fused, part, slots = ops.wino_conv(dyc, ud, c, dil, out=old.clone() if acc else None, accumulate=acc, bnb=(pre, coef, relu))
+    assert torch.equal(fused, plain)
+    outs = []
+    for p, s in ((None, 0), (part, slots)):
+        dg, db = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        dx = ops.bn_backward(plain, None, pre, mean, invstd, gamma, dg, db, relu=relu, beta=beta, partials=p, slots=s)
+        outs.append((dx, dg, db))
+    for a, b, what in zip(outs[1], outs[0], ('dx', 'dgamma', 'dbeta')):
+        assert rel(a, b) < 2e-6, (what, rel(a, b))

@@ -170,7 +170,7 @@ def test_winograd_presplit_elementwise_and_what_the_norm_bound_costs(ops, case):
         call('pfst_wino_input', xd.data_ptr(), ci * H * W, v.data_ptr(), n, ci, H, W, d, m, va.data_ptr(), 0, 0, st)
         call('pfst_wino_gemm_f16x3', v.data_ptr(), uf.data_ptr(), af.data_ptr(), va.data_ptr(), mb.data_ptr(), n, ci, co, t, m, 0, st)
         y = torch.empty(n, co, H, W, device=DEV)
-        call('pfst_wino_output', mb.data_ptr(), y.data_ptr(), co * H * W, n, co, H, W, d, 0, 0, 0, m, st)
+        call('pfst_wino_output', mb.data_ptr(), y.data_ptr(), co * H * W, n, co, H, W, d, 0, 0, 0, 0, 0, 0, 0, m, st)
         return y, float(va.max())
 
     y_true, vmax = run_true_max()

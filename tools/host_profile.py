@@ -55,10 +55,18 @@ def main():
         log.append((time.perf_counter(), name))
         return inner(name, *a)
     hip_ops.call = stamped
+    ev_sync = torch.cuda.Event.synchronize
+
+    def stamped_sync(self):                # the step's blocking read (and the label-presence read) return here
+        r = ev_sync(self)
+        log.append((time.perf_counter(), '<Event.synchronize returned>'))
+        return r
+    torch.cuda.Event.synchronize = stamped_sync
     t0 = time.perf_counter()
     run(2)
     torch.cuda.synchronize()
     hip_ops.call = inner
+    torch.cuda.Event.synchronize = ev_sync
     names = [n for _, n in log]
     # the second step starts at the second pfst_ema_update
     k = [i for i, n in enumerate(names) if n == 'pfst_ema_update']
@@ -66,7 +74,7 @@ def main():
         i0 = k[1]
         print('host time stamps around the step boundary (ms relative to the last launch of the previous step):')
         base = log[i0 - 1][0]
-        for t, n in log[max(0, i0 - 4):i0 + 40]:
+        for t, n in log[max(0, i0 - 5):i0 + 30]:
             print(f'  {1e3 * (t - base):8.3f}  {n}')
     print(f'launches per step: {len(log) / 2:.0f}; host wall per step {1e3 * (time.perf_counter() - t0) / 2:.1f} ms')
     pr = cProfile.Profile()

@@ -24,7 +24,7 @@ for m in (4, 2):
         v = torch.empty(nx * B * c * t, device='cuda')
         nb = x.numel() * 4
         ti = timeit(lambda: call('pfst_wino_input', x.data_ptr(), c * hw * hw, v.data_ptr(), B, c, hw, hw, d, m, 0, 0, st))
-        to = timeit(lambda: call('pfst_wino_output', v.data_ptr(), y.data_ptr(), c * hw * hw, B, c, hw, hw, d, 0, 0, 0, m, st))
+        to = timeit(lambda: call('pfst_wino_output', v.data_ptr(), y.data_ptr(), c * hw * hw, B, c, hw, hw, d, 0, 0, 0, 0, 0, 0, 0, m, st))
         td = timeit(lambda: call('pfst_wino_dy', x.data_ptr(), c * hw * hw, v.data_ptr(), B, c, hw, hw, d, m, 0, 0, st))
         f = 1 + nx / m ** 2
         print(f'm={m} {name:14s} input {ti:6.3f} ms {nb * f / ti / 1e6:6.0f} GB/s | output {to:6.3f} ms {nb * f / to / 1e6:6.0f} GB/s | dy {td:6.3f} ms {nb * f / td / 1e6:6.0f} GB/s', flush=True)
