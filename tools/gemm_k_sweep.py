@@ -14,6 +14,7 @@ def main():
     ap.add_argument('--m', default='512,2048')
     ap.add_argument('--reps', type=int, default=30)
     ap.add_argument('--stats', type=int, default=0, help='1: with the fused BatchNorm statistics (as every conv -> BN layer runs), 2: + min / max partials')
+    ap.add_argument('--bnl', action='store_true', help='the normalising form: the input is a pre-BN tensor, normalised between load and split (K <= 2048)')
     args = ap.parse_args()
     n, hw = 8, 128
     for m in [int(v) for v in args.m.split(',')]:
@@ -24,12 +25,15 @@ def main():
             w4f, _, wa = H.pack_weight_f16x2(w, True, False)
             xa = H.absmax(x)
             out = torch.empty(n, m, hw, hw, device='cuda')
+            coef = None
+            if args.bnl and H.conv_fprop_bnl_ok(k, m, 1):
+                coef = torch.stack([torch.zeros(k), torch.ones(k), torch.rand(k) + 0.5, torch.randn(k) * 0.1], 1).cuda().contiguous()
             for _ in range(3):
-                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1)
+                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1, bnl=coef)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(args.reps):
-                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1)
+                H.conv_fprop_f16x3(x, w4f, wa, xa, m, 1, out=out, want_stats=args.stats > 0, want_minmax=args.stats > 1, bnl=coef)
             e.record()
             torch.cuda.synchronize()
             ms = s.elapsed_time(e) / args.reps
