@@ -23,7 +23,7 @@ for m in (4, 2):
         t = ops.wino_tiles(hw, hw, d, m)
         v = torch.empty(nx * B * c * t, device='cuda')
         nb = x.numel() * 4
-        ti = timeit(lambda: call('pfst_wino_input', x.data_ptr(), c * hw * hw, v.data_ptr(), B, c, hw, hw, d, m, 0, 0, st))
+        ti = timeit(lambda: call('pfst_wino_input', x.data_ptr(), c * hw * hw, v.data_ptr(), B, c, hw, hw, d, m, 0, 0, 0, st))
         to = timeit(lambda: call('pfst_wino_output', v.data_ptr(), y.data_ptr(), c * hw * hw, B, c, hw, hw, d, 0, 0, 0, 0, 0, 0, 0, m, st))
         td = timeit(lambda: call('pfst_wino_dy', x.data_ptr(), c * hw * hw, v.data_ptr(), B, c, hw, hw, d, m, 0, 0, st))
         f = 1 + nx / m ** 2
