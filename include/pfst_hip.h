@@ -46,6 +46,8 @@ typedef struct pfst_bnb_fuse {
   const float* coef;         /* [M][4] = (mean, invstd, sc, sh) of that layer as pfst_bn_finalize_partials / pfst_bn_stats wrote them */
   float* partials;           /* out: [M][T][2] = (sum dz, sum dz * x) per channel and slot */
   int relu;
+  const unsigned long long* y_mask; /* optional, with y: pfst_bn_apply's ReLU bitmask of y ([N][M][HW / 64] words, HW % 256 == 0) -- the f16x3
+                                      kernel then takes a residual layer's gate bits from it instead of reading y */
 } pfst_bnb_fuse_t;
 
 /* What a kernel needs to apply the SECOND pass of BatchNorm backward on the fly, per channel: dx = gs * (dz - m1 - xhat * m2) with

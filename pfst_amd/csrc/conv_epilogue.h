@@ -96,7 +96,8 @@ __device__ __forceinline__ float half_wave_rowsum_lds(const float (&v)[16], floa
   return s + lane_xchg<0>(s);
 }
 
-// BNB: 0 = off; fused BatchNorm-backward sums with the ReLU gate 1 = recomputed from x, 2 = read from y, 3 = none (layer without ReLU)
+// BNB: 0 = off; fused BatchNorm-backward sums with the ReLU gate 1 = recomputed from x, 2 = read from y, 3 = none (layer without ReLU),
+// 4 = from bn_apply's bitmask of y (residual layers; P % 256 == 0)
 // LDSRED: the per-row sums are reduced through the LDS scratch `lds` (half_wave_rowsum_lds) instead of the DPP butterfly
 template <int TM, int TN, int WAVES_N, int BN, int BNB = 0, bool LDSRED = false>
 __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float* __restrict__ out, const float* __restrict__ bias,
@@ -310,7 +311,10 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
       const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bnb.y ? bnb.y + (i64)n * bnb.y_bs : bnb.x), 0,
                                                                           M * P * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bnb.coef), 0, M * 16, 0x00020000);
-      constexpr bool gate_x = BNB == 1, gate_y = BNB == 2;
+      constexpr bool gate_x = BNB == 1, gate_y = BNB == 2, gate_m = BNB == 4;
+      // gate_m: one 4-byte mask word per accumulator row serves both column blocks (as for the gated addend above)
+      const __amdgpu_buffer_rsrc_t ymr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned long long*>(gate_m ? bnb.y_mask + (i64)n * M * (P >> 6) : nullptr), 0, gate_m ? M * (P >> 6) * 8 : 0, 0x00020000);
       const unsigned cvoff = 64u * (unsigned)lh + 8u;           // row + 4 lh, fields (sc, sh)
       const int gxp = (P + BN - 1) / BN;
       const int slot = (n * gxp + bx) * WAVES_N + (wid % WAVES_N);
@@ -318,6 +322,12 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         float sv[16], sq[16];
+        int yw[gate_m ? 16 : 1];
+        if constexpr (gate_m) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            yw[r] = __builtin_amdgcn_raw_buffer_load_b32(ymr, mvoff, 8 * (P >> 6) * (row0 + i * 32 + (r & 3) + 8 * (r >> 2)), 0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
@@ -336,6 +346,8 @@ __device__ __forceinline__ void conv_epilogue(pfst_f32x16 (&acc)[TM][TN], float*
               dz = yv > 0.f ? dz : 0.f;
             } else if (gate_x) {
               dz = __fmaf_rn(xv, sc, sh) > 0.f ? dz : 0.f;
+            } else if constexpr (gate_m) {
+              dz = __builtin_bit_cast(float, __builtin_bit_cast(int, dz) & __builtin_amdgcn_sbfe(yw[r], (unsigned)((gbit & 31) + 8 * j), 1u));
             }
             a += dz;
             b = fmaf(dz, xv, b);

@@ -1033,6 +1033,7 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
     gate.mask = gate_mask;
   }
   PFST_CHECK_ARG(!bnb || (bnb->x && bnb->x_bs >= (i64)M * Ho * Wo && (!bnb->y || bnb->y_bs >= (i64)M * Ho * Wo)));
+  PFST_CHECK_ARG(!bnb || !bnb->y_mask || (bnb->y && bnb->relu && ((i64)Ho * Wo) % 256 == 0));      // the gate bits of a residual layer's y
   PFST_CHECK_ARG((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && dil >= 1 && pad >= 0 && (mode == 0 || mode == 1));
   PFST_CHECK_ARG(in_bs >= (i64)C * Hi * Wi && out_bs >= (i64)M * Ho * Wo && N <= 65535);
   // 32-bit buffer ranges and offsets (the out-of-range marker 0x80000000 is ADDED to them): one image of either operand and the weight
@@ -1073,14 +1074,17 @@ extern "C" int pfst_conv_igemm_f16x3(const float* in, long long in_bs, const voi
                        out, (i64)out_bs, C, Hi, Wi, M, Ho, Wo, ksize, a, b, c, d, accumulate, stats, stats_T, w_amax, in_amax, 1, N, chain, *bnb, gate)
     if (big) {
       if (!bnb->relu) PFST_LAUNCH_F16_BNB_BIG(3);
+      else if (bnb->y_mask) PFST_LAUNCH_F16_BNB_BIG(4);
       else if (bnb->y) PFST_LAUNCH_F16_BNB_BIG(2);
       else PFST_LAUNCH_F16_BNB_BIG(1);
     } else if (one) {
       if (!bnb->relu) PFST_LAUNCH_F16_BNB(3, true);
+      else if (bnb->y_mask) PFST_LAUNCH_F16_BNB(4, true);
       else if (bnb->y) PFST_LAUNCH_F16_BNB(2, true);
       else PFST_LAUNCH_F16_BNB(1, true);
     } else {
       if (!bnb->relu) PFST_LAUNCH_F16_BNB(3, false);
+      else if (bnb->y_mask) PFST_LAUNCH_F16_BNB(4, false);
       else if (bnb->y) PFST_LAUNCH_F16_BNB(2, false);
       else PFST_LAUNCH_F16_BNB(1, false);
     }

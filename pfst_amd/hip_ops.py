@@ -183,7 +183,7 @@ def bn_finalize_partials(stats, slots, c, count, running_mean=None, running_var=
 
 class _BnbFuseStruct(ctypes.Structure):           # pfst_bnb_fuse_t (include/pfst_hip.h)
     _fields_ = [('x', ctypes.c_void_p), ('x_bs', ctypes.c_longlong), ('y', ctypes.c_void_p), ('y_bs', ctypes.c_longlong),
-                ('coef', ctypes.c_void_p), ('partials', ctypes.c_void_p), ('relu', ctypes.c_int)]
+                ('coef', ctypes.c_void_p), ('partials', ctypes.c_void_p), ('relu', ctypes.c_int), ('y_mask', ctypes.c_void_p)]
 
 
 def bnb_tile_rows(m):
@@ -419,12 +419,14 @@ def conv_dgrad_f16x3(dy, wk4_d, w_amax, dy_amax, cin, in_hw, ksize, stride=1, di
 
 def _bnb_struct(bnb, n, cin, hi, wi, co, dev):
     """-> (ctypes struct kept alive by the caller, partials tensor, slots) for a fused BatchNorm-backward data-gradient launch"""
-    pre, y, coef, relu = bnb
+    pre, y, coef, relu = bnb[:4]
+    mask = bnb[4] if len(bnb) > 4 else None            # bn_apply's ReLU bitmask of y: the f16x3 epilogue reads the gate bits instead of y
     assert tuple(pre.shape) == (n, cin, hi, wi) and (y is None or tuple(y.shape) == tuple(pre.shape))
+    assert mask is None or (y is not None and relu and (hi * wi) % 256 == 0 and mask.dtype == torch.int64 and mask.numel() == n * cin * hi * wi // 64)
     assert co % 16 == 0 and cin % bnb_tile_rows(cin) == 0 and tuple(coef.shape) == (cin, 4)
     slots = conv_stats_slots(n, cin, hi, wi)
     part = torch.empty(2 * cin * slots, dtype=F32, device=dev)     # owned by the consumer layer's context until its bn_backward ran
-    st = _BnbFuseStruct(pre.data_ptr(), _bs(pre), _p(y), 0 if y is None else _bs(y), _dense(coef).data_ptr(), part.data_ptr(), int(relu))
+    st = _BnbFuseStruct(pre.data_ptr(), _bs(pre), _p(y), 0 if y is None else _bs(y), _dense(coef).data_ptr(), part.data_ptr(), int(relu), _p(mask))
     return st, part, slots
 
 

@@ -92,14 +92,18 @@ FUSE_BN_BWD_MIN_K_SPLIT = 512
 # inputs where they have a single producer ...): saves the reduction pass of those layers -- -0.95 ms per step in the same-box A/B taken while the
 # switch read the environment (profiles/r05_ab_bnb_wino.txt)
 FUSE_BN_BWD_WINO = True
+# a residual layer's gate inside the fused sums: from bn_apply's 1-bit mask of y instead of y (a compile-time variant of the f16x3 epilogue;
+# -0.8 ms per step, profiles/r05_ab_bnb_mask.txt)
+BNB_GATE_FROM_MASK = True
 
 
 class BnBackwardCtx:
     """what the launch completing a conv -> BN layer's output gradient needs to emit that layer's BatchNorm-backward sums"""
-    __slots__ = ('pre', 'y', 'coef', 'relu', 'partials', 'slots')
+    __slots__ = ('pre', 'y', 'coef', 'relu', 'partials', 'slots', 'mask')
 
-    def __init__(self, pre, y, coef, relu):
+    def __init__(self, pre, y, coef, relu, mask=None):
         self.pre, self.y, self.coef, self.relu = pre, y, coef, relu
+        self.mask = mask                 # bn_apply's ReLU bitmask of y (residual layers): the f16x3 epilogue gates with its bits instead of reading y
         self.partials, self.slots = None, 0
 
 
@@ -227,7 +231,7 @@ class Conv2dP(nn.Module):
             if bn is not None:
                 _, bn.partials, bn.slots = ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride,
                                                                 self.dilation, self.padding, out=out, accumulate=accumulate,
-                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu), gate=gate)
+                                                                bnb=(bn.pre, bn.y, bn.coef, bn.relu, bn.mask), gate=gate)
                 return out
             return ops.conv_dgrad_f16x3(dy, self.w4d, self.w_amax, amax, self.cin, in_hw, self.k, self.stride, self.dilation,
                                         self.padding, out=out, accumulate=accumulate, gate=gate)
@@ -859,7 +863,8 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     if coef is not None and out_var is None and post_scale is None and (not defer or (need_pred and not into_slice)):
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
-        yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu)
+        yv.bn = BnBackwardCtx(pre, y if (relu and residual is not None) else None, coef, relu,
+                              gate if (BNB_GATE_FROM_MASK and relu and residual is not None) else None)
 
     def bwd():
         ext_gate = None

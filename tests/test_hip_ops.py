@@ -322,6 +322,14 @@ def test_f16x3_dgrad_adds_the_gated_identity_gradient(ops, case):
     out_a, part_a, slots = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, bnb=(pre2, y2, coef2, True), gate=(gsrc, mask))
     out_b, part_b, _ = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, out=gated.clone(), accumulate=True, bnb=(pre2, y2, coef2, True))
     assert torch.equal(out_a, out_b) and torch.equal(part_a, part_b)
+    # the residual layer's gate taken from bn_apply's bitmask of y instead of y itself (pfst_bnb_fuse_t.y_mask): the same bits, the same sums
+    y2m, mask2 = ops.bn_apply(pre2, m2, i2, one, zero, True, residual=torch.randn(x.shape, generator=g(14)).to(DEV), want_mask=True)
+    assert mask2 is not None and torch.equal(y2m, y2)
+    out_c, part_c, _ = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, bnb=(pre2, y2, coef2, True, mask2), gate=(gsrc, mask))
+    out_d, part_d, _ = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, bnb=(pre2, y2, coef2, True, mask2))
+    out_e, part_e, _ = ops.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (H, W), k, s, d, p, bnb=(pre2, y2, coef2, True))
+    assert torch.equal(out_c, out_a) and torch.equal(part_c, part_a)
+    assert torch.equal(out_d, out_e) and torch.equal(part_d, part_e)
 
 
 @pytest.mark.parametrize('spread', [0.0, 2.5])

@@ -29,7 +29,7 @@ def timeit(fn, reps=10):
 
 def main():
     n, hw = 8, 128
-    print(f'{"dy -> dx":>14s} {"plain":>8s} {"bnb x":>8s} {"bnb y":>8s} {"sums":>8s}   ms; fused costs (bnb - plain) against the separate pass (sums)')
+    print(f'{"dy -> dx":>14s} {"plain":>8s} {"bnb x":>8s} {"bnb y":>8s} {"bnb bits":>8s} {"sums":>8s}   ms; fused costs (bnb - plain) against the separate pass (sums)')
     for co, ci in ((2048, 512), (1024, 256), (512, 2048), (256, 1024), (512, 128)):
         if not H.f16x3_eligible(co, ci, 1):
             continue
@@ -48,8 +48,9 @@ def main():
         ok = ci % H.bnb_tile_rows(ci) == 0
         t1 = timeit(lambda: H.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (hw, hw), 1, out=out, bnb=(pre, None, coef, True))) if ok else float('nan')
         t2 = timeit(lambda: H.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (hw, hw), 1, out=out, bnb=(pre, y, coef, True))) if ok else float('nan')
+        t2m = timeit(lambda: H.conv_dgrad_f16x3(dy, w4d, wa, da, ci, (hw, hw), 1, out=out, bnb=(pre, y, coef, True, mask))) if ok else float('nan')
         t3 = timeit(lambda: H.bn_backward_sums(out, pre, mean, invstd, g, b, dg, db))
-        print(f'{co:6d} -> {ci:4d} {t0:8.3f} {t1:8.3f} {t2:8.3f} {t3:8.3f}   +{t1 - t0:.3f} / +{t2 - t0:.3f} vs {t3:.3f}', flush=True)
+        print(f'{co:6d} -> {ci:4d} {t0:8.3f} {t1:8.3f} {t2:8.3f} {t2m:8.3f} {t3:8.3f}   +{t1 - t0:.3f} / +{t2 - t0:.3f} / +{t2m - t0:.3f} vs {t3:.3f}', flush=True)
 
 
 if __name__ == '__main__':
