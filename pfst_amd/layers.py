@@ -87,6 +87,7 @@ FUSE_RES_GATE = True
 FUSE_BN_BWD_MIN_K = 512
 # the bf16x6 data-gradient kernel carries the same epilogue; measured (b=8, 4-step runs): 439.2 ms with every launch fused, 437.7 ms with none --
 # the cost is not VALU-vs-MFMA contention but the longer workgroup lifetime, in either arithmetic
+# (round 5, with the mask-gated epilogue: 256 instead of 512 moves 2.1 ms out of bn_backward and 1.7 ms into the GEMMs: -0.4 ms per step, left at 512)
 FUSE_BN_BWD_MIN_K_SPLIT = 512
 # the same sums out of the Winograd output transform of a data-gradient launch (bn1 behind a Winograd conv2, the aux head's / ASPP bottleneck's
 # inputs where they have a single producer ...): saves the reduction pass of those layers -- -0.95 ms per step in the same-box A/B taken while the
