@@ -135,6 +135,47 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ x, i64 x_bs, fl
     yp[o] = v;
   }
 }
+// x2 up-sampling (the decoder's resize of the ASPP output to the c1 resolution, sep_aspp_head.py:96-100).  At scale 1/2 the source index of
+// output o is o/2 - 1/4: outputs 4j .. 4j+3 of a row blend the source column pairs (2j-1, 2j), (2j, 2j+1), (2j, 2j+1), (2j+1, 2j+2) with
+// weights (.25, .75), (.75, .25), (.25, .75), (.75, .25) -- exactly what bilin_src returns there (0.5 (o + 0.5) - 0.5 and its fraction are
+// exact in fp32) --, the first output of a row being the clamped case (weights 1, 0 on columns 0, 1); output rows 2p-1 and 2p blend the SAME
+// source rows p-1, p.  One thread: one 8-byte load + two clamped scalars from each of the two source rows, eight outputs, two 16-byte stores;
+// row weights from bilin_src, the blend is bilin_blend: bit-identical to the generic kernel, which gathers four values, runs two index
+// computations and stores four bytes per output (2.3 TB/s).   grid: ((Hi + 1) / 4 rounded up, C, N), 256 threads = four row pairs; Wi even
+__global__ __launch_bounds__(256) void resize_bilinear2x_kernel(const float* __restrict__ x, i64 x_bs, float* __restrict__ y, i64 y_bs, int C,
+                                                                int Hi, int Wi) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Ho = 2 * Hi, Wo = 2 * Wi, W4 = Wo >> 2;
+  const float* xp = x + (i64)n * x_bs + (i64)c * Hi * Wi;
+  float* yp = y + (i64)n * y_bs + (i64)c * Ho * Wo;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);            // output rows 2p-1 (p >= 1) and 2p (p <= Hi-1) from source rows p-1, p
+  if (p > Hi) return;
+  const int ra = max(p - 1, 0), rb = min(p, Hi - 1);
+  const float* r0 = xp + (i64)ra * Wi;
+  const float* r1 = xp + (i64)rb * Wi;
+  const bool hasA = p >= 1, hasB = p <= Hi - 1;
+  int y0, y1;
+  float la0 = 0.f, la1 = 0.f, lb0 = 0.f, lb1 = 0.f;
+  if (hasA) bilin_src(2 * p - 1, 0.5f, Hi, y0, y1, la0, la1);  // (y0, y1) = (ra, rb)
+  if (hasB) bilin_src(2 * p, 0.5f, Hi, y0, y1, lb0, lb1);      // (ra, rb) too; p = 0: (0, 1) with weights (1, 0) -- row 1 is not read, its weight is 0
+  float4* outA = reinterpret_cast<float4*>(yp + (i64)(2 * p - 1) * Wo);
+  float4* outB = reinterpret_cast<float4*>(yp + (i64)(2 * p) * Wo);
+  for (int j = threadIdx.x & 63; j < W4; j += 64) {
+    const int cl = max(2 * j - 1, 0), cr = min(2 * j + 2, Wi - 1);
+    const float2 m0 = *reinterpret_cast<const float2*>(r0 + 2 * j), m1 = *reinterpret_cast<const float2*>(r1 + 2 * j);
+    const float l0 = r0[cl], l1 = r1[cl], g0 = r0[cr], g1 = r1[cr];
+    auto row = [&](float ly0, float ly1) {
+      float4 o;
+      o.x = j > 0 ? bilin_blend(l0, m0.x, l1, m1.x, 0.25f, 0.75f, ly0, ly1) : bilin_blend(m0.x, m0.y, m1.x, m1.y, 1.f, 0.f, ly0, ly1);
+      o.y = bilin_blend(m0.x, m0.y, m1.x, m1.y, 0.75f, 0.25f, ly0, ly1);
+      o.z = bilin_blend(m0.x, m0.y, m1.x, m1.y, 0.25f, 0.75f, ly0, ly1);
+      o.w = bilin_blend(m0.y, g0, m1.y, g1, 0.75f, 0.25f, ly0, ly1);
+      return o;
+    };
+    if (hasA) outA[j] = row(la0, la1);
+    if (hasB) outB[j] = row(lb0, lb1);
+  }
+}
 // adjoint as a gather over input pixels (deterministic, no atomics)
 __global__ void resize_bilinear_bwd_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dx, i64 dx_bs, int C, int Hi,
                                            int Wi, int Ho, int Wo, float sh, float sw, int accumulate) {
@@ -190,6 +231,60 @@ __global__ __launch_bounds__(256) void resize_bilinear2x_bwd_kernel(const float*
       acc = fmaf(wy[a], wx[0] * lft + wx[1] * mid.x + wx[2] * mid.y + wx[3] * rgt, acc);
     }
     dp[i] = accumulate ? dp[i] + acc : acc;
+  }
+}
+
+// the same adjoint, a 2 x 2 block of input pixels per thread (Hi, Wi even, 16-byte aligned dy rows): the block's taps lie in 6 rows x 6
+// columns of dy -- one 16-byte load + two clamped scalars per row instead of (8-byte load + two scalars) x 4 rows per input pixel -- with the
+// taps and weights of resize_bilinear2x_bwd_kernel (a weight-0 tap multiplies whichever finite value sits in its register).
+// grid: (blocks over Hi*Wi/4, C, N)
+__global__ __launch_bounds__(256) void resize_bilinear2x_bwd_q_kernel(const float* __restrict__ dy, i64 dy_bs, float* __restrict__ dx,
+                                                                      i64 dx_bs, int C, int Hi, int Wi, int accumulate) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int Wo = 2 * Wi, Ho = 2 * Hi, W2 = Wi >> 1, H2 = Hi >> 1;
+  const float* gp = dy + (i64)n * dy_bs + (i64)c * 4 * Hi * Wi;
+  float* dp = dx + (i64)n * dx_bs + (i64)c * Hi * Wi;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < H2 * W2; b += gridDim.x * blockDim.x) {
+    const int by = b / W2, bx = b - by * W2;
+    const int iy0 = 2 * by, ix0 = 2 * bx;
+    // columns 2 ix0 - 1 .. 2 ix0 + 4 of dy rows 2 iy0 - 1 .. 2 iy0 + 4 (clamped: those taps carry weight 0)
+    float v[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int oy = min(max(2 * iy0 - 1 + r, 0), Ho - 1);
+      const float* row = gp + (i64)oy * Wo + 2 * ix0;
+      const float4 mid = *reinterpret_cast<const float4*>(row);
+      v[r][0] = row[ix0 > 0 ? -1 : 0];
+      v[r][1] = mid.x; v[r][2] = mid.y; v[r][3] = mid.z; v[r][4] = mid.w;
+      v[r][5] = row[ix0 + 1 < Wi - 1 ? 4 : 3];
+    }
+    float o[2][2];
+#pragma unroll
+    for (int dyi = 0; dyi < 2; ++dyi) {
+      const int iy = iy0 + dyi;
+      float wy[4];
+      wy[0] = iy > 0 ? 0.25f : 0.f;  wy[1] = iy > 0 ? 0.75f : 1.f;  wy[2] = iy < Hi - 1 ? 0.75f : 1.f;  wy[3] = iy < Hi - 1 ? 0.25f : 0.f;
+#pragma unroll
+      for (int dxi = 0; dxi < 2; ++dxi) {
+        const int ix = ix0 + dxi;
+        float wx[4];
+        wx[0] = ix > 0 ? 0.25f : 0.f;  wx[1] = ix > 0 ? 0.75f : 1.f;  wx[2] = ix < Wi - 1 ? 0.75f : 1.f;  wx[3] = ix < Wi - 1 ? 0.25f : 0.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float* q = &v[2 * dyi + a][2 * dxi];
+          acc = fmaf(wy[a], wx[0] * q[0] + wx[1] * q[1] + wx[2] * q[2] + wx[3] * q[3], acc);
+        }
+        o[dyi][dxi] = acc;
+      }
+    }
+#pragma unroll
+    for (int dyi = 0; dyi < 2; ++dyi) {
+      float2* d2 = reinterpret_cast<float2*>(dp + (i64)(iy0 + dyi) * Wi + ix0);
+      float2 w2 = make_float2(o[dyi][0], o[dyi][1]);
+      if (accumulate) { const float2 old = *d2; w2.x = old.x + w2.x; w2.y = old.y + w2.y; }
+      *d2 = w2;
+    }
   }
 }
 
@@ -352,6 +447,12 @@ extern "C" int pfst_maxpool3x3s2_bwd(const float* dy, const unsigned char* idx, 
 
 extern "C" int pfst_resize_bilinear(const float* x, long long x_bs, float* y, long long y_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, pfst_stream_t stream) {
   PFST_CHECK_ARG(x && y && N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C <= 65535 && N <= 65535);
+  if (Ho == 2 * Hi && Wo == 2 * Wi && Hi > 1 && Wi > 1 && (Wi & 1) == 0 && (x_bs & 1) == 0 && (y_bs & 3) == 0 &&
+      (reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {                  // decoder up-sampling
+    hipLaunchKernelGGL(resize_bilinear2x_kernel, dim3(cdiv(Hi + 1, 4), C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, y_bs, C, Hi, Wi);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(hw_blocks(Ho * Wo), C, N), dim3(256), 0, (hipStream_t)stream, x, x_bs, y, y_bs, C, Hi,
                      Wi, Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
   PFST_CHECK_LAUNCH();
@@ -359,6 +460,13 @@ extern "C" int pfst_resize_bilinear(const float* x, long long x_bs, float* y, lo
 }
 extern "C" int pfst_resize_bilinear_bwd(const float* dy, long long dy_bs, float* dx, long long dx_bs, int N, int C, int Hi, int Wi, int Ho, int Wo, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(dy && dx && N > 0 && C > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C <= 65535 && N <= 65535);
+  if (Ho == 2 * Hi && Wo == 2 * Wi && Hi > 1 && Wi > 1 && (Hi & 1) == 0 && (Wi & 1) == 0 && (dy_bs & 3) == 0 && (dx_bs & 1) == 0 &&
+      (reinterpret_cast<uintptr_t>(dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0) {       // decoder up-sampling, 2 x 2 blocks
+    hipLaunchKernelGGL(resize_bilinear2x_bwd_q_kernel, dim3(hw_blocks(Hi * Wi / 4), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dx,
+                       dx_bs, C, Hi, Wi, accumulate);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   if (Ho == 2 * Hi && Wo == 2 * Wi && Hi > 1 && Wi > 1 && (dy_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(dy) & 7) == 0) {   // decoder up-sampling
     hipLaunchKernelGGL(resize_bilinear2x_bwd_kernel, dim3(hw_blocks(Hi * Wi), C, N), dim3(256), 0, (hipStream_t)stream, dy, dy_bs, dx,
                        dx_bs, C, Hi, Wi, accumulate);

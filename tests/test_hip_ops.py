@@ -647,7 +647,7 @@ def test_maxpool(ops, H, W):
 
 
 @pytest.mark.parametrize('hi,wi,ho,wo', [(8, 8, 16, 16), (16, 12, 64, 48), (5, 7, 13, 9), (1, 1, 6, 6), (16, 16, 128, 128),
-                                         (6, 10, 12, 20), (2, 2, 4, 4), (33, 17, 66, 34)])   # the last three: exact-2x fast path
+                                         (6, 10, 12, 20), (2, 2, 4, 4), (33, 17, 66, 34), (32, 48, 64, 96), (128, 128, 256, 256)])   # from (6, 10): exact-2x fast paths
 def test_bilinear_resize(ops, hi, wi, ho, wo):
     x = torch.randn(2, 5, hi, wi, generator=g(1)).requires_grad_()
     y_ref = F.interpolate(x, size=(ho, wo), mode='bilinear', align_corners=False)
@@ -659,6 +659,13 @@ def test_bilinear_resize(ops, hi, wi, ho, wo):
     assert_close(dx, x.grad, 1e-5, 'resize bwd')
     dx2 = ops.resize_bilinear_bwd(dy.to(DEV), (hi, wi), out=dx.clone(), accumulate=True)
     assert_close(dx2, 2 * x.grad, 1e-5, 'resize bwd accumulate')
+    if ho == 2 * hi and wo == 2 * wi and hi % 2 == 0 and wi % 2 == 0:
+        # the 2 x 2-block adjoint against the one-pixel kernel (reached through an 8-byte aligned view): the same taps and weights, the
+        # compiler contracts the two expressions into differently grouped fmas
+        pad = torch.zeros(2, 5 * ho * wo + 2, device=DEV)
+        pad[:, 2:] = dy.to(DEV).reshape(2, -1)
+        dx1 = ops.resize_bilinear_bwd(pad[:, 2:].reshape(2, 5, ho, wo), (hi, wi))       # 8-byte aligned images: the one-pixel kernel
+        assert_close(dx, dx1.double(), 1e-6, 'resize bwd, 2x2 blocks vs one pixel per thread')
 
 
 def test_pool_broadcast_dropout(ops):
@@ -774,7 +781,7 @@ def test_pseudo_label_tie_rule_is_softmax_then_max(ops, C, up):
                 assert int((z.argmax(1) != l_cpu).sum()) > 100
 
 
-@pytest.mark.parametrize('hi,ho', [(32, 128), (16, 128), (33, 100), (24, 96), (64, 256), (96, 192)])
+@pytest.mark.parametrize('hi,ho', [(32, 128), (16, 128), (33, 100), (24, 96), (64, 256), (96, 192), (128, 256), (34, 68), (66, 132)])
 def test_resize_bilinear_bit_exact(ops, hi, ho):
     """the up-sampling arithmetic is pinned to torch's (source index = one fma; blend = fma(lx0, v00, lx1*v01), fma(ly0, t0, ly1*t1)):
     what torch's GPU kernel and its vectorised CPU kernel evaluate.  (torch-CPU switches to a differently rounded scalar loop for
@@ -783,6 +790,10 @@ def test_resize_bilinear_bit_exact(ops, hi, ho):
     x = torch.randn(2, 5, hi, hi, generator=g(hi)) * 3
     ref = F.interpolate(x, size=(ho, ho), mode='bilinear', align_corners=False)
     assert torch.equal(ops.resize_bilinear(x.to(DEV), (ho, ho)).cpu(), ref)
+    # into a channel slice of a concat buffer (the decoder: the x2 kernel's 16-byte stores on a strided batch)
+    cat = torch.zeros(2, 9, ho, ho, device=DEV)
+    ops.resize_bilinear(x.to(DEV), (ho, ho), out=cat[:, 0:5])
+    assert torch.equal(cat[:, 0:5].cpu(), ref) and float(cat[:, 5:].abs().max()) == 0.0
 
 
 def test_class_mix_exact(ops):
