@@ -68,6 +68,61 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
   }
   if (amax) amax_publish(amax, am);
 }
+// the same pool, two adjacent outputs per thread (W % 4 == 0, 16-byte aligned planes): their windows cover input columns 4k-1 .. 4k+3 of three
+// rows -- one 16-byte load + one scalar per row instead of nine scalar loads per output, every tap normalised once -- scanned per output in
+// the same row-major order with the same comparison (first maximum wins, NaN propagates): identical values and indices.
+__global__ __launch_bounds__(256) void maxpool_pair_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                                           int H, int W, int Ho, int Wo, const float4* __restrict__ bnl, int C,
+                                                           float* __restrict__ amax) {
+  float am = 0.f;
+  const int nc = blockIdx.y;
+  const float* xp = x + (i64)nc * H * W;
+  const float bsc = bnl ? bnl[nc % C].z : 1.f, bsh = bnl ? bnl[nc % C].w : 0.f;
+  const int W2 = Wo >> 1;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Ho * W2; q += gridDim.x * blockDim.x) {
+    const int oy = q / W2, k = q - oy * W2;
+    float v[3][5];                       // columns 4k-1 .. 4k+3 of rows 2oy-1 .. 2oy+1
+    bool rok[3];
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      const int sy = oy * 2 - 1 + ty;
+      rok[ty] = sy >= 0 && sy < H;
+      const float* row = xp + (i64)(rok[ty] ? sy : 0) * W + 4 * k;
+      const float4 m = *reinterpret_cast<const float4*>(row);
+      const float l = row[k > 0 ? -1 : 0];
+      v[ty][0] = l; v[ty][1] = m.x; v[ty][2] = m.y; v[ty][3] = m.z; v[ty][4] = m.w;
+      if (bnl) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) v[ty][i] = fmaxf(__fmaf_rn(v[ty][i], bsc, bsh), 0.f);
+      }
+    }
+    float best[2];
+    int bt[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {        // output ox = 2k + e: taps at columns 2ox-1 .. 2ox+1 = registers 2e .. 2e+2
+      float b = -INFINITY;
+      int t = 0;
+      bool first = true;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        if (!rok[ty]) continue;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          if (e == 0 && tx == 0 && k == 0) continue;          // column -1
+          const float u = v[ty][2 * e + tx];
+          if (first || u > b || u != u) { b = u; t = ty * 3 + tx; first = false; }
+        }
+      }
+      best[e] = b;
+      bt[e] = t;
+      am = fmaxf(am, fabsf(b));
+    }
+    const i64 o = (i64)nc * Ho * Wo + (i64)oy * Wo + 2 * k;
+    *reinterpret_cast<float2*>(y + o) = make_float2(best[0], best[1]);
+    *reinterpret_cast<uchar2*>(idx + o) = make_uchar2((unsigned char)bt[0], (unsigned char)bt[1]);
+  }
+  if (amax) amax_publish(amax, am);
+}
 __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
                                    int H, int W, int Ho, int Wo) {
   const int nc = blockIdx.y;
@@ -427,6 +482,13 @@ extern "C" int pfst_maxpool3x3s2(const float* x, float* y, unsigned char* idx, i
   PFST_CHECK_ARG(!bn_on_load_coef || (C > 0 && NC % C == 0));
   PFST_CHECK_ARG(x && y && idx && NC > 0 && NC <= 65535 * 16 && H > 0 && W > 0);
   PFST_CHECK_ARG(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1 && NC <= 65535);
+  if ((W & 3) == 0 && (H & 1) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
+      (reinterpret_cast<uintptr_t>(idx) & 1) == 0) {                                   // the stem's pool: two outputs per thread
+    hipLaunchKernelGGL(maxpool_pair_kernel, dim3(hw_blocks(Ho * Wo / 2), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo,
+                       reinterpret_cast<const float4*>(bn_on_load_coef), C > 0 ? C : 1, y_amax);
+    PFST_CHECK_LAUNCH();
+    return PFST_OK;
+  }
   hipLaunchKernelGGL(maxpool_kernel, dim3(hw_blocks(Ho * Wo), NC), dim3(256), 0, (hipStream_t)stream, x, y, idx, H, W, Ho, Wo,
                      reinterpret_cast<const float4*>(bn_on_load_coef), C > 0 ? C : 1, y_amax);
   PFST_CHECK_LAUNCH();

@@ -617,7 +617,7 @@ def test_batchnorm_relu_bitmask_equals_saved_output(ops, shape):
     assert none is None
 
 
-@pytest.mark.parametrize('H,W', [(17, 22), (16, 24), (2, 2), (64, 64)])      # odd sizes: generic kernel; even: 2x2-block backward
+@pytest.mark.parametrize('H,W', [(17, 22), (16, 24), (2, 2), (64, 64), (6, 4), (128, 96)])      # odd sizes: generic kernels; even, W % 4 == 0: pair forward, 2x2-block backward
 def test_maxpool(ops, H, W):
     x = torch.randn(2, 8, H, W, generator=g(1)).requires_grad_()
     with torch.no_grad():
@@ -627,6 +627,16 @@ def test_maxpool(ops, H, W):
     y_ref.backward(dy)
     y, idx = ops.maxpool(x.detach().to(DEV))
     assert torch.equal(y.cpu(), y_ref.detach())
+    xn = x.detach().clone()
+    xn[1, 3, H // 2, W // 2] = float('nan')          # a NaN tap wins its windows, as in torch
+    yn, idn = ops.maxpool(xn.to(DEV))
+    assert torch.equal(torch.isnan(yn).cpu(), torch.isnan(F.max_pool2d(xn, 3, 2, 1)))
+    # the pair kernel (even sizes, W % 4 == 0) against the one-output kernel, reached through a 4-byte aligned view: same values, same taps
+    if H % 2 == 0 and W % 4 == 0:
+        pad = torch.zeros(2 * 8 * H * W + 1, device=DEV)
+        pad[1:] = x.detach().to(DEV).reshape(-1)
+        y1, idx1 = ops.maxpool(pad[1:].reshape(2, 8, H, W))
+        assert torch.equal(y1, y) and torch.equal(idx1, idx)
     dx = ops.maxpool_bwd(dy.to(DEV), idx, (H, W))
     assert_close(dx, x.grad, 1e-6)
     # normalise-on-load (stem.6 -> max-pool): pooling the pre-BatchNorm tensor with (sc, sh, ReLU) applied per tap = pooling what bn_apply
