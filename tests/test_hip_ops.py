@@ -699,7 +699,7 @@ def test_pool_broadcast_dropout(ops):
 
 
 @pytest.mark.parametrize('C,h,H,use_w,use_cw', [(6, 16, 64, True, False), (6, 8, 64, False, False),
-                                                (33, 12, 48, True, True), (2, 16, 64, True, False)])
+                                                (33, 12, 48, True, True), (2, 16, 64, True, False), (6, 64, 256, True, True), (8, 32, 128, False, False)])
 def test_ce_upsample_fwd_bwd(ops, C, h, H, use_w, use_cw):
     n = 2
     logits = (torch.randn(n, C, h, h, generator=g(1)) * 3).requires_grad_()
