@@ -134,27 +134,43 @@ __device__ __forceinline__ void sum_partial_slots(const float2* __restrict__ p, 
 }
 
 // statistics from the conv epilogue's partials: part[c][T][2] (sum, sum of squares per slot)   grid: C blocks
-__global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* __restrict__ part, int T, double count,
+// BD threads: 256, or 1024 for the long slot rows of the full- / half- / quarter-resolution layers (T >= 4096: few channels, so few
+// workgroups, each walking 64-256 KB per array -- latency-bound on the loads one workgroup keeps in flight)
+template <int BD>
+__global__ __launch_bounds__(BD) void bn_finalize_partials_kernel(const float* __restrict__ part, int T, double count,
                                                                     float* __restrict__ mean, float* __restrict__ invstd,
                                                                     float* __restrict__ rmean, float* __restrict__ rvar,
                                                                     float momentum, float eps, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float4* __restrict__ coef,
                                                                     const float* __restrict__ minmax, int relu, float* __restrict__ y_amax) {
   __shared__ double sm[32];
-  __shared__ float mm[2][4];
+  __shared__ float mm[2][BD / 64];
   const int c = blockIdx.x;
-  double s, ss;
-  sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, ss);
-  block_sum2_d(s, ss, sm);
-  // minmax != NULL: [C][T][2] (minimum, maximum) partials of the same producer -> the channel's extrema of the pre-activation
+  // minmax != NULL: [C][T][2] (minimum, maximum) partials of the same producer -> the channel's extrema of the pre-activation.  Its loads are
+  // issued BEFORE the sums' barrier, so that both slot arrays are in flight together (the kernel is one round trip of latency, not two)
   float lo = __builtin_inff(), hi = -__builtin_inff();
   if (minmax) {
     const float2* q = reinterpret_cast<const float2*>(minmax) + (i64)c * T;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    int done = 0;
+    if (((uintptr_t)q & 15) == 0) {
+      const float4* q4 = reinterpret_cast<const float4*>(q);
+      const int T2 = T >> 1;
+      for (int i = threadIdx.x; i < T2; i += blockDim.x) {
+        const float4 v = q4[i];
+        lo = fminf(lo, fminf(v.x, v.z));
+        hi = fmaxf(hi, fmaxf(v.y, v.w));
+      }
+      done = T2 * 2;
+    }
+    for (int i = done + threadIdx.x; i < T; i += blockDim.x) {
       const float2 v = q[i];
       lo = fminf(lo, v.x);
       hi = fmaxf(hi, v.y);
     }
+  }
+  double s, ss;
+  sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, ss);
+  if (minmax) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       lo = fminf(lo, __shfl_xor(lo, o));
@@ -164,15 +180,21 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
       mm[0][threadIdx.x >> 6] = lo;
       mm[1][threadIdx.x >> 6] = hi;
     }
-    __syncthreads();
   }
+  // the per-channel scalars of the tail, requested before the barrier as well
+  const float g_c = gamma ? gamma[c] : 1.f, b_c = beta ? beta[c] : 0.f;
+  const float rm_c = rmean ? rmean[c] : 0.f, rv_c = rmean ? rvar[c] : 0.f;
+  block_sum2_d(s, ss, sm);                 // (its barriers also publish mm)
   if (threadIdx.x == 0) {
     const double m = s / count;
     double var = ss / count - m * m;
     if (var < 0.0) var = 0.0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    write_coef(coef, gamma, beta, c, mean[c], invstd[c]);
+    const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = mf;
+    invstd[c] = isf;
+    float sc, sh;
+    bn_affine(mf, isf, g_c, b_c, sc, sh);
+    if (coef) coef[c] = make_float4(mf, isf, sc, sh);
     if (minmax && y_amax) {
       // y = [relu](fma(x, sc, sh)) is monotone in x for fixed (sc, sh) -- fma rounds monotonically --, so the channel's extreme outputs are the
       // images of its extreme inputs: max |y| of the tensor the normalisation pass WOULD write, exactly, before (or without) writing it
@@ -180,16 +202,14 @@ __global__ __launch_bounds__(256) void bn_finalize_partials_kernel(const float* 
         lo = fminf(lo, mm[0][w]);
         hi = fmaxf(hi, mm[1][w]);
       }
-      float sc, sh;
-      bn_affine(mean[c], invstd[c], gamma[c], beta[c], sc, sh);
       const float ya = __fmaf_rn(lo, sc, sh), yb = __fmaf_rn(hi, sc, sh);
       const float am = relu ? fmaxf(fmaxf(ya, yb), 0.f) : fmaxf(fabsf(ya), fabsf(yb));
       if (am > 0.f) atomicMax(reinterpret_cast<unsigned*>(y_amax) + (c & (PFST_AMAX_SUB - 1)), __builtin_bit_cast(unsigned, am));
     }
     if (rmean) {
       const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)m;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+      rmean[c] = (1.f - momentum) * rm_c + momentum * (float)m;
+      rvar[c] = (1.f - momentum) * rv_c + momentum * (float)unb;
     }
   }
 }
@@ -393,10 +413,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __res
   const int c = blockIdx.x;
   double s, sx;
   sum_partial_slots(reinterpret_cast<const float2*>(part) + (i64)c * T, T, s, sx);
+  const float mu = mean[c], is = invstd[c];        // requested before the barrier
   block_sum2_d(s, sx, sm);
   if (threadIdx.x == 0) {
     ws[2 * c] = s;
-    ws[2 * c + 1] = (double)invstd[c] * (sx - (double)mean[c] * s);
+    ws[2 * c + 1] = (double)is * (sx - (double)mu * s);
   }
 }
 
@@ -567,8 +588,12 @@ extern "C" int pfst_bn_finalize_partials(const float* partials, int T, int C, do
   PFST_CHECK_ARG(!coef || (gamma && beta));
   PFST_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
   PFST_CHECK_ARG((minmax == nullptr) == (y_amax == nullptr) && (!minmax || (gamma && beta)));
-  hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
-                     running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef), minmax, relu, y_amax);
+  if (T >= 4096)
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
+                       running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef), minmax, relu, y_amax);
+  else
+    hipLaunchKernelGGL(bn_finalize_partials_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, T, count, mean, invstd,
+                       running_mean, running_var, momentum, eps, gamma, beta, reinterpret_cast<float4*>(coef), minmax, relu, y_amax);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

@@ -6,6 +6,7 @@
 // losses/cross_entropy_loss.py:45-65, losses/utils.py:60-69, losses/accuracy.py:6-61,
 // uda/pfgst.py:259-300 (pseudo labels, class mix), utils/dacs_transforms.py:110-144.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "../../include/pfst_hip.h"
 
@@ -314,7 +315,10 @@ inline int px_blocks(i64 n) {
 extern "C" int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, int w, const unsigned char* label, const float* pix_weight,
                                     const float* class_weight, int H, int W, int ignore_index, float* lse, double* acc, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && label && lse && acc && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(px_blocks((i64)H * W), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+  // 16 pixels per thread: every workgroup ends in three same-address fp64 atomics, and 8192 workgroups of four pixels per thread spent
+  // half of the launch in that tail (profiles/r05_small_kernels.txt: 322 -> 149 us at 8 x 1024^2)
+  const int gx = (int)std::max<i64>(1, std::min<i64>(4096, ((i64)H * W + 4095) / 4096));
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
                      pix_weight, class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, acc);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
