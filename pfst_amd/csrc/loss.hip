@@ -88,6 +88,107 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   }
 }
 
+// The x4 case (H == 4h, W == 4w, C <= 8) by inter-cell blocks, as ce_bwd_x4_kernel below: one thread per 4 x 4 block of full-resolution
+// pixels that interpolate from the same four cells -- their 4 x C logits are loaded once instead of once per pixel.  Per pixel the arithmetic
+// is the one above (same coordinates and weights from bilin_src, same class order): bit-identical lse, the same loss terms.
+// Two tiles of 16 x 16 blocks per workgroup: every workgroup ends in four block sums and three fp64 atomics on one cache line; measured at
+// 8 x 1024^2: one tile 122 us, two 97, four 109 (too few workgroups), 1024-thread workgroups of four tiles 113 (profiles/r05_small_kernels.txt).
+// grid: (ceil((w + 1) / 16), ceil((h + 1) / 32), N), 16 x 16 threads
+__global__ __launch_bounds__(256) void ce_fwd_x4_kernel(const float* __restrict__ logits, int C, int h, int w,
+                                                        const unsigned char* __restrict__ label, const float* __restrict__ pw,
+                                                        const float* __restrict__ cw, int ignore, float* __restrict__ lse,
+                                                        double* __restrict__ acc) {
+  constexpr int S = 4;
+  __shared__ double sm[16];
+  const int n = blockIdx.z, H = S * h, W = S * w, hw = h * w;
+  const int bx = blockIdx.x * 16 + (threadIdx.x & 15) - 1;
+  const float* lp = logits + (i64)n * C * hw;
+  const unsigned char* lab = label + (i64)n * H * W;
+  float* ls = lse + (i64)n * H * W;
+  const float* pwp = pw ? pw + (i64)n * H * W : nullptr;
+  double loss = 0.0, correct = 0.0, valid = 0.0, bad = 0.0;
+  for (int it = 0; it < 2; ++it) {
+    const int by = (blockIdx.y * 2 + it) * 16 + (threadIdx.x >> 4) - 1;
+    if (bx > w - 1 || by > h - 1) continue;
+    const int xl = max(bx, 0), xr = min(xl + 1, w - 1), yt = max(by, 0), yb = min(yt + 1, h - 1);
+    float v[2][2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = lp + (i64)(c < C ? c : 0) * hw;
+      v[0][0][c] = q[yt * w + xl];
+      v[0][1][c] = q[yt * w + xr];
+      v[1][0][c] = q[yb * w + xl];
+      v[1][1][c] = q[yb * w + xr];
+    }
+    float lx0[S], lx1[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int ox = S * bx + S / 2 + j;
+      int x0, x1;
+      lx0[j] = lx1[j] = 0.f;
+      if (ox >= 0 && ox < W) bilin_src(ox, 0.25f, w, x0, x1, lx0[j], lx1[j]);
+    }
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const int oy = S * by + S / 2 + r;
+      if (oy < 0 || oy >= H) continue;
+      int y0, y1;
+      float ly0, ly1;
+      bilin_src(oy, 0.25f, h, y0, y1, ly0, ly1);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int ox = S * bx + S / 2 + 2 * half;
+        if (ox < 0 || ox >= W) continue;
+        const i64 p = (i64)oy * W + ox;
+        const unsigned short l2 = *reinterpret_cast<const unsigned short*>(lab + p);
+        float2 g2 = make_float2(1.f, 1.f);
+        if (pwp) g2 = *reinterpret_cast<const float2*>(pwp + p);
+        float lo[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int j = 2 * half + k;
+          const int l = k ? (l2 >> 8) : (l2 & 255);
+          float mx = -INFINITY, zl = 0.f, se = 0.f;
+          int arg = 0;
+          float zc[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            zc[c] = c < C ? bilin_blend(v[0][0][c], v[0][1][c], v[1][0][c], v[1][1][c], lx0[j], lx1[j], ly0, ly1) : -INFINITY;
+            if (c < C && zc[c] > mx) { mx = zc[c]; arg = c; }
+            if (c == l) zl = zc[c];
+          }
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (c < C) se += expf(zc[c] - mx);
+          const float e = mx + logf(se);
+          lo[k] = e;
+          if (l != ignore && l < C) {
+            float wgt = k ? g2.y : g2.x;
+            if (!pwp) wgt = 1.f;
+            if (cw) wgt *= cw[l];
+            loss += (double)(wgt * (e - zl));
+            valid += 1.0;
+            if (arg == l) correct += 1.0;
+          } else if (l != ignore) {
+            bad += 1.0;
+          }
+        }
+        *reinterpret_cast<float2*>(ls + p) = make_float2(lo[0], lo[1]);
+      }
+    }
+  }
+  bad = block_sum_d(bad, sm);
+  if (threadIdx.x == 0 && bad > 0.0) atomicAdd(&acc[3], bad);
+  loss = block_sum_d(loss, sm);
+  correct = block_sum_d(correct, sm);
+  valid = block_sum_d(valid, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&acc[0], loss);
+    atomicAdd(&acc[1], correct);
+    atomicAdd(&acc[2], valid);
+  }
+}
+
 // grid: (blocks over h*w, C, N).  One thread per low-resolution logit; gathers its full-res footprint.
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int C, int h, int w,
                                                      const unsigned char* __restrict__ label, const float* __restrict__ pw,
@@ -188,6 +289,127 @@ __global__ __launch_bounds__(256) void ce_bwd_cells_kernel(const float* __restri
         const float a = acc[c] * scale;
         dp[(i64)c * hw + i] = accumulate ? dp[(i64)c * hw + i] + a : a;
       }
+    }
+  }
+}
+
+// The x4 case of the same gradient (H == 4h, W == 4w: the decode heads' logits at 1/4 resolution; C <= 8) by INTER-CELL BLOCKS instead of
+// cells.  The 4 x 4 full-resolution pixels between four neighbouring cell centres -- pixels 4b+2 ... 4b+5 of block b in each direction,
+// b = -1 ... w-1 (the outermost blocks are the half-width borders whose taps are clamped) -- all interpolate from the same four cells:
+// one thread loads those 4 x C logits ONCE, evaluates each pixel's softmax once (the per-cell gather above evaluates every pixel in each
+// of the up to four cells it touches: 4x the exponentials, 16x the logit loads), and keeps the 4 x C corner sums in registers.  A
+// workgroup is 16 x 16 blocks; the corner sums meet in LDS in four conflict-free phases (in a phase every thread adds to a different
+// cell), and the 15 x 15 cells whose four blocks all lie inside the workgroup are written out -- neighbouring workgroups overlap by one
+// block row / column.  Per pixel and tap the term is the one of ce_bwd_cells_kernel (same source coordinates, weights, interpolation and
+// fma); the ORDER of a cell's <= 64 terms differs (block by block instead of raster order), deterministically.
+// grid: (ceil(w / 15), ceil(h / 15), N)
+__global__ __launch_bounds__(256) void ce_bwd_x4_kernel(const float* __restrict__ logits, int C, int h, int w,
+                                                        const unsigned char* __restrict__ label, const float* __restrict__ pw,
+                                                        const float* __restrict__ cw, int ignore, const float* __restrict__ lse, float scale,
+                                                        float* __restrict__ dlogits, int accumulate) {
+  constexpr int S = 4, TB = 16, OWN = TB - 1;
+  __shared__ float cell[8][TB + 1][TB + 1];
+  const int n = blockIdx.z, H = S * h, W = S * w, hw = h * w;
+  const int tx = threadIdx.x & (TB - 1), ty = threadIdx.x >> 4;
+  const int cx0 = blockIdx.x * OWN, cy0 = blockIdx.y * OWN;        // first cell this workgroup owns
+  const int bx = cx0 - 1 + tx, by = cy0 - 1 + ty;                  // this thread's block: taps (b, b + 1), clamped at the borders
+  const float* lp = logits + (i64)n * C * hw;
+  const unsigned char* lab = label + (i64)n * H * W;
+  const float* ls = lse + (i64)n * H * W;
+  const float* pwp = pw ? pw + (i64)n * H * W : nullptr;
+  for (int i = threadIdx.x; i < 8 * (TB + 1) * (TB + 1); i += 256) (&cell[0][0][0])[i] = 0.f;
+  float acc[2][2][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[a][b][c] = 0.f;
+  if (bx <= w - 1 && by <= h - 1) {
+    // the four cells every pixel of the block interpolates from (what bilin_src returns for each of them)
+    const int xl = max(bx, 0), xr = min(xl + 1, w - 1), yt = max(by, 0), yb = min(yt + 1, h - 1);
+    float v[2][2][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* q = lp + (i64)(c < C ? c : 0) * hw;
+      v[0][0][c] = q[yt * w + xl];
+      v[0][1][c] = q[yt * w + xr];
+      v[1][0][c] = q[yb * w + xl];
+      v[1][1][c] = q[yb * w + xr];
+    }
+    // column taps of the block's four pixel columns: weight towards cell bx (L) and cell bx + 1 (R)
+    float lx0[S], lx1[S], wxl[S], wxr[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      const int ox = S * bx + S / 2 + j;
+      int x0 = 0, x1 = 0;
+      lx0[j] = lx1[j] = 0.f;
+      if (ox >= 0 && ox < W) bilin_src(ox, 0.25f, w, x0, x1, lx0[j], lx1[j]);
+      wxl[j] = (x0 == bx ? lx0[j] : 0.f) + (x1 == bx ? lx1[j] : 0.f);
+      wxr[j] = (x0 == bx + 1 ? lx0[j] : 0.f) + (x1 == bx + 1 ? lx1[j] : 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const int oy = S * by + S / 2 + r;
+      if (oy < 0 || oy >= H) continue;
+      int y0, y1;
+      float ly0, ly1;
+      bilin_src(oy, 0.25f, h, y0, y1, ly0, ly1);
+      const float wyt = (y0 == by ? ly0 : 0.f) + (y1 == by ? ly1 : 0.f);
+      const float wyb = (y0 == by + 1 ? ly0 : 0.f) + (y1 == by + 1 ? ly1 : 0.f);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int ox = S * bx + S / 2 + 2 * half;                  // pixel pairs are inside the image together (W = 4w, ox even)
+        if (ox < 0 || ox >= W) continue;
+        const i64 p = (i64)oy * W + ox;
+        const unsigned short l2 = *reinterpret_cast<const unsigned short*>(lab + p);
+        const float2 ls2 = *reinterpret_cast<const float2*>(ls + p);
+        float2 g2 = make_float2(1.f, 1.f);
+        if (pwp) g2 = *reinterpret_cast<const float2*>(pwp + p);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int j = 2 * half + k;
+          const int l = k ? (l2 >> 8) : (l2 & 255);
+          if (l == ignore || l >= C) continue;
+          float g = k ? g2.y : g2.x;
+          if (cw) g *= cw[l];
+          const float lsp = k ? ls2.y : ls2.x;
+          const float wtl = wyt * wxl[j] * g, wtr = wyt * wxr[j] * g, wbl = wyb * wxl[j] * g, wbr = wyb * wxr[j] * g;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (c < C) {
+              const float z = bilin_blend(v[0][0][c], v[0][1][c], v[1][0][c], v[1][1][c], lx0[j], lx1[j], ly0, ly1);
+              const float d = expf(z - lsp) - (l == c ? 1.f : 0.f);
+              acc[0][0][c] = fmaf(wtl, d, acc[0][0][c]);
+              acc[0][1][c] = fmaf(wtr, d, acc[0][1][c]);
+              acc[1][0][c] = fmaf(wbl, d, acc[1][0][c]);
+              acc[1][1][c] = fmaf(wbr, d, acc[1][1][c]);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < C) cell[c][ty + a][tx + b] += acc[a][b][c];
+      __syncthreads();
+    }
+  }
+  float* dp = dlogits + (i64)n * C * hw;
+  for (int i = threadIdx.x; i < OWN * OWN; i += 256) {
+    const int u = i / OWN, q = i - u * OWN;
+    const int gy = cy0 + u, gx = cx0 + q;
+    if (gy >= h || gx >= w) continue;
+    for (int c = 0; c < C; ++c) {
+      const float a = cell[c][u + 1][q + 1] * scale;
+      float* o = dp + (i64)c * hw + gy * w + gx;
+      *o = accumulate ? *o + a : a;
     }
   }
 }
@@ -318,8 +540,12 @@ extern "C" int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, in
   // 16 pixels per thread: every workgroup ends in three same-address fp64 atomics, and 8192 workgroups of four pixels per thread spent
   // half of the launch in that tail (profiles/r05_small_kernels.txt: 322 -> 149 us at 8 x 1024^2)
   const int gx = (int)std::max<i64>(1, std::min<i64>(4096, ((i64)H * W + 4095) / 4096));
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
-                     pix_weight, class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, acc);
+  if (C <= 8 && H == 4 * h && W == 4 * w && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0 && h < 65535 * 32)
+    hipLaunchKernelGGL(ce_fwd_x4_kernel, dim3(cdiv(w + 1, 16), cdiv(h + 1, 32), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w,
+                       label, pix_weight, class_weight, ignore_index, lse, acc);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+                       pix_weight, class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, acc);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }
@@ -329,7 +555,10 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
                                     float* dlogits, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && label && lse && dlogits && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   int gx = cdiv((i64)h * w, 256);
-  if (C <= 8)          // one thread per low-resolution cell, all classes in registers; more classes: one launch row per class
+  if (C <= 8 && H == 4 * h && W == 4 * w && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0)
+    hipLaunchKernelGGL(ce_bwd_x4_kernel, dim3(cdiv(w, 15), cdiv(h, 15), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+                       pix_weight, class_weight, ignore_index, lse, scale, dlogits, accumulate);
+  else if (C <= 8)     // one thread per low-resolution cell, all classes in registers; more classes: one launch row per class
     hipLaunchKernelGGL(ce_bwd_cells_kernel, dim3(gx, 1, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,
                        class_weight, H, W, ignore_index, (float)h / (float)H, (float)w / (float)W, lse, scale, dlogits, accumulate);
   else

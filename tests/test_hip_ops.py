@@ -699,7 +699,8 @@ def test_pool_broadcast_dropout(ops):
 
 
 @pytest.mark.parametrize('C,h,H,use_w,use_cw', [(6, 16, 64, True, False), (6, 8, 64, False, False),
-                                                (33, 12, 48, True, True), (2, 16, 64, True, False), (6, 64, 256, True, True), (8, 32, 128, False, False)])
+                                                (33, 12, 48, True, True), (2, 16, 64, True, False), (6, 64, 256, True, True), (8, 32, 128, False, False),
+                                                (6, 7, 28, False, True), (5, 31, 124, True, True), (6, 2, 8, True, False)])
 def test_ce_upsample_fwd_bwd(ops, C, h, H, use_w, use_cw):
     n = 2
     logits = (torch.randn(n, C, h, h, generator=g(1)) * 3).requires_grad_()
@@ -725,6 +726,43 @@ def test_ce_upsample_fwd_bwd(ops, C, h, H, use_w, use_cw):
     assert abs(float(out[1]) - acc_ref) < 1e-3
     dl = ops.ce_upsample_bwd(ld, l8, lse, 0.4 / (n * H * H), pwd, cwd)
     assert_close(dl, logits.grad, 1e-4, 'ce bwd')
+
+
+@pytest.mark.parametrize('C,h,w', [(6, 33, 17), (8, 16, 46), (1, 15, 15), (6, 30, 31), (3, 1, 9)])
+def test_ce_backward_x4_blocks_match_the_cell_gather(ops, C, h, w):
+    """H == 4h, W == 4w: the inter-cell-block kernel (ce_bwd_x4_kernel) against autograd AND against the per-cell gather it replaces (taken
+    by giving the label map an odd address, which the block kernel's 2-byte label loads refuse): same terms, another summation order"""
+    n, H, W = 3, 4 * h, 4 * w
+    logits = (torch.randn(n, C, h, w, generator=g(1)) * 3).requires_grad_()
+    label = torch.randint(0, C + 1, (n, H, W), generator=g(2))
+    label[label == C] = 255
+    label[:, :3, :] = 255
+    pw = torch.rand(n, H, W, generator=g(3))
+    cw = torch.rand(C, generator=g(4)) + 0.5
+    up = F.interpolate(logits, size=(H, W), mode='bilinear', align_corners=False)
+    per = F.cross_entropy(up, label, weight=cw, reduction='none', ignore_index=255) * pw
+    (per.sum() * 0.01).backward()
+    ld, pwd, cwd = logits.detach().to(DEV), pw.to(DEV), cw.to(DEV)
+    l8 = ops.to_u8(label.to(DEV))
+    odd = torch.empty(l8.numel() + 1, dtype=torch.uint8, device=DEV)[1:].view(n, H, W)
+    odd.copy_(l8)
+    assert l8.data_ptr() % 2 == 0 and odd.data_ptr() % 2 == 1
+    lse, acc = ops.ce_upsample_fwd(ld, l8, pwd, cwd)
+    # forward: the block kernel (ce_fwd_x4_kernel) evaluates every pixel exactly as the one-pixel-per-thread kernel does
+    lse_px, acc_px = ops.ce_upsample_fwd(ld, odd, pwd, cwd)
+    assert torch.equal(lse, lse_px), 'x4 forward: lse must be bit-identical to the per-pixel kernel'
+    assert torch.equal(acc[1:], acc_px[1:]) and abs(float(acc[0] - acc_px[0])) <= 1e-12 * abs(float(acc_px[0]))
+    assert abs(float(acc[0]) * 0.01 - float(per.sum() * 0.01)) < 1e-5 * max(1.0, abs(float(per.sum() * 0.01)))
+    dl = ops.ce_upsample_bwd(ld, l8, lse, 0.01, pwd, cwd)
+    dl_cells = ops.ce_upsample_bwd(ld, odd, lse, 0.01, pwd, cwd)
+    assert_close(dl, logits.grad, 1e-4, 'ce bwd x4 vs autograd')
+    assert_close(dl, dl_cells, 2e-6, 'ce bwd x4 vs the per-cell gather')
+    # accumulate form, and no pixel / class weights
+    base = torch.randn(n, C, h, w, generator=g(5)).to(DEV)
+    acc = ops.ce_upsample_bwd(ld, l8, lse, 0.01, pwd, cwd, out=base.clone(), accumulate=True)
+    assert_close(acc, base + dl, 1e-6, 'ce bwd x4 accumulate')
+    lse2, _ = ops.ce_upsample_fwd(ld, l8)
+    assert_close(ops.ce_upsample_bwd(ld, l8, lse2, 0.01), ops.ce_upsample_bwd(ld, odd, lse2, 0.01), 2e-6, 'ce bwd x4, unweighted')
 
 
 def test_pseudo_label_bit_exact(ops):

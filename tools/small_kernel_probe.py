@@ -53,6 +53,10 @@ def main():
         t0 = timeit(lambda: H.ce_upsample_fwd(lg, lab), n=50)
         t1 = timeit(lambda: H.ce_upsample_fwd(lg, lab, pix_weight=pw), n=50)
         lse, acc = H.ce_upsample_fwd(lg, lab, pix_weight=pw)
+        lab[:, :7] = 255
+        out = torch.empty_like(lg)
+        t2 = timeit(lambda: H.ce_upsample_bwd(lg, lab, lse, 1e-3, pix_weight=pw, out=out), n=50)
+        print(f'  ce_upsample_bwd 8 x 6 x {hw}^2 <- {S}^2: {t2:7.1f}')
         print(f'  ce_upsample_fwd 8 x 6 x {hw}^2 -> {S}^2: {t0:7.1f}   with pixel weights {t1:7.1f}   (incl. two small allocations)  acc {acc.tolist()}')
 
 
