@@ -421,6 +421,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partials_kernel(const float* __res
   }
 }
 
+#ifndef PFST_BN_BWD_APPLY_U
+#define PFST_BN_BWD_APPLY_U 1
+#endif
 // backward pass 2     grid: (blocks over HW, C, N)
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, i64 dy_bs, const float* __restrict__ y,
@@ -456,37 +459,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   float* drp = dres ? dres + (i64)n * dres_bs + base : nullptr;
   const int stride = gridDim.x * blockDim.x;
   if (VEC) {
-    for (int i4 = bxi * blockDim.x + threadIdx.x; i4 < (HW >> 2); i4 += stride) {
-#ifdef PFST_BN_BWD_NT                              // A/B build: the apply pass is the last reader of dy and of the pre-BN tensor
-      typedef float pfst_v4f __attribute__((ext_vector_type(4)));
-      float4 g = __builtin_bit_cast(float4, __builtin_nontemporal_load(&reinterpret_cast<const pfst_v4f*>(gp)[i4]));
-      const float4 xv = __builtin_bit_cast(float4, __builtin_nontemporal_load(&reinterpret_cast<const pfst_v4f*>(xp)[i4]));
-#else
-      float4 g = reinterpret_cast<const float4*>(gp)[i4];
-      const float4 xv = reinterpret_cast<const float4*>(xp)[i4];
-#endif
-      if (post) { g.x *= pm; g.y *= pm; g.z *= pm; g.w *= pm; }
-      if (relu) {
-        bool on[4];
-        relu_on4(mp, yp, i4, xv, sc, sh, on);
-        if (!on[0]) g.x = 0.f;
-        if (!on[1]) g.y = 0.f;
-        if (!on[2]) g.z = 0.f;
-        if (!on[3]) g.w = 0.f;
-      }
-      float4 o;
-      o.x = (float)(gs * ((double)g.x - m1 - (((double)xv.x - (double)mu) * (double)is) * m2));
-      o.y = (float)(gs * ((double)g.y - m1 - (((double)xv.y - (double)mu) * (double)is) * m2));
-      o.z = (float)(gs * ((double)g.z - m1 - (((double)xv.z - (double)mu) * (double)is) * m2));
-      o.w = (float)(gs * ((double)g.w - m1 - (((double)xv.w - (double)mu) * (double)is) * m2));
-      reinterpret_cast<float4*>(dxp)[i4] = o;
-      am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
-      if (drp) {
-        if (dres_acc) {
-          const float4 old = reinterpret_cast<const float4*>(drp)[i4];
-          g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+    // PFST_BN_BWD_APPLY_U 16-byte loads per operand in flight per thread (the host sizes the grid to match)
+    constexpr int U = PFST_BN_BWD_APPLY_U;
+    const int n4 = HW >> 2;
+    for (int i0 = bxi * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+      float4 gq[U], xq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i4 = i0 + u * stride;
+        if (i4 < n4) {
+          gq[u] = reinterpret_cast<const float4*>(gp)[i4];
+          xq[u] = reinterpret_cast<const float4*>(xp)[i4];
         }
-        reinterpret_cast<float4*>(drp)[i4] = g;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i4 = i0 + u * stride;
+        if (i4 >= n4) break;
+        float4 g = gq[u];
+        const float4 xv = xq[u];
+        if (post) { g.x *= pm; g.y *= pm; g.z *= pm; g.w *= pm; }
+        if (relu) {
+          bool on[4];
+          relu_on4(mp, yp, i4, xv, sc, sh, on);
+          if (!on[0]) g.x = 0.f;
+          if (!on[1]) g.y = 0.f;
+          if (!on[2]) g.z = 0.f;
+          if (!on[3]) g.w = 0.f;
+        }
+        float4 o;
+        o.x = (float)(gs * ((double)g.x - m1 - (((double)xv.x - (double)mu) * (double)is) * m2));
+        o.y = (float)(gs * ((double)g.y - m1 - (((double)xv.y - (double)mu) * (double)is) * m2));
+        o.z = (float)(gs * ((double)g.z - m1 - (((double)xv.z - (double)mu) * (double)is) * m2));
+        o.w = (float)(gs * ((double)g.w - m1 - (((double)xv.w - (double)mu) * (double)is) * m2));
+        reinterpret_cast<float4*>(dxp)[i4] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        if (drp) {
+          if (dres_acc) {
+            const float4 old = reinterpret_cast<const float4*>(drp)[i4];
+            g.x += old.x; g.y += old.y; g.z += old.z; g.w += old.w;
+          }
+          reinterpret_cast<float4*>(drp)[i4] = g;
+        }
       }
     }
   } else {
@@ -643,7 +657,7 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
   PFST_CHECK_ARG(det_ok);
   const bool vec = (HW & 3) == 0 && ((dy_bs | x_bs | dx_bs | (y ? y_bs : 0) | (dres ? dres_bs : 0)) & 3) == 0 &&
                    (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)y | (uintptr_t)dres) & 15) == 0;
-  int gx = cdiv(HW, 256 * 4);
+  int gx = cdiv(HW, 256 * 4 * (vec ? PFST_BN_BWD_APPLY_U : 1));
   if (gx < 1) gx = 1;
   const double inv_count = 1.0 / ((double)N * HW);
   if (vec) {
