@@ -88,17 +88,18 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   }
 }
 
-// The x4 case (H == 4h, W == 4w, C <= 8) by inter-cell blocks, as ce_bwd_x4_kernel below: one thread per 4 x 4 block of full-resolution
+// The x4 / x8 cases (H == S h, W == S w, S = 4: the decode head's logits at 1/4 resolution, 8: the auxiliary head's at 1/8; C <= 8) by
+// inter-cell blocks, as ce_bwd_blocks_kernel below: one thread per S x S block of full-resolution
 // pixels that interpolate from the same four cells -- their 4 x C logits are loaded once instead of once per pixel.  Per pixel the arithmetic
 // is the one above (same coordinates and weights from bilin_src, same class order): bit-identical lse, the same loss terms.
 // Two tiles of 16 x 16 blocks per workgroup: every workgroup ends in four block sums and three fp64 atomics on one cache line; measured at
 // 8 x 1024^2: one tile 122 us, two 97, four 109 (too few workgroups), 1024-thread workgroups of four tiles 113 (profiles/r05_small_kernels.txt).
 // grid: (ceil((w + 1) / 16), ceil((h + 1) / 32), N), 16 x 16 threads
-__global__ __launch_bounds__(256) void ce_fwd_x4_kernel(const float* __restrict__ logits, int C, int h, int w,
+template <int S, int TILES>
+__global__ __launch_bounds__(256) void ce_fwd_blocks_kernel(const float* __restrict__ logits, int C, int h, int w,
                                                         const unsigned char* __restrict__ label, const float* __restrict__ pw,
                                                         const float* __restrict__ cw, int ignore, float* __restrict__ lse,
                                                         double* __restrict__ acc) {
-  constexpr int S = 4;
   __shared__ double sm[16];
   const int n = blockIdx.z, H = S * h, W = S * w, hw = h * w;
   const int bx = blockIdx.x * 16 + (threadIdx.x & 15) - 1;
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256) void ce_fwd_x4_kernel(const float* __restrict_
   float* ls = lse + (i64)n * H * W;
   const float* pwp = pw ? pw + (i64)n * H * W : nullptr;
   double loss = 0.0, correct = 0.0, valid = 0.0, bad = 0.0;
-  for (int it = 0; it < 2; ++it) {
-    const int by = (blockIdx.y * 2 + it) * 16 + (threadIdx.x >> 4) - 1;
+  for (int it = 0; it < TILES; ++it) {
+    const int by = (blockIdx.y * TILES + it) * 16 + (threadIdx.x >> 4) - 1;
     if (bx > w - 1 || by > h - 1) continue;
     const int xl = max(bx, 0), xr = min(xl + 1, w - 1), yt = max(by, 0), yb = min(yt + 1, h - 1);
     float v[2][2][8];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void ce_fwd_x4_kernel(const float* __restrict_
       const int ox = S * bx + S / 2 + j;
       int x0, x1;
       lx0[j] = lx1[j] = 0.f;
-      if (ox >= 0 && ox < W) bilin_src(ox, 0.25f, w, x0, x1, lx0[j], lx1[j]);
+      if (ox >= 0 && ox < W) bilin_src(ox, 1.f / S, w, x0, x1, lx0[j], lx1[j]);
     }
 #pragma unroll
     for (int r = 0; r < S; ++r) {
@@ -134,9 +135,9 @@ __global__ __launch_bounds__(256) void ce_fwd_x4_kernel(const float* __restrict_
       if (oy < 0 || oy >= H) continue;
       int y0, y1;
       float ly0, ly1;
-      bilin_src(oy, 0.25f, h, y0, y1, ly0, ly1);
+      bilin_src(oy, 1.f / S, h, y0, y1, ly0, ly1);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < S / 2; ++half) {
         const int ox = S * bx + S / 2 + 2 * half;
         if (ox < 0 || ox >= W) continue;
         const i64 p = (i64)oy * W + ox;
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(256) void ce_bwd_cells_kernel(const float* __restri
   }
 }
 
-// The x4 case of the same gradient (H == 4h, W == 4w: the decode heads' logits at 1/4 resolution; C <= 8) by INTER-CELL BLOCKS instead of
-// cells.  The 4 x 4 full-resolution pixels between four neighbouring cell centres -- pixels 4b+2 ... 4b+5 of block b in each direction,
+// The x4 / x8 cases of the same gradient (H == S h, W == S w: the decode head's logits at 1/4, the auxiliary head's at 1/8 resolution; C <= 8)
+// by INTER-CELL BLOCKS instead of cells.  The S x S full-resolution pixels between four neighbouring cell centres -- pixels S b + S/2 ...
+// S b + 3S/2 - 1 of block b in each direction (4b+2 ... 4b+5 at S = 4),
 // b = -1 ... w-1 (the outermost blocks are the half-width borders whose taps are clamped) -- all interpolate from the same four cells:
 // one thread loads those 4 x C logits ONCE, evaluates each pixel's softmax once (the per-cell gather above evaluates every pixel in each
 // of the up to four cells it touches: 4x the exponentials, 16x the logit loads), and keeps the 4 x C corner sums in registers.  A
@@ -303,11 +305,12 @@ __global__ __launch_bounds__(256) void ce_bwd_cells_kernel(const float* __restri
 // block row / column.  Per pixel and tap the term is the one of ce_bwd_cells_kernel (same source coordinates, weights, interpolation and
 // fma); the ORDER of a cell's <= 64 terms differs (block by block instead of raster order), deterministically.
 // grid: (ceil(w / 15), ceil(h / 15), N)
-__global__ __launch_bounds__(256) void ce_bwd_x4_kernel(const float* __restrict__ logits, int C, int h, int w,
+template <int S>
+__global__ __launch_bounds__(256) void ce_bwd_blocks_kernel(const float* __restrict__ logits, int C, int h, int w,
                                                         const unsigned char* __restrict__ label, const float* __restrict__ pw,
                                                         const float* __restrict__ cw, int ignore, const float* __restrict__ lse, float scale,
                                                         float* __restrict__ dlogits, int accumulate) {
-  constexpr int S = 4, TB = 16, OWN = TB - 1;
+  constexpr int TB = 16, OWN = TB - 1;
   __shared__ float cell[8][TB + 1][TB + 1];
   const int n = blockIdx.z, H = S * h, W = S * w, hw = h * w;
   const int tx = threadIdx.x & (TB - 1), ty = threadIdx.x >> 4;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void ce_bwd_x4_kernel(const float* __restrict_
       const int ox = S * bx + S / 2 + j;
       int x0 = 0, x1 = 0;
       lx0[j] = lx1[j] = 0.f;
-      if (ox >= 0 && ox < W) bilin_src(ox, 0.25f, w, x0, x1, lx0[j], lx1[j]);
+      if (ox >= 0 && ox < W) bilin_src(ox, 1.f / S, w, x0, x1, lx0[j], lx1[j]);
       wxl[j] = (x0 == bx ? lx0[j] : 0.f) + (x1 == bx ? lx1[j] : 0.f);
       wxr[j] = (x0 == bx + 1 ? lx0[j] : 0.f) + (x1 == bx + 1 ? lx1[j] : 0.f);
     }
@@ -354,11 +357,11 @@ __global__ __launch_bounds__(256) void ce_bwd_x4_kernel(const float* __restrict_
       if (oy < 0 || oy >= H) continue;
       int y0, y1;
       float ly0, ly1;
-      bilin_src(oy, 0.25f, h, y0, y1, ly0, ly1);
+      bilin_src(oy, 1.f / S, h, y0, y1, ly0, ly1);
       const float wyt = (y0 == by ? ly0 : 0.f) + (y1 == by ? ly1 : 0.f);
       const float wyb = (y0 == by + 1 ? ly0 : 0.f) + (y1 == by + 1 ? ly1 : 0.f);
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int half = 0; half < S / 2; ++half) {
         const int ox = S * bx + S / 2 + 2 * half;                  // pixel pairs are inside the image together (W = 4w, ox even)
         if (ox < 0 || ox >= W) continue;
         const i64 p = (i64)oy * W + ox;
@@ -540,8 +543,12 @@ extern "C" int pfst_ce_upsample_fwd(const float* logits, int N, int C, int h, in
   // 16 pixels per thread: every workgroup ends in three same-address fp64 atomics, and 8192 workgroups of four pixels per thread spent
   // half of the launch in that tail (profiles/r05_small_kernels.txt: 322 -> 149 us at 8 x 1024^2)
   const int gx = (int)std::max<i64>(1, std::min<i64>(4096, ((i64)H * W + 4095) / 4096));
-  if (C <= 8 && H == 4 * h && W == 4 * w && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0 && h < 65535 * 32)
-    hipLaunchKernelGGL(ce_fwd_x4_kernel, dim3(cdiv(w + 1, 16), cdiv(h + 1, 32), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w,
+  const bool blocks_ok = C <= 8 && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0 && h < 65535 * 16;
+  if (blocks_ok && H == 4 * h && W == 4 * w)
+    hipLaunchKernelGGL((ce_fwd_blocks_kernel<4, 2>), dim3(cdiv(w + 1, 16), cdiv(h + 1, 32), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w,
+                       label, pix_weight, class_weight, ignore_index, lse, acc);
+  else if (blocks_ok && H == 8 * h && W == 8 * w)        // the auxiliary head's logits at 1/8 resolution: 64 pixels per thread, one tile per workgroup
+    hipLaunchKernelGGL((ce_fwd_blocks_kernel<8, 1>), dim3(cdiv(w + 1, 16), cdiv(h + 1, 16), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w,
                        label, pix_weight, class_weight, ignore_index, lse, acc);
   else
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(gx, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
@@ -555,8 +562,12 @@ extern "C" int pfst_ce_upsample_bwd(const float* logits, int N, int C, int h, in
                                     float* dlogits, int accumulate, pfst_stream_t stream) {
   PFST_CHECK_ARG(logits && label && lse && dlogits && N > 0 && C > 0 && C <= 255 && h > 0 && w > 0 && H > 0 && W > 0 && N <= 65535);
   int gx = cdiv((i64)h * w, 256);
-  if (C <= 8 && H == 4 * h && W == 4 * w && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0)
-    hipLaunchKernelGGL(ce_bwd_x4_kernel, dim3(cdiv(w, 15), cdiv(h, 15), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+  const bool blocks_ok = C <= 8 && (((uintptr_t)lse | (uintptr_t)pix_weight) & 7) == 0 && ((uintptr_t)label & 1) == 0 && h < 65535 * 15;
+  if (blocks_ok && H == 4 * h && W == 4 * w)
+    hipLaunchKernelGGL(ce_bwd_blocks_kernel<4>, dim3(cdiv(w, 15), cdiv(h, 15), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
+                       pix_weight, class_weight, ignore_index, lse, scale, dlogits, accumulate);
+  else if (blocks_ok && H == 8 * h && W == 8 * w)
+    hipLaunchKernelGGL(ce_bwd_blocks_kernel<8>, dim3(cdiv(w, 15), cdiv(h, 15), N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label,
                        pix_weight, class_weight, ignore_index, lse, scale, dlogits, accumulate);
   else if (C <= 8)     // one thread per low-resolution cell, all classes in registers; more classes: one launch row per class
     hipLaunchKernelGGL(ce_bwd_cells_kernel, dim3(gx, 1, N), dim3(256), 0, (hipStream_t)stream, logits, C, h, w, label, pix_weight,

@@ -728,11 +728,13 @@ def test_ce_upsample_fwd_bwd(ops, C, h, H, use_w, use_cw):
     assert_close(dl, logits.grad, 1e-4, 'ce bwd')
 
 
+@pytest.mark.parametrize('S', [4, 8])
 @pytest.mark.parametrize('C,h,w', [(6, 33, 17), (8, 16, 46), (1, 15, 15), (6, 30, 31), (3, 1, 9)])
-def test_ce_backward_x4_blocks_match_the_cell_gather(ops, C, h, w):
-    """H == 4h, W == 4w: the inter-cell-block kernel (ce_bwd_x4_kernel) against autograd AND against the per-cell gather it replaces (taken
-    by giving the label map an odd address, which the block kernel's 2-byte label loads refuse): same terms, another summation order"""
-    n, H, W = 3, 4 * h, 4 * w
+def test_ce_inter_cell_block_kernels_match_the_per_pixel_and_per_cell_kernels(ops, C, h, w, S):
+    """H == S h, W == S w (S = 4: the decode head, 8: the auxiliary head): the inter-cell-block kernels (ce_fwd_blocks_kernel,
+    ce_bwd_blocks_kernel) against autograd AND against the kernels they replace (taken by giving the label map an odd address, which the block
+    kernels' 2-byte label loads refuse): forward bit-identical, backward the same terms in another summation order"""
+    n, H, W = 3, S * h, S * w
     logits = (torch.randn(n, C, h, w, generator=g(1)) * 3).requires_grad_()
     label = torch.randint(0, C + 1, (n, H, W), generator=g(2))
     label[label == C] = 255
@@ -748,7 +750,7 @@ def test_ce_backward_x4_blocks_match_the_cell_gather(ops, C, h, w):
     odd.copy_(l8)
     assert l8.data_ptr() % 2 == 0 and odd.data_ptr() % 2 == 1
     lse, acc = ops.ce_upsample_fwd(ld, l8, pwd, cwd)
-    # forward: the block kernel (ce_fwd_x4_kernel) evaluates every pixel exactly as the one-pixel-per-thread kernel does
+    # forward: the block kernel evaluates every pixel exactly as the one-pixel-per-thread kernel does
     lse_px, acc_px = ops.ce_upsample_fwd(ld, odd, pwd, cwd)
     assert torch.equal(lse, lse_px), 'x4 forward: lse must be bit-identical to the per-pixel kernel'
     assert torch.equal(acc[1:], acc_px[1:]) and abs(float(acc[0] - acc_px[0])) <= 1e-12 * abs(float(acc_px[0]))

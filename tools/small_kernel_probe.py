@@ -46,7 +46,7 @@ def main():
         t0 = timeit(lambda: H.bn_finalize_partials(st, t, c, 8.0 * 128 * 128, rm, rv, gamma=g, beta=b), flush=flush)
         t1 = timeit(lambda: H.bn_finalize_partials(st, t, c, 8.0 * 128 * 128, rm, rv, gamma=g, beta=b, predict_amax=am), flush=flush)
         print(f'  bn_finalize_partials C={c:5d} T={t:6d}: sums {t0:7.1f}   sums + (min, max) {t1:7.1f}')
-    for hw, S in ((256, 1024), (128, 512)):
+    for hw, S in ((256, 1024), (128, 1024), (128, 512)):
         lg = torch.randn(8, 6, hw, hw, device=dev)
         lab = torch.randint(0, 6, (8, S, S), device=dev, dtype=torch.uint8)
         pw = torch.rand(8, S, S, device=dev)
