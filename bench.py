@@ -130,6 +130,8 @@ class KernelTimer:
         if name == 'pfst_bn_backward':                    # minimum: read dy, x (+ y for the residual form), write dx (+ dres)
             nel = 4.0 * a[17] * a[18] * a[19]
             return name, 0.0, nel * (3 + (1 if a[2] else 0) + (1 if a[12] else 0))
+        if name == 'pfst_bn_backward_dual':               # two layers behind one gated gradient: read dy, xa, xb, write dxa, dxb (booked with the family)
+            return 'pfst_bn_backward', 0.0, 4.0 * a[27] * a[28] * a[29] * 5
         if name == 'pfst_sim_map':                        # read the feature map once, write the 9-channel map
             return name, 0.0, 4.0 * a[1] * a[3] * a[4] * (a[2] + 10)
         if name == 'pfst_sim_map_bwd':                    # read features + 9-channel maps, write the feature gradient

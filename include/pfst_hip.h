@@ -283,6 +283,19 @@ int pfst_bn_backward(const float* dy, long long dy_bs, const float* y, long long
                      double* ws, const float* bwd_partials, int bwd_slots, float* dx_amax, const float* post_scale, pfst_stream_t stream);
 /* post_scale: the factors pfst_bn_apply folded into y: dy is the gradient of the SCALED output, dz = dy * post_scale[n][c] * gate (no dres, no
  * bwd_partials then) */
+/* Two BatchNorm layers behind ONE gated gradient -- the last BN of a stage's first Bottleneck (a: bn3) and its downsample branch's BN (b),
+ * out = relu(bn3(conv3(.)) + bn_d(conv_d(x))), resnet.py:298-307: both receive g = (relu_mask bit ? dy : 0).  One reduction pass over
+ * (dy, xa, xb) and one apply pass writing dxa and dxb replace the two pfst_bn_backward calls (8 N instead of 10 N of traffic); the results
+ * are those of pfst_bn_backward(relu = 1, relu_mask) per layer.  bwd_partials_a: layer a's sums from the launch that wrote dy (as in
+ * pfst_bn_backward).  ws_a, ws_b: >= 2*C doubles each.  Needs HW % 256 == 0 and 16-byte aligned planes; PFST_ERR_UNSUPPORTED otherwise and in
+ * deterministic mode (the caller then runs the layers one by one). */
+int pfst_bn_backward_dual(const float* dy, long long dy_bs, const unsigned long long* relu_mask,
+                          const float* xa, long long xa_bs, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                          float* dxa, long long dxa_bs, float* dgamma_a, float* dbeta_a, double* ws_a,
+                          const float* bwd_partials_a, int bwd_slots_a, float* dxa_amax,
+                          const float* xb, long long xb_bs, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                          float* dxb, long long dxb_bs, float* dgamma_b, float* dbeta_b, double* ws_b, float* dxb_amax,
+                          int N, int C, int HW, pfst_stream_t stream);
 /* The FIRST half of pfst_bn_backward alone, for a conv -> BN -> ReLU layer without residual whose convolution is depthwise: the two sums
  * (from bwd_partials, else by the reduction pass), dgamma += sum dz*xhat, dbeta += sum dz, and rec[C] for the consumer that applies the
  * second half while it loads dy and x (no dx is written here: 3 N of traffic less per layer).  ws: >= 2*C doubles. */

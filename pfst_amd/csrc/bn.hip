@@ -519,6 +519,133 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   if (amax) amax_publish(amax, am);
 }
 
+// ---- two BatchNorm layers behind ONE gated gradient (pfst_bn_backward_dual) --------------------------------------------------------------
+// A stage's first Bottleneck ends in out = relu(bn3(conv3(.)) + bn_d(conv_d(x))) (resnet.py:298-307): bn3 and the downsample branch's BN both
+// receive g = [out > 0] dL/dout.  Layer by layer that is four passes reading g (two reductions, two apply passes: 10 N of traffic); here one
+// reduction reads (g, xa, xb) and one apply pass writes both input gradients: 8 N.  Same arithmetic as the single-layer kernels, element by
+// element (fp64 projections, the same summation order inside a workgroup).
+struct BnDualSide {
+  const float* x; i64 x_bs;             // the layer's pre-BN tensor
+  const float* mean; const float* invstd; const float* gamma;
+  float* dx; i64 dx_bs;                 // out: dL/dx
+  float* dgamma; float* dbeta;          // += (may be NULL)
+  double* ws;                           // [2 C]: (sum g, sum g * xhat)
+  float* amax;                          // NULL, or the slot group receiving max |dx|
+};
+
+// reduction: ws_a / ws_b [2c], [2c+1] += over the chunk     grid: (splits, C, N); planes 16-byte aligned, HW % 256 == 0
+__global__ __launch_bounds__(256) void bn_bwd_reduce_dual_kernel(const float* __restrict__ dy, i64 dy_bs, const unsigned long long* __restrict__ mask,
+                                                                 BnDualSide a, BnDualSide b, int HW, int chunk, int rev) {
+  __shared__ double sm[32];
+  const int c = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
+  const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  const float mua = a.mean[c], isa = a.invstd[c], mub = b.mean[c], isb = b.invstd[c];
+  const i64 base = (i64)c * HW;
+  const float* gp = dy + (i64)n * dy_bs + base;
+  const unsigned long long* mp = mask + ((i64)n * gridDim.y + c) * (HW >> 6);
+  const float* xap = a.x + (i64)n * a.x_bs + base;
+  const float* xbp = b.x + (i64)n * b.x_bs + base;
+  const int beg = bxi * chunk;
+  const int end = min(beg + chunk, HW);
+  double s = 0.0, sa = 0.0, sb = 0.0;
+  constexpr int U = 4;
+  const int e4 = end >> 2;
+  for (int i0 = (beg >> 2) + threadIdx.x; i0 < e4; i0 += U * blockDim.x) {
+    float4 gq[U], aq[U], bq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i4 = i0 + u * blockDim.x;
+      if (i4 < e4) {
+        gq[u] = reinterpret_cast<const float4*>(gp)[i4];
+        aq[u] = reinterpret_cast<const float4*>(xap)[i4];
+        bq[u] = reinterpret_cast<const float4*>(xbp)[i4];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i4 = i0 + u * blockDim.x;
+      if (i4 >= e4) break;
+      float4 g = gq[u];
+      const float4 xa = aq[u], xb = bq[u];
+      bool on[4];
+      relu_on4(mp, nullptr, i4, xa, 0.f, 0.f, on);
+      if (!on[0]) g.x = 0.f;
+      if (!on[1]) g.y = 0.f;
+      if (!on[2]) g.z = 0.f;
+      if (!on[3]) g.w = 0.f;
+      s += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+      sa += ((double)g.x * (double)((xa.x - mua) * isa) + (double)g.y * (double)((xa.y - mua) * isa)) +
+            ((double)g.z * (double)((xa.z - mua) * isa) + (double)g.w * (double)((xa.w - mua) * isa));
+      sb += ((double)g.x * (double)((xb.x - mub) * isb) + (double)g.y * (double)((xb.y - mub) * isb)) +
+            ((double)g.z * (double)((xb.z - mub) * isb) + (double)g.w * (double)((xb.w - mub) * isb));
+    }
+  }
+  double s2 = s;
+  block_sum2_d(s, sa, sm);
+  __syncthreads();
+  block_sum2_d(s2, sb, sm);
+  if (threadIdx.x == 0) {
+    atomicAdd(&a.ws[2 * c], s);
+    atomicAdd(&a.ws[2 * c + 1], sa);
+    atomicAdd(&b.ws[2 * c], s2);
+    atomicAdd(&b.ws[2 * c + 1], sb);
+  }
+}
+
+// apply: dxa, dxb from one read of g     grid: (blocks over HW, C, N)
+__global__ __launch_bounds__(256) void bn_bwd_apply_dual_kernel(const float* __restrict__ dy, i64 dy_bs, const unsigned long long* __restrict__ mask,
+                                                                BnDualSide a, BnDualSide b, int C, int HW, double inv_count, int rev) {
+  const int c = rev ? C - 1 - blockIdx.y : blockIdx.y, n = rev ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
+  const int bxi = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+  float ama = 0.f, amb = 0.f;
+  const float mua = a.mean[c], isa = a.invstd[c], mub = b.mean[c], isb = b.invstd[c];
+  const double m1a = a.ws[2 * c] * inv_count, m2a = a.ws[2 * c + 1] * inv_count;
+  const double m1b = b.ws[2 * c] * inv_count, m2b = b.ws[2 * c + 1] * inv_count;
+  const double gsa = (double)a.gamma[c] * (double)isa, gsb = (double)b.gamma[c] * (double)isb;
+  if (bxi == 0 && n == 0 && threadIdx.x == 0) {
+    if (a.dgamma) a.dgamma[c] += (float)a.ws[2 * c + 1];
+    if (a.dbeta) a.dbeta[c] += (float)a.ws[2 * c];
+    if (b.dgamma) b.dgamma[c] += (float)b.ws[2 * c + 1];
+    if (b.dbeta) b.dbeta[c] += (float)b.ws[2 * c];
+  }
+  const i64 base = (i64)c * HW;
+  const float* gp = dy + (i64)n * dy_bs + base;
+  const unsigned long long* mp = mask + ((i64)n * C + c) * (HW >> 6);
+  const float* xap = a.x + (i64)n * a.x_bs + base;
+  const float* xbp = b.x + (i64)n * b.x_bs + base;
+  float* dap = a.dx + (i64)n * a.dx_bs + base;
+  float* dbp = b.dx + (i64)n * b.dx_bs + base;
+  const int stride = gridDim.x * blockDim.x;
+  const int n4 = HW >> 2;
+  for (int i4 = bxi * blockDim.x + threadIdx.x; i4 < n4; i4 += stride) {
+    float4 g = reinterpret_cast<const float4*>(gp)[i4];
+    const float4 xa = reinterpret_cast<const float4*>(xap)[i4];
+    const float4 xb = reinterpret_cast<const float4*>(xbp)[i4];
+    bool on[4];
+    relu_on4(mp, nullptr, i4, xa, 0.f, 0.f, on);
+    if (!on[0]) g.x = 0.f;
+    if (!on[1]) g.y = 0.f;
+    if (!on[2]) g.z = 0.f;
+    if (!on[3]) g.w = 0.f;
+    float4 o;
+    o.x = (float)(gsa * ((double)g.x - m1a - (((double)xa.x - (double)mua) * (double)isa) * m2a));
+    o.y = (float)(gsa * ((double)g.y - m1a - (((double)xa.y - (double)mua) * (double)isa) * m2a));
+    o.z = (float)(gsa * ((double)g.z - m1a - (((double)xa.z - (double)mua) * (double)isa) * m2a));
+    o.w = (float)(gsa * ((double)g.w - m1a - (((double)xa.w - (double)mua) * (double)isa) * m2a));
+    reinterpret_cast<float4*>(dap)[i4] = o;
+    ama = fmaxf(fmaxf(ama, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    o.x = (float)(gsb * ((double)g.x - m1b - (((double)xb.x - (double)mub) * (double)isb) * m2b));
+    o.y = (float)(gsb * ((double)g.y - m1b - (((double)xb.y - (double)mub) * (double)isb) * m2b));
+    o.z = (float)(gsb * ((double)g.z - m1b - (((double)xb.z - (double)mub) * (double)isb) * m2b));
+    o.w = (float)(gsb * ((double)g.w - m1b - (((double)xb.w - (double)mub) * (double)isb) * m2b));
+    reinterpret_cast<float4*>(dbp)[i4] = o;
+    amb = fmaxf(fmaxf(amb, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+  }
+  if (a.amax) amax_publish(a.amax, ama);
+  __syncthreads();                     // (amax_publish's LDS slots are reused by the second call)
+  if (b.amax) amax_publish(b.amax, amb);
+}
+
 // after the two sums are in ws: parameter gradients + the per-channel record a consumer needs to apply the second pass itself
 __global__ void bn_bwd_rec_kernel(const double* __restrict__ ws, const float* __restrict__ mean, const float* __restrict__ invstd,
                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma,
@@ -675,6 +802,47 @@ extern "C" int pfst_bn_backward(const float* dy, long long dy_bs, const float* y
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(gx, C, N), dim3(256), 0, s, dy, dy_bs, y, y_bs, x, x_bs, mean, invstd, gamma, beta,
                        dx, dx_bs, dres, dres_bs, dres_accumulate, dgamma, dbeta, C, HW, inv_count, relu, relu_mask, ws, (pfst_bn_order() >> 2) & 1, dx_amax, post_scale);
   }
+  PFST_CHECK_LAUNCH();
+  return PFST_OK;
+}
+
+extern "C" int pfst_bn_backward_dual(const float* dy, long long dy_bs, const unsigned long long* relu_mask,
+                                     const float* xa, long long xa_bs, const float* mean_a, const float* invstd_a, const float* gamma_a,
+                                     float* dxa, long long dxa_bs, float* dgamma_a, float* dbeta_a, double* ws_a,
+                                     const float* bwd_partials_a, int bwd_slots_a, float* dxa_amax,
+                                     const float* xb, long long xb_bs, const float* mean_b, const float* invstd_b, const float* gamma_b,
+                                     float* dxb, long long dxb_bs, float* dgamma_b, float* dbeta_b, double* ws_b, float* dxb_amax,
+                                     int N, int C, int HW, pfst_stream_t stream) {
+  PFST_CHECK_ARG(dy && relu_mask && xa && mean_a && invstd_a && gamma_a && dxa && ws_a && xb && mean_b && invstd_b && gamma_b && dxb && ws_b);
+  PFST_CHECK_ARG(ws_a != ws_b && dxa != dxb && N > 0 && C > 0 && HW > 0 && C <= 65535 && N <= 65535);
+  PFST_CHECK_ARG(!bwd_partials_a || bwd_slots_a > 0);
+  if (pfst_deterministic() || HW % 256 != 0 || ((dy_bs | xa_bs | xb_bs | dxa_bs | dxb_bs) & 3) != 0 ||
+      (((uintptr_t)dy | (uintptr_t)xa | (uintptr_t)xb | (uintptr_t)dxa | (uintptr_t)dxb) & 15) != 0) {
+    pfst_set_error(__FILE__, __LINE__, "dual BatchNorm backward needs HW % 256 == 0, 16-byte aligned planes and the default (atomic) reductions: "
+                                       "run the two layers through pfst_bn_backward");
+    return PFST_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const BnDualSide a{xa, (i64)xa_bs, mean_a, invstd_a, gamma_a, dxa, (i64)dxa_bs, dgamma_a, dbeta_a, ws_a, dxa_amax};
+  const BnDualSide b{xb, (i64)xb_bs, mean_b, invstd_b, gamma_b, dxb, (i64)dxb_bs, dgamma_b, dbeta_b, ws_b, dxb_amax};
+  int splits, chunk;
+  split_for(HW, C, N, splits, chunk);
+  if (hipMemsetAsync(ws_b, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+  if (bwd_partials_a) {
+    // layer a's sums came out of the launch that completed dL/dout (pfst_bnb_fuse_t): only layer b's reduction reads the tensors
+    const float* none = nullptr;
+    double* nodet = nullptr;
+    hipLaunchKernelGGL(bn_bwd_partials_kernel, dim3(C), dim3(256), 0, s, bwd_partials_a, bwd_slots_a, mean_a, invstd_a, ws_a);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, none, (i64)0, xb, (i64)xb_bs, mean_b, invstd_b,
+                       gamma_b, none, HW, chunk, 1, relu_mask, ws_b, (pfst_bn_order() >> 1) & 1, none, nodet);
+  } else {
+    if (hipMemsetAsync(ws_a, 0, sizeof(double) * 2 * C, s) != hipSuccess) return PFST_ERR_LAUNCH;
+    hipLaunchKernelGGL(bn_bwd_reduce_dual_kernel, dim3(splits, C, N), dim3(256), 0, s, dy, (i64)dy_bs, relu_mask, a, b, HW, chunk,
+                       (pfst_bn_order() >> 1) & 1);
+  }
+  const int gx = cdiv(HW, 256 * 4);
+  hipLaunchKernelGGL(bn_bwd_apply_dual_kernel, dim3(gx, C, N), dim3(256), 0, s, dy, (i64)dy_bs, relu_mask, a, b, C, HW, 1.0 / ((double)N * HW),
+                     (pfst_bn_order() >> 2) & 1);
   PFST_CHECK_LAUNCH();
   return PFST_OK;
 }

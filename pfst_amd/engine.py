@@ -19,7 +19,7 @@ class Var:
     The claim is enforced at run time: after a writer has declared itself final (`grad_target(final=True)`), any further
     `grad_target()` on the Var raises instead of silently invalidating the fused sums."""
     __slots__ = ('data', '_grad', 'requires_grad', 'parent', 'c0', 'c1', 'bn', '_claimed', '_sealed', 'amax', 'lazy', 'gate_consumer', 'pending', 'coef_table',
-                 'lazy_norelu')
+                 'lazy_norelu', 'dual')
 
     def __init__(self, data, requires_grad=False, parent=None, c0=0, c1=0):
         self.data = data
@@ -40,6 +40,9 @@ class Var:
         # first, written out after all (_flush_pending: same values, one more pass).
         self.gate_consumer = False
         self.pending = None
+        # a downsample layer's output (conv -> BN, no ReLU; read only as the residual of the block's bn3): what bn3's backward needs to run BOTH
+        # layers' BatchNorm backward in one reduction + one apply pass (layers.FUSE_BN_BWD_DUAL); 'done' = (dL/dpre, its amax group) once it has
+        self.dual = None
         # a concat buffer whose writers leave their PRE-normalisation outputs in its slices (layers.conv_bn_act(defer='slice')): [C, 4] rows
         # (mean, invstd, sc, sh) per channel, filled slice by slice; the owner turns the buffer into a lazy Var for its single consumer
         self.coef_table = None

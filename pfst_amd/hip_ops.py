@@ -799,6 +799,26 @@ def bn_backward(dy, y, x, mean, invstd, gamma, dgamma, dbeta, relu=True, dres=No
     return dx
 
 
+def bn_backward_dual(dy, mask, a, b):
+    """the BatchNorm backward of TWO layers that receive the same gated gradient g = (mask bit ? dy : 0) -- bn3 and the downsample branch's BN of
+    a stage's first Bottleneck -- in one reduction and one apply pass (pfst_bn_backward_dual).  a / b: dicts x (pre-BN tensor), mean, invstd,
+    gamma, dgamma, dbeta, amax (slot group or None); a may carry partials / slots (its sums from the launch that wrote dy).  Returns
+    (dxa, dxb), or None when the entry point does not take the case (deterministic mode, unaligned planes): the caller runs the layers one by one"""
+    n, c, h, w = a['x'].shape
+    assert dy.shape == a['x'].shape == b['x'].shape
+    assert mask.dtype == torch.int64 and mask.numel() == n * c * h * w // 64 and (h * w) % 256 == 0
+    if is_deterministic() or any(_bs(t) % 4 or t.data_ptr() % 16 for t in (dy, a["x"], b["x"])):
+        return None
+    dxa, dxb = torch.empty(n, c, h, w, device=dy.device), torch.empty(n, c, h, w, device=dy.device)
+    ws = torch.empty(4 * c, dtype=torch.float64, device=dy.device)
+    call('pfst_bn_backward_dual', dy.data_ptr(), _bs(dy), mask.data_ptr(),
+         a['x'].data_ptr(), _bs(a['x']), a['mean'].data_ptr(), a['invstd'].data_ptr(), _dense(a['gamma']).data_ptr(), dxa.data_ptr(), _bs(dxa),
+         _p(a['dgamma']), _p(a['dbeta']), ws.data_ptr(), _p(a.get('partials')), int(a.get('slots', 0)), _p(a.get('amax')),
+         b['x'].data_ptr(), _bs(b['x']), b['mean'].data_ptr(), b['invstd'].data_ptr(), _dense(b['gamma']).data_ptr(), dxb.data_ptr(), _bs(dxb),
+         _p(b['dgamma']), _p(b['dbeta']), ws[2 * c:].data_ptr(), _p(b.get('amax')), n, c, h * w, _stream())
+    return dxa, dxb
+
+
 def relu_gate_(out, g, mask, accumulate=False):
     """out (+)= g where bn_apply's ReLU bitmask `mask` has the element's bit"""
     n, c, h, w = g.shape

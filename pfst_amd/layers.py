@@ -485,6 +485,11 @@ FOLD_BN_DWSEP = True
 # (pfst_bn_apply residual_coef).  Four tensors of 0.27-1.07 GB per pass are not written and not re-read: -2.1 ms per step in the same-box A/B
 # taken while the switch read the environment (profiles/r05_ab_fold_bn_residual.txt).  False: bn_apply writes them
 FOLD_BN_RESIDUAL = True
+# BatchNorm backward of a stage's first block: bn3 and the downsample branch's BN receive the same gated gradient -- one reduction over (g, pre3,
+# pre_d) and one apply pass writing both input gradients (pfst_bn_backward_dual) on the four largest tensors
+# of a pass: 8 N instead of 10 N per block).  False: layer by layer.  -1.25 ms of kernel time, -0.4 ms on the step in the same-box A/B taken while
+# the switch read the environment (profiles/r05_ab_bn_bwd_dual.txt)
+FUSE_BN_BWD_DUAL = True
 # depthwise conv -> BN -> ReLU layers: the second pass of BatchNorm backward is applied by the depthwise backward kernel while it stages its
 # operands (dL/dpre is never written)
 
@@ -858,9 +863,15 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
     in_hw = xd.shape[-2:]
     if final and x.lazy is None and x.requires_grad and conv.dgrad_can_gate(in_hw):
         x.gate_consumer = True            # this layer's data gradient completes dL/dx and can add a gated identity-branch gradient (Var.pending)
+    def need_dpre_amax():                 # f16x3: does a kernel reading dL/dpre of this layer scale it from a published maximum?
+        return CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
+                                                                or conv.wino_f16 or conv.wgrad_f16q_ok(pre.shape[2], pre.shape[3]))
+
     if FUSE_RES_GATE and not relu and residual is None and out_var is None and post_scale is None and (not defer or as_residual) and not conv.depthwise \
             and (pre.shape[2] * pre.shape[3]) % 256 == 0:
         yv.gate_consumer = True           # a downsample layer (conv -> BN, no ReLU): its BatchNorm backward takes (g, mask) as its gated dy
+        if FUSE_BN_BWD_DUAL:              # ... or rides in the bn3 backward of the block it is the residual of (same g: one reduction, one apply pass)
+            yv.dual = dict(x=pre, mean=mean, invstd=invstd, bn=bn, need_amax=need_dpre_amax, done=None)
     if coef is not None and out_var is None and post_scale is None and (not defer or (need_pred and not into_slice)):
         # the launch completing dL/dy may emit this layer's BatchNorm-backward sums; ReLU gate: from y for residual layers
         # (y > 0 <=> the bitmask), else recomputed from the pre-BN tensor as bn_apply computed it
@@ -868,24 +879,46 @@ def conv_bn_act(x, conv, bn, tape, relu=True, residual=None, out=None, post_scal
                               gate if (BNB_GATE_FROM_MASK and relu and residual is not None) else None)
 
     def bwd():
+        if yv.dual is not None and yv.dual['done'] is not None:
+            # a downsample layer whose BatchNorm backward already ran inside the block's bn3 backward (pfst_bn_backward_dual)
+            (dpre, dpre_amax), yv.dual = yv.dual['done'], None
+            conv_backward(x, conv, dpre, saved_v, final, dy_amax=dpre_amax)
+            if yv.parent is None:
+                yv.free_grad()
+            return
         ext_gate = None
         if yv.pending is not None and yv.grad_unwritten() and yv.gate_consumer and not relu and residual is None:
             dy, ext_gate = yv.take_pending()          # downsample layer: dL/dy = g where the block's final ReLU passed; the mask is the gate
         else:
             dy = yv.grad
         dres = dacc = None
+        part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
+        dpre_amax = ops.amax_slots(pre.device) if need_dpre_amax() else None
         if residual is not None and residual.requires_grad:
             if (FUSE_RES_GATE and gate is not None and relu and residual.gate_consumer and residual.pending is None and residual.parent is None
                     and residual.grad_unwritten()):
+                dual = residual.dual if (FUSE_BN_BWD_DUAL and post_scale is None and not conv.depthwise) else None
+                if dual is not None:
+                    # the residual is a downsample layer's output: its BatchNorm backward and this layer's read the same gated gradient
+                    ds_amax = ops.amax_slots(pre.device) if dual['need_amax']() else None
+                    ds_bn = dual['bn']
+                    both = ops.bn_backward_dual(
+                        dy, gate,
+                        dict(x=pre, mean=mean, invstd=invstd, gamma=bn.weight.data, dgamma=bn.weight.grad, dbeta=bn.bias.grad, partials=part,
+                             slots=nslots, amax=dpre_amax),
+                        dict(x=dual['x'], mean=dual['mean'], invstd=dual['invstd'], gamma=ds_bn.weight.data, dgamma=ds_bn.weight.grad,
+                             dbeta=ds_bn.bias.grad, amax=ds_amax))
+                    if both is not None:
+                        dual['done'] = (both[1], ds_amax)
+                        conv_backward(x, conv, both[0], saved_v, final, dy_amax=dpre_amax)
+                        if yv.parent is None:
+                            yv.free_grad()
+                        return
                 residual.pending = (dy, gate)         # dL/dresidual = dy * gate: left to the launch that completes the residual's gradient
             else:
                 dres, dacc = residual.grad_target()
         # without a residual the ReLU mask is recomputed from the pre-BN tensor (one HBM read less per pass)
         ymask = y if (relu and residual is not None and gate is None) else None
-        part, nslots = (yv.bn.partials, yv.bn.slots) if yv.bn is not None else (None, 0)
-        need_amax = CONV_MATH == 'f16x3' and not conv.depthwise and ((conv.f16_d and x.requires_grad) or (conv.cout > 64 and conv.k == 1)
-                                                                    or conv.wino_f16 or conv.wgrad_f16q_ok(pre.shape[2], pre.shape[3]))
-        dpre_amax = ops.amax_slots(pre.device) if need_amax else None
         if (conv.depthwise and relu and residual is None and gate is None
                 and post_scale is None and x.requires_grad):
             # the depthwise backward forms dL/dpre itself from (dy, pre) and the record of the two sums: 3 N of traffic less

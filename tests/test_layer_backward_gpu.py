@@ -841,6 +841,108 @@ def test_downsample_branch_folded_into_bn3s_normalisation_pass():
     assert e < 1e-4, e
 
 
+def test_bn_backward_of_two_layers_behind_one_gated_gradient():
+    """pfst_bn_backward_dual (round 5): bn3 and the downsample branch's BN of a stage's first block (out = relu(bn3(.) + bn_d(.)),
+    /root/reference/rsiseg/models/backbones/resnet.py:298-307) receive the same gated gradient; one reduction + one apply pass replace the two
+    pfst_bn_backward calls.  Kernel level: both input gradients, both parameter gradients and both published maxima against the single-layer
+    entry point (same per-element arithmetic; the sums differ by the atomics' order), with and without layer a's sums arriving as partials."""
+    import pfst_amd  # noqa: F401
+    from pfst_amd import hip_ops as ops
+
+    g = torch.Generator().manual_seed(11)
+    for (n, c, h, w) in [(2, 24, 32, 32), (3, 7, 16, 48)]:
+        dy = torch.randn(n, c, h, w, generator=g).cuda() + 0.3          # a common mode: the projections cancel
+        xa = (torch.randn(n, c, h, w, generator=g) * 2 + 1).cuda()
+        xb = (torch.randn(n, c, h, w, generator=g) * 0.5 - 2).cuda()
+        out = torch.randn(n, c, h, w, generator=g).cuda()
+        # the block's ReLU bitmask as pfst_bn_apply writes it (gamma = 1, beta = 0 on a standardised tensor: bit = out > 0)
+        zero, one = torch.zeros(c, device='cuda'), torch.ones(c, device='cuda')
+        _, mask = ops.bn_apply(out, zero, one, one, zero, True, torch.zeros_like(out), want_mask=True)
+        side = {}
+        for k, x in (('a', xa), ('b', xb)):
+            mean = x.mean(dim=(0, 2, 3)).contiguous()
+            invstd = torch.rsqrt(x.var(dim=(0, 2, 3), unbiased=False) + 1e-5).contiguous()
+            gamma = (torch.rand(c, generator=g) + 0.5).cuda() * (1 if k == 'a' else -1)
+            side[k] = dict(x=x, mean=mean, invstd=invstd, gamma=gamma)
+        ref = {}
+        for k in 'ab':
+            sd = side[k]
+            dg, db, am = torch.zeros(c, device='cuda'), torch.zeros(c, device='cuda'), ops.amax_slots(dy.device)
+            dx = ops.bn_backward(dy, None, sd['x'], sd['mean'], sd['invstd'], sd['gamma'], dg, db, True, mask=mask, amax=am)
+            ref[k] = (dx, dg, db, float(am.max()))
+        got = {k: dict(side[k], dgamma=torch.zeros(c, device='cuda'), dbeta=torch.zeros(c, device='cuda'), amax=ops.amax_slots(dy.device)) for k in 'ab'}
+        both = ops.bn_backward_dual(dy, mask, got['a'], got['b'])
+        assert both is not None
+        torch.cuda.synchronize()
+        for k, dx in zip('ab', both):
+            rdx, rdg, rdb, ram = ref[k]
+            assert float((dx - rdx).abs().max()) <= 1e-6 * float(rdx.abs().max()), k
+            assert torch.allclose(got[k]['dgamma'], rdg, rtol=1e-6, atol=1e-6) and torch.allclose(got[k]['dbeta'], rdb, rtol=1e-6, atol=1e-6), k
+            assert float(got[k]['amax'].max()) == float(dx.abs().max()), k              # the published maximum is the written tensor's
+            assert abs(float(got[k]['amax'].max()) - ram) <= 1e-6 * ram, k
+        # against torch autograd of the two-branch sum (fp64)
+        xa64, xb64 = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+        ya = torch.nn.functional.batch_norm(xa64, None, None, side['a']['gamma'].double(), None, True, 0.0, 1e-5)
+        yb = torch.nn.functional.batch_norm(xb64, None, None, side['b']['gamma'].double(), None, True, 0.0, 1e-5)
+        ((ya + yb) * (dy.double() * (out > 0))).sum().backward()
+        for dx, x64 in zip(both, (xa64, xb64)):
+            assert float((dx.double() - x64.grad).abs().max()) <= 2e-5 * float(x64.grad.abs().max())
+
+
+def test_first_block_bn_backward_runs_both_layers_in_one_pass():
+    """layers.FUSE_BN_BWD_DUAL: one segmentor forward + backward with the dual BatchNorm backward on and off -- four pfst_bn_backward_dual
+    launches replace eight pfst_bn_backward ones (layer1-4's first blocks), identical logits, gradients equal to the atomics' order."""
+    import pfst_amd  # noqa: F401
+    from oracle import pfst_oracle as O
+    from pfst_amd import hip_ops as ops
+    from pfst_amd import layers
+    from pfst_amd.engine import ParamArena, Tape
+    from pfst_amd.registry import build_segmentor
+    from pfst_amd.synthetic import synth_batch
+
+    if not layers.FUSE_RES_GATE:
+        pytest.skip('needs the gated identity gradient')
+    C, b, S = 6, 2, 128
+    _, student, _ = seeded_pfgst_state(O, 9)
+    batch = synth_batch(b, S, C, seed=43)
+    runs, seen_by = {}, {}
+    prev = layers.FUSE_BN_BWD_DUAL
+    inner = ops.call
+    try:
+        for dual in (True, False):
+            layers.FUSE_BN_BWD_DUAL = dual
+            model = build_segmentor(model_cfg(C, 3, dropout=0.0))
+            model.load_state_dict(student, strict=True)
+            model.cuda()
+            arena = ParamArena(list(model.named_parameters()), torch.device('cuda'), with_grad=True)
+            model.repack_weights(need_dgrad=True)
+            seen = {}
+
+            def counting(name, *a):
+                seen[name] = seen.get(name, 0) + 1
+                return inner(name, *a)
+            ops.call = counting
+            try:
+                tape = Tape()
+                out = model.forward_train(batch['img'].cuda(), batch['img_metas'], ops.to_u8(batch['gt_semantic_seg'].cuda()), None,
+                                          return_logits=True, tape=tape)
+                tape.backward()
+                torch.cuda.synchronize()
+            finally:
+                ops.call = inner
+            runs[dual] = (out['logits'].data.clone(), arena.grad.clone())
+            seen_by[dual] = seen
+    finally:
+        layers.FUSE_BN_BWD_DUAL = prev
+    on, off = seen_by[True], seen_by[False]
+    assert on.get('pfst_bn_backward_dual', 0) == 4 and off.get('pfst_bn_backward_dual', 0) == 0, (on, off)
+    assert off['pfst_bn_backward'] - on['pfst_bn_backward'] == 8, (off['pfst_bn_backward'], on['pfst_bn_backward'])
+    assert torch.equal(runs[True][0], runs[False][0])
+    _, e = mixed_err(runs[True][1], runs[False][1])
+    print(f'   gradient arena, dual BatchNorm backward on vs off: {e:.2e}')
+    assert e < 1e-4, e
+
+
 def test_published_maxima_cover_every_f16x3_operand():
     """f16x3 mode: the scale of an activation operand comes from the slot group its producer(s) published max |.| into -- the normalisation
     pass, the max-pool (layer1's input) and, for the ASPP head's concat, all five writers of the buffer into ONE group (four normalisation
