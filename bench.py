@@ -44,7 +44,8 @@ class KernelTimer:
 
     def __init__(self, inner):
         self.inner = inner
-        self.records = []      # (key, start_evt, end_evt, flops)
+        self.records = []      # (key, start_evt, end_evt, flops, bytes, fused-epilogue operand bytes)
+        self.fused_bytes = {}
         self.enabled = False
         self.per_layer = False
         self.only = None       # kernel-name prefix: bracket only those launches (the timed region), None = all
@@ -152,21 +153,31 @@ class KernelTimer:
                    'pfst_wino_gemm_f16x3': (5, 6, 7, 8), 'pfst_conv_wgrad_f16x3': (5, 6, 7, 8),
                    'pfst_conv_wgrad_f16x3_q': (5, 6, 7, 9, 10, 11)}[name]
             key = key + (' wino ' if 'wino' in name else ' ') + ' '.join(str(args[i]) for i in idx)
+        extra = 0.0
+        if name == 'pfst_conv_igemm_f16x3':
+            # operands of the fused epilogues, NOT part of the convolution's algorithmic bytes but part of the launch's HBM traffic: the pre-BN
+            # tensor a data-gradient launch reads for the BatchNorm-backward sums it emits (bnb), the gated identity gradient it adds
+            # (gate_dy), the old contents of an accumulated output -- one [N][M][pixels] fp32 tensor each
+            a = args
+            px = a[13] * a[14] if a[19] == 0 else a[10] * a[11]
+            extra = 4.0 * a[8] * a[12] * px * (bool(a[22]) + bool(a[23]) + bool(a[20]))
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         self.inner(name, *args)
         e.record()
-        self.records.append((key, s, e, flops, nbytes))
+        self.records.append((key, s, e, flops, nbytes, extra))
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, s, e, flops, nbytes in self.records:
+        self.fused_bytes = {}          # per key: bytes of the fused epilogues' extra operands over the same launches
+        for key, s, e, flops, nbytes, extra in self.records:
             d = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += 1
             d[1] += s.elapsed_time(e)
             d[2] += flops
             d[3] += nbytes
+            self.fused_bytes[key] = self.fused_bytes.get(key, 0.0) + extra
         return agg
 
 
@@ -193,8 +204,8 @@ def pmc_traffic(kernel):
     # software-pipelined K=16 loop, the K=32 pairing and its fused-epilogue variants, the plain loop for short contractions)
     family = {'conv_igemm_split_kernel': ('conv_igemm_split_pair_kernel', 'conv_igemm_split_pair_bnb_kernel', 'conv_igemm_split_pipe_kernel'),
               'conv_wgrad_split_q_kernel': ('conv_wgrad_split_q_pipe_kernel',)}.get(base, ()) if want == ['128'] else ()
-    if base == 'conv_igemm_f16x3_kernel':          # + the variants with the fused BatchNorm-backward epilogue
-        family = ('conv_igemm_f16x3_bnb_kernel',)
+    if base == 'conv_igemm_f16x3_kernel':          # + the variants with the fused BatchNorm-backward epilogue and the normalise-on-load form
+        family = ('conv_igemm_f16x3_bnb_kernel', 'conv_igemm_f16x3_bnl_kernel')
     if base == 'conv_wgrad_f16x3_kernel':          # the K=32-per-step kernels the entry point launches by default (whole-line loads)
         family = ('conv_wgrad_f16x3_pair_kernel', 'conv_wgrad_f16x3_line_kernel')
     tot, calls = 0.0, 0
@@ -202,6 +213,8 @@ def pmc_traffic(kernel):
         if not isinstance(v, dict):   # <128, 0..3> of conv_igemm_q_kernel<128>), weighted by their launch counts
             continue
         b, a = split(k)
+        if base == 'conv_igemm_f16x3_kernel' and not want and a and a[-1] == '64':
+            continue                  # the 64-row tile is timed as a family of its own ('conv_igemm_f16x3_kernel<64>')
         if (b == base and a[:len(want)] == want) or b in family:
             tot += (v['fetch_MB_corrected'] + v['write_MB']) * 1e6 * v['calls']
             calls += v['calls']
@@ -425,12 +438,17 @@ def main():
             return {'mfma_flops_per_algorithmic_flop': mult_, 'executed_tflops': mult_ * alg_tflops, 'frac_of_peak': mult_ * alg_tflops / peak,
                     'structural_ceiling_tflops_algorithmic': peak / mult_, 'frac_of_structural_ceiling': alg_tflops / (peak / mult_)}
         traffic, src = pmc_traffic(dom[0])
+        fused_per_launch = timer.fused_bytes.get(dom[0], 0.0) / agg[dom[0]][0] if dom[0] in agg else None      # (from the table pass: same launches)
         out['roofline'] = {'kernel': dom[0], 'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': unit, 'frac': achieved / peak,
                            'traffic': traffic, 'traffic_source': src, 'launches': cnt, 'avg_launch_ms': ms / cnt, 'measured_in': measured_in,
                            'algorithmic_flops_per_launch': fl / cnt, 'mfma_pipe_utilisation': pipe(mult, achieved),
                            'fp32_equivalent_tflops': achieved,
                            'fp32_equivalent_vs_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                            'algorithmic_bytes_per_launch': nb / cnt,
+                           'fused_epilogue_operand_bytes_per_launch': fused_per_launch,
+                           'traffic_note': 'traffic = L2-miss bytes by the counters, all launches of the family; algorithmic bytes = the convolution alone; the '
+                                           'fused epilogues (BatchNorm-backward sums, gated identity gradient, accumulation) read further whole tensors, '
+                                           'counted in fused_epilogue_operand_bytes_per_launch',
                            'ms_per_step': ms / args.steps}
         # the weight-gradient kernel in the same form, so its over-fetch ratio (PMC traffic vs algorithmic bytes) is visible too
         wk = 'conv_wgrad_f16x3_kernel' if math == 'f16x3' else 'conv_wgrad_split_q_kernel<128>' if split else 'conv_wgrad_q_kernel<128,1>'
