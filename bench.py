@@ -376,7 +376,8 @@ def main():
             out = model.train_step(batch, opt)
             state['it'] += 1
             if times is not None:
-                times.append(time.perf_counter() - t0)      # host clock: every step ends in its one blocking read of the log vector
+                times.append(time.perf_counter() - t0)      # host clock: every step ends in its one blocking read of the log vector (which waits for the
+                # step's FORWARD passes since layers.EARLY_LOG_READ: the host runs up to one backward sweep ahead of the device, the mean still is the step)
         return out
 
     def timed_steps(model, opt, n, times=None):

@@ -608,6 +608,11 @@ FORK_TEACHER = os.environ.get('PFST_FORK_TEACHER', '1') == '1'
 # the step boundary (uda.PFGST): the optimizer step queued before the host blocks on the step's log values, the student's weight images
 # packed behind the forked teacher pass -- the device has work while the host crosses from one step into the next (tools/gap_analysis.py)
 STEP_BOUNDARY_OVERLAP = True
+# the step's packed log values (all forward results) are copied to the host in front of the backward sweep: the blocking read at the end of
+# PFGST.forward_train waits for the forward passes only and the next step's host-side start runs under the queued backward sweep
+# -- where the reference reads them too (`_parse_losses` before `total_loss.backward()`, pfgst.py:338-344).  -2.2 ms per step in the same-box A/B
+# taken while the switch read the environment (profiles/r05_ab_early_log_read.txt).  False: the copy is queued behind the backward sweep
+EARLY_LOG_READ = True
 WGRAD_STREAM_LDS_PAD = 24000
 _side_stream = None
 _teacher_stream = None

@@ -475,6 +475,29 @@ class PFGST(UDADecorator):
                 scalars.update(aux)
                 vis_states.update(vis)
 
+        # ---- the step's log values: every one of them is a FORWARD result (losses, accuracies, PFGSTLoss terms, the CE kernels' bad-label
+        # counts), so their packed copy to the host is queued HERE, in front of the backward sweep (layers.EARLY_LOG_READ): the blocking read at
+        # the end of the step then waits for the forward passes only, the host returns while the device still has the whole backward sweep and
+        # the optimizer step queued, and the next step's host-side start (EMA, weight images, label conversion, the first launches of the teacher
+        # pass: 2-3 ms during which the device used to idle) runs under it.  The reference reads its log values at the same point
+        # (`_parse_losses` before `loss.backward()`, pfgst.py:340-344)
+        def start_log_read():
+            names = list(scalars.keys())
+            packed = torch.cat([scalars[k].reshape(1) for k in names])
+            if pdist.is_distributed():
+                if self.local_iter == 0:
+                    pdist.check_same_keys(names)
+                packed = pdist.reduce_log_vector(packed)
+            host = getattr(self, '_log_host', None)
+            if host is None or host.numel() < packed.numel():
+                host = self._log_host = torch.empty(max(64, packed.numel()), dtype=torch.float32, pin_memory=True)
+            host[:packed.numel()].copy_(packed, non_blocking=True)
+            evt = torch.cuda.Event()
+            evt.record()
+            return names, host, packed.numel(), evt
+
+        log_read = start_log_read() if layers.EARLY_LOG_READ else None
+
         # ---- one backward over both student graphs + aux (pfgst.py:344)
         tape.backward()
         layers.join_side_stream()
@@ -486,12 +509,8 @@ class PFGST(UDADecorator):
             if self.use_decoded_feats:
                 dbg.update(ema_dec=ema_dec.data, src_dec=src_dec.data)
 
-        # ---- gradient all-reduce (student only), log scalars packed into ONE vector
-        names = list(scalars.keys())
-        packed = torch.cat([scalars[k].reshape(1) for k in names])
+        # ---- gradient all-reduce (student only)
         if pdist.is_distributed():
-            if self.local_iter == 0:
-                pdist.check_same_keys(names)
             if reducer is not None:
                 reducer.finish()                       # the tail buckets have been in flight since the source pass's backward
             else:
@@ -508,25 +527,20 @@ class PFGST(UDADecorator):
                 for p in loss_module.parameters():     # trainable parameters of an auxiliary loss (PFGSTLoss.proj_net)
                     if p.grad is not None:
                         pdist.allreduce_mean_(p.grad.view(-1))
-            packed = pdist.reduce_log_vector(packed)
         if step_stats is not None:
             import time
             t_read = time.perf_counter()
-        # the step's single blocking read: an asynchronous copy into pinned memory + an event, so that the optimizer step (train_step hands
-        # it over as `_before_read`) can be queued BEHIND the copy and run while the host wakes up, unpacks the values and enters the next step
-        host = getattr(self, '_log_host', None)
-        if host is None or host.numel() < packed.numel():
-            host = self._log_host = torch.empty(max(64, packed.numel()), dtype=torch.float32, pin_memory=True)
-        host[:packed.numel()].copy_(packed, non_blocking=True)
-        read_evt = torch.cuda.Event()
-        read_evt.record()
+        # the step's single blocking read: an asynchronous copy into pinned memory + an event (queued in front of the backward sweep, see
+        # above; layers.EARLY_LOG_READ off: here, behind it), so that the optimizer step (train_step hands it over as `_before_read`) is
+        # queued before the host waits, unpacks the values and enters the next step
+        names, host, n_log, read_evt = log_read if log_read is not None else start_log_read()
         before_read, self._before_read = getattr(self, '_before_read', None), None
         if before_read is not None and layers.STEP_BOUNDARY_OVERLAP:
             before_read()
         read_evt.synchronize()
         if before_read is not None and not layers.STEP_BOUNDARY_OVERLAP:
             before_read()
-        vals = host[:packed.numel()].tolist()
+        vals = host[:n_log].tolist()
         if step_stats is not None:
             step_stats['host_read_s'] = time.perf_counter() - t_read
         log_vars = OrderedDict(zip(names, vals))
