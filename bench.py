@@ -368,28 +368,39 @@ def main():
         model.to(dev)
         return model, build_optimizer(model, OPTIMIZER)
 
-    def run_steps(model, opt, n, times=None):
+    def run_steps(model, opt, n, marks=None):
         for _ in range(n):
-            t0 = time.perf_counter()
             for g in opt.param_groups:
                 g['lr'] = poly_lr(OPTIMIZER['lr'], state['it'], cfg['max_iters'])
             out = model.train_step(batch, opt)
             state['it'] += 1
-            if times is not None:
-                times.append(time.perf_counter() - t0)      # host clock: every step ends in its one blocking read of the log vector (which waits for the
-                # step's FORWARD passes since layers.EARLY_LOG_READ: the host runs up to one backward sweep ahead of the device, the mean still is the step)
+            if marks is not None:
+                # DEVICE clock: an event behind the step's last launch (the optimizer kernel).  The host clock no longer brackets a step: its
+                # blocking read waits for the step's FORWARD passes only (layers.EARLY_LOG_READ), the host runs up to one backward sweep ahead
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
         return out
 
     def timed_steps(model, opt, n, times=None):
+        """-> (wall seconds of the n steps between two synchronisations, the last step's outputs); times: filled with the n per-step durations
+        on the device (seconds, event to event on the launch stream)"""
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+        marks = None
+        if times is not None:
+            marks = [torch.cuda.Event(enable_timing=True)]
+            marks[0].record()
         t0 = time.perf_counter()
-        out = run_steps(model, opt, n, times)
+        out = run_steps(model, opt, n, marks)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        return time.perf_counter() - t0, out
+        dt = time.perf_counter() - t0
+        if times is not None:
+            times.extend(1e-3 * marks[i].elapsed_time(marks[i + 1]) for i in range(n))
+        return dt, out
 
     def kernel_tables(model, opt, math, dom_agg):
         """second, untimed pass of the same K steps with EVERY launch bracketed -> roofline legs and per-kernel tables"""
