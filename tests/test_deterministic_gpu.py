@@ -13,7 +13,7 @@ from helpers import seeded_pfgst_state, to_dev, uda_cfg
 pytestmark = pytest.mark.gpu
 
 
-def _one_step(det, seed=123, overlap=None):
+def _one_step(det, seed=123, overlap=None, early_read=None):
     import pfst_amd  # noqa: F401
     from oracle import pfst_oracle as O
     from pfst_amd import hip_ops
@@ -25,6 +25,9 @@ def _one_step(det, seed=123, overlap=None):
     prev_overlap = (layers.WGRAD_STREAM, layers.FORK_TEACHER)
     if overlap is not None:
         layers.set_overlap(*overlap)
+    prev_early = layers.EARLY_LOG_READ
+    if early_read is not None:
+        layers.EARLY_LOG_READ = early_read
     try:
         model = UDA.build(uda_cfg(threshold=0.30, dropout=0.1))
         both, _, _ = seeded_pfgst_state(O, 9)
@@ -43,6 +46,7 @@ def _one_step(det, seed=123, overlap=None):
     finally:
         hip_ops.set_deterministic(False)
         layers.set_overlap(*prev_overlap)
+        layers.EARLY_LOG_READ = prev_early
 
 
 def test_deterministic_mode_gives_bit_identical_gradients():
@@ -73,3 +77,17 @@ def test_deterministic_mode_gives_bit_identical_gradients():
     assert rel < 1e-4, rel
     for k in a[0]:
         assert abs(a[0][k] - c[0][k]) <= 1e-5 * max(abs(c[0][k]), 1e-2), (k, a[0][k], c[0][k])
+
+
+def test_log_values_read_before_the_backward_sweep_are_the_steps_log_values():
+    """layers.EARLY_LOG_READ (round 5, late): the packed log values are copied to the host in front of `tape.backward()` -- the reference parses
+    its losses at the same point (`_parse_losses` before `total_loss.backward()`, /root/reference/rsiseg/models/uda/pfgst.py:338-344) -- so the
+    step's blocking read waits for the forward passes only and the host queues the next step while the device still works on the backward sweep
+    and the optimizer step.  Pure scheduling: in the fixed-order mode two consecutive steps give BIT-IDENTICAL gradients and weights with the
+    copy in front of and behind the sweep, and the same 14 log values (fp64 round-off of their atomics)."""
+    a, b = _one_step(True, early_read=True), _one_step(True, early_read=False)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    for la, lb in ((a[0], b[0]), (a[2], b[2])):
+        assert list(la) == list(lb) and len(la) >= 14
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-12 * max(1.0, abs(la[k])), (k, la[k], lb[k])
