@@ -484,13 +484,27 @@ class PFGST(UDADecorator):
         def start_log_read():
             names = list(scalars.keys())
             packed = torch.cat([scalars[k].reshape(1) for k in names])
-            if pdist.is_distributed():
-                if self.local_iter == 0:
-                    pdist.check_same_keys(names)
-                packed = pdist.reduce_log_vector(packed)
             host = getattr(self, '_log_host', None)
             if host is None or host.numel() < packed.numel():
                 host = self._log_host = torch.empty(max(64, packed.numel()), dtype=torch.float32, pin_memory=True)
+            if pdist.is_distributed():
+                if self.local_iter == 0:
+                    pdist.check_same_keys(names)
+                # the mean over ranks of the log vector (what `_parse_losses` does key by key, segmentors/base.py:178-222) and its copy run on a
+                # stream of their own: the main stream never waits for this collective, so a rank whose forward passes ran late does not hold
+                # the others' backward sweeps; every rank issues it at the same point of its program, ahead of its gradient buckets
+                main = torch.cuda.current_stream()
+                ls = getattr(self, '_log_stream', None)
+                if ls is None:
+                    ls = self._log_stream = torch.cuda.Stream()
+                ls.wait_stream(main)
+                with torch.cuda.stream(ls):
+                    red = pdist.reduce_log_vector(packed)
+                    host[:red.numel()].copy_(red, non_blocking=True)
+                    evt = torch.cuda.Event()
+                    evt.record()
+                packed.record_stream(ls)
+                return names, host, packed.numel(), evt
             host[:packed.numel()].copy_(packed, non_blocking=True)
             evt = torch.cuda.Event()
             evt.record()
